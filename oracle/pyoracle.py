@@ -1,0 +1,288 @@
+"""Python front-end of the CPU oracle.  TEST INFRASTRUCTURE ONLY.
+
+Two interchangeable back-ends with the same methods:
+
+  Oracle("port")       oracle/libgs_oracle.so  -- this repo's C restatement (gs_oracle.c)
+  Oracle("reference")  oracle/_ref/libgs_ref.so -- the unmodified reference header compiled
+                       by oracle/Makefile (present in the build container and shipped to
+                       the GPU box as a prebuilt, git-ignored binary)
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from grayskull_amd._abi import (GsImage, GsLbpCascade, KEYPOINT_DTYPE, MATCH_DTYPE, RECT_DTYPE)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PORT_SO = os.path.join(HERE, "libgs_oracle.so")
+REF_SO = os.path.join(HERE, "_ref", "libgs_ref.so")
+
+u8p = C.POINTER(C.c_uint8)
+
+
+def build():
+    """Compile the C restatement (and, when /root/reference exists, oracle/_ref)."""
+    subprocess.check_call(["make", "-s", "-C", HERE, "all"])
+
+
+def have_reference():
+    return os.path.exists(REF_SO)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _img(a):
+    h, w = a.shape
+    return GsImage(w, h, a.ctypes.data)
+
+
+class Oracle:
+    def __init__(self, kind="port"):
+        self.kind = kind
+        if kind == "port":
+            if not os.path.exists(PORT_SO):
+                build()
+            self.lib = C.CDLL(PORT_SO)
+        elif kind == "reference":
+            self.lib = C.CDLL(REF_SO)
+        else:
+            raise ValueError(kind)
+        self.port = kind == "port"
+        L = self.lib
+        if self.port:
+            L.orc_fnv1a.restype = C.c_uint32
+            L.orc_fnv1a.argtypes = [C.c_void_p, C.c_uint64]
+            L.orc_otsu_threshold.restype = C.c_uint8
+            L.orc_otsu_from_hist.restype = C.c_uint8
+            L.orc_orientation.restype = C.c_float
+            L.orc_lbp_detect.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p,
+                                         C.c_uint, C.c_float, C.c_float, C.c_float, C.c_int]
+            L.orc_lbp_window.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_int,
+                                         C.c_int, C.c_float]
+            L.orc_match_orb.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_uint, C.c_void_p,
+                                        C.c_uint, C.c_float]
+        else:
+            L.gs_otsu_threshold.restype = C.c_uint8
+            L.gs_otsu_threshold.argtypes = [GsImage]
+            L.gs_compute_orientation.restype = C.c_float
+            L.gs_compute_orientation.argtypes = [GsImage, C.c_uint, C.c_uint, C.c_uint]
+            L.gs_lbp_detect.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p,
+                                        C.c_uint, C.c_float, C.c_float, C.c_float, C.c_int]
+            L.gs_lbp_window.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_int,
+                                        C.c_int, C.c_float]
+            L.gs_match_orb.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_uint, C.c_void_p,
+                                       C.c_uint, C.c_float]
+            L.gs_blur.argtypes = [GsImage, GsImage, C.c_uint]
+            for f in ("gs_sobel", "gs_erode", "gs_dilate", "gs_downsample"):
+                getattr(L, f).argtypes = [GsImage, GsImage]
+            L.gs_histogram.argtypes = [GsImage, C.c_void_p]
+            L.gs_threshold.argtypes = [GsImage, C.c_uint8]
+            L.gs_adaptive_threshold.argtypes = [GsImage, GsImage, C.c_uint, C.c_int]
+            L.gs_filter.argtypes = [GsImage, GsImage, GsImage, C.c_uint]
+            L.gs_integral.argtypes = [GsImage, C.c_void_p]
+            L.gs_fast.argtypes = [GsImage, GsImage, C.c_void_p, C.c_uint, C.c_uint]
+            L.gs_brief_descriptor.argtypes = [GsImage, C.c_void_p]
+            L.gs_orb_extract.argtypes = [GsImage, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p]
+            L.ref_atan2.restype = C.c_float
+            L.ref_atan2.argtypes = [C.c_float, C.c_float]
+            L.ref_sin.restype = C.c_float
+            L.ref_sin.argtypes = [C.c_float]
+
+    # ------------------------------------------------------------ helpers
+    @staticmethod
+    def synth(w, h, seed):
+        lib = Oracle._port_lib()
+        a = np.empty((h, w), np.uint8)
+        lib.orc_synth(_p(a), C.c_uint(w), C.c_uint(h), C.c_uint32(seed))
+        return a
+
+    @staticmethod
+    def fnv1a(a):
+        lib = Oracle._port_lib()
+        a = np.ascontiguousarray(a)
+        return int(lib.orc_fnv1a(_p(a), a.nbytes))
+
+    _port = None
+
+    @staticmethod
+    def _port_lib():
+        if Oracle._port is None:
+            Oracle._port = Oracle("port").lib
+        return Oracle._port
+
+    # ------------------------------------------------------------ stencils
+    def _unary(self, name, src, dst=None, *extra):
+        src = np.ascontiguousarray(src, np.uint8)
+        h, w = src.shape
+        out = np.zeros_like(src) if dst is None else np.ascontiguousarray(dst, np.uint8).copy()
+        if self.port:
+            getattr(self.lib, "orc_" + name)(_p(out), _p(src), C.c_uint(w), C.c_uint(h), *extra)
+        else:
+            getattr(self.lib, "gs_" + name)(_img(out), _img(src), *extra)
+        return out
+
+    def blur(self, src, radius):
+        return self._unary("blur", src, None, C.c_uint(radius))
+
+    def sobel(self, src, dst=None):
+        """dst: initial contents of the output (its 1-px frame is never written)."""
+        return self._unary("sobel", src, dst)
+
+    def erode(self, src):
+        return self._unary("erode", src)
+
+    def dilate(self, src):
+        return self._unary("dilate", src)
+
+    def adaptive_threshold(self, src, radius, c):
+        return self._unary("adaptive_threshold", src, None, C.c_uint(radius), C.c_int(c))
+
+    def filter(self, src, kernel, norm):
+        src = np.ascontiguousarray(src, np.uint8)
+        k = np.ascontiguousarray(kernel).astype(np.int8).view(np.uint8)
+        h, w = src.shape
+        kh, kw = k.shape
+        out = np.zeros_like(src)
+        if self.port:
+            self.lib.orc_filter(_p(out), _p(src), C.c_uint(w), C.c_uint(h), _p(k), C.c_uint(kw),
+                                C.c_uint(kh), C.c_uint(norm))
+        else:
+            self.lib.gs_filter(_img(out), _img(src), _img(k), C.c_uint(norm))
+        return out
+
+    def downsample(self, src):
+        src = np.ascontiguousarray(src, np.uint8)
+        h, w = src.shape
+        out = np.zeros((h // 2, w // 2), np.uint8)
+        if self.port:
+            self.lib.orc_downsample(_p(out), _p(src), C.c_uint(w), C.c_uint(h))
+        else:
+            self.lib.gs_downsample(_img(out), _img(src))
+        return out
+
+    def histogram(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        hist = np.zeros(256, np.uint32)
+        if self.port:
+            self.lib.orc_histogram(_p(img), C.c_uint(w), C.c_uint(h), _p(hist))
+        else:
+            self.lib.gs_histogram(_img(img), _p(hist))
+        return hist
+
+    def otsu_threshold(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        if self.port:
+            return int(self.lib.orc_otsu_threshold(_p(img), C.c_uint(w), C.c_uint(h)))
+        return int(self.lib.gs_otsu_threshold(_img(img)))
+
+    def otsu_from_hist(self, hist, npix):
+        assert self.port
+        hist = np.ascontiguousarray(hist, np.uint32)
+        return int(self.lib.orc_otsu_from_hist(_p(hist), C.c_uint(npix)))
+
+    def threshold(self, img, t):
+        out = np.ascontiguousarray(img, np.uint8).copy()
+        h, w = out.shape
+        if self.port:
+            self.lib.orc_threshold(_p(out), C.c_uint(w), C.c_uint(h), C.c_uint8(t))
+        else:
+            self.lib.gs_threshold(_img(out), C.c_uint8(t))
+        return out
+
+    # ------------------------------------------------------------ integral / LBP
+    def integral(self, src):
+        src = np.ascontiguousarray(src, np.uint8)
+        h, w = src.shape
+        ii = np.zeros((h, w), np.uint32)
+        if self.port:
+            self.lib.orc_integral(_p(src), C.c_uint(w), C.c_uint(h), _p(ii))
+        else:
+            self.lib.gs_integral(_img(src), _p(ii))
+        return ii
+
+    def lbp_window(self, cascade, ii, x, y, scale):
+        ii = np.ascontiguousarray(ii, np.uint32)
+        ih, iw = ii.shape
+        f = self.lib.orc_lbp_window if self.port else self.lib.gs_lbp_window
+        return int(f(C.addressof(cascade.as_struct()), _p(ii), iw, ih, x, y, scale))
+
+    def lbp_detect(self, cascade, ii, max_rects, scale_factor, min_scale, max_scale, step):
+        ii = np.ascontiguousarray(ii, np.uint32)
+        ih, iw = ii.shape
+        rects = np.zeros(max(max_rects, 1), RECT_DTYPE)
+        f = self.lib.orc_lbp_detect if self.port else self.lib.gs_lbp_detect
+        n = f(C.addressof(cascade.as_struct()), _p(ii), iw, ih, _p(rects), max_rects,
+              scale_factor, min_scale, max_scale, step)
+        return rects[:n].copy()
+
+    # ------------------------------------------------------------ FAST / ORB
+    def fast(self, img, nkps, threshold, scoremap=None):
+        """returns (keypoints[n], scoremap).  scoremap: initial contents (3-px frame kept)."""
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        sm = np.zeros_like(img) if scoremap is None else np.ascontiguousarray(scoremap).copy()
+        kps = np.zeros(max(nkps, 1), KEYPOINT_DTYPE)
+        if self.port:
+            n = self.lib.orc_fast(_p(img), C.c_uint(w), C.c_uint(h), _p(sm), _p(kps),
+                                  C.c_uint(nkps), C.c_uint(threshold))
+        else:
+            if w < 7 or h < 7:
+                return kps[:0].copy(), sm  # the reference loops are empty (or wrap) here
+            n = self.lib.gs_fast(_img(img), _img(sm), _p(kps), C.c_uint(nkps),
+                                 C.c_uint(threshold))
+        return kps[:n].copy(), sm
+
+    def orientation(self, img, x, y, r=15):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        if self.port:
+            return float(self.lib.orc_orientation(_p(img), C.c_uint(w), C.c_uint(h), C.c_uint(x),
+                                                  C.c_uint(y), C.c_uint(r)))
+        return float(self.lib.gs_compute_orientation(_img(img), x, y, r))
+
+    def brief(self, img, x, y, angle):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        kp = np.zeros(1, KEYPOINT_DTYPE)
+        kp["x"], kp["y"], kp["angle"] = x, y, angle
+        if self.port:
+            self.lib.orc_brief(_p(img), C.c_uint(w), C.c_uint(h), _p(kp))
+        else:
+            self.lib.gs_brief_descriptor(_img(img), _p(kp))
+        return kp["desc"][0].copy()
+
+    def orb_extract(self, img, nkps, threshold, scoremap=None):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        sm = np.zeros_like(img) if scoremap is None else np.ascontiguousarray(scoremap).copy()
+        kps = np.zeros(max(nkps, 1), KEYPOINT_DTYPE)
+        if self.port:
+            n = self.lib.orc_orb_extract(_p(img), C.c_uint(w), C.c_uint(h), _p(kps),
+                                         C.c_uint(nkps), C.c_uint(threshold), _p(sm))
+        else:
+            if w < 7 or h < 7:
+                return kps[:0].copy()
+            n = self.lib.gs_orb_extract(_img(img), _p(kps), C.c_uint(nkps), C.c_uint(threshold),
+                                        _p(sm))
+        return kps[:n].copy()
+
+    def match_orb(self, k1, k2, max_matches, max_distance):
+        k1 = np.ascontiguousarray(k1, KEYPOINT_DTYPE)
+        k2 = np.ascontiguousarray(k2, KEYPOINT_DTYPE)
+        out = np.zeros(max(max_matches, 1), MATCH_DTYPE)
+        f = self.lib.orc_match_orb if self.port else self.lib.gs_match_orb
+        n = f(_p(k1), len(k1), _p(k2), len(k2), _p(out), max_matches, max_distance)
+        return out[:n].copy()
+
+    # libm as the reference calls it (grayskull.h:100-101)
+    def atan2(self, y, x):
+        assert not self.port
+        return float(self.lib.ref_atan2(y, x))
