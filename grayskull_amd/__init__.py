@@ -1,1 +1,377 @@
-"""grayskull_amd -- MI355X-native Grayskull hot path (binding filled in below)."""
+"""grayskull_amd -- MI355X-native implementation of Grayskull's pixel-array hot path.
+
+Python mirror of the C boundary (include/grayskull.h + include/grayskull_hip.h) over ctypes.
+Names, argument order and error behaviour follow the reference header
+(/root/reference/grayskull.h; each wrapper cites the definition it fronts).  All compute
+happens in libgrayskull_hip.so (hand-written HIP kernels, gfx950); there is no Python or CPU
+fallback -- if the library is missing this module raises at first use.
+
+Image arguments may be numpy uint8 arrays (host memory: staged through the GPU, synchronous)
+or torch CUDA tensors / anything with ``data_ptr()`` (device memory: zero-copy).
+
+    import grayskull_amd as gs
+    gs.blur(dst, src, 2); gs.sobel(edges, dst); t = gs.otsu_threshold(edges); gs.threshold(edges, t)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from ._abi import (GsImage, GsLbpCascade, KEYPOINT_DTYPE, MATCH_DTYPE, RECT_DTYPE)
+from .cascade import Cascade
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIBRARY = os.path.join(_HERE, "libgrayskull_hip.so")
+
+__all__ = ["Grayskull", "Cascade", "lib", "KEYPOINT_DTYPE", "MATCH_DTYPE", "RECT_DTYPE"]
+
+
+def _ptr(a):
+    """address of a numpy array or of a torch tensor (host or device)"""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        if not a.flags["C_CONTIGUOUS"]:
+            raise ValueError("array must be C-contiguous")
+        return a.ctypes.data
+    if hasattr(a, "data_ptr"):
+        if not a.is_contiguous():
+            raise ValueError("tensor must be contiguous")
+        return a.data_ptr()
+    if isinstance(a, int):
+        return a
+    raise TypeError("expected numpy array, torch tensor or raw address, got %r" % type(a))
+
+
+def _img(a):
+    if a.ndim != 2:
+        raise ValueError("expected a 2-D (h, w) uint8 image")
+    return GsImage(int(a.shape[1]), int(a.shape[0]), _ptr(a))
+
+
+_SIGS = {
+    # drop-in (include/grayskull.h)
+    "gs_blur": (None, [GsImage, GsImage, C.c_uint]),
+    "gs_sobel": (None, [GsImage, GsImage]),
+    "gs_erode": (None, [GsImage, GsImage]),
+    "gs_dilate": (None, [GsImage, GsImage]),
+    "gs_histogram": (None, [GsImage, C.c_void_p]),
+    "gs_otsu_threshold": (C.c_uint8, [GsImage]),
+    "gs_threshold": (None, [GsImage, C.c_uint8]),
+    "gs_integral": (None, [GsImage, C.c_void_p]),
+    "gs_lbp_window": (C.c_uint, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_int, C.c_int,
+                                 C.c_float]),
+    "gs_lbp_detect": (C.c_uint, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p, C.c_uint,
+                                 C.c_float, C.c_float, C.c_float, C.c_int]),
+    "gs_fast": (C.c_uint, [GsImage, GsImage, C.c_void_p, C.c_uint, C.c_uint]),
+    "gs_compute_orientation": (C.c_float, [GsImage, C.c_uint, C.c_uint, C.c_uint]),
+    "gs_brief_descriptor": (None, [GsImage, C.c_void_p]),
+    "gs_orb_extract": (C.c_uint, [GsImage, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p]),
+    "gs_match_orb": (C.c_uint, [C.c_void_p, C.c_uint, C.c_void_p, C.c_uint, C.c_void_p, C.c_uint,
+                                C.c_float]),
+    "gs_adaptive_threshold": (None, [GsImage, GsImage, C.c_uint, C.c_int]),
+    "gs_filter": (None, [GsImage, GsImage, GsImage, C.c_uint]),
+    "gs_downsample": (None, [GsImage, GsImage]),
+    # runtime + batch (include/grayskull_hip.h)
+    "gsh_version": (C.c_char_p, []),
+    "gsh_device_count": (C.c_int, []),
+    "gsh_set_device": (None, [C.c_int]),
+    "gsh_set_stream": (None, [C.c_void_p]),
+    "gsh_get_stream": (C.c_void_p, []),
+    "gsh_set_async": (None, [C.c_int]),
+    "gsh_sync": (None, []),
+    "gsh_shutdown": (None, []),
+    "gsh_malloc": (C.c_void_p, [C.c_size_t]),
+    "gsh_free": (None, [C.c_void_p]),
+    "gsh_memset": (None, [C.c_void_p, C.c_int, C.c_size_t]),
+    "gsh_upload": (None, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "gsh_download": (None, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "gsh_is_device_ptr": (C.c_int, [C.c_void_p]),
+    "gsh_blur_batch": (None, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_uint]),
+    "gsh_sobel_batch": (None, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint]),
+    "gsh_erode_batch": (None, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint]),
+    "gsh_dilate_batch": (None, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint]),
+    "gsh_histogram_batch": (None, [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_void_p]),
+    "gsh_otsu_batch": (None, [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p]),
+    "gsh_threshold_batch": (None, [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_uint8]),
+    "gsh_threshold_batch_dev": (None, [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_void_p]),
+    "gsh_edge_pipeline_batch": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint,
+                                       C.c_uint, C.c_uint, C.c_void_p, C.c_void_p]),
+    "gsh_integral_batch": (None, [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_void_p]),
+    "gsh_cascade_create": (C.c_void_p, [C.c_void_p]),
+    "gsh_cascade_destroy": (None, [C.c_void_p]),
+    "gsh_lbp_detect_batch": (None, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint,
+                                    C.c_void_p, C.c_void_p, C.c_uint, C.c_float, C.c_float,
+                                    C.c_float, C.c_int]),
+    "gsh_lbp_window_count": (C.c_uint64, [C.c_void_p, C.c_uint, C.c_uint, C.c_float, C.c_float,
+                                          C.c_float, C.c_int]),
+    "gsh_fast_batch": (None, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_void_p,
+                              C.c_void_p, C.c_uint, C.c_uint]),
+    "gsh_orb_extract": (C.c_uint, [C.c_void_p, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p,
+                                   C.c_uint, C.c_uint]),
+    "gsh_match_orb_dev": (None, [C.c_void_p, C.c_uint, C.c_void_p, C.c_uint, C.c_void_p,
+                                 C.c_void_p, C.c_uint, C.c_float]),
+    "gsh_adaptive_threshold_batch": (None, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint,
+                                            C.c_uint, C.c_int]),
+    "gsh_filter_batch": (None, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_void_p,
+                                C.c_uint, C.c_uint, C.c_uint]),
+    "gsh_downsample_batch": (None, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint]),
+    "gsh_synth_batch": (None, [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_uint32]),
+    "gsh_checksum_batch": (None, [C.c_void_p, C.c_size_t, C.c_uint, C.c_void_p]),
+}
+EXPORTED_SYMBOLS = tuple(sorted(_SIGS))
+
+
+class Grayskull:
+    """Bound libgrayskull_hip.so.  `path` is for the test-suite's emulator build only."""
+
+    def __init__(self, path=None):
+        path = path or HIP_LIBRARY
+        if not os.path.exists(path):
+            raise ImportError(
+                "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). grayskull_amd has no CPU fallback." % path)
+        self.path = path
+        self.c = C.CDLL(path)
+        for name, (res, args) in _SIGS.items():
+            f = getattr(self.c, name)
+            f.restype, f.argtypes = res, args
+
+    # ------------------------------------------------------------------ runtime
+    def version(self):
+        return self.c.gsh_version().decode()
+
+    def device_count(self):
+        return int(self.c.gsh_device_count())
+
+    def set_device(self, i):
+        self.c.gsh_set_device(int(i))
+
+    def use_torch_stream(self):
+        """enqueue on torch's current stream (so torch.cuda.Event brackets see the kernels)"""
+        import torch
+        self.c.gsh_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream))
+
+    def set_stream(self, handle):
+        self.c.gsh_set_stream(C.c_void_p(handle))
+
+    def set_async(self, on):
+        self.c.gsh_set_async(1 if on else 0)
+
+    def sync(self):
+        self.c.gsh_sync()
+
+    # ------------------------------------------------------------------ drop-in (one image)
+    def blur(self, dst, src, radius):  # grayskull.h:268
+        self.c.gs_blur(_img(dst), _img(src), radius)
+
+    def sobel(self, dst, src):  # grayskull.h:306
+        self.c.gs_sobel(_img(dst), _img(src))
+
+    def erode(self, dst, src):  # grayskull.h:303
+        self.c.gs_erode(_img(dst), _img(src))
+
+    def dilate(self, dst, src):  # grayskull.h:304
+        self.c.gs_dilate(_img(dst), _img(src))
+
+    def histogram(self, img):  # grayskull.h:199
+        hist = np.zeros(256, np.uint32)
+        self.c.gs_histogram(_img(img), hist.ctypes.data)
+        return hist
+
+    def otsu_threshold(self, img):  # grayskull.h:205
+        return int(self.c.gs_otsu_threshold(_img(img)))
+
+    def threshold(self, img, t):  # grayskull.h:225 (in place)
+        self.c.gs_threshold(_img(img), t)
+
+    def adaptive_threshold(self, dst, src, radius, c):  # grayskull.h:230
+        self.c.gs_adaptive_threshold(_img(dst), _img(src), radius, c)
+
+    def filter(self, dst, src, kernel, norm):  # grayskull.h:255; kernel: int8-valued 2-D array
+        k = np.ascontiguousarray(kernel).astype(np.int8).view(np.uint8)
+        self.c.gs_filter(_img(dst), _img(src), _img(k), norm)
+
+    def downsample(self, dst, src):  # grayskull.h:189
+        self.c.gs_downsample(_img(dst), _img(src))
+
+    def integral(self, src, ii=None):  # grayskull.h:744
+        if ii is None:
+            ii = np.zeros(src.shape, np.uint32)
+        self.c.gs_integral(_img(src), _ptr(ii))
+        return ii
+
+    def lbp_window(self, cascade, ii, x, y, scale):  # grayskull.h:790
+        ih, iw = ii.shape
+        return int(self.c.gs_lbp_window(C.addressof(cascade.as_struct()), _ptr(ii), iw, ih, x, y,
+                                        scale))
+
+    def lbp_detect(self, cascade, ii, max_rects, scale_factor, min_scale, max_scale, step):
+        """grayskull.h:815 -> RECT_DTYPE array of the detections, reference order"""
+        ih, iw = ii.shape
+        rects = np.zeros(max(max_rects, 1), RECT_DTYPE)
+        n = self.c.gs_lbp_detect(C.addressof(cascade.as_struct()), _ptr(ii), iw, ih,
+                                 rects.ctypes.data, max_rects, scale_factor, min_scale, max_scale,
+                                 step)
+        return rects[:n].copy()
+
+    def fast(self, img, scoremap, nkps, threshold):  # grayskull.h:482
+        kps = np.zeros(max(nkps, 1), KEYPOINT_DTYPE)
+        n = self.c.gs_fast(_img(img), _img(scoremap), kps.ctypes.data, nkps, threshold)
+        return kps[:n].copy()
+
+    def compute_orientation(self, img, x, y, r=15):  # grayskull.h:608
+        return float(self.c.gs_compute_orientation(_img(img), x, y, r))
+
+    def brief_descriptor(self, img, x, y, angle):  # grayskull.h:623
+        kp = np.zeros(1, KEYPOINT_DTYPE)
+        kp["x"], kp["y"], kp["angle"] = x, y, angle
+        self.c.gs_brief_descriptor(_img(img), kp.ctypes.data)
+        return kp["desc"][0].copy()
+
+    def orb_extract(self, img, nkps, threshold, scoremap):  # grayskull.h:651
+        kps = np.zeros(max(nkps, 1), KEYPOINT_DTYPE)
+        n = self.c.gs_orb_extract(_img(img), kps.ctypes.data, nkps, threshold, _ptr(scoremap))
+        return kps[:n].copy()
+
+    def match_orb(self, k1, k2, max_matches, max_distance):  # grayskull.h:680
+        k1 = np.ascontiguousarray(k1, KEYPOINT_DTYPE)
+        k2 = np.ascontiguousarray(k2, KEYPOINT_DTYPE)
+        out = np.zeros(max(max_matches, 1), MATCH_DTYPE)
+        n = self.c.gs_match_orb(k1.ctypes.data, len(k1), k2.ctypes.data, len(k2), out.ctypes.data,
+                                max_matches, max_distance)
+        return out[:n].copy()
+
+    # ------------------------------------------------------------------ batches (device resident)
+    @staticmethod
+    def _nhw(a):
+        if a.ndim != 3:
+            raise ValueError("expected (n, h, w)")
+        return int(a.shape[0]), int(a.shape[1]), int(a.shape[2])
+
+    def blur_batch(self, dst, src, radius):
+        n, h, w = self._nhw(src)
+        self.c.gsh_blur_batch(_ptr(dst), _ptr(src), w, h, n, radius)
+
+    def sobel_batch(self, dst, src):
+        n, h, w = self._nhw(src)
+        self.c.gsh_sobel_batch(_ptr(dst), _ptr(src), w, h, n)
+
+    def erode_batch(self, dst, src):
+        n, h, w = self._nhw(src)
+        self.c.gsh_erode_batch(_ptr(dst), _ptr(src), w, h, n)
+
+    def dilate_batch(self, dst, src):
+        n, h, w = self._nhw(src)
+        self.c.gsh_dilate_batch(_ptr(dst), _ptr(src), w, h, n)
+
+    def histogram_batch(self, img, hist):
+        n, h, w = self._nhw(img)
+        self.c.gsh_histogram_batch(_ptr(img), w, h, n, _ptr(hist))
+
+    def otsu_batch(self, img, hist_scratch, thr):
+        n, h, w = self._nhw(img)
+        self.c.gsh_otsu_batch(_ptr(img), w, h, n, _ptr(hist_scratch), _ptr(thr))
+
+    def threshold_batch(self, img, t):
+        n, h, w = self._nhw(img)
+        if isinstance(t, int):
+            self.c.gsh_threshold_batch(_ptr(img), w, h, n, t)
+        else:
+            self.c.gsh_threshold_batch_dev(_ptr(img), w, h, n, _ptr(t))
+
+    def edge_pipeline_batch(self, dst, tmp, src, radius, hist_scratch, thr):
+        n, h, w = self._nhw(src)
+        self.c.gsh_edge_pipeline_batch(_ptr(dst), _ptr(tmp), _ptr(src), w, h, n, radius,
+                                       _ptr(hist_scratch), _ptr(thr))
+
+    def integral_batch(self, src, ii):
+        n, h, w = self._nhw(src)
+        self.c.gsh_integral_batch(_ptr(src), w, h, n, _ptr(ii))
+
+    def cascade_create(self, cascade):
+        return DeviceCascade(self, cascade)
+
+    def lbp_detect_batch(self, dcascade, ii, rects, counts, max_rects, scale_factor, min_scale,
+                         max_scale, step):
+        n, h, w = self._nhw(ii)
+        self.c.gsh_lbp_detect_batch(dcascade.handle, _ptr(ii), w, h, n, _ptr(rects), _ptr(counts),
+                                    max_rects, scale_factor, min_scale, max_scale, step)
+
+    def lbp_window_count(self, cascade, iw, ih, scale_factor, min_scale, max_scale, step):
+        return int(self.c.gsh_lbp_window_count(C.addressof(cascade.as_struct()), iw, ih,
+                                               scale_factor, min_scale, max_scale, step))
+
+    def fast_batch(self, img, scoremap, kps, counts, nkps, threshold):
+        n, h, w = self._nhw(img)
+        self.c.gsh_fast_batch(_ptr(img), _ptr(scoremap), w, h, n, _ptr(kps), _ptr(counts), nkps,
+                              threshold)
+
+    def orb_extract_dev(self, img, scoremap, nkps, threshold):
+        h, w = int(img.shape[0]), int(img.shape[1])
+        kps = np.zeros(max(nkps, 1), KEYPOINT_DTYPE)
+        n = self.c.gsh_orb_extract(_ptr(img), w, h, _ptr(scoremap), kps.ctypes.data, nkps, threshold)
+        return kps[:n].copy()
+
+    def match_orb_dev(self, k1, n1, k2, n2, matches, count, max_matches, max_distance):
+        self.c.gsh_match_orb_dev(_ptr(k1), n1, _ptr(k2), n2, _ptr(matches), _ptr(count),
+                                 max_matches, max_distance)
+
+    def adaptive_threshold_batch(self, dst, src, radius, c):
+        n, h, w = self._nhw(src)
+        self.c.gsh_adaptive_threshold_batch(_ptr(dst), _ptr(src), w, h, n, radius, c)
+
+    def filter_batch(self, dst, src, kernel, norm):
+        n, h, w = self._nhw(src)
+        k = np.ascontiguousarray(kernel).astype(np.int8)
+        self.c.gsh_filter_batch(_ptr(dst), _ptr(src), w, h, n, k.ctypes.data, k.shape[1], k.shape[0],
+                                norm)
+
+    def downsample_batch(self, dst, src):
+        n, h, w = self._nhw(src)
+        self.c.gsh_downsample_batch(_ptr(dst), _ptr(src), w, h, n)
+
+    def synth_batch(self, dst, seed0):
+        n, h, w = self._nhw(dst)
+        self.c.gsh_synth_batch(_ptr(dst), w, h, n, seed0)
+
+    def checksum_batch(self, img, sums):
+        n = int(img.shape[0])
+        frame_bytes = int(np.prod(img.shape[1:])) * (img.element_size() if hasattr(img, "element_size") else img.itemsize)
+        self.c.gsh_checksum_batch(_ptr(img), frame_bytes, n, _ptr(sums))
+
+
+class DeviceCascade:
+    """cascade tables flattened into device memory (gsh_cascade_create)"""
+
+    def __init__(self, gs, cascade):
+        self._gs, self._keep = gs, cascade
+        self.handle = gs.c.gsh_cascade_create(C.addressof(cascade.as_struct()))
+
+    def close(self):
+        if self.handle:
+            self._gs.c.gsh_cascade_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default = None
+
+
+def lib():
+    """the process-wide binding of libgrayskull_hip.so (raises ImportError if not built)"""
+    global _default
+    if _default is None:
+        _default = Grayskull()
+    return _default
+
+
+def __getattr__(name):  # gs.blur(...) == gs.lib().blur(...)
+    if name.startswith("_"):
+        raise AttributeError(name)
+    return getattr(lib(), name)

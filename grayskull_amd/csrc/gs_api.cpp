@@ -1,0 +1,1169 @@
+/*
+ * gs_api.cpp -- host runtime and C-ABI of libgrayskull_hip.so.
+ *
+ * Exports (a) the reference's own function names/signatures for the hot path (declared in
+ * include/grayskull.h, each citing the reference definition it replaces) and (b) the
+ * device-resident batch entry points of include/grayskull_hip.h.  Every compute step is a
+ * HIP kernel from k_*.h; the only arithmetic done on the host is what the reference itself
+ * delegates to libm (atan2f / sinf, grayskull.h:100-101), the float32 scale progression of
+ * gs_lbp_detect (ref :819-821, :799-804) and the stable sort of <= 5000 candidates (ref :639).
+ * There is no CPU fallback: without a HIP device every entry point aborts.
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "k_fast.h"
+#include "k_integral.h"
+#include "k_lbp.h"
+#include "k_orb.h"
+#include "k_pointwise.h"
+#include "k_stencil.h"
+
+#include "../../include/grayskull_hip.h"
+
+#define GS_ASSERT(cond)                                 \
+  do {                                                  \
+    if (!(cond)) {                                      \
+      fprintf(stderr, "Assertion failed: %s\n", #cond); \
+      abort();                                          \
+    }                                                   \
+  } while (0)
+
+#define GS_HIP(call)                                                                   \
+  do {                                                                                 \
+    hipError_t e_ = (call);                                                            \
+    if (e_ != hipSuccess) {                                                            \
+      fprintf(stderr, "grayskull_hip: %s failed: %s (%s:%d)\n", #call,                 \
+              hipGetErrorString(e_), __FILE__, __LINE__);                              \
+      abort();                                                                         \
+    }                                                                                  \
+  } while (0)
+
+using namespace gs;
+
+namespace {
+
+/* ------------------------------------------------------------------ per-thread context */
+enum Slot { SL_IN = 0, SL_OUT, SL_AUX, SL_AUX2, SL_II, SL_PAD, SL_MASK, SL_CNT, SL_PFX, SL_TOT,
+            SL_HISTP, SL_HIST, SL_THR, SL_KPS, SL_MOM, SL_KIN, SL_DESC, SL_TAB, SL_JUMP, SL_LEV,
+            SL_BEST, SL_COUNT };
+
+struct Ctx {
+  int device = 0;
+  bool device_set = false;
+  hipStream_t stream = nullptr;
+  bool own_stream = false, user_stream = false, async = false;
+  struct Buf { void *p = nullptr; size_t cap = 0; } slot[SL_COUNT];
+
+  void ensure_device() {
+    if (device_set) return;
+    int n = 0;
+#ifndef GS_EMU
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+      fprintf(stderr, "grayskull_hip: no HIP device visible (%s); there is no CPU fallback\n",
+              e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+      abort();
+    }
+#endif
+    GS_HIP(hipSetDevice(device));
+    device_set = true;
+  }
+  hipStream_t s() {
+    ensure_device();
+    if (user_stream) return stream;
+    if (!own_stream) {
+      GS_HIP(hipStreamCreate(&stream));
+      own_stream = true;
+    }
+    return stream;
+  }
+  void sync() { GS_HIP(hipStreamSynchronize(s())); }
+  /* grow-only device scratch; growing synchronises (old buffer may be in flight) */
+  void *scratch(int i, size_t bytes) {
+    ensure_device();
+    Buf &b = slot[i];
+    if (b.cap < bytes) {
+      if (b.p) {
+        sync();
+        GS_HIP(hipFree(b.p));
+      }
+      size_t cap = bytes + bytes / 4 + 256;
+      GS_HIP(hipMalloc(&b.p, cap));
+      b.cap = cap;
+    }
+    return b.p;
+  }
+  void release() {
+    for (auto &b : slot) {
+      if (b.p) (void)hipFree(b.p);
+      b.p = nullptr, b.cap = 0;
+    }
+    if (own_stream) (void)hipStreamDestroy(stream);
+    own_stream = false;
+    if (!user_stream) stream = nullptr;
+  }
+};
+Ctx &ctx() {
+  static thread_local Ctx c;
+  return c;
+}
+
+bool is_dev(const void *p) {
+#ifdef GS_EMU
+  (void)p;
+  return false;
+#else
+  if (!p) return false;
+  ctx().ensure_device();
+  hipPointerAttribute_t a;
+  hipError_t e = hipPointerGetAttributes(&a, p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError(); /* plain host memory: not an error for us */
+    return false;
+  }
+  return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+#endif
+}
+
+/* host buffer -> device scratch (or pass a device pointer through) */
+const void *stage_in(const void *p, size_t bytes, int slot) {
+  if (is_dev(p)) return p;
+  void *d = ctx().scratch(slot, bytes);
+  GS_HIP(hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, ctx().s()));
+  return d;
+}
+void finish(bool any_host_output) {
+  if (any_host_output || !ctx().async) ctx().sync();
+}
+dim3 grid2d(unsigned w, unsigned h, unsigned n) { return dim3((w + 63) / 64, (h + 3) / 4, n); }
+inline bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+
+/* rows per band for the strip kernels: enough waves to fill 256 CUs, bands as tall as possible */
+unsigned strip_rows(unsigned w, unsigned h, unsigned n) {
+  const unsigned long long cols = (w + 1023) / 1024;
+  unsigned long long t = (unsigned long long)h * cols * n / 16384ull;
+  if (t < 8) t = 8;
+  if (t > 64) t = 64;
+  return (unsigned)t;
+}
+constexpr unsigned kMaxZ = 32768; /* frames per launch (grid.z limit 65535) */
+
+/* ------------------------------------------------------------------ stencil launchers */
+void launch_sobel(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned n) {
+  if (w < 3 || h < 3 || n == 0) return;
+  hipStream_t st = ctx().s();
+  const size_t fb = (size_t)w * h;
+  for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
+    const unsigned nn = std::min(kMaxZ, n - f0);
+    uint8_t *d = dst + fb * f0;
+    const uint8_t *s = src + fb * f0;
+    if (w % 16 == 0 && al16(d) && al16(s)) {
+      const unsigned T = strip_rows(w, h, nn), nb = (h - 2 + T - 1) / T;
+      GS_LAUNCH(k_sobel16, dim3((w + 1023) / 1024, (nb + 3) / 4, nn), dim3(64, 4), 0, st, d, s, w,
+                h, T, fb);
+    } else {
+      GS_LAUNCH(k_sobel_px, grid2d(w, h, nn), dim3(64, 4), 0, st, d, s, w, h, fb);
+    }
+  }
+}
+
+template <bool DILATE>
+void launch_morph(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned n) {
+  if (n == 0) return;
+  hipStream_t st = ctx().s();
+  const size_t fb = (size_t)w * h;
+  for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
+    const unsigned nn = std::min(kMaxZ, n - f0);
+    uint8_t *d = dst + fb * f0;
+    const uint8_t *s = src + fb * f0;
+    if (w % 16 == 0 && al16(d) && al16(s)) {
+      const unsigned T = strip_rows(w, h, nn), nb = (h + T - 1) / T;
+      GS_LAUNCH(k_morph16<DILATE>, dim3((w + 1023) / 1024, (nb + 3) / 4, nn), dim3(64, 4), 0, st,
+                d, s, w, h, T, fb);
+    } else {
+      GS_LAUNCH(k_morph_px<DILATE>, grid2d(w, h, nn), dim3(64, 4), 0, st, d, s, w, h, fb);
+    }
+  }
+}
+
+void launch_integral(const uint8_t *src, unsigned w, unsigned h, unsigned n, unsigned *ii) {
+  if (n == 0) return;
+  hipStream_t st = ctx().s();
+  const size_t fp = (size_t)w * h;
+  for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
+    const unsigned nn = std::min(kMaxZ, n - f0);
+    GS_LAUNCH(k_integral_rows, dim3(h, nn), dim3(256), 0, st, src + fp * f0, w, h, ii + fp * f0);
+    GS_LAUNCH(k_integral_cols, dim3((w + 255) / 256, nn), dim3(256), 0, st, ii + fp * f0, w, h);
+  }
+}
+
+/* gs_blur for any radius: register strips for r = 1..3 on aligned frames, otherwise clipped box
+ * sums from a scratch integral image (exact: both are u32-modular like the reference). */
+template <int MODE>
+void launch_box_generic(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned n,
+                        unsigned radius, int c) {
+  hipStream_t st = ctx().s();
+  const size_t fp = (size_t)w * h;
+  const unsigned r = std::min(radius, std::max(w, h)); /* larger windows clip identically */
+  const unsigned group = (unsigned)std::max<size_t>(1, std::min<size_t>(n, (256u << 20) / (fp * 4) + 1));
+  unsigned *ii = (unsigned *)ctx().scratch(SL_II, fp * 4 * group);
+  for (unsigned f0 = 0; f0 < n; f0 += group) {
+    const unsigned nn = std::min(group, n - f0);
+    launch_integral(src + fp * f0, w, h, nn, ii);
+    GS_LAUNCH(k_box_px<MODE>, grid2d(w, h, nn), dim3(64, 4), 0, st, dst + fp * f0, src + fp * f0,
+              (const unsigned *)ii, w, h, r, c, fp);
+  }
+}
+
+void launch_blur(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned n,
+                 unsigned radius) {
+  if (n == 0) return;
+  hipStream_t st = ctx().s();
+  const size_t fb = (size_t)w * h;
+  if (radius >= 1 && radius <= 3 && w % 16 == 0 && al16(dst) && al16(src)) {
+    for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
+      const unsigned nn = std::min(kMaxZ, n - f0);
+      const unsigned T = strip_rows(w, h, nn), nb = (h + T - 1) / T;
+      const dim3 g((w + 1023) / 1024, (nb + 3) / 4, nn), b(64, 4);
+      uint8_t *d = dst + fb * f0;
+      const uint8_t *s = src + fb * f0;
+      if (radius == 1) GS_LAUNCH(k_blur16<1>, g, b, 0, st, d, s, w, h, T, fb);
+      else if (radius == 2) GS_LAUNCH(k_blur16<2>, g, b, 0, st, d, s, w, h, T, fb);
+      else GS_LAUNCH(k_blur16<3>, g, b, 0, st, d, s, w, h, T, fb);
+    }
+    return;
+  }
+  if (radius == 0) { /* 1x1 window: identity (sum/1) */
+    if (dst != src) GS_HIP(hipMemcpyAsync(dst, src, fb * n, hipMemcpyDeviceToDevice, st));
+    return;
+  }
+  launch_box_generic<0>(dst, src, w, h, n, radius, 0);
+}
+
+/* ------------------------------------------------------------------ histogram / otsu / threshold */
+unsigned hist_bpf(size_t frame_bytes) {
+  size_t b = (frame_bytes + (256 * 16 * 8 - 1)) / (256 * 16 * 8);
+  return (unsigned)std::max<size_t>(1, std::min<size_t>(b, 64));
+}
+void launch_histogram(const uint8_t *img, size_t frame_bytes, unsigned n, unsigned *hist) {
+  if (n == 0) return;
+  hipStream_t st = ctx().s();
+  const unsigned bpf = hist_bpf(frame_bytes);
+  for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
+    const unsigned nn = std::min(kMaxZ, n - f0);
+    unsigned *partial = (unsigned *)ctx().scratch(SL_HISTP, (size_t)nn * bpf * 256 * 4);
+    GS_LAUNCH(k_hist_partial, dim3(bpf, nn), dim3(256), 0, st, img + frame_bytes * f0, frame_bytes,
+              partial);
+    GS_LAUNCH(k_hist_reduce, dim3(nn), dim3(256), 0, st, (const unsigned *)partial, bpf,
+              hist + (size_t)f0 * 256);
+  }
+}
+void launch_threshold(uint8_t *img, size_t frame_bytes, unsigned n, const uint8_t *thr_dev,
+                      unsigned thr_const) {
+  if (n == 0) return;
+  hipStream_t st = ctx().s();
+  const size_t chunks = frame_bytes / 16 + 2;
+  const unsigned bx = (unsigned)std::max<size_t>(1, std::min<size_t>((chunks + 255) / 256, 2048));
+  for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
+    const unsigned nn = std::min(kMaxZ, n - f0);
+    GS_LAUNCH(k_threshold, dim3(bx, nn), dim3(256), 0, st, img + frame_bytes * f0, frame_bytes,
+              thr_dev ? thr_dev + f0 : nullptr, thr_const);
+  }
+}
+void launch_otsu(const uint8_t *img, unsigned w, unsigned h, unsigned n, unsigned *hist,
+                 uint8_t *thr) {
+  launch_histogram(img, (size_t)(w * h), n, hist);
+  GS_LAUNCH(k_otsu_scan, dim3((n + 63) / 64), dim3(64), 0, ctx().s(), (const unsigned *)hist,
+            w * h, n, thr);
+}
+
+/* ------------------------------------------------------------------ ordered compaction driver */
+template <class F>
+void run_compaction(unsigned long long *mask, unsigned *cnt, unsigned nchunks, unsigned n,
+                    unsigned cap, unsigned *totals_dev, F emit) {
+  hipStream_t st = ctx().s();
+  unsigned *pfx = (unsigned *)ctx().scratch(SL_PFX, (size_t)n * nchunks * 4);
+  GS_LAUNCH(k_chunk_scan, dim3(n), dim3(1024), 0, st, (const unsigned *)cnt, nchunks, pfx,
+            totals_dev, cap);
+  GS_LAUNCH(k_emit<F>, dim3((nchunks + 255) / 256, n), dim3(256), 0, st,
+            (const unsigned long long *)mask, (const unsigned *)cnt, (const unsigned *)pfx, nchunks,
+            cap, emit);
+}
+
+/* ------------------------------------------------------------------ FAST */
+void launch_fast(const uint8_t *img, uint8_t *score, unsigned w, unsigned h, unsigned n,
+                 unsigned *kps, unsigned *counts, unsigned nkps, unsigned threshold) {
+  hipStream_t st = ctx().s();
+  if (n == 0) return;
+  if (w < 7 || h < 7) { /* reference loops are empty for 3 <= dim < 7 */
+    GS_HIP(hipMemsetAsync(counts, 0, (size_t)n * 4, st));
+    return;
+  }
+  const size_t fb = (size_t)w * h;
+  const unsigned nitems = (w - 6) * (h - 6);
+  const unsigned nchunks = (nitems + kChunkItems - 1) / kChunkItems;
+  GS_LAUNCH(k_fast_score_px, grid2d(w - 6, h - 6, n), dim3(64, 4), 0, st, img, score, w, h, fb,
+            threshold);
+  unsigned long long *mask =
+      (unsigned long long *)ctx().scratch(SL_MASK, (size_t)n * nchunks * kChunkWords * 8);
+  unsigned *cnt = (unsigned *)ctx().scratch(SL_CNT, (size_t)n * nchunks * 4);
+  GS_HIP(hipMemsetAsync(cnt, 0, (size_t)n * nchunks * 4, st));
+  GS_LAUNCH(k_fast_nms, dim3(nchunks, n), dim3(256), 0, st, (const uint8_t *)score, w, h, fb, mask,
+            cnt, nchunks);
+  run_compaction(mask, cnt, nchunks, n, nkps, counts,
+                 FastEmit{score, w, fb, kps, nkps});
+}
+
+/* ------------------------------------------------------------------ LBP cascade */
+}  // namespace
+
+struct gsh_cascade {
+  unsigned window_w, window_h, nfeatures, nweaks, nstages;
+  std::vector<int8_t> features;
+  std::vector<uint16_t> weak_feature_idx;
+  LbpWeak *d_weak = nullptr;
+  LbpStage *d_stage = nullptr;
+  int32_t *d_subsets = nullptr;
+  /* geometry cache (last call) */
+  unsigned g_iw = 0, g_ih = 0;
+  float g_sf = 0, g_min = 0, g_max = 0;
+  int g_step = 0;
+  std::vector<LbpScale> scales;
+  LbpScale *d_scales = nullptr;
+  LbpGeom *d_geom = nullptr;
+  size_t d_scales_cap = 0, d_geom_cap = 0;
+  unsigned total_chunks = 0, max_chunks = 0;
+  bool guard = false;
+  unsigned long long nwindows = 0;
+};
+
+namespace {
+
+/* The reference's scale loop and per-feature truncation (ref :819-821, :799-804), float32. */
+void build_scales(const gsh_cascade &c, unsigned iw, unsigned ih, float scale_factor,
+                  float min_scale, float max_scale, int step, std::vector<LbpScale> &scales,
+                  std::vector<LbpGeom> &geom, bool &guard, unsigned long long &nwin) {
+  scales.clear();
+  geom.clear();
+  guard = false;
+  nwin = 0;
+  unsigned chunk_base = 0;
+  const unsigned S = iw + 1;
+  for (float scale = min_scale; scale <= max_scale; scale *= scale_factor) {
+    const int win_w = (int)((int)c.window_w * scale), win_h = (int)((int)c.window_h * scale);
+    if (win_w > (int)iw || win_h > (int)ih) break;
+    LbpScale sc;
+    sc.win_w = win_w, sc.win_h = win_h;
+    sc.nx = ((unsigned)((int)iw - win_w)) / (unsigned)step + 1;
+    sc.ny = ((unsigned)((int)ih - win_h)) / (unsigned)step + 1;
+    sc.chunk_base = chunk_base;
+    sc.nchunks = (sc.nx * sc.ny + kChunkItems - 1) / kChunkItems;
+    chunk_base += sc.nchunks;
+    nwin += (unsigned long long)sc.nx * sc.ny;
+    for (unsigned wi = 0; wi < c.nweaks; wi++) {
+      const int fi = c.weak_feature_idx[wi];
+      int fx = (int)((int)c.features[fi * 4 + 0] * scale);
+      int fy = (int)((int)c.features[fi * 4 + 1] * scale);
+      int fw = (int)((int)c.features[fi * 4 + 2] * scale);
+      int fh = (int)((int)c.features[fi * 4 + 3] * scale);
+      if (fw < 1) fw = 1;
+      if (fh < 1) fh = 1;
+      if (fx < 0 || fy < 0 || fx + 3 * fw > win_w || fy + 3 * fh > win_h) guard = true;
+      geom.push_back(LbpGeom{fy * (int)S + fx, fw, fh * (int)S, 0});
+    }
+    scales.push_back(sc);
+    if (scales.size() >= 4096 || !(scale_factor > 1.0f)) break; /* the reference would not terminate */
+  }
+}
+
+void cascade_prepare(gsh_cascade *dc, unsigned iw, unsigned ih, float sf, float mn, float mx,
+                     int step) {
+  if (dc->g_iw == iw && dc->g_ih == ih && dc->g_sf == sf && dc->g_min == mn && dc->g_max == mx &&
+      dc->g_step == step && dc->d_scales)
+    return;
+  std::vector<LbpGeom> geom;
+  build_scales(*dc, iw, ih, sf, mn, mx, step, dc->scales, geom, dc->guard, dc->nwindows);
+  ctx().sync(); /* tables may be in use by an earlier launch */
+  const size_t sb = std::max<size_t>(1, dc->scales.size()) * sizeof(LbpScale);
+  const size_t gb = std::max<size_t>(1, geom.size()) * sizeof(LbpGeom);
+  if (dc->d_scales_cap < sb) {
+    if (dc->d_scales) GS_HIP(hipFree(dc->d_scales));
+    GS_HIP(hipMalloc((void **)&dc->d_scales, sb));
+    dc->d_scales_cap = sb;
+  }
+  if (dc->d_geom_cap < gb) {
+    if (dc->d_geom) GS_HIP(hipFree(dc->d_geom));
+    GS_HIP(hipMalloc((void **)&dc->d_geom, gb));
+    dc->d_geom_cap = gb;
+  }
+  if (!dc->scales.empty()) {
+    GS_HIP(hipMemcpy(dc->d_scales, dc->scales.data(), dc->scales.size() * sizeof(LbpScale),
+                     hipMemcpyHostToDevice));
+    GS_HIP(hipMemcpy(dc->d_geom, geom.data(), geom.size() * sizeof(LbpGeom), hipMemcpyHostToDevice));
+  }
+  dc->total_chunks = 0, dc->max_chunks = 0;
+  for (auto &s : dc->scales) {
+    dc->total_chunks += s.nchunks;
+    dc->max_chunks = std::max(dc->max_chunks, s.nchunks);
+  }
+  dc->g_iw = iw, dc->g_ih = ih, dc->g_sf = sf, dc->g_min = mn, dc->g_max = mx, dc->g_step = step;
+}
+
+/* padded: n frames of (iw+1)*(ih+1) u32 on device */
+void launch_lbp_padded(gsh_cascade *dc, const unsigned *padded, unsigned iw, unsigned ih,
+                       unsigned n, unsigned *rects, unsigned *counts, unsigned max_rects,
+                       int step) {
+  hipStream_t st = ctx().s();
+  if (dc->scales.empty() || max_rects == 0) {
+    GS_HIP(hipMemsetAsync(counts, 0, (size_t)n * 4, st));
+    return;
+  }
+  const unsigned nch = dc->total_chunks;
+  unsigned long long *mask =
+      (unsigned long long *)ctx().scratch(SL_MASK, (size_t)n * nch * kChunkWords * 8);
+  unsigned *cnt = (unsigned *)ctx().scratch(SL_CNT, (size_t)n * nch * 4);
+  GS_HIP(hipMemsetAsync(cnt, 0, (size_t)n * nch * 4, st));
+  LbpArgs a;
+  a.padded = padded;
+  a.frame_stride = (size_t)(iw + 1) * (ih + 1);
+  a.S = iw + 1;
+  a.limit = a.frame_stride - 1;
+  a.step = step;
+  a.nweaks = dc->nweaks, a.nstages = dc->nstages;
+  a.scales = dc->d_scales, a.geom = dc->d_geom, a.weak = dc->d_weak, a.stage = dc->d_stage;
+  a.subsets = dc->d_subsets;
+  a.mask = mask, a.chunk_count = cnt, a.total_chunks = nch;
+  const dim3 g(dc->max_chunks, (unsigned)dc->scales.size(), n);
+  if (dc->guard) GS_LAUNCH(k_lbp_cascade<true>, g, dim3(256), 0, st, a);
+  else GS_LAUNCH(k_lbp_cascade<false>, g, dim3(256), 0, st, a);
+  run_compaction(mask, cnt, nch, n, max_rects, counts,
+                 LbpEmit{dc->d_scales, (unsigned)dc->scales.size(), step, rects, max_rects});
+}
+
+constexpr unsigned kLbpGroup = 8; /* frames per cascade launch (bounds mask/padded scratch) */
+
+void launch_lbp_unpadded(gsh_cascade *dc, const unsigned *ii, unsigned iw, unsigned ih, unsigned n,
+                         unsigned *rects, unsigned *counts, unsigned max_rects, float sf, float mn,
+                         float mx, int step) {
+  GS_ASSERT(step > 0);
+  cascade_prepare(dc, iw, ih, sf, mn, mx, step);
+  hipStream_t st = ctx().s();
+  const size_t fp = (size_t)iw * ih, pp = (size_t)(iw + 1) * (ih + 1);
+  for (unsigned f0 = 0; f0 < n; f0 += kLbpGroup) {
+    const unsigned nn = std::min(kLbpGroup, n - f0);
+    unsigned *padded = (unsigned *)ctx().scratch(SL_PAD, pp * 4 * nn);
+    GS_LAUNCH(k_integral_pad, dim3((iw + 64) / 64, (ih + 4) / 4, nn), dim3(64, 4), 0, st,
+              ii + fp * f0, iw, ih, padded);
+    launch_lbp_padded(dc, padded, iw, ih, nn, rects + (size_t)f0 * max_rects * 4, counts + f0,
+                      max_rects, step);
+  }
+}
+
+/* one window on a (win_w+1) x (win_h+1) table: grid 1, block 64, lane 0 decides */
+__global__ void k_lbp_single(LbpArgs a, const LbpGeom *geom, unsigned *out) {
+#ifndef GS_EMU
+#pragma clang fp contract(off)
+#endif
+  if (threadIdx.x == 0) out[0] = lbp_window_pass<true>(a, a.padded, 0, geom) ? 1u : 0u;
+}
+
+/* ------------------------------------------------------------------ ORB host logic */
+struct Cand { unsigned x, y, response; int m01, m10; };
+
+/* FAST candidates + moments of every candidate on the device; returns them on the host */
+unsigned orb_candidates(const uint8_t *img_dev, unsigned w, unsigned h, uint8_t *score_dev,
+                        unsigned cap, unsigned threshold, std::vector<Cand> &out) {
+  hipStream_t st = ctx().s();
+  unsigned *kps = (unsigned *)ctx().scratch(SL_KPS, (size_t)cap * 48 + 16);
+  unsigned *cnt = (unsigned *)ctx().scratch(SL_TOT, 16);
+  launch_fast(img_dev, score_dev, w, h, 1, kps, cnt, cap, threshold);
+  unsigned n = 0;
+  GS_HIP(hipMemcpyAsync(&n, cnt, 4, hipMemcpyDeviceToHost, st));
+  ctx().sync();
+  out.resize(n);
+  if (!n) return 0;
+  int *mom = (int *)ctx().scratch(SL_MOM, (size_t)n * 8);
+  GS_LAUNCH(k_orient_moments, dim3(n), dim3(64), 0, st, img_dev, w, h, (const unsigned *)kps, 12u,
+            15u, mom);
+  std::vector<unsigned> hk((size_t)n * 12);
+  std::vector<int> hm((size_t)n * 2);
+  GS_HIP(hipMemcpyAsync(hk.data(), kps, (size_t)n * 48, hipMemcpyDeviceToHost, st));
+  GS_HIP(hipMemcpyAsync(hm.data(), mom, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+  ctx().sync();
+  for (unsigned i = 0; i < n; i++)
+    out[i] = Cand{hk[i * 12], hk[i * 12 + 1], hk[i * 12 + 2], hm[2 * i], hm[2 * i + 1]};
+  return n;
+}
+
+/* ref :651-669 after FAST: stable sort (desc response), 15-px border filter, angle, BRIEF */
+unsigned orb_finish(const uint8_t *img_dev, unsigned w, unsigned h, std::vector<Cand> &cand,
+                    gs_keypoint *kps_host, unsigned nkps) {
+  hipStream_t st = ctx().s();
+  std::stable_sort(cand.begin(), cand.end(),
+                   [](const Cand &a, const Cand &b) { return a.response > b.response; });
+  const unsigned r = 15;
+  std::vector<KpIn> kin;
+  unsigned n = 0;
+  for (size_t i = 0; i < cand.size() && n < nkps; i++) {
+    const Cand &c = cand[i];
+    if (c.x >= r && c.y >= r && c.x < w - r && c.y < h - r) {
+      gs_keypoint &k = kps_host[n];
+      k.pt.x = c.x, k.pt.y = c.y, k.response = c.response;
+      k.angle = atan2f((float)c.m01, (float)c.m10); /* ref :620, :100 */
+      const float angle = k.angle;
+      kin.push_back(KpIn{c.x, c.y, sinf(angle), sinf((float)(angle + 1.57079f))}); /* ref :626 */
+      n++;
+    }
+  }
+  if (!n) return 0;
+  KpIn *dk = (KpIn *)ctx().scratch(SL_KIN, (size_t)n * sizeof(KpIn));
+  uint32_t *dd = (uint32_t *)ctx().scratch(SL_DESC, (size_t)n * 32);
+  GS_HIP(hipMemcpyAsync(dk, kin.data(), (size_t)n * sizeof(KpIn), hipMemcpyHostToDevice, st));
+  GS_LAUNCH(k_brief, dim3(n), dim3(256), 0, st, img_dev, w, h, (const KpIn *)dk, dd);
+  std::vector<uint32_t> hd((size_t)n * 8);
+  GS_HIP(hipMemcpyAsync(hd.data(), dd, (size_t)n * 32, hipMemcpyDeviceToHost, st));
+  ctx().sync();
+  for (unsigned i = 0; i < n; i++) memcpy(kps_host[i].descriptor, &hd[(size_t)i * 8], 32);
+  return n;
+}
+
+void launch_match(const uint32_t *k1, unsigned n1, const uint32_t *k2, unsigned n2,
+                  unsigned *matches, unsigned *count, unsigned max_matches, float max_distance) {
+  hipStream_t st = ctx().s();
+  if (n1 == 0 || max_matches == 0) {
+    GS_HIP(hipMemsetAsync(count, 0, 4, st));
+    return;
+  }
+  const unsigned blocks = (n1 + 255) / 256, words = blocks * 4;
+  const unsigned nchunks = (words + kChunkWords - 1) / kChunkWords;
+  unsigned long long *mask =
+      (unsigned long long *)ctx().scratch(SL_MASK, (size_t)nchunks * kChunkWords * 8);
+  unsigned *cnt = (unsigned *)ctx().scratch(SL_CNT, (size_t)nchunks * 4);
+  unsigned *best = (unsigned *)ctx().scratch(SL_BEST, (size_t)n1 * 8);
+  GS_HIP(hipMemsetAsync(mask, 0, (size_t)nchunks * kChunkWords * 8, st));
+  GS_HIP(hipMemsetAsync(cnt, 0, (size_t)nchunks * 4, st));
+  GS_LAUNCH(k_match, dim3(blocks), dim3(256), 0, st, k1, n1, k2, n2, max_distance, best, best + n1,
+            mask, cnt);
+  run_compaction(mask, cnt, nchunks, 1, max_matches, count,
+                 MatchEmit{best, best + n1, matches});
+}
+
+void synth_jump_table(SynthJump &J) {
+  auto step = [](uint32_t x) {
+    x ^= x << 13;
+    x ^= x >> 17;
+    x ^= x << 5;
+    return x;
+  };
+  for (int b = 0; b < 32; b++) J.col[0][b] = step(1u << b);
+  for (int k = 1; k < 32; k++)
+    for (int b = 0; b < 32; b++) {
+      uint32_t v = J.col[k - 1][b], r = 0;
+      for (int q = 0; q < 32; q++)
+        if ((v >> q) & 1u) r ^= J.col[k - 1][q];
+      J.col[k][b] = r;
+    }
+}
+
+}  // namespace
+
+/* =====================================================================================
+ *                                   C ABI
+ * ===================================================================================== */
+extern "C" {
+
+const char *gsh_version(void) {
+#ifdef GS_EMU
+  return "grayskull_hip 0.1 (kernel-logic emulator build -- test tool, not a product)";
+#else
+  return "grayskull_hip 0.1 gfx950";
+#endif
+}
+int gsh_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+void gsh_set_device(int ordinal) {
+  Ctx &c = ctx();
+  if (c.device_set && c.device != ordinal) c.release();
+  c.device = ordinal;
+  c.device_set = false;
+  c.ensure_device();
+}
+void gsh_set_stream(void *s) {
+  Ctx &c = ctx();
+  if (c.own_stream) {
+    c.sync();
+    (void)hipStreamDestroy(c.stream);
+    c.own_stream = false;
+  }
+  c.stream = (hipStream_t)s;
+  c.user_stream = s != nullptr;
+}
+void *gsh_get_stream(void) { return (void *)ctx().s(); }
+void gsh_set_async(int on) { ctx().async = on != 0; }
+void gsh_sync(void) { ctx().sync(); }
+void gsh_shutdown(void) { ctx().release(); }
+void *gsh_malloc(size_t bytes) {
+  ctx().ensure_device();
+  void *p = nullptr;
+  GS_HIP(hipMalloc(&p, bytes ? bytes : 1));
+  return p;
+}
+void gsh_free(void *p) {
+  if (p) GS_HIP(hipFree(p));
+}
+void gsh_memset(void *dev, int byte, size_t bytes) {
+  GS_HIP(hipMemsetAsync(dev, byte, bytes, ctx().s()));
+}
+void gsh_upload(void *dev, const void *host, size_t bytes) {
+  GS_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, ctx().s()));
+  ctx().sync();
+}
+void gsh_download(void *host, const void *dev, size_t bytes) {
+  GS_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx().s()));
+  ctx().sync();
+}
+int gsh_is_device_ptr(const void *p) { return is_dev(p) ? 1 : 0; }
+
+/* ---------------------------------------------------------------- batch: stencils */
+void gsh_blur_batch(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned n,
+                    unsigned radius) {
+  GS_ASSERT(dst && src && w > 0 && h > 0);
+  launch_blur(dst, src, w, h, n, radius);
+}
+void gsh_sobel_batch(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned n) {
+  GS_ASSERT(dst && src && w > 0 && h > 0);
+  launch_sobel(dst, src, w, h, n);
+}
+void gsh_erode_batch(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned n) {
+  GS_ASSERT(dst && src && w > 0 && h > 0);
+  launch_morph<false>(dst, src, w, h, n);
+}
+void gsh_dilate_batch(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned n) {
+  GS_ASSERT(dst && src && w > 0 && h > 0);
+  launch_morph<true>(dst, src, w, h, n);
+}
+
+/* ---------------------------------------------------------------- batch: histogram etc. */
+void gsh_histogram_batch(const uint8_t *img, unsigned w, unsigned h, unsigned n, unsigned *hist) {
+  GS_ASSERT(img && hist && w > 0 && h > 0);
+  launch_histogram(img, (size_t)(w * h), n, hist); /* 32-bit product like ref :202 */
+}
+void gsh_otsu_batch(const uint8_t *img, unsigned w, unsigned h, unsigned n, unsigned *hist_scratch,
+                    uint8_t *thr) {
+  GS_ASSERT(img && hist_scratch && thr && w > 0 && h > 0);
+  launch_otsu(img, w, h, n, hist_scratch, thr);
+}
+void gsh_threshold_batch(uint8_t *img, unsigned w, unsigned h, unsigned n, uint8_t thresh) {
+  GS_ASSERT(img && w > 0 && h > 0);
+  launch_threshold(img, (size_t)(w * h), n, nullptr, thresh);
+}
+void gsh_threshold_batch_dev(uint8_t *img, unsigned w, unsigned h, unsigned n, const uint8_t *thr) {
+  GS_ASSERT(img && thr && w > 0 && h > 0);
+  launch_threshold(img, (size_t)(w * h), n, thr, 0);
+}
+void gsh_edge_pipeline_batch(uint8_t *dst, uint8_t *tmp, const uint8_t *src, unsigned w, unsigned h,
+                             unsigned n, unsigned radius, unsigned *hist_scratch, uint8_t *thr) {
+  GS_ASSERT(dst && tmp && src && hist_scratch && thr && w > 0 && h > 0);
+  const size_t fb = (size_t)w * h;
+  launch_blur(tmp, src, w, h, n, radius);
+  /* sobel never writes its 1-px frame (ref :308-309): config 2 runs it into a zeroed image */
+  GS_HIP(hipMemsetAsync(dst, 0, fb * n, ctx().s()));
+  launch_sobel(dst, tmp, w, h, n);
+  launch_otsu(dst, w, h, n, hist_scratch, thr);
+  launch_threshold(dst, fb, n, thr, 0);
+}
+
+/* ---------------------------------------------------------------- batch: integral + LBP */
+void gsh_integral_batch(const uint8_t *src, unsigned w, unsigned h, unsigned n, unsigned *ii) {
+  GS_ASSERT(src && ii && w > 0 && h > 0);
+  launch_integral(src, w, h, n, ii);
+}
+
+gsh_cascade *gsh_cascade_create(const struct gs_lbp_cascade *c) {
+  GS_ASSERT(c && c->features && c->weak_feature_idx && c->subsets);
+  ctx().ensure_device();
+  gsh_cascade *dc = new gsh_cascade();
+  dc->window_w = c->window_w, dc->window_h = c->window_h;
+  dc->nfeatures = c->nfeatures, dc->nweaks = c->nweaks, dc->nstages = c->nstages;
+  dc->features.assign(c->features, c->features + (size_t)c->nfeatures * 4);
+  dc->weak_feature_idx.assign(c->weak_feature_idx, c->weak_feature_idx + c->nweaks);
+  std::vector<LbpWeak> wk(c->nweaks);
+  unsigned nsub = 0;
+  for (unsigned i = 0; i < c->nweaks; i++) {
+    wk[i] = LbpWeak{c->weak_left_val[i], c->weak_right_val[i], c->weak_subset_offset[i],
+                    c->weak_num_subsets[i]};
+    nsub = std::max(nsub, (unsigned)c->weak_subset_offset[i] + c->weak_num_subsets[i]);
+  }
+  std::vector<LbpStage> stg(c->nstages);
+  for (unsigned i = 0; i < c->nstages; i++)
+    stg[i] = LbpStage{c->stage_weak_start[i], c->stage_nweaks[i], c->stage_threshold[i], 0.0f};
+  GS_HIP(hipMalloc((void **)&dc->d_weak, std::max<size_t>(1, wk.size()) * sizeof(LbpWeak)));
+  GS_HIP(hipMalloc((void **)&dc->d_stage, std::max<size_t>(1, stg.size()) * sizeof(LbpStage)));
+  GS_HIP(hipMalloc((void **)&dc->d_subsets, std::max<size_t>(1, nsub) * 4));
+  GS_HIP(hipMemcpy(dc->d_weak, wk.data(), wk.size() * sizeof(LbpWeak), hipMemcpyHostToDevice));
+  GS_HIP(hipMemcpy(dc->d_stage, stg.data(), stg.size() * sizeof(LbpStage), hipMemcpyHostToDevice));
+  GS_HIP(hipMemcpy(dc->d_subsets, c->subsets, (size_t)nsub * 4, hipMemcpyHostToDevice));
+  return dc;
+}
+void gsh_cascade_destroy(gsh_cascade *dc) {
+  if (!dc) return;
+  ctx().sync();
+  (void)hipFree(dc->d_weak), (void)hipFree(dc->d_stage), (void)hipFree(dc->d_subsets);
+  if (dc->d_scales) (void)hipFree(dc->d_scales);
+  if (dc->d_geom) (void)hipFree(dc->d_geom);
+  delete dc;
+}
+void gsh_lbp_detect_batch(const gsh_cascade *dc, const unsigned *ii, unsigned iw, unsigned ih,
+                          unsigned n, struct gs_rect *rects, unsigned *counts, unsigned max_rects,
+                          float scale_factor, float min_scale, float max_scale, int step) {
+  GS_ASSERT(dc && ii && rects && counts && iw > 0 && ih > 0);
+  launch_lbp_unpadded(const_cast<gsh_cascade *>(dc), ii, iw, ih, n, (unsigned *)rects, counts,
+                      max_rects, scale_factor, min_scale, max_scale, step);
+}
+uint64_t gsh_lbp_window_count(const struct gs_lbp_cascade *c, unsigned iw, unsigned ih,
+                              float scale_factor, float min_scale, float max_scale, int step) {
+  gsh_cascade tmp;
+  tmp.window_w = c->window_w, tmp.window_h = c->window_h, tmp.nweaks = 0;
+  std::vector<LbpScale> sc;
+  std::vector<LbpGeom> ge;
+  bool guard;
+  unsigned long long nwin;
+  build_scales(tmp, iw, ih, scale_factor, min_scale, max_scale, step, sc, ge, guard, nwin);
+  return nwin;
+}
+
+/* ---------------------------------------------------------------- batch: FAST / ORB / match */
+void gsh_fast_batch(const uint8_t *img, uint8_t *scoremap, unsigned w, unsigned h, unsigned n,
+                    struct gs_keypoint *kps, unsigned *counts, unsigned nkps, unsigned threshold) {
+  GS_ASSERT(img && scoremap && kps && counts && nkps > 0 && w > 0 && h > 0);
+  launch_fast(img, scoremap, w, h, n, (unsigned *)kps, counts, nkps, threshold);
+}
+unsigned gsh_orb_extract(const uint8_t *img_dev, unsigned w, unsigned h, uint8_t *scoremap_dev,
+                         struct gs_keypoint *kps_host, unsigned nkps, unsigned threshold) {
+  GS_ASSERT(img_dev && scoremap_dev && kps_host && nkps > 0 && w > 0 && h > 0);
+  std::vector<Cand> cand;
+  orb_candidates(img_dev, w, h, scoremap_dev, std::min(nkps * 4u, 5000u), threshold, cand);
+  return orb_finish(img_dev, w, h, cand, kps_host, nkps);
+}
+void gsh_match_orb_dev(const struct gs_keypoint *k1, unsigned n1, const struct gs_keypoint *k2,
+                       unsigned n2, struct gs_match *matches, unsigned *count,
+                       unsigned max_matches, float max_distance) {
+  GS_ASSERT(k1 && k2 && matches && count);
+  launch_match((const uint32_t *)k1, n1, (const uint32_t *)k2, n2, (unsigned *)matches, count,
+               max_matches, max_distance);
+}
+
+/* ---------------------------------------------------------------- batch: "next" rows */
+void gsh_adaptive_threshold_batch(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h,
+                                  unsigned n, unsigned radius, int c) {
+  GS_ASSERT(dst && src && w > 0 && h > 0);
+  if (n) launch_box_generic<1>(dst, src, w, h, n, radius, c);
+}
+void gsh_filter_batch(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned n,
+                      const int8_t *kernel_host, unsigned kw, unsigned kh, unsigned norm) {
+  GS_ASSERT(dst && src && kernel_host && w > 0 && h > 0 && kw > 0 && kh > 0 && norm > 0);
+  hipStream_t st = ctx().s();
+  int8_t *dk = (int8_t *)ctx().scratch(SL_TAB, (size_t)kw * kh);
+  GS_HIP(hipMemcpyAsync(dk, kernel_host, (size_t)kw * kh, hipMemcpyHostToDevice, st));
+  ctx().sync(); /* kernel_host may be a temporary */
+  const size_t fb = (size_t)w * h;
+  for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
+    const unsigned nn = std::min(kMaxZ, n - f0);
+    GS_LAUNCH(k_filter_px, grid2d(w, h, nn), dim3(64, 4), 0, st, dst + fb * f0, src + fb * f0, w, h,
+              fb, (const int8_t *)dk, kw, kh, norm);
+  }
+}
+void gsh_downsample_batch(uint8_t *dst, const uint8_t *src, unsigned sw, unsigned sh, unsigned n) {
+  GS_ASSERT(dst && src && sw > 1 && sh > 1);
+  hipStream_t st = ctx().s();
+  const size_t sfb = (size_t)sw * sh, dfb = (size_t)(sw / 2) * (sh / 2);
+  for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
+    const unsigned nn = std::min(kMaxZ, n - f0);
+    GS_LAUNCH(k_downsample_px, grid2d(sw / 2, sh / 2, nn), dim3(64, 4), 0, st, dst + dfb * f0,
+              src + sfb * f0, sw, sh);
+  }
+}
+
+/* ---------------------------------------------------------------- synthetic frames, checksums */
+void gsh_synth_batch(uint8_t *dst, unsigned w, unsigned h, unsigned n, uint32_t seed0) {
+  GS_ASSERT(dst && w > 0 && h > 0);
+  if (!n) return;
+  hipStream_t st = ctx().s();
+  static thread_local bool jump_ready = false;
+  SynthJump *dj = (SynthJump *)ctx().scratch(SL_JUMP, sizeof(SynthJump));
+  if (!jump_ready) {
+    SynthJump J;
+    synth_jump_table(J);
+    GS_HIP(hipMemcpyAsync(dj, &J, sizeof J, hipMemcpyHostToDevice, st));
+    ctx().sync();
+    jump_ready = true;
+  }
+  const unsigned nlev = ((w + 31) / 32) * ((h + 31) / 32);
+  const size_t npx = (size_t)w * h;
+  for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
+    const unsigned nn = std::min(kMaxZ, n - f0);
+    uint8_t *lev = (uint8_t *)ctx().scratch(SL_LEV, (size_t)nlev * nn);
+    const unsigned per = 256 * kSynthRun;
+    GS_LAUNCH(k_synth_levels, dim3((nlev + per - 1) / per, nn), dim3(256), 0, st, lev, nlev,
+              seed0 + f0, (const SynthJump *)dj);
+    GS_LAUNCH(k_synth_pixels, dim3((unsigned)((npx + per - 1) / per), nn), dim3(256), 0, st,
+              dst + npx * f0, (const uint8_t *)lev, w, h, seed0 + f0, (const SynthJump *)dj);
+  }
+}
+void gsh_checksum_batch(const uint8_t *img, size_t frame_bytes, unsigned n, uint64_t *sums) {
+  GS_ASSERT(img && sums && frame_bytes > 0);
+  if (!n) return;
+  hipStream_t st = ctx().s();
+  GS_HIP(hipMemsetAsync(sums, 0, (size_t)n * 8, st));
+  const unsigned bx = (unsigned)std::max<size_t>(1, std::min<size_t>((frame_bytes + 4095) / 4096, 256));
+  for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
+    const unsigned nn = std::min(kMaxZ, n - f0);
+    GS_LAUNCH(k_checksum, dim3(bx, nn), dim3(256), 0, st, img + frame_bytes * f0, frame_bytes,
+              (unsigned long long *)sums + f0);
+  }
+}
+
+/* =====================================================================================
+ *              drop-in functions: the reference's own names and signatures
+ * ===================================================================================== */
+#define GS_VALID(i) ((i).data && (i).w > 0 && (i).h > 0)
+
+/* dst written in full by the kernel: upload src, run, download dst */
+static void unary_full(struct gs_image dst, struct gs_image src,
+                       void (*run)(uint8_t *, const uint8_t *, unsigned, unsigned, unsigned,
+                                   unsigned, int),
+                       unsigned p0, int p1) {
+  const size_t nb = (size_t)src.w * src.h;
+  const uint8_t *s = (const uint8_t *)stage_in(src.data, nb, SL_IN);
+  const bool dhost = !is_dev(dst.data);
+  uint8_t *d = dhost ? (uint8_t *)ctx().scratch(SL_OUT, nb) : dst.data;
+  run(d, s, src.w, src.h, 1, p0, p1);
+  if (dhost) GS_HIP(hipMemcpyAsync(dst.data, d, nb, hipMemcpyDeviceToHost, ctx().s()));
+  finish(dhost);
+}
+
+void gs_blur(struct gs_image dst, struct gs_image src, unsigned radius) { /* ref :268 */
+  GS_ASSERT(GS_VALID(src) && GS_VALID(dst) && dst.w == src.w && dst.h == src.h);
+  unary_full(dst, src, [](uint8_t *d, const uint8_t *s, unsigned w, unsigned h, unsigned n,
+                          unsigned r, int) { launch_blur(d, s, w, h, n, r); }, radius, 0);
+}
+void gs_erode(struct gs_image dst, struct gs_image src) { /* ref :303 */
+  GS_ASSERT(GS_VALID(dst) && GS_VALID(src) && dst.w == src.w && dst.h == src.h);
+  unary_full(dst, src, [](uint8_t *d, const uint8_t *s, unsigned w, unsigned h, unsigned n,
+                          unsigned, int) { launch_morph<false>(d, s, w, h, n); }, 0, 0);
+}
+void gs_dilate(struct gs_image dst, struct gs_image src) { /* ref :304 */
+  GS_ASSERT(GS_VALID(dst) && GS_VALID(src) && dst.w == src.w && dst.h == src.h);
+  unary_full(dst, src, [](uint8_t *d, const uint8_t *s, unsigned w, unsigned h, unsigned n,
+                          unsigned, int) { launch_morph<true>(d, s, w, h, n); }, 0, 0);
+}
+void gs_adaptive_threshold(struct gs_image dst, struct gs_image src, unsigned radius, int c) {
+  GS_ASSERT(GS_VALID(dst) && GS_VALID(src) && dst.w == src.w && dst.h == src.h); /* ref :232 */
+  unary_full(dst, src, [](uint8_t *d, const uint8_t *s, unsigned w, unsigned h, unsigned n,
+                          unsigned r, int cc) { launch_box_generic<1>(d, s, w, h, n, r, cc); },
+             radius, c);
+}
+
+void gs_sobel(struct gs_image dst, struct gs_image src) { /* ref :306 */
+  GS_ASSERT(GS_VALID(dst) && GS_VALID(src) && dst.w == src.w && dst.h == src.h);
+  const unsigned w = src.w, h = src.h;
+  if (w < 3 || h < 3) return; /* reference loops are empty */
+  const size_t nb = (size_t)w * h;
+  const uint8_t *s = (const uint8_t *)stage_in(src.data, nb, SL_IN);
+  const bool dhost = !is_dev(dst.data);
+  uint8_t *d = dhost ? (uint8_t *)ctx().scratch(SL_OUT, nb) : dst.data;
+  launch_sobel(d, s, w, h, 1);
+  /* the 1-px frame of dst is never written (ref :308-309): copy back the interior only */
+  if (dhost)
+    GS_HIP(hipMemcpy2DAsync(dst.data + w + 1, w, d + w + 1, w, w - 2, h - 2, hipMemcpyDeviceToHost,
+                            ctx().s()));
+  finish(dhost);
+}
+
+void gs_filter(struct gs_image dst, struct gs_image src, struct gs_image kernel, unsigned norm) {
+  GS_ASSERT(GS_VALID(src) && GS_VALID(dst) && dst.w == src.w && dst.h == src.h && norm > 0);
+  const size_t nb = (size_t)src.w * src.h, kb = (size_t)kernel.w * kernel.h;
+  /* ref :260-261: the kernel is read through gs_get, so an invalid kernel contributes nothing */
+  std::vector<int8_t> k(std::max<size_t>(1, kb), 0);
+  unsigned kw = kernel.w, kh = kernel.h;
+  if (GS_VALID(kernel)) {
+    if (is_dev(kernel.data)) gsh_download(k.data(), kernel.data, kb);
+    else memcpy(k.data(), kernel.data, kb);
+  } else {
+    kw = kh = 1; /* empty loop in the reference: sum = 0 */
+    k[0] = 0;
+  }
+  const uint8_t *s = (const uint8_t *)stage_in(src.data, nb, SL_IN);
+  const bool dhost = !is_dev(dst.data);
+  uint8_t *d = dhost ? (uint8_t *)ctx().scratch(SL_OUT, nb) : dst.data;
+  gsh_filter_batch(d, s, src.w, src.h, 1, k.data(), kw, kh, norm);
+  if (dhost) GS_HIP(hipMemcpyAsync(dst.data, d, nb, hipMemcpyDeviceToHost, ctx().s()));
+  finish(dhost);
+}
+
+void gs_downsample(struct gs_image dst, struct gs_image src) { /* ref :189 */
+  GS_ASSERT(GS_VALID(src) && GS_VALID(dst) && dst.w == src.w / 2 && dst.h == src.h / 2);
+  const size_t nb = (size_t)src.w * src.h, db = (size_t)dst.w * dst.h;
+  const uint8_t *s = (const uint8_t *)stage_in(src.data, nb, SL_IN);
+  const bool dhost = !is_dev(dst.data);
+  uint8_t *d = dhost ? (uint8_t *)ctx().scratch(SL_OUT, db) : dst.data;
+  gsh_downsample_batch(d, s, src.w, src.h, 1);
+  if (dhost) GS_HIP(hipMemcpyAsync(dst.data, d, db, hipMemcpyDeviceToHost, ctx().s()));
+  finish(dhost);
+}
+
+void gs_histogram(struct gs_image img, unsigned hist[256]) { /* ref :199 */
+  GS_ASSERT(GS_VALID(img) && hist != NULL);
+  const size_t nb = (size_t)(img.w * img.h);
+  const uint8_t *s = (const uint8_t *)stage_in(img.data, nb, SL_IN);
+  const bool hhost = !is_dev(hist);
+  unsigned *dh = hhost ? (unsigned *)ctx().scratch(SL_HIST, 1024) : hist;
+  launch_histogram(s, nb, 1, dh);
+  if (hhost) GS_HIP(hipMemcpyAsync(hist, dh, 1024, hipMemcpyDeviceToHost, ctx().s()));
+  finish(hhost);
+}
+
+uint8_t gs_otsu_threshold(struct gs_image img) { /* ref :205 */
+  GS_ASSERT(GS_VALID(img));
+  const size_t nb = (size_t)(img.w * img.h);
+  const uint8_t *s = (const uint8_t *)stage_in(img.data, nb, SL_IN);
+  unsigned *dh = (unsigned *)ctx().scratch(SL_HIST, 1024);
+  uint8_t *dt = (uint8_t *)ctx().scratch(SL_THR, 16);
+  launch_otsu(s, img.w, img.h, 1, dh, dt);
+  uint8_t t = 0;
+  GS_HIP(hipMemcpyAsync(&t, dt, 1, hipMemcpyDeviceToHost, ctx().s()));
+  ctx().sync();
+  return t;
+}
+
+void gs_threshold(struct gs_image img, uint8_t thresh) { /* ref :225 */
+  GS_ASSERT(GS_VALID(img));
+  const size_t nb = (size_t)(img.w * img.h);
+  const bool host = !is_dev(img.data);
+  uint8_t *d = host ? (uint8_t *)ctx().scratch(SL_IN, nb) : img.data;
+  if (host) GS_HIP(hipMemcpyAsync(d, img.data, nb, hipMemcpyHostToDevice, ctx().s()));
+  launch_threshold(d, nb, 1, nullptr, thresh);
+  if (host) GS_HIP(hipMemcpyAsync(img.data, d, nb, hipMemcpyDeviceToHost, ctx().s()));
+  finish(host);
+}
+
+void gs_integral(struct gs_image src, unsigned *ii) { /* ref :744 */
+  GS_ASSERT(GS_VALID(src) && ii);
+  const size_t np = (size_t)src.w * src.h;
+  const uint8_t *s = (const uint8_t *)stage_in(src.data, np, SL_IN);
+  const bool host = !is_dev(ii);
+  unsigned *d = host ? (unsigned *)ctx().scratch(SL_II, np * 4) : ii;
+  launch_integral(s, src.w, src.h, 1, d);
+  if (host) GS_HIP(hipMemcpyAsync(ii, d, np * 4, hipMemcpyDeviceToHost, ctx().s()));
+  finish(host);
+}
+
+/* cascade flattening is cached per calling thread, keyed by the struct's contents */
+static gsh_cascade *cached_cascade(const struct gs_lbp_cascade *c) {
+  static thread_local gsh_cascade *dc = nullptr;
+  static thread_local struct gs_lbp_cascade key;
+  if (dc && memcmp(&key, c, sizeof key) == 0) return dc;
+  if (dc) gsh_cascade_destroy(dc);
+  dc = gsh_cascade_create(c);
+  key = *c;
+  return dc;
+}
+
+unsigned gs_lbp_detect(const struct gs_lbp_cascade *c, const unsigned *ii, unsigned iw,
+                       unsigned ih, struct gs_rect *rects, unsigned max_rects, float scale_factor,
+                       float min_scale, float max_scale, int step) { /* ref :815 */
+  GS_ASSERT(c && ii && iw > 0 && ih > 0 && (rects || max_rects == 0));
+  if (max_rects == 0) return 0;
+  gsh_cascade *dc = cached_cascade(c);
+  const size_t np = (size_t)iw * ih;
+  const unsigned *dii = (const unsigned *)stage_in(ii, np * 4, SL_II);
+  const bool rhost = !is_dev(rects);
+  unsigned *dr = rhost ? (unsigned *)ctx().scratch(SL_OUT, (size_t)max_rects * 16) : (unsigned *)rects;
+  unsigned *dcnt = (unsigned *)ctx().scratch(SL_TOT, 16);
+  launch_lbp_unpadded(dc, dii, iw, ih, 1, dr, dcnt, max_rects, scale_factor, min_scale, max_scale,
+                      step);
+  unsigned n = 0;
+  GS_HIP(hipMemcpyAsync(&n, dcnt, 4, hipMemcpyDeviceToHost, ctx().s()));
+  ctx().sync();
+  if (rhost && n) GS_HIP(hipMemcpy(rects, dr, (size_t)n * 16, hipMemcpyDeviceToHost));
+  return n;
+}
+
+unsigned gs_lbp_window(const struct gs_lbp_cascade *c, const unsigned *ii, unsigned iw, unsigned ih,
+                       int x, int y, float scale) { /* ref :790 */
+  GS_ASSERT(c && ii);
+  const int win_w = (int)((int)c->window_w * scale), win_h = (int)((int)c->window_h * scale);
+  if (x + win_w > (int)iw || y + win_h > (int)ih) return 0; /* ref :793 */
+  if (x < 0 || y < 0 || win_w <= 0 || win_h <= 0) return 0;
+  gsh_cascade *dc = cached_cascade(c);
+  hipStream_t st = ctx().s();
+  /* (win_w+1) x (win_h+1) zero-bordered sub-table around the window: the cascade only ever
+   * forms D + A - B - C differences, so absolute table values carry over unchanged */
+  const unsigned S = (unsigned)win_w + 1, R = (unsigned)win_h + 1;
+  unsigned *tab = (unsigned *)ctx().scratch(SL_PAD, (size_t)S * R * 4 + 64);
+  GS_HIP(hipMemsetAsync(tab, 0, (size_t)S * R * 4, st));
+  const unsigned cx = x > 0 ? 1 : 0, cy = y > 0 ? 1 : 0;
+  const unsigned *src0 = ii + (size_t)(y - (int)cy) * iw + (x - (int)cx);
+  GS_HIP(hipMemcpy2DAsync(tab + (size_t)(1 - cy) * S + (1 - cx), (size_t)S * 4, src0, (size_t)iw * 4,
+                          (size_t)(win_w + cx) * 4, (size_t)(win_h + cy),
+                          is_dev(ii) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+  std::vector<LbpGeom> geom(dc->nweaks);
+  for (unsigned wi = 0; wi < dc->nweaks; wi++) {
+    const int fi = dc->weak_feature_idx[wi];
+    int fx = (int)((int)dc->features[fi * 4 + 0] * scale), fy = (int)((int)dc->features[fi * 4 + 1] * scale);
+    int fw = (int)((int)dc->features[fi * 4 + 2] * scale), fh = (int)((int)dc->features[fi * 4 + 3] * scale);
+    if (fw < 1) fw = 1;
+    if (fh < 1) fh = 1;
+    geom[wi] = LbpGeom{fy * (int)S + fx, fw, fh * (int)S, 0};
+  }
+  LbpGeom *dg = (LbpGeom *)ctx().scratch(SL_TAB, std::max<size_t>(1, geom.size()) * sizeof(LbpGeom));
+  GS_HIP(hipMemcpyAsync(dg, geom.data(), geom.size() * sizeof(LbpGeom), hipMemcpyHostToDevice, st));
+  unsigned *dout = (unsigned *)ctx().scratch(SL_TOT, 16);
+  LbpArgs a;
+  memset(&a, 0, sizeof a);
+  a.padded = tab, a.frame_stride = (size_t)S * R, a.S = S, a.limit = (size_t)S * R - 1, a.step = 1;
+  a.nweaks = dc->nweaks, a.nstages = dc->nstages;
+  a.weak = dc->d_weak, a.stage = dc->d_stage, a.subsets = dc->d_subsets;
+  GS_LAUNCH(k_lbp_single, dim3(1), dim3(64), 0, st, a, (const LbpGeom *)dg, dout);
+  unsigned r = 0;
+  GS_HIP(hipMemcpyAsync(&r, dout, 4, hipMemcpyDeviceToHost, st));
+  ctx().sync();
+  return r;
+}
+
+unsigned gs_fast(struct gs_image img, struct gs_image scoremap, struct gs_keypoint *kps,
+                 unsigned nkps, unsigned threshold) { /* ref :482 */
+  GS_ASSERT(GS_VALID(img) && kps && nkps > 0);
+  const unsigned w = img.w, h = img.h;
+  if (w < 7 || h < 7) return 0;
+  /* the reference goes through gs_set/gs_get, which tolerate an invalid or differently sized
+   * scoremap; the device path needs the usual same-size map (what every caller passes) */
+  GS_ASSERT(GS_VALID(scoremap) && scoremap.w == w && scoremap.h == h);
+  const size_t nb = (size_t)w * h;
+  const uint8_t *s = (const uint8_t *)stage_in(img.data, nb, SL_IN);
+  const bool mhost = !is_dev(scoremap.data);
+  uint8_t *dm = mhost ? (uint8_t *)ctx().scratch(SL_AUX, nb) : scoremap.data;
+  /* NMS reads the caller's 3-px frame (ref :524): ship the whole map in */
+  if (mhost) GS_HIP(hipMemcpyAsync(dm, scoremap.data, nb, hipMemcpyHostToDevice, ctx().s()));
+  const bool khost = !is_dev(kps);
+  unsigned *dk = khost ? (unsigned *)ctx().scratch(SL_KPS, (size_t)nkps * 48) : (unsigned *)kps;
+  unsigned *dcnt = (unsigned *)ctx().scratch(SL_TOT, 16);
+  launch_fast(s, dm, w, h, 1, dk, dcnt, nkps, threshold);
+  unsigned n = 0;
+  GS_HIP(hipMemcpyAsync(&n, dcnt, 4, hipMemcpyDeviceToHost, ctx().s()));
+  if (mhost) GS_HIP(hipMemcpyAsync(scoremap.data, dm, nb, hipMemcpyDeviceToHost, ctx().s()));
+  ctx().sync();
+  if (khost && n) GS_HIP(hipMemcpy(kps, dk, (size_t)n * 48, hipMemcpyDeviceToHost));
+  return n;
+}
+
+/* image patch [x-r, x+r] x [y-r, y+r] zero-filled outside the image, on the device */
+static const uint8_t *stage_patch(struct gs_image img, int x, int y, int r, int slot) {
+  const int side = 2 * r + 1;
+  uint8_t *d = (uint8_t *)ctx().scratch(slot, (size_t)side * side);
+  hipStream_t st = ctx().s();
+  GS_HIP(hipMemsetAsync(d, 0, (size_t)side * side, st));
+  const int xa = std::max(0, x - r), xb = std::min((int)img.w - 1, x + r);
+  const int ya = std::max(0, y - r), yb = std::min((int)img.h - 1, y + r);
+  if (xa <= xb && ya <= yb)
+    GS_HIP(hipMemcpy2DAsync(d + (size_t)(ya - (y - r)) * side + (xa - (x - r)), side,
+                            img.data + (size_t)ya * img.w + xa, img.w, (size_t)(xb - xa + 1),
+                            (size_t)(yb - ya + 1),
+                            is_dev(img.data) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+  return d;
+}
+
+float gs_compute_orientation(struct gs_image img, unsigned x, unsigned y, unsigned r) { /* ref :608 */
+  GS_ASSERT(GS_VALID(img) && x >= r && y >= r && x < img.w - r && y < img.h - r);
+  hipStream_t st = ctx().s();
+  const uint8_t *patch = stage_patch(img, (int)x, (int)y, (int)r, SL_AUX2);
+  unsigned pt[2] = {r, r};
+  unsigned *dp = (unsigned *)ctx().scratch(SL_KIN, 16);
+  int *dm = (int *)ctx().scratch(SL_MOM, 16);
+  GS_HIP(hipMemcpyAsync(dp, pt, 8, hipMemcpyHostToDevice, st));
+  GS_LAUNCH(k_orient_moments, dim3(1), dim3(64), 0, st, patch, 2 * r + 1, 2 * r + 1,
+            (const unsigned *)dp, 2u, r, dm);
+  int m[2];
+  GS_HIP(hipMemcpyAsync(m, dm, 8, hipMemcpyDeviceToHost, st));
+  ctx().sync();
+  return atan2f((float)m[0], (float)m[1]); /* ref :620 -> libm, as the reference (ref :100) */
+}
+
+void gs_brief_descriptor(struct gs_image img, struct gs_keypoint *kp) { /* ref :623 */
+  GS_ASSERT(GS_VALID(img) && kp);
+  hipStream_t st = ctx().s();
+  const int R = 22; /* |pattern| <= 15 rotated reaches <= 21 px */
+  gs_keypoint k;
+  if (is_dev(kp)) gsh_download(&k, kp, sizeof k);
+  else k = *kp;
+  const uint8_t *patch = stage_patch(img, (int)k.pt.x, (int)k.pt.y, R, SL_AUX2);
+  const float angle = k.angle;
+  KpIn in{(unsigned)R, (unsigned)R, sinf(angle), sinf((float)(angle + 1.57079f))};
+  KpIn *dk = (KpIn *)ctx().scratch(SL_KIN, sizeof in);
+  uint32_t *dd = (uint32_t *)ctx().scratch(SL_DESC, 32);
+  GS_HIP(hipMemcpyAsync(dk, &in, sizeof in, hipMemcpyHostToDevice, st));
+  GS_LAUNCH(k_brief, dim3(1), dim3(256), 0, st, patch, 2u * R + 1, 2u * R + 1, (const KpIn *)dk, dd);
+  GS_HIP(hipMemcpyAsync(k.descriptor, dd, 32, hipMemcpyDeviceToHost, st));
+  ctx().sync();
+  if (is_dev(kp)) gsh_upload(kp, &k, sizeof k);
+  else memcpy(kp->descriptor, k.descriptor, 32);
+}
+
+unsigned gs_orb_extract(struct gs_image img, struct gs_keypoint *kps, unsigned nkps,
+                        unsigned threshold, uint8_t *scoremap_buffer) { /* ref :651 */
+  GS_ASSERT(GS_VALID(img) && kps && nkps > 0 && scoremap_buffer);
+  const unsigned w = img.w, h = img.h;
+  if (w < 7 || h < 7) return 0;
+  const size_t nb = (size_t)w * h;
+  const uint8_t *s = (const uint8_t *)stage_in(img.data, nb, SL_IN);
+  const bool mhost = !is_dev(scoremap_buffer);
+  uint8_t *dm = mhost ? (uint8_t *)ctx().scratch(SL_AUX, nb) : scoremap_buffer;
+  if (mhost) GS_HIP(hipMemcpyAsync(dm, scoremap_buffer, nb, hipMemcpyHostToDevice, ctx().s()));
+  std::vector<Cand> cand;
+  orb_candidates(s, w, h, dm, std::min(nkps * 4u, 5000u), threshold, cand);
+  if (mhost) GS_HIP(hipMemcpyAsync(scoremap_buffer, dm, nb, hipMemcpyDeviceToHost, ctx().s()));
+  const bool khost = !is_dev(kps);
+  std::vector<gs_keypoint> tmp;
+  gs_keypoint *out = kps;
+  if (!khost) {
+    tmp.resize(nkps);
+    out = tmp.data();
+  }
+  const unsigned n = orb_finish(s, w, h, cand, out, nkps);
+  ctx().sync();
+  if (!khost && n) gsh_upload(kps, out, (size_t)n * sizeof(gs_keypoint));
+  return n;
+}
+
+unsigned gs_match_orb(const struct gs_keypoint *kps1, unsigned n1, const struct gs_keypoint *kps2,
+                      unsigned n2, struct gs_match *matches, unsigned max_matches,
+                      float max_distance) { /* ref :680 */
+  GS_ASSERT(kps1 && kps2 && matches);
+  if (n1 == 0 || max_matches == 0) return 0;
+  const uint32_t *d1 = (const uint32_t *)stage_in(kps1, (size_t)n1 * 48, SL_IN);
+  const uint32_t *d2 = n2 ? (const uint32_t *)stage_in(kps2, (size_t)n2 * 48, SL_AUX)
+                          : (const uint32_t *)ctx().scratch(SL_AUX, 48);
+  const bool mhost = !is_dev(matches);
+  unsigned *dm = mhost ? (unsigned *)ctx().scratch(SL_OUT, (size_t)max_matches * 12) : (unsigned *)matches;
+  unsigned *dcnt = (unsigned *)ctx().scratch(SL_TOT, 16);
+  launch_match(d1, n1, d2, n2, dm, dcnt, max_matches, max_distance);
+  unsigned n = 0;
+  GS_HIP(hipMemcpyAsync(&n, dcnt, 4, hipMemcpyDeviceToHost, ctx().s()));
+  ctx().sync();
+  if (mhost && n) GS_HIP(hipMemcpy(matches, dm, (size_t)n * 12, hipMemcpyDeviceToHost));
+  return n;
+}
+
+}  /* extern "C" */

@@ -1,0 +1,209 @@
+/*
+ * k_pointwise.h -- gs_threshold, gs_histogram, gs_otsu_threshold, checksums, synthetic frames.
+ * Reference semantics: grayskull.h:199-228.  All HBM-bound: threshold 2 B/px (in-place R+W),
+ * histogram 1 B/px.
+ */
+#ifndef GS_K_POINTWISE_H
+#define GS_K_POINTWISE_H
+#include "k_stencil.h" /* U4 */
+
+namespace gs {
+
+/* The 16-byte chunks of [base, base+n) are addressed relative to base rounded down to 16 B, so
+ * the body is aligned dwordx4 traffic for ANY base; only the first/last chunk go bytewise. */
+struct Chunking {
+  uintptr_t a0; /* aligned-down base */
+  size_t lo, hi; /* valid byte range relative to a0 */
+  size_t nchunks;
+};
+__host__ __device__ inline Chunking make_chunking(const void *base, size_t n) {
+  Chunking c;
+  c.a0 = (uintptr_t)base & ~(uintptr_t)15;
+  c.lo = (uintptr_t)base - c.a0;
+  c.hi = c.lo + n;
+  c.nchunks = (c.hi + 15) / 16;
+  return c;
+}
+
+/* per-byte x > t ? 0xff : 0 on four bytes at once (SWAR, no cross-byte carries) */
+GS_DEV uint32_t swar_gt_u8(uint32_t x, uint32_t trep) {
+  const uint32_t Hb = 0x80808080u;
+  uint32_t d = (trep | Hb) - (x & ~Hb);                  /* bit7 = (t&0x7f) >= (x&0x7f) */
+  uint32_t ge = ((trep & ~x) | (~(trep ^ x) & d)) & Hb;  /* bit7 = t >= x */
+  uint32_t gt = ~ge & Hb;                                /* bit7 = x > t  */
+  return (gt >> 7) * 0xffu;
+}
+
+/* ref :225-228, in place.  grid (blocks, n frames); thr_dev (per-frame) overrides thr_const */
+__global__ __launch_bounds__(256) void k_threshold(uint8_t *img, size_t frame_bytes,
+                                                   const uint8_t *thr_dev, unsigned thr_const) {
+  uint8_t *base = img + (size_t)blockIdx.y * frame_bytes;
+  const unsigned t = thr_dev ? thr_dev[blockIdx.y] : thr_const;
+  const uint32_t trep = t * 0x01010101u;
+  const Chunking c = make_chunking(base, frame_bytes);
+  for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < c.nchunks;
+       i += (size_t)gridDim.x * 256u) {
+    const size_t b0 = i * 16, b1 = b0 + 16;
+    uint8_t *p = (uint8_t *)(c.a0 + b0);
+    if (b0 >= c.lo && b1 <= c.hi) {
+      U4 v = *(U4 *)p;
+      v.x = swar_gt_u8(v.x, trep), v.y = swar_gt_u8(v.y, trep);
+      v.z = swar_gt_u8(v.z, trep), v.w = swar_gt_u8(v.w, trep);
+      *(U4 *)p = v;
+    } else {
+      const size_t s = b0 < c.lo ? c.lo : b0, e = b1 > c.hi ? c.hi : b1;
+      for (size_t k = s; k < e; k++) {
+        uint8_t *q = (uint8_t *)(c.a0 + k);
+        *q = *q > t ? 255 : 0;
+      }
+    }
+  }
+}
+
+/* ref :199-203.  LDS-privatised histogram: 32 copies of the 256 bins, copy = lane & 31, so a
+ * wave's 64 ds_add_u32 never collide on a bank whatever the pixel values are (flat image
+ * regions would otherwise serialise 64-way).  grid (bpf, n frames); each block writes its
+ * 256 partial counts to partial[(frame*bpf + block)*256 ..]; k_hist_reduce sums them
+ * (no global atomics, deterministic). */
+__global__ __launch_bounds__(256) void k_hist_partial(const uint8_t *img, size_t frame_bytes,
+                                                      unsigned *partial) {
+  __shared__ unsigned lh[256 * 32];
+  const unsigned tid = threadIdx.x, copy = tid & 31u;
+  for (unsigned i = tid; i < 256 * 32; i += 256) lh[i] = 0;
+  __syncthreads();
+  const uint8_t *base = img + (size_t)blockIdx.y * frame_bytes;
+  const Chunking c = make_chunking(base, frame_bytes);
+  for (size_t i = (size_t)blockIdx.x * 256u + tid; i < c.nchunks; i += (size_t)gridDim.x * 256u) {
+    const size_t b0 = i * 16, b1 = b0 + 16;
+    if (b0 >= c.lo && b1 <= c.hi) {
+      const U4 v = *(const U4 *)(c.a0 + b0);
+      const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 16; k++)
+        atomicAdd(&lh[((d[k >> 2] >> (8 * (k & 3))) & 0xffu) * 32u + copy], 1u);
+    } else {
+      const size_t s = b0 < c.lo ? c.lo : b0, e = b1 > c.hi ? c.hi : b1;
+      for (size_t k = s; k < e; k++) atomicAdd(&lh[(unsigned)*(const uint8_t *)(c.a0 + k) * 32u + copy], 1u);
+    }
+  }
+  __syncthreads();
+  unsigned s = 0;
+#pragma unroll 8
+  for (unsigned k = 0; k < 32; k++) s += lh[tid * 32u + ((k + tid) & 31u)]; /* rotated: conflict-free */
+  partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256u + tid] = s;
+}
+
+/* grid n frames, block 256 */
+__global__ __launch_bounds__(256) void k_hist_reduce(const unsigned *partial, unsigned bpf,
+                                                     unsigned *hist) {
+  const unsigned *p = partial + (size_t)blockIdx.x * bpf * 256u + threadIdx.x;
+  unsigned s = 0;
+  for (unsigned b = 0; b < bpf; b++) s += p[(size_t)b * 256u];
+  hist[(size_t)blockIdx.x * 256u + threadIdx.x] = s;
+}
+
+/* ref :205-223 -- the 256-step float32 scan, one thread per frame, same expression order,
+ * no FMA contraction (IEEE add/mul/div are correctly rounded on gfx950 as on x86-64). */
+__global__ void k_otsu_scan(const unsigned *hist, unsigned npix, unsigned n, uint8_t *thr) {
+#ifndef GS_EMU
+#pragma clang fp contract(off)
+#endif
+  const unsigned f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n) return;
+  const unsigned *hg = hist + (size_t)f * 256u;
+  unsigned wb = 0, wf = 0, best = 0;
+  float sum = 0, sumB = 0, varMax = -1.0f;
+  for (unsigned i = 0; i < 256; i++) sum += (float)i * (float)hg[i];
+  for (unsigned t = 0; t < 256; t++) {
+    wb += hg[t];
+    if (wb == 0) continue;
+    wf = npix - wb;
+    if (wf == 0) break;
+    sumB += (float)t * (float)hg[t];
+    const float mB = sumB / (float)wb;
+    const float mF = (sum - sumB) / (float)wf;
+    const float between = (float)wb * (float)wf * (mB - mF) * (mB - mF);
+    if (between > varMax) varMax = between, best = t;
+  }
+  thr[f] = (uint8_t)best;
+}
+
+/* sums[f] += sum over bytes of (index+1)*(byte+1) mod 2^64 (order independent). */
+__global__ __launch_bounds__(256) void k_checksum(const uint8_t *img, size_t frame_bytes,
+                                                  unsigned long long *sums) {
+  const uint8_t *base = img + (size_t)blockIdx.y * frame_bytes;
+  unsigned long long acc = 0;
+  for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < frame_bytes;
+       i += (size_t)gridDim.x * 256u)
+    acc += (unsigned long long)(i + 1) * ((unsigned long long)base[i] + 1ull);
+  /* wave reduce (two 32-bit halves), then one atomic per wave */
+  uint32_t lo = (uint32_t)acc, hi = (uint32_t)(acc >> 32);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const uint32_t olo = shfl(lo, (int)(lane_id() ^ (unsigned)d));
+    const uint32_t ohi = shfl(hi, (int)(lane_id() ^ (unsigned)d));
+    const unsigned long long t =
+        (((unsigned long long)hi << 32) | lo) + (((unsigned long long)ohi << 32) | olo);
+    lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
+  }
+  if (lane_id() == 0) atomicAdd(&sums[blockIdx.y], ((unsigned long long)hi << 32) | lo);
+}
+
+/* ---- synthetic block-noise frames on device (SURVEY.md 8c generator) -----------------
+ * xorshift32 is a linear map over GF(2); jump[k] holds the 32x32 bit matrix of 2^k steps
+ * (column images, computed on the host), so each thread jumps straight to its run of RUN
+ * pixels and then iterates.  Bit-identical to the CPU generator. */
+struct SynthJump { uint32_t col[32][32]; }; /* col[k][b] = M^(2^k) applied to bit b */
+
+GS_DEV uint32_t xs32(uint32_t x) {
+  x ^= x << 13;
+  x ^= x >> 17;
+  x ^= x << 5;
+  return x;
+}
+GS_DEV uint32_t xs_jump(const SynthJump *J, uint32_t s, uint64_t steps) {
+  for (int k = 0; k < 32 && steps; k++, steps >>= 1)
+    if (steps & 1) {
+      uint32_t r = 0;
+      for (int b = 0; b < 32; b++)
+        if ((s >> b) & 1u) r ^= J->col[k][b];
+      s = r;
+    }
+  return s;
+}
+constexpr unsigned kSynthRun = 256;
+/* grid (ceil(w*h/(256*RUN)), n), block 256.  levels: n * bw*bh bytes scratch */
+__global__ __launch_bounds__(256) void k_synth_levels(uint8_t *levels, unsigned nlev,
+                                                      uint32_t seed0, const SynthJump *J) {
+  const unsigned f = blockIdx.y;
+  const unsigned i0 = (blockIdx.x * 256u + threadIdx.x) * kSynthRun;
+  if (i0 >= nlev) return;
+  uint32_t seed = seed0 + f;
+  uint32_t s = xs_jump(J, seed ? seed : 1u, i0);
+  for (unsigned i = i0; i < i0 + kSynthRun && i < nlev; i++) {
+    s = xs32(s);
+    levels[(size_t)f * nlev + i] = (uint8_t)(s & 0xff);
+  }
+}
+__global__ __launch_bounds__(256) void k_synth_pixels(uint8_t *dst, const uint8_t *levels,
+                                                      unsigned w, unsigned h, uint32_t seed0,
+                                                      const SynthJump *J) {
+  const unsigned f = blockIdx.y;
+  const unsigned bw = (w + 31) / 32, bh = (h + 31) / 32, nlev = bw * bh;
+  const size_t npx = (size_t)w * h;
+  const size_t i0 = ((size_t)blockIdx.x * 256u + threadIdx.x) * kSynthRun;
+  if (i0 >= npx) return;
+  uint32_t seed = seed0 + f;
+  uint32_t s = xs_jump(J, seed ? seed : 1u, (uint64_t)nlev + i0);
+  const uint8_t *lv = levels + (size_t)f * nlev;
+  uint8_t *out = dst + (size_t)f * npx;
+  for (size_t i = i0; i < i0 + kSynthRun && i < npx; i++) {
+    s = xs32(s);
+    const unsigned x = (unsigned)(i % w), y = (unsigned)(i / w);
+    int v = (int)lv[(y / 32) * bw + x / 32] + (int)(s & 15u) - 8;
+    out[i] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+  }
+}
+
+}  // namespace gs
+#endif

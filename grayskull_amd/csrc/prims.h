@@ -1,0 +1,147 @@
+/*
+ * prims.h -- wave64 / packed-math primitives used by the gfx950 kernels.
+ *
+ * One spelling per primitive; the HIP build maps each to the CDNA4 instruction named in
+ * its comment, the -DGS_EMU build (tests/emu, host fibers) restates it in scalar C++.
+ */
+#ifndef GS_PRIMS_H
+#define GS_PRIMS_H
+
+#ifdef GS_EMU
+#include "hip_emu.h"
+#define GS_DYN_LDS(name) char *name = emu::S().dyn_lds
+#else
+#include <hip/hip_runtime.h>
+#define GS_LAUNCH(kernel, grid, block, shmem, stream, ...) \
+  hipLaunchKernelGGL(kernel, (grid), (block), (shmem), (stream), __VA_ARGS__)
+#define GS_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#endif
+
+#include <stdint.h>
+
+#define GS_DEV __device__ __forceinline__
+
+namespace gs {
+
+constexpr int kWave = 64; /* CDNA wavefront */
+
+#ifdef GS_EMU
+/* ------------------------------------------------------------------ emulation */
+GS_DEV unsigned lane_id() { return emu::lane_id(); }
+GS_DEV uint64_t ballot(bool p) {
+  return emu::wave_exchange(p ? 1 : 0, [](const uint64_t *s, const bool *v) {
+    uint64_t m = 0;
+    for (int i = 0; i < 64; i++)
+      if (v[i] && s[i]) m |= 1ull << i;
+    return m;
+  });
+}
+GS_DEV uint32_t wave_shr1(uint32_t x, uint32_t fill) {
+  unsigned l = lane_id();
+  return emu::wave_exchange(x, [=](const uint64_t *s, const bool *v) {
+    return (l > 0 && v[l - 1]) ? (uint32_t)s[l - 1] : fill;
+  });
+}
+GS_DEV uint32_t wave_shl1(uint32_t x, uint32_t fill) {
+  unsigned l = lane_id();
+  return emu::wave_exchange(x, [=](const uint64_t *s, const bool *v) {
+    return (l < 63 && v[l + 1]) ? (uint32_t)s[l + 1] : fill;
+  });
+}
+GS_DEV uint32_t shfl(uint32_t x, int src) {
+  return emu::wave_exchange(x, [=](const uint64_t *s, const bool *v) {
+    return v[src & 63] ? (uint32_t)s[src & 63] : 0u;
+  });
+}
+GS_DEV uint32_t perm_b32(uint32_t hi, uint32_t lo, uint32_t sel) { /* v_perm_b32 */
+  uint64_t src = ((uint64_t)hi << 32) | lo;
+  uint32_t r = 0;
+  for (int i = 0; i < 4; i++) {
+    unsigned s = (sel >> (8 * i)) & 0xff;
+    unsigned b = s <= 7 ? (unsigned)(src >> (8 * s)) & 0xff : (s == 0x0c ? 0u : (s >= 0x0d ? 0xffu : 0u));
+    r |= b << (8 * i);
+  }
+  return r;
+}
+GS_DEV uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { /* v_alignbit_b32 */
+  return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31));
+}
+#define GS_PK2(expr_lo, expr_hi) ((uint32_t)((expr_lo) & 0xffffu) | ((uint32_t)((expr_hi) & 0xffffu) << 16))
+GS_DEV uint32_t pk_add_u16(uint32_t a, uint32_t b) { return GS_PK2((a & 0xffff) + (b & 0xffff), (a >> 16) + (b >> 16)); }
+GS_DEV uint32_t pk_sub_u16(uint32_t a, uint32_t b) { return GS_PK2((a & 0xffff) - (b & 0xffff), (a >> 16) - (b >> 16)); }
+GS_DEV uint32_t pk_mul_u16(uint32_t a, uint32_t b) { return GS_PK2((a & 0xffff) * (b & 0xffff), (a >> 16) * (b >> 16)); }
+GS_DEV uint32_t pk_shl_u16(uint32_t a, unsigned s) { return GS_PK2((a & 0xffff) << s, (a >> 16) << s); }
+GS_DEV uint32_t pk_shr_u16(uint32_t a, unsigned s) { return GS_PK2((a & 0xffff) >> s, (a >> 16) >> s); }
+GS_DEV uint32_t pk_min_u16(uint32_t a, uint32_t b) {
+  uint32_t al = a & 0xffff, bl = b & 0xffff, ah = a >> 16, bh = b >> 16;
+  return GS_PK2(al < bl ? al : bl, ah < bh ? ah : bh);
+}
+GS_DEV uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+  uint32_t al = a & 0xffff, bl = b & 0xffff, ah = a >> 16, bh = b >> 16;
+  return GS_PK2(al > bl ? al : bl, ah > bh ? ah : bh);
+}
+GS_DEV uint32_t pk_abs_i16(uint32_t a) {
+  int al = (int16_t)(a & 0xffff), ah = (int16_t)(a >> 16);
+  return GS_PK2((uint32_t)(al < 0 ? -al : al), (uint32_t)(ah < 0 ? -ah : ah));
+}
+#else
+/* ------------------------------------------------------------------ gfx950 */
+GS_DEV unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+GS_DEV uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+/* v_mov_b32_dpp wave_shr:1 -- lane i receives lane i-1; lane 0 keeps `fill` */
+GS_DEV uint32_t wave_shr1(uint32_t x, uint32_t fill) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)x, 0x138, 0xf, 0xf, false);
+}
+/* v_mov_b32_dpp wave_shl:1 -- lane i receives lane i+1; lane 63 keeps `fill` */
+GS_DEV uint32_t wave_shl1(uint32_t x, uint32_t fill) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)x, 0x130, 0xf, 0xf, false);
+}
+GS_DEV uint32_t shfl(uint32_t x, int src) { /* ds_bpermute_b32 */
+  return (uint32_t)__builtin_amdgcn_ds_bpermute((src & 63) << 2, (int)x);
+}
+GS_DEV uint32_t perm_b32(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+GS_DEV uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
+
+typedef unsigned short gs_u16x2 __attribute__((ext_vector_type(2)));
+typedef short gs_i16x2 __attribute__((ext_vector_type(2)));
+#define GS_U2(x) __builtin_bit_cast(gs_u16x2, (uint32_t)(x))
+#define GS_I2(x) __builtin_bit_cast(gs_i16x2, (uint32_t)(x))
+#define GS_R(x) __builtin_bit_cast(uint32_t, (x))
+GS_DEV uint32_t pk_add_u16(uint32_t a, uint32_t b) { return GS_R((gs_u16x2)(GS_U2(a) + GS_U2(b))); }  /* v_pk_add_u16 */
+GS_DEV uint32_t pk_sub_u16(uint32_t a, uint32_t b) { return GS_R((gs_u16x2)(GS_U2(a) - GS_U2(b))); }  /* v_pk_sub_u16 */
+GS_DEV uint32_t pk_mul_u16(uint32_t a, uint32_t b) { return GS_R((gs_u16x2)(GS_U2(a) * GS_U2(b))); }  /* v_pk_mul_lo_u16 */
+GS_DEV uint32_t pk_shl_u16(uint32_t a, unsigned s) { return GS_R((gs_u16x2)(GS_U2(a) << (unsigned short)s)); } /* v_pk_lshlrev_b16 */
+GS_DEV uint32_t pk_shr_u16(uint32_t a, unsigned s) { return GS_R((gs_u16x2)(GS_U2(a) >> (unsigned short)s)); } /* v_pk_lshrrev_b16 */
+GS_DEV uint32_t pk_min_u16(uint32_t a, uint32_t b) { return GS_R(__builtin_elementwise_min(GS_U2(a), GS_U2(b))); } /* v_pk_min_u16 */
+GS_DEV uint32_t pk_max_u16(uint32_t a, uint32_t b) { return GS_R(__builtin_elementwise_max(GS_U2(a), GS_U2(b))); } /* v_pk_max_u16 */
+GS_DEV uint32_t pk_abs_i16(uint32_t a) { return GS_R(__builtin_elementwise_abs(GS_I2(a))); }           /* v_pk_sub_i16 + v_pk_max_i16 */
+#endif
+
+/* ------------------------------------------------------------------ common */
+GS_DEV uint32_t readlane0(uint32_t x) { return shfl(x, 0); }
+
+/* inclusive add-scan across the wave (Hillis-Steele over wave_shr-style shuffles) */
+GS_DEV uint32_t wave_incl_scan(uint32_t v) {
+  unsigned l = lane_id();
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t t = shfl(v, (int)l - d);
+    if ((int)l >= d) v += t;
+  }
+  return v;
+}
+GS_DEV uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += shfl(v, (int)(lane_id() ^ (unsigned)d));
+  return v;
+}
+GS_DEV int wave_sum_i(int v) { return (int)wave_sum((uint32_t)v); }
+
+/* bytes {b0,b1,b2,b3} of a dword -> two dwords of u16 pairs: lo=(b0,b1) hi=(b2,b3) */
+GS_DEV uint32_t unpack_lo(uint32_t d) { return perm_b32(0, d, 0x0c010c00u); }
+GS_DEV uint32_t unpack_hi(uint32_t d) { return perm_b32(0, d, 0x0c030c02u); }
+/* inverse: low bytes of the u16 pairs (lo=(p0,p1), hi=(p2,p3)) -> one dword */
+GS_DEV uint32_t pack_lohi(uint32_t lo, uint32_t hi) { return perm_b32(hi, lo, 0x06040200u); }
+
+}  // namespace gs
+#endif

@@ -1,0 +1,116 @@
+/*
+ * include/grayskull_hip.h -- device-resident / batched entry points of
+ * libgrayskull_hip.so (MI355X, gfx950).  Plain C ABI: pointers and sizes only.
+ *
+ * The reference API (grayskull.h) is one image per call on caller-owned host
+ * memory.  A 4K frame is ~2 us of HBM traffic, the same as one kernel boundary, so
+ * throughput needs (a) images that already live in HBM and (b) many frames per
+ * launch.  The gsh_* functions are that: every pointer is a DEVICE pointer, a
+ * batch is `n` frames of w*h bytes laid out back to back, calls are enqueued on
+ * the calling thread's stream and return immediately (no host sync) unless noted.
+ *
+ * Each batch function computes, per frame, exactly what the cited reference
+ * function computes (bit-exact; tests/ compare against the oracle).
+ */
+#ifndef GRAYSKULL_HIP_H
+#define GRAYSKULL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "grayskull.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- runtime ------------------------------------------------------------------- */
+const char *gsh_version(void);
+int gsh_device_count(void);               /* 0 when no GPU is visible                 */
+void gsh_set_device(int ordinal);         /* per calling thread; default device 0      */
+void gsh_set_stream(void *hip_stream);    /* NULL => the library's own per-thread one   */
+void *gsh_get_stream(void);
+void gsh_set_async(int on);               /* drop-in gs_* calls on device pointers skip
+                                             the final stream sync when on             */
+void gsh_sync(void);                      /* hipStreamSynchronize(current stream)       */
+void gsh_shutdown(void);                  /* free this thread's scratch + stream        */
+
+void *gsh_malloc(size_t bytes);           /* hipMalloc; aborts on failure               */
+void gsh_free(void *dev);
+void gsh_memset(void *dev, int byte, size_t bytes);             /* stream-ordered      */
+void gsh_upload(void *dev, const void *host, size_t bytes);     /* synchronous         */
+void gsh_download(void *host, const void *dev, size_t bytes);   /* synchronous         */
+int gsh_is_device_ptr(const void *p);
+
+/* ---- stencils over a batch (ref grayskull.h:268, :306, :303-304) ----------------- */
+void gsh_blur_batch(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned n,
+                    unsigned radius);
+void gsh_sobel_batch(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned n);
+void gsh_erode_batch(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned n);
+void gsh_dilate_batch(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned n);
+
+/* ---- histogram / otsu / threshold (ref :199, :205, :225) ------------------------- */
+/* hist: n x 256 u32 (device).  thr: n x u8 (device). */
+void gsh_histogram_batch(const uint8_t *img, unsigned w, unsigned h, unsigned n, unsigned *hist);
+void gsh_otsu_batch(const uint8_t *img, unsigned w, unsigned h, unsigned n, unsigned *hist_scratch,
+                    uint8_t *thr);
+void gsh_threshold_batch(uint8_t *img, unsigned w, unsigned h, unsigned n, uint8_t thresh);
+void gsh_threshold_batch_dev(uint8_t *img, unsigned w, unsigned h, unsigned n, const uint8_t *thr);
+
+/* config-2 chain per frame: blur(radius) -> sobel (dst frame pre-zeroed) -> otsu -> threshold.
+ * tmp and dst are n*w*h bytes each; thr receives the n Otsu thresholds. */
+void gsh_edge_pipeline_batch(uint8_t *dst, uint8_t *tmp, const uint8_t *src, unsigned w, unsigned h,
+                             unsigned n, unsigned radius, unsigned *hist_scratch, uint8_t *thr);
+
+/* ---- integral image + LBP cascade (ref :744, :815) ------------------------------- */
+/* ii: n frames of w*h u32, same unpadded layout as the reference. */
+void gsh_integral_batch(const uint8_t *src, unsigned w, unsigned h, unsigned n, unsigned *ii);
+
+/* Cascade tables are flattened once into device memory. `c` points at HOST tables. */
+typedef struct gsh_cascade gsh_cascade;
+gsh_cascade *gsh_cascade_create(const struct gs_lbp_cascade *c);
+void gsh_cascade_destroy(gsh_cascade *dc);
+
+/* Per frame f: rects[f*max_rects ...] gets the first min(count,max_rects) detections in the
+ * reference's (scale, y, x) order, counts[f] that number.  ii as produced by gsh_integral_batch.
+ * rects/counts are device pointers.  Stream-ordered. */
+void gsh_lbp_detect_batch(const gsh_cascade *dc, const unsigned *ii, unsigned iw, unsigned ih,
+                          unsigned n, struct gs_rect *rects, unsigned *counts, unsigned max_rects,
+                          float scale_factor, float min_scale, float max_scale, int step);
+/* number of windows gs_lbp_detect visits for this geometry (for Mwin/s reporting) */
+uint64_t gsh_lbp_window_count(const struct gs_lbp_cascade *c, unsigned iw, unsigned ih,
+                              float scale_factor, float min_scale, float max_scale, int step);
+
+/* ---- FAST / ORB / matching (ref :482, :651, :680) -------------------------------- */
+/* kps: n*nkps records (device), counts: n (device).  scoremap: n frames; only the interior is
+ * written, the 3-px frame is read by the NMS exactly like the reference does. */
+void gsh_fast_batch(const uint8_t *img, uint8_t *scoremap, unsigned w, unsigned h, unsigned n,
+                    struct gs_keypoint *kps, unsigned *counts, unsigned nkps, unsigned threshold);
+
+/* Device image -> HOST keypoints.  Synchronous (orientation uses the host libm, like the
+ * reference: grayskull.h:100-101).  Returns the number of keypoints written. */
+unsigned gsh_orb_extract(const uint8_t *img_dev, unsigned w, unsigned h, uint8_t *scoremap_dev,
+                         struct gs_keypoint *kps_host, unsigned nkps, unsigned threshold);
+
+/* All pointers device; matches: max_matches records; count: 1 u32.  Stream-ordered. */
+void gsh_match_orb_dev(const struct gs_keypoint *k1, unsigned n1, const struct gs_keypoint *k2,
+                       unsigned n2, struct gs_match *matches, unsigned *count,
+                       unsigned max_matches, float max_distance);
+
+/* ---- "next" rows (ref :230, :255, :189) ------------------------------------------ */
+void gsh_adaptive_threshold_batch(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h,
+                                  unsigned n, unsigned radius, int c);
+void gsh_filter_batch(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned n,
+                      const int8_t *kernel_host, unsigned kw, unsigned kh, unsigned norm);
+void gsh_downsample_batch(uint8_t *dst, const uint8_t *src, unsigned sw, unsigned sh, unsigned n);
+
+/* ---- synthetic frames + checksums on device (SURVEY.md 8c generator) ------------- */
+/* frame f = synth(w, h, seed0 + f): bit-identical to the CPU generator. */
+void gsh_synth_batch(uint8_t *dst, unsigned w, unsigned h, unsigned n, uint32_t seed0);
+/* sums[f] = order-independent 64-bit checksum of frame f (sum of (i+1)*FNVmix(byte)) */
+void gsh_checksum_batch(const uint8_t *img, size_t frame_bytes, unsigned n, uint64_t *sums);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRAYSKULL_HIP_H */
