@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the Grayskull hot path on MI355X (driver contract: one JSON line).
+
+Workload (BASELINE.json configs[1]): per frame gs_blur(r=2) -> gs_sobel (into a zeroed image) ->
+gs_otsu_threshold -> gs_threshold on 3840x2160 uint8, over a device-resident batch of
+synthetic block-noise frames (SURVEY.md 8c generator, run on the GPU, bit-identical to the CPU
+one).  A step = one pass of that chain over the whole batch; value = input Mpix/s, whole job.
+Frames shard by frame across ranks (weak scaling: --frames per GPU); no data-path collective.
+
+roofline: the slowest kernel of the chain, timed live with events on the launch stream;
+algorithmic bytes = SURVEY.md 8(d) per-pixel traffic x pixels per launch.
+cpu_baseline: the unmodified reference (oracle/_ref, kind "reference") or the C restatement
+(kind "port") on the host cores, same chain, bounded frame sample, rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+
+def time_stream(torch, fn, reps):
+    """average ms per call of fn(), events recorded on the (shared) launch stream"""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def cpu_baseline(w, h, radius, frames_target=48):
+    import threading
+    import numpy as np
+    from oracle import pyoracle
+    kind = "reference" if pyoracle.have_reference() else "port"
+    cores = max(1, min(os.cpu_count() or 1, 32))
+    per = max(1, frames_target // cores)
+    frames = per * cores
+    imgs = [pyoracle.Oracle.synth(w, h, 1000 + i) for i in range(cores)]
+
+    def work(i):
+        o = pyoracle.Oracle(kind)  # ctypes releases the GIL inside the C calls
+        for _ in range(per):
+            s = o.sobel(o.blur(imgs[i], radius))
+            o.threshold(s, o.otsu_threshold(s))
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+    t0 = time.time()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    dt = time.time() - t0
+    return {"value": round(frames * w * h / dt / 1e6, 2), "unit": "Mpix/s", "cores": cores,
+            "kind": kind, "seconds": round(dt, 2),
+            "sample": "%d frames %dx%d, blur(r=%d)->sobel->otsu->threshold, %d threads x %d frames, "
+                      "unmodified reference C (gcc -std=c99 -O2)" % (frames, w, h, radius, cores, per)
+            if kind == "reference" else
+            "%d frames %dx%d, same chain, C restatement (oracle/gs_oracle.c)" % (frames, w, h)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=64, help="frames per GPU (64 x 8.3 MB = 531 MB/plane >> 256 MiB L3)")
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--radius", type=int, default=2)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import grayskull_amd as gs
+    from grayskull_amd.shard import Sharder
+
+    sh = Sharder()
+    assert sh.world == args.gpus or sh.world == 1, "WORLD_SIZE must match --gpus"
+    torch.cuda.set_device(sh.local_rank)
+    g = gs.lib()
+    g.set_device(sh.local_rank)
+    g.use_torch_stream()
+
+    w, h, F, r = args.width, args.height, args.frames, args.radius
+    lo = sh.rank * F  # weak scaling: every rank owns F frames, global index lo..lo+F
+    src = torch.empty((F, h, w), dtype=torch.uint8, device="cuda")
+    tmp = torch.empty_like(src)
+    dst = torch.empty_like(src)
+    hist = torch.zeros((F, 256), dtype=torch.int32, device="cuda")
+    thr = torch.zeros(F, dtype=torch.uint8, device="cuda")
+    g.synth_batch(src, 1000 + lo)  # inputs resident in HBM before the timed region
+    torch.cuda.synchronize()
+
+    def step():
+        g.edge_pipeline_batch(dst, tmp, src, r, hist, thr)
+
+    for _ in range(args.warmup):
+        step()
+    sh.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    sh.barrier()
+    dt = sh.max_over_ranks(time.perf_counter() - t0)
+    npx = F * w * h
+    value = sh.world * npx * args.steps / dt / 1e6
+
+    # ---- per-kernel timing on the launch stream (after the timed region) -------------------
+    reps = max(5, min(args.steps, 20))
+    kernels = {
+        "gs_blur(r=%d) k_blur16" % r: (lambda: g.blur_batch(tmp, src, r), 2.0 * npx),
+        "gs_sobel k_sobel16": (lambda: g.sobel_batch(dst, tmp), float(F * (w * h + (w - 2) * (h - 2)))),
+        "gs_histogram+otsu": (lambda: g.otsu_batch(dst, hist, thr), 1.0 * npx),
+        "gs_threshold k_threshold": (lambda: g.threshold_batch(dst, thr), 2.0 * npx),
+        "gs_erode k_morph16": (lambda: g.erode_batch(dst, src), 2.0 * npx),
+    }
+    ktab = {}
+    for name, (fn, nbytes) in kernels.items():
+        ms = time_stream(torch, fn, reps)
+        ktab[name] = {"ms": round(ms, 4), "GB/s": round(nbytes / ms / 1e6, 1),
+                      "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4), "bytes": nbytes}
+    chain = [k for k in ktab if "erode" not in k]
+    dom = max(chain, key=lambda k: ktab[k]["ms"])
+    roof = {"bound": "hbm", "kernel": dom, "achieved": ktab[dom]["GB/s"], "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": ktab[dom]["frac"], "traffic": None,
+            "algorithmic_bytes_per_launch": ktab[dom]["bytes"], "avg_launch_ms": ktab[dom]["ms"],
+            "frac_of_measured_copy_ceiling_6290": round(ktab[dom]["GB/s"] / 6290.0, 4)}
+
+    # north-star shape: gs_sobel alone on 4096x4096, rotating over 64 distinct frames (1 GiB/plane)
+    ns = None
+    if sh.world == 1:
+        del tmp
+        n4 = 64
+        a4 = torch.empty((n4, 4096, 4096), dtype=torch.uint8, device="cuda")
+        b4 = torch.zeros_like(a4)
+        g.synth_batch(a4, 2)
+        ms = time_stream(torch, lambda: g.sobel_batch(b4, a4), reps)
+        by = float(n4 * (4096 * 4096 + 4094 * 4094))
+        ns = {"Mpix/s": round(n4 * 4096 * 4096 / ms / 1e3, 1), "GB/s": round(by / ms / 1e6, 1),
+              "frac_hbm_peak": round(by / ms / 1e6 / HBM_PEAK_GBS, 4), "frames": n4}
+        del a4, b4
+
+    # ---- verification against the oracle (outside the timed region) -------------------------
+    parity = "skipped"
+    if not args.no_verify and sh.rank == 0:
+        from oracle.pyoracle import Oracle
+        o = Oracle("port")
+        step()
+        torch.cuda.synchronize()
+        ok = True
+        for f in (0, F - 1):
+            img = Oracle.synth(w, h, 1000 + lo + f)
+            s = o.sobel(o.blur(img, r))
+            t = o.otsu_threshold(s)
+            ok &= int(thr[f]) == t and np.array_equal(dst[f].cpu().numpy(), o.threshold(s, t))
+        parity = "bit-exact vs oracle on frames 0 and %d" % (F - 1) if ok else "MISMATCH"
+    thr_all = sh.all_gather_frames(thr, F * sh.world)  # KB-scale result exchange (RCCL when N>1)
+
+    out = {
+        "metric": "Mpix/s for gs_blur(r=2)+gs_sobel+gs_threshold(otsu) on 4K uint8",
+        "value": round(value, 1), "unit": "Mpix/s", "n_gpus": sh.world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+        "data": "synthetic",
+        "config": {"workload": "configs[1]: gs_blur(r=%d) -> gs_sobel -> gs_otsu_threshold -> gs_threshold, "
+                               "%dx%d uint8, %d frames per GPU resident in HBM" % (r, w, h, F),
+                   "frames_per_gpu": F, "global_frames": F * sh.world, "sharding": "by frame, no data-path collective",
+                   "chain_algorithmic_bytes_per_px_unfused": 7, "hbm_peak_GBs": HBM_PEAK_GBS},
+        "roofline": roof, "kernels": ktab, "sobel_4096x4096": ns, "parity": parity,
+        "otsu_thresholds_gathered": int(thr_all.numel()),
+    }
+    if sh.rank == 0 and sh.world == 1 and not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(w, h, r)
+    if sh.rank == 0:
+        print(json.dumps(out))
+    sh.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -208,6 +208,12 @@ class Oracle:
             self.lib.gs_integral(_img(src), _p(ii))
         return ii
 
+    def integral_sum(self, ii, x, y, w, h):
+        ii = np.ascontiguousarray(ii, np.uint32)
+        f = self.lib.orc_integral_sum if self.port else self.lib.ref_integral_sum
+        f.restype = C.c_uint
+        return int(f(_p(ii), C.c_uint(ii.shape[1]), C.c_uint(x), C.c_uint(y), C.c_uint(w), C.c_uint(h)))
+
     def lbp_window(self, cascade, ii, x, y, scale):
         ii = np.ascontiguousarray(ii, np.uint32)
         ih, iw = ii.shape

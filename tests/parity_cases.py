@@ -1,0 +1,168 @@
+"""Backend-agnostic parity checks: HIP path (or its emulated kernel logic) vs the CPU oracle.
+
+`g`   : grayskull_amd.Grayskull bound to a library
+`o`   : oracle.pyoracle.Oracle
+`mem` : Mem("host") -> numpy arrays (staged path) or Mem("device") -> torch CUDA tensors
+        (zero-copy path)
+Integer/byte/index outputs are compared bit-exact; the only float output (keypoint angle) is
+also compared bit-exact because the angle comes from the same host libm as the oracle's.
+"""
+import numpy as np
+
+from grayskull_amd import KEYPOINT_DTYPE, MATCH_DTYPE, RECT_DTYPE
+from oracle.pyoracle import Oracle
+from util import assert_same
+
+SENTINEL = 0xAB
+
+
+class Mem:
+    def __init__(self, kind="host"):
+        self.kind = kind
+
+    def put(self, a):
+        a = np.ascontiguousarray(a)
+        if self.kind == "host":
+            return a.copy()
+        import torch
+        if a.dtype == np.uint32:  # torch has no uint32 arithmetic; carry the bits as int32
+            return torch.from_numpy(a.view(np.int32).copy()).cuda()
+        return torch.from_numpy(a.copy()).cuda()
+
+    def get(self, t, dtype=None):
+        if self.kind == "host":
+            return t
+        a = t.cpu().numpy()
+        return a.view(dtype) if dtype is not None else a
+
+    def zeros(self, shape, dtype=np.uint8, fill=0):
+        return self.put(np.full(shape, fill, dtype))
+
+
+def stencils(g, o, img, mem, radii=(1, 2, 3, 5)):
+    s = mem.put(img)
+    for r in radii:
+        d = mem.zeros(img.shape, fill=SENTINEL)
+        g.blur(d, s, r)
+        assert_same(mem.get(d), o.blur(img, r), "gs_blur r=%d %s" % (r, img.shape))
+    d = mem.zeros(img.shape, fill=SENTINEL)
+    g.sobel(d, s)
+    assert_same(mem.get(d), o.sobel(img, np.full_like(img, SENTINEL)),
+                "gs_sobel (1-px frame must keep the sentinel) %s" % (img.shape,))
+    for name in ("erode", "dilate"):
+        d = mem.zeros(img.shape, fill=SENTINEL)
+        getattr(g, name)(d, s)
+        assert_same(mem.get(d), getattr(o, name)(img), "gs_%s %s" % (name, img.shape))
+
+
+def pointwise(g, o, img, mem):
+    s = mem.put(img)
+    assert_same(g.histogram(s), o.histogram(img), "gs_histogram")
+    assert g.otsu_threshold(s) == o.otsu_threshold(img), "gs_otsu_threshold"
+    for t in (0, 1, 100, 254, 255, o.otsu_threshold(img)):
+        d = mem.put(img)
+        g.threshold(d, t)
+        assert_same(mem.get(d), o.threshold(img, t), "gs_threshold t=%d" % t)
+
+
+def integral(g, o, img, mem):
+    s = mem.put(img)
+    if mem.kind == "host":
+        ii = g.integral(s)
+    else:
+        ii_t = mem.put(np.zeros(img.shape, np.uint32))
+        g.integral(s, ii_t)
+        ii = mem.get(ii_t, np.uint32)
+    assert_same(ii, o.integral(img), "gs_integral")
+
+
+def next_rows(g, o, img, mem):
+    s = mem.put(img)
+    for (r, c) in ((1, 0), (3, 5), (15, 5), (2, -7), (4, 300)):
+        d = mem.zeros(img.shape, fill=SENTINEL)
+        g.adaptive_threshold(d, s, r, c)
+        assert_same(mem.get(d), o.adaptive_threshold(img, r, c), "gs_adaptive_threshold r=%d c=%d" % (r, c))
+    kernels = {"sharpen": ([[0, -1, 0], [-1, 5, -1], [0, -1, 0]], 1),
+               "emboss": ([[-2, -1, 0], [-1, 1, 1], [0, 1, 2]], 1),
+               "box": ([[1, 1, 1], [1, 1, 1], [1, 1, 1]], 9),
+               "gauss": ([[1, 2, 1], [2, 4, 2], [1, 2, 1]], 16),
+               "neg_norm": ([[0, -1, 0], [-1, 2, -1], [0, -1, 0]], 3),
+               "wide": ([[1, 0, -1, 2, 1]], 2)}
+    for name, (k, norm) in kernels.items():
+        k = np.array(k, np.int8)
+        d = mem.zeros(img.shape, fill=SENTINEL)
+        g.filter(d, s, k, norm)
+        assert_same(mem.get(d), o.filter(img, k, norm), "gs_filter %s" % name)
+    if img.shape[0] >= 2 and img.shape[1] >= 2:
+        d = mem.zeros((img.shape[0] // 2, img.shape[1] // 2), fill=SENTINEL)
+        g.downsample(d, s)
+        assert_same(mem.get(d), o.downsample(img), "gs_downsample")
+
+
+def fast(g, o, img, mem, threshold=20, caps=(5000, 7)):
+    h, w = img.shape
+    rs = np.random.RandomState(w * 131 + h)
+    sm0 = rs.randint(0, 256, (h, w)).astype(np.uint8)  # caller-owned frame content is read by NMS
+    s = mem.put(img)
+    for cap in caps:
+        sm = mem.put(sm0)
+        k = g.fast(s, sm, cap, threshold)
+        ko, smo = o.fast(img, cap, threshold, sm0)
+        assert_same(k, ko, "gs_fast keypoints cap=%d" % cap)
+        assert_same(mem.get(sm), smo, "gs_fast scoremap (3-px frame untouched)")
+
+
+def fast_unsigned_wrap_quirk(g, o, mem):
+    """SURVEY 8c quirk KAT: p < threshold makes the 'darker' bound wrap (grayskull.h:498)"""
+    img = np.full((9, 9), 5, np.uint8)
+    for dx, dy in zip((0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1),
+                      (-3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3)):
+        img[4 + dy, 4 + dx] = 20
+    sm = mem.put(np.zeros_like(img))
+    k = g.fast(mem.put(img), sm, 16, 20)
+    ko, smo = o.fast(img, 16, 20)
+    assert_same(k, ko, "FAST wrap quirk keypoints")
+    assert len(k) == 1 and k[0]["response"] == 15 and mem.get(sm)[4, 4] == 15
+
+
+def orb(g, o, img, mem, nkps=50, threshold=20):
+    h, w = img.shape
+    s = mem.put(img)
+    sm = mem.put(np.zeros_like(img))
+    k = g.orb_extract(s, nkps, threshold, sm)
+    ko = o.orb_extract(img, nkps, threshold)
+    assert len(k) == len(ko), "gs_orb_extract count %d vs %d" % (len(k), len(ko))
+    for f in ("x", "y", "response", "desc"):
+        assert_same(k[f], ko[f], "gs_orb_extract." + f)
+    # angle tolerance per north_star is 1e-5; same host libm => we also expect identical bits
+    assert np.allclose(k["angle"], ko["angle"], rtol=0, atol=1e-5), "gs_orb_extract.angle"
+    assert_same(k["angle"].view(np.uint32), ko["angle"].view(np.uint32), "gs_orb_extract.angle bits")
+    # shifted second view -> matching
+    B = np.zeros_like(img)
+    B[:h - 3, :w - 5] = img[3:, 5:]
+    kb = g.orb_extract(mem.put(B), nkps, threshold, mem.put(np.zeros_like(img)))
+    kbo = o.orb_extract(B, nkps, threshold)
+    assert_same(kb, kbo, "gs_orb_extract (shifted frame)")
+    for (mm, md) in ((4 * nkps, 60.0), (3, 80.0), (4 * nkps, 0.0), (4 * nkps, 256.0)):
+        m = g.match_orb(k, kb, mm, md)
+        mo = o.match_orb(ko, kbo, mm, md)
+        assert_same(m, mo, "gs_match_orb max=%d dist=%g" % (mm, md))
+    # single-keypoint API
+    for (x, y) in ((20, 20), (w - 16, h - 16), (15, 15)):
+        if x >= 15 and y >= 15 and x < w - 15 and y < h - 15:
+            a, ao = g.compute_orientation(s, x, y, 15), o.orientation(img, x, y, 15)
+            assert np.float32(a).view(np.uint32) == np.float32(ao).view(np.uint32), "gs_compute_orientation"
+    for (x, y, ang) in ((30, 22, 0.7), (3, 2, -2.1), (w - 1, h - 1, 3.0), (w // 2, h // 2, 0.0)):
+        assert_same(g.brief_descriptor(s, x, y, ang), o.brief(img, x, y, ang), "gs_brief_descriptor")
+
+
+def lbp(g, o, img, mem, casc, params=((4096, 1.1, 1.0, 4.0, 1),), windows=((0, 0, 1.0),)):
+    ii = o.integral(img)
+    ii_m = mem.put(ii)
+    for (mr, sf, mn, mx, step) in params:
+        r = g.lbp_detect(casc, ii_m, mr, sf, mn, mx, step)
+        ro = o.lbp_detect(casc, ii, mr, sf, mn, mx, step)
+        assert_same(r, ro, "gs_lbp_detect max=%d sf=%g [%g,%g] step=%d" % (mr, sf, mn, mx, step))
+    for (x, y, sc) in windows:
+        assert g.lbp_window(casc, ii_m, x, y, sc) == o.lbp_window(casc, ii, x, y, sc), \
+            "gs_lbp_window (%d,%d,%g)" % (x, y, sc)

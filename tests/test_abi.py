@@ -1,0 +1,85 @@
+"""The C boundary: headers compile as strict C99, struct layouts match the reference ABI,
+the product library loads and exports every symbol the headers declare (no compute here)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+INC = os.path.join(ROOT, "include")
+
+
+def declared_functions():
+    names = set()
+    for hdr in ("grayskull.h", "grayskull_hip.h"):
+        txt = open(os.path.join(INC, hdr)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        txt = "\n".join(ln for ln in txt.splitlines() if not ln.lstrip().startswith("#define"))
+        for m in re.finditer(r"\b(gsh?_[a-z0-9_]+)\s*\(", txt):
+            names.add(m.group(1))
+    # header inlines / macros are not library symbols
+    return names - {"gs_valid", "gs_get", "gs_set", "gs_integral_sum", "gs_for"}
+
+
+def test_headers_are_strict_c99_and_layouts_match(tmp_path):
+    src = tmp_path / "abi.c"
+    src.write_text(r'''
+#include <stddef.h>
+#include <stdio.h>
+#include "grayskull_hip.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu ", sizeof(struct gs_image), sizeof(struct gs_rect),
+         sizeof(struct gs_point), sizeof(struct gs_keypoint), sizeof(struct gs_match),
+         sizeof(struct gs_lbp_cascade));
+  printf("%zu %zu %zu %zu %zu\n", offsetof(struct gs_image, data), offsetof(struct gs_keypoint, response),
+         offsetof(struct gs_keypoint, angle), offsetof(struct gs_keypoint, descriptor),
+         offsetof(struct gs_lbp_cascade, features));
+  return 0;
+}''')
+    exe = tmp_path / "abi"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", INC,
+                           str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)]).decode().split()
+    # 16/16/8/48/12/96; data@8, response@8, angle@12, descriptor@16, features@16
+    assert out == ["16", "16", "8", "48", "12", "96", "8", "8", "12", "16", "16"]
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    import grayskull_amd as G
+    lib = G.lib()  # raises ImportError if libgrayskull_hip.so was not built
+    assert "gfx950" in lib.version()
+    declared = declared_functions()
+    assert declared == set(G.EXPORTED_SYMBOLS), declared ^ set(G.EXPORTED_SYMBOLS)
+    nm = subprocess.check_output(["nm", "-D", "--defined-only", G.HIP_LIBRARY]).decode()
+    exported = {ln.split()[-1] for ln in nm.splitlines() if " T " in ln}
+    missing = declared - exported
+    assert not missing, "declared in include/*.h but not exported: %s" % sorted(missing)
+
+
+def test_product_library_has_gfx950_code_and_no_oracle():
+    import grayskull_amd as G
+    blob = open(G.HIP_LIBRARY, "rb").read()
+    assert b"gfx950" in blob
+    nm = subprocess.check_output(["nm", "-D", G.HIP_LIBRARY]).decode()
+    assert "orc_" not in nm and "emu" not in nm.lower().replace("hipmemu", "")
+
+
+def test_c99_dropin_program_against_emulated_kernels(tmp_path, emu):
+    """tests/c/test_dropin.c (C99, -pedantic) linked with the kernel-logic emulator build"""
+    exe = tmp_path / "dropin"
+    emu_dir = os.path.join(ROOT, "tests", "emu")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", INC,
+                           os.path.join(ROOT, "tests", "c", "test_dropin.c"), "-o", str(exe),
+                           "-L", emu_dir, "-l:libgs_kernel_emu.so", "-Wl,-rpath," + emu_dir])
+    out = subprocess.check_output([str(exe)]).decode()
+    assert "all passed" in out
+
+
+def test_blur_magic_divisions_are_exact():
+    """(s*MUL)>>SHIFT == s // d over the whole reachable range (k_stencil.h BlurMagic)"""
+    for r, mul, shift in ((1, 7282, 16), (2, 5243, 17), (3, 2675, 17)):
+        d = (2 * r + 1) ** 2
+        for s in range(0, 255 * d + 1):
+            assert (s * mul) >> shift == s // d
+            assert s * mul < 2 ** 32

@@ -1,0 +1,126 @@
+"""Kernel LOGIC parity on CPU: the same kernel sources (grayskull_amd/csrc/k_*.h + gs_api.cpp)
+compiled for the host-fiber SIMT emulator (tests/emu) and compared with the oracle on tiny
+inputs.  This is a development/CI aid for a container without a GPU -- the real parity tests are
+the `-m gpu` ones in test_gpu_parity.py, which run the HIP build on the MI355X."""
+import numpy as np
+import pytest
+
+import parity_cases as pc
+from oracle.pyoracle import Oracle
+from util import lena, random_cascade
+
+MEM = pc.Mem("host")
+
+# widths: ragged (px kernels), multiples of 16 (strip kernels), >1024 (wave seams), tiny
+SHAPES = [(67, 45), (64, 40), (16, 16), (1040, 7), (2064, 5), (33, 3), (1, 1), (2, 2), (3, 3), (16, 1), (7, 64)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_stencils(emu, oracle, shape):
+    w, h = shape
+    pc.stencils(emu, oracle, Oracle.synth(w, h, w * 7 + h), MEM)
+    rs = np.random.RandomState(w + h)
+    pc.stencils(emu, oracle, rs.randint(0, 256, (h, w)).astype(np.uint8), MEM, radii=(1, 2, 3, 9))
+
+
+def test_stencils_extremes(emu, oracle):
+    for v in (0, 255):
+        pc.stencils(emu, oracle, np.full((9, 48), v, np.uint8), MEM)
+    chk = ((np.indices((10, 32)).sum(0) % 2) * 255).astype(np.uint8)
+    pc.stencils(emu, oracle, chk, MEM)
+    pc.stencils(emu, oracle, Oracle.synth(20, 9, 3), MEM, radii=(0, 20, 1000))  # radius >= image
+
+
+@pytest.mark.parametrize("shape", [(67, 45), (64, 40), (1, 1), (5, 1), (1031, 3), (48, 33)])
+def test_pointwise_and_integral(emu, oracle, shape):
+    w, h = shape
+    img = Oracle.synth(w, h, 11 + w)
+    pc.pointwise(emu, oracle, img, MEM)
+    pc.integral(emu, oracle, img, MEM)
+    pc.integral(emu, oracle, np.full((h, w), 255, np.uint8), MEM)
+
+
+def test_otsu_scan_float_order(emu, oracle):
+    """histograms whose float32 sums exceed 2^24 (rounding order matters)"""
+    rs = np.random.RandomState(5)
+    for _ in range(3):
+        img = rs.choice(256, size=(96, 256), p=rs.dirichlet(np.ones(256) * 0.3)).astype(np.uint8)
+        assert emu.otsu_threshold(img) == oracle.otsu_threshold(img)
+
+
+@pytest.mark.parametrize("shape", [(67, 45), (40, 24)])
+def test_next_rows(emu, oracle, shape):
+    w, h = shape
+    pc.next_rows(emu, oracle, Oracle.synth(w, h, 21), MEM)
+
+
+@pytest.mark.parametrize("shape", [(67, 45), (96, 80), (7, 7), (6, 30), (40, 8)])
+def test_fast(emu, oracle, shape):
+    w, h = shape
+    pc.fast(emu, oracle, Oracle.synth(w, h, 5), MEM)
+    rs = np.random.RandomState(1)
+    pc.fast(emu, oracle, rs.randint(0, 256, (h, w)).astype(np.uint8), MEM, threshold=5, caps=(5000, 1))
+    pc.fast(emu, oracle, rs.randint(0, 40, (h, w)).astype(np.uint8), MEM, threshold=30)  # p < t everywhere
+
+
+def test_fast_quirk(emu, oracle):
+    pc.fast_unsigned_wrap_quirk(emu, oracle, MEM)
+
+
+@pytest.mark.parametrize("shape", [(96, 80), (67, 45)])
+def test_orb_and_match(emu, oracle, shape):
+    w, h = shape
+    pc.orb(emu, oracle, Oracle.synth(w, h, 7), MEM)
+
+
+def test_lbp(emu, oracle, cascade):
+    img = Oracle.synth(96, 80, 7)
+    pc.lbp(emu, oracle, img, MEM, cascade, params=((4096, 1.1, 1.0, 4.0, 1), (10, 1.3, 1.0, 2.0, 3)),
+           windows=((0, 0, 1.0), (5, 3, 1.2), (72, 56, 1.0), (73, 56, 1.0), (0, 0, 3.4)))
+    # a permissive random cascade: hundreds of hits -> exercises (scale, y, x) order and the cap
+    rc = random_cascade(1)
+    pc.lbp(emu, oracle, Oracle.synth(64, 48, 9), MEM, rc,
+           params=((4096, 1.25, 1.0, 2.0, 2), (37, 1.25, 1.0, 2.0, 1), (1, 1.5, 1.0, 1.6, 1)),
+           windows=((0, 0, 1.0), (1, 0, 1.0), (0, 1, 1.5), (40, 24, 1.0)))
+
+
+def test_lena_pipeline(emu, oracle, kat):
+    """config 1 on the reference's own fixture, against the reference-generated hashes"""
+    from util import fnv
+    img = lena()
+    a, b = np.zeros_like(img), np.zeros_like(img)
+    emu.blur(a, img, 2)
+    emu.sobel(b, a)
+    assert fnv(a) == kat["lena"]["blur"]["2"] and fnv(b) == kat["lena"]["blur_sobel"]
+    t = emu.otsu_threshold(img)
+    assert t == kat["lena"]["otsu_src"]
+    c = img.copy()
+    emu.threshold(c, t)
+    assert fnv(c) == kat["lena"]["thr_src"]
+
+
+def test_batch_entry_points(emu, oracle):
+    """gsh_* batch calls (emulator: 'device' memory is host memory)"""
+    n, h, w = 3, 20, 48
+    src = np.stack([Oracle.synth(w, h, 100 + i) for i in range(n)])
+    dst = np.zeros_like(src)
+    emu.blur_batch(dst, src, 2)
+    for i in range(n):
+        assert np.array_equal(dst[i], oracle.blur(src[i], 2))
+    tmp, out = np.zeros_like(src), np.full_like(src, 7)
+    hist = np.zeros((n, 256), np.uint32)
+    thr = np.zeros(n, np.uint8)
+    emu.edge_pipeline_batch(out, tmp, src, 2, hist, thr)
+    for i in range(n):
+        s = oracle.sobel(oracle.blur(src[i], 2))
+        t = oracle.otsu_threshold(s)
+        assert thr[i] == t and np.array_equal(hist[i], oracle.histogram(s))
+        assert np.array_equal(out[i], oracle.threshold(s, t))
+    gen = np.zeros((2, 45, 67), np.uint8)
+    emu.synth_batch(gen, 5)
+    assert np.array_equal(gen[0], Oracle.synth(67, 45, 5)) and np.array_equal(gen[1], Oracle.synth(67, 45, 6))
+    sums = np.zeros(2, np.uint64)
+    emu.checksum_batch(gen, sums)
+    idx = np.arange(1, 67 * 45 + 1, dtype=np.uint64)
+    for i in range(2):
+        assert sums[i] == np.sum(idx * (gen[i].reshape(-1).astype(np.uint64) + 1), dtype=np.uint64)

@@ -1,0 +1,302 @@
+"""Parity tests proper: the HIP path on a real MI355X, called through the C ABI, against the CPU
+oracle on the same seeded inputs -- bit-exact for every integer/byte/index output; the ORB angle
+is within 1e-5 (and in fact identical bits, same host libm).  Also the reference-generated golden
+vectors at BASELINE.json's full sizes and size-independent properties on batches."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import parity_cases as pc
+from oracle.pyoracle import Oracle
+from util import assert_same, fnv, lena, random_cascade
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST, DEV = pc.Mem("host"), pc.Mem("device")
+
+SHAPES = [(67, 45), (64, 40), (16, 16), (1040, 7), (2064, 5), (33, 3), (1, 1), (3, 3), (16, 1),
+          (640, 480), (1280, 720), (1001, 333), (4095, 9), (4097, 5), (4112, 6)]
+
+
+@pytest.mark.parametrize("mem", [HOST, DEV], ids=["host", "device"])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_stencils(hip, oracle, shape, mem):
+    w, h = shape
+    pc.stencils(hip, oracle, Oracle.synth(w, h, w * 7 + h), mem)
+    rs = np.random.RandomState(w + h)
+    pc.stencils(hip, oracle, rs.randint(0, 256, (h, w)).astype(np.uint8), mem, radii=(1, 2, 3, 9))
+
+
+def test_stencils_extremes(hip, oracle):
+    for mem in (HOST, DEV):
+        for v in (0, 255):
+            pc.stencils(hip, oracle, np.full((9, 48), v, np.uint8), mem)
+        chk = ((np.indices((10, 32)).sum(0) % 2) * 255).astype(np.uint8)
+        pc.stencils(hip, oracle, chk, mem)
+        pc.stencils(hip, oracle, Oracle.synth(20, 9, 3), mem, radii=(0, 20, 1000))
+        pc.stencils(hip, oracle, Oracle.synth(2048, 64, 4), mem, radii=(1, 2, 3, 20))
+
+
+def test_strip_kernels_on_unaligned_device_views(hip, oracle):
+    """frames at odd byte offsets inside a device buffer must fall back correctly"""
+    import torch
+    img = Oracle.synth(64, 40, 1)
+    for off in (1, 4, 16):
+        buf = torch.zeros(64 * 40 * 2 + 64, dtype=torch.uint8, device="cuda")
+        s = buf[off:off + 64 * 40].view(40, 64)
+        s.copy_(torch.from_numpy(img))
+        d = torch.full((64 * 40 + 64,), 0xAB, dtype=torch.uint8, device="cuda")
+        dv = d[off:off + 64 * 40].view(40, 64)
+        hip.blur(dv, s, 2)
+        assert_same(dv.cpu().numpy(), oracle.blur(img, 2), "blur at offset %d" % off)
+        assert int(d[off - 1]) == 0xAB and int(d[off + 64 * 40]) == 0xAB
+        hip.threshold(dv, 90)
+        assert_same(dv.cpu().numpy(), oracle.threshold(oracle.blur(img, 2), 90), "threshold at offset %d" % off)
+        assert int(d[off - 1]) == 0xAB and int(d[off + 64 * 40]) == 0xAB
+        assert_same(hip.histogram(s), oracle.histogram(img), "hist at offset %d" % off)
+
+
+@pytest.mark.parametrize("mem", [HOST, DEV], ids=["host", "device"])
+@pytest.mark.parametrize("shape", [(67, 45), (64, 40), (1, 1), (5, 1), (1031, 3), (1920, 1080), (4096, 512)])
+def test_pointwise_and_integral(hip, oracle, shape, mem):
+    w, h = shape
+    img = Oracle.synth(w, h, 11 + w)
+    pc.pointwise(hip, oracle, img, mem)
+    pc.integral(hip, oracle, img, mem)
+    pc.integral(hip, oracle, np.full((h, w), 255, np.uint8), mem)
+
+
+def test_otsu_scan_float_order(hip, oracle):
+    rs = np.random.RandomState(5)
+    for _ in range(8):
+        img = rs.choice(256, size=(2160, 3840), p=rs.dirichlet(np.ones(256) * 0.3)).astype(np.uint8)
+        assert hip.otsu_threshold(img) == oracle.otsu_threshold(img)
+
+
+@pytest.mark.parametrize("mem", [HOST, DEV], ids=["host", "device"])
+@pytest.mark.parametrize("shape", [(67, 45), (640, 480)])
+def test_next_rows(hip, oracle, shape, mem):
+    w, h = shape
+    pc.next_rows(hip, oracle, Oracle.synth(w, h, 21), mem)
+
+
+@pytest.mark.parametrize("mem", [HOST, DEV], ids=["host", "device"])
+@pytest.mark.parametrize("shape", [(67, 45), (96, 80), (7, 7), (6, 30), (40, 8), (640, 480), (1283, 517)])
+def test_fast(hip, oracle, shape, mem):
+    w, h = shape
+    pc.fast(hip, oracle, Oracle.synth(w, h, 5), mem)
+    rs = np.random.RandomState(1)
+    pc.fast(hip, oracle, rs.randint(0, 256, (h, w)).astype(np.uint8), mem, threshold=5, caps=(5000, 1))
+    pc.fast(hip, oracle, rs.randint(0, 40, (h, w)).astype(np.uint8), mem, threshold=30)
+
+
+def test_fast_quirk(hip, oracle):
+    pc.fast_unsigned_wrap_quirk(hip, oracle, HOST)
+    pc.fast_unsigned_wrap_quirk(hip, oracle, DEV)
+
+
+@pytest.mark.parametrize("mem", [HOST, DEV], ids=["host", "device"])
+@pytest.mark.parametrize("shape", [(96, 80), (67, 45), (640, 480)])
+def test_orb_and_match(hip, oracle, shape, mem):
+    w, h = shape
+    pc.orb(hip, oracle, Oracle.synth(w, h, 7), mem, nkps=50 if w < 600 else 500)
+
+
+@pytest.mark.parametrize("mem", [HOST, DEV], ids=["host", "device"])
+def test_lbp(hip, oracle, cascade, mem):
+    pc.lbp(hip, oracle, Oracle.synth(96, 80, 7), mem, cascade,
+           params=((4096, 1.1, 1.0, 4.0, 1), (10, 1.3, 1.0, 2.0, 3)),
+           windows=((0, 0, 1.0), (5, 3, 1.2), (72, 56, 1.0), (73, 56, 1.0), (0, 0, 3.4)))
+    rc = random_cascade(1)
+    pc.lbp(hip, oracle, Oracle.synth(320, 200, 9), mem, rc,
+           params=((4096, 1.25, 1.0, 2.0, 2), (37, 1.25, 1.0, 2.0, 1), (1, 1.5, 1.0, 1.6, 1), (100000, 1.2, 1.0, 3.0, 1)),
+           windows=((0, 0, 1.0), (1, 0, 1.0), (0, 1, 1.5), (40, 24, 1.0)))
+    pc.lbp(hip, oracle, Oracle.synth(640, 480, 3), mem, cascade, params=((4096, 1.2, 1.0, 4.0, 2),))
+
+
+# ---- golden vectors generated by the unmodified reference, at the BASELINE.json sizes --------
+def test_kat_lena(hip, kat):
+    k, img = kat["lena"], lena()
+    a, b = np.zeros_like(img), np.zeros_like(img)
+    for r, hsh in k["blur"].items():
+        hip.blur(a, img, int(r))
+        assert fnv(a) == hsh
+    hip.blur(a, img, 2)
+    hip.sobel(b, a)
+    assert fnv(b) == k["blur_sobel"]
+    assert hip.otsu_threshold(img) == k["otsu_src"]
+    c = img.copy()
+    hip.threshold(c, k["otsu_src"])
+    assert fnv(c) == k["thr_src"]
+    for name in ("sobel", "erode", "dilate"):
+        d = np.zeros_like(img)
+        getattr(hip, name)(d, img)
+        assert fnv(d) == k[name]
+    ii = hip.integral(img)
+    assert fnv(ii) == k["integral"] and int(ii[-1, -1]) == k["integral_last"]
+    d = np.zeros_like(img)
+    hip.adaptive_threshold(d, img, 15, 5)
+    assert fnv(d) == k["adaptive_r15_c5"]
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2, 3, 4])
+def test_kat_synth_config2_chain(hip, kat, idx):
+    """config 2: gs_blur(r=2) -> gs_sobel (zeroed dst) -> gs_otsu_threshold -> gs_threshold"""
+    import torch
+    k = kat["synth"][idx]
+    w, h = k["w"], k["h"]
+    src = torch.zeros((1, h, w), dtype=torch.uint8, device="cuda")
+    hip.synth_batch(src, k["seed"])
+    img = src[0].cpu().numpy()
+    assert fnv(img) == k["src"], "device generator == CPU generator"
+    a = torch.zeros_like(src[0])
+    b = torch.zeros_like(src[0])
+    hip.blur(a, src[0], 2)
+    assert fnv(a.cpu().numpy()) == k["blur2"]
+    hip.sobel(b, a)
+    assert fnv(b.cpu().numpy()) == k["blur_sobel"]
+    t = hip.otsu_threshold(b)
+    assert t == k["otsu"]
+    hip.threshold(b, t)
+    assert fnv(b.cpu().numpy()) == k["thr"]
+    for name in ("sobel", "erode", "dilate"):
+        d = torch.zeros_like(src[0])
+        getattr(hip, name)(d, src[0])
+        assert fnv(d.cpu().numpy()) == k[name], name
+    ii = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+    hip.integral(src[0], ii)
+    assert fnv(ii.cpu().numpy()) == k["integral"]
+    # the fused batch entry point must give the same bytes
+    tmp, out = torch.zeros_like(src), torch.full_like(src, 9)
+    hist = torch.zeros((1, 256), dtype=torch.int32, device="cuda")
+    thr = torch.zeros(1, dtype=torch.uint8, device="cuda")
+    hip.edge_pipeline_batch(out, tmp, src, 2, hist, thr)
+    assert int(thr[0]) == k["otsu"] and fnv(out[0].cpu().numpy()) == k["thr"]
+
+
+@pytest.mark.parametrize("idx", [2, 3, 4])
+def test_kat_synth_features(hip, kat, cascade, idx):
+    """configs 3 and 4: integral + LBP cascade, FAST, ORB on the reference-generated vectors"""
+    k = kat["synth"][idx]
+    img = Oracle.synth(k["w"], k["h"], k["seed"])
+    p = kat["fast_params"]
+    sm = np.zeros_like(img)
+    kps = hip.fast(img, sm, p["nkps"], p["threshold"])
+    assert len(kps) == k["fast"]["n"] and fnv(kps) == k["fast"]["kp"] and fnv(sm) == k["fast"]["scoremap"]
+    p = kat["orb_params"]
+    ok = hip.orb_extract(img, p["nkps"], p["threshold"], np.zeros_like(img))
+    assert len(ok) == k["orb"]["n"] and fnv(ok) == k["orb"]["kp"]
+    p = kat["lbp_params"]
+    r = hip.lbp_detect(cascade, hip.integral(img), p["max_rects"], p["scale_factor"], p["min_scale"],
+                       p["max_scale"], p["step"])
+    assert len(r) == k["lbp"]["n"] and fnv(r) == k["lbp"]["rects"]
+
+
+def test_kat_orb_match(hip, kat):
+    k = kat["orb_match"]
+    A = Oracle.synth(k["w"], k["h"], k["seed"])
+    B = np.zeros_like(A)
+    sx, sy = k["shift"]
+    B[:k["h"] - sy, :k["w"] - sx] = A[sy:, sx:]
+    ka = hip.orb_extract(A, k["nkps"], k["threshold"], np.zeros_like(A))
+    kb = hip.orb_extract(B, k["nkps"], k["threshold"], np.zeros_like(A))
+    m = hip.match_orb(ka, kb, k["max_matches"], k["max_distance"])
+    assert len(m) == k["n"] and fnv(m) == k["matches"]
+    ka = hip.orb_extract(A, 2500, k["threshold"], np.zeros_like(A))
+    kb = hip.orb_extract(B, 2500, k["threshold"], np.zeros_like(A))
+    assert len(hip.match_orb(ka, kb, 2500, k["max_distance"])) == k["n_nkps2500"]
+
+
+# ---- batches at full size: oracle on a sample of frames + size-independent properties ---------
+def test_batch_4k_properties(hip, oracle):
+    import torch
+    n, h, w = 12, 2160, 3840
+    src = torch.zeros((n, h, w), dtype=torch.uint8, device="cuda")
+    hip.synth_batch(src, 1000)
+    assert np.array_equal(src[5].cpu().numpy(), Oracle.synth(w, h, 1005))
+    blur, sob, ero, dil = (torch.zeros_like(src) for _ in range(4))
+    hip.blur_batch(blur, src, 2)
+    hip.sobel_batch(sob, blur)
+    hip.erode_batch(ero, src)
+    hip.dilate_batch(dil, src)
+    hip.sync()
+    for f in (0, 7, 11):  # oracle on a sample
+        s = src[f].cpu().numpy()
+        b = oracle.blur(s, 2)
+        assert_same(blur[f].cpu().numpy(), b, "blur_batch frame %d" % f)
+        assert_same(sob[f].cpu().numpy(), oracle.sobel(b), "sobel_batch frame %d" % f)
+        assert_same(ero[f].cpu().numpy(), oracle.erode(s), "erode_batch frame %d" % f)
+        assert_same(dil[f].cpu().numpy(), oracle.dilate(s), "dilate_batch frame %d" % f)
+    # properties over the whole batch
+    assert bool((ero <= src).all()) and bool((src <= dil).all())
+    assert int(sob[:, 0, :].max()) == 0 and int(sob[:, :, 0].max()) == 0  # frame never written
+    hist = torch.zeros((n, 256), dtype=torch.int32, device="cuda")
+    hip.histogram_batch(src, hist)
+    assert bool((hist.sum(1) == w * h).all())
+    # checksum of checksums: the per-frame device checksums equal the CPU ones for every frame
+    sums = torch.zeros(n, dtype=torch.int64, device="cuda")
+    hip.checksum_batch(blur, sums)
+    idx = np.arange(1, w * h + 1, dtype=np.uint64)
+    for f in (0, 3):
+        exp = np.sum(idx * (oracle.blur(src[f].cpu().numpy(), 2).reshape(-1).astype(np.uint64) + 1), dtype=np.uint64)
+        assert np.uint64(sums[f].cpu().numpy().view(np.uint64)) == exp
+    # threshold is idempotent, and edge_pipeline == the separate calls
+    thr = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    out, tmp = torch.full_like(src, 3), torch.zeros_like(src)
+    hip.edge_pipeline_batch(out, tmp, src, 2, hist, thr)
+    once = out.clone()
+    hip.threshold_batch(out, thr)
+    assert bool((once == out).all())
+    assert bool(((out == 0) | (out == 255)).all())
+    for f in (2, 9):
+        s = oracle.sobel(oracle.blur(src[f].cpu().numpy(), 2))
+        t = oracle.otsu_threshold(s)
+        assert int(thr[f]) == t
+        assert_same(once[f].cpu().numpy(), oracle.threshold(s, t), "edge pipeline frame %d" % f)
+
+
+def test_batch_integral_lbp_fast(hip, oracle, cascade):
+    import torch
+    n, h, w = 3, 480, 640
+    frames = np.stack([Oracle.synth(w, h, 50 + i) for i in range(n)])
+    src = torch.from_numpy(frames).cuda()
+    ii = torch.zeros((n, h, w), dtype=torch.int32, device="cuda")
+    hip.integral_batch(src, ii)
+    rc = random_cascade(2)
+    for casc, cap in ((cascade, 4096), (rc, 300)):
+        dc = hip.cascade_create(casc)
+        rects = torch.zeros((n, cap, 4), dtype=torch.int32, device="cuda")
+        counts = torch.zeros(n, dtype=torch.int32, device="cuda")
+        hip.lbp_detect_batch(dc, ii, rects, counts, cap, 1.2, 1.0, 3.0, 2)
+        hip.sync()
+        for f in range(n):
+            ro = oracle.lbp_detect(casc, oracle.integral(frames[f]), cap, 1.2, 1.0, 3.0, 2)
+            assert int(counts[f]) == len(ro)
+            got = rects[f, :len(ro)].cpu().numpy().view(np.uint32)
+            assert_same(got, np.stack([ro["x"], ro["y"], ro["w"], ro["h"]], 1) if len(ro) else got, "lbp batch frame %d" % f)
+        dc.close()
+    sm = torch.zeros_like(src)
+    kps = torch.zeros((n, 800, 12), dtype=torch.int32, device="cuda")
+    counts = torch.zeros(n, dtype=torch.int32, device="cuda")
+    hip.fast_batch(src, sm, kps, counts, 800, 20)
+    hip.sync()
+    for f in range(n):
+        ko, smo = oracle.fast(frames[f], 800, 20)
+        assert int(counts[f]) == len(ko)
+        assert_same(kps[f, :len(ko)].cpu().numpy().reshape(-1).view(ko.dtype), ko, "fast batch frame %d" % f)
+        assert_same(sm[f].cpu().numpy(), smo, "fast batch scoremap %d" % f)
+
+
+def test_c99_dropin_program_on_gpu(tmp_path):
+    """tests/c/test_dropin.c (strict C99) linked against the real libgrayskull_hip.so"""
+    exe = tmp_path / "dropin"
+    libdir = os.path.join(ROOT, "grayskull_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I",
+                           os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "test_dropin.c"),
+                           "-o", str(exe), "-L", libdir, "-l:libgrayskull_hip.so", "-Wl,-rpath," + libdir,
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.check_output([str(exe)]).decode()
+    assert "all passed" in out
