@@ -143,7 +143,6 @@ def main():
     # north-star shape: gs_sobel alone on 4096x4096, rotating over 64 distinct frames (1 GiB/plane)
     ns = None
     if sh.world == 1:
-        del tmp
         n4 = 64
         a4 = torch.empty((n4, 4096, 4096), dtype=torch.uint8, device="cuda")
         b4 = torch.zeros_like(a4)
