@@ -80,6 +80,8 @@ _SIGS = {
     "gsh_get_stream": (C.c_void_p, []),
     "gsh_set_async": (None, [C.c_int]),
     "gsh_sync": (None, []),
+    "gsh_tune": (None, [C.c_int, C.c_int]),
+    "gsh_probe_strip_copy": (None, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint]),
     "gsh_shutdown": (None, []),
     "gsh_malloc": (C.c_void_p, [C.c_size_t]),
     "gsh_free": (None, [C.c_void_p]),
@@ -160,6 +162,13 @@ class Grayskull:
 
     def sync(self):
         self.c.gsh_sync()
+
+    def tune(self, key, value):
+        self.c.gsh_tune(int(key), int(value))
+
+    def probe_strip_copy(self, dst, src):
+        n, h, w = self._nhw(src)
+        self.c.gsh_probe_strip_copy(_ptr(dst), _ptr(src), w, h, n)
 
     # ------------------------------------------------------------------ drop-in (one image)
     def blur(self, dst, src, radius):  # grayskull.h:268

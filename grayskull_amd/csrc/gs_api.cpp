@@ -26,6 +26,7 @@
 
 #include "../../include/grayskull_hip.h"
 
+#define GS_COMMA ,
 #define GS_ASSERT(cond)                                 \
   do {                                                  \
     if (!(cond)) {                                      \
@@ -51,7 +52,7 @@ namespace {
 /* ------------------------------------------------------------------ per-thread context */
 enum Slot { SL_IN = 0, SL_OUT, SL_AUX, SL_AUX2, SL_II, SL_PAD, SL_MASK, SL_CNT, SL_PFX, SL_TOT,
             SL_HISTP, SL_HIST, SL_THR, SL_KPS, SL_MOM, SL_KIN, SL_DESC, SL_TAB, SL_JUMP, SL_LEV,
-            SL_BEST, SL_COUNT };
+            SL_BEST, SL_COLS, SL_COUNT };
 
 struct Ctx {
   int device = 0;
@@ -144,18 +145,41 @@ void finish(bool any_host_output) {
 dim3 grid2d(unsigned w, unsigned h, unsigned n) { return dim3((w + 63) / 64, (h + 3) / 4, n); }
 inline bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
-/* rows per band for the strip kernels: enough waves to fill 256 CUs, bands as tall as possible */
-unsigned strip_rows(unsigned w, unsigned h, unsigned n) {
-  const unsigned long long cols = (w + 1023) / 1024;
-  unsigned long long t = (unsigned long long)h * cols * n / 16384ull;
-  if (t < 8) t = 8;
-  if (t > 64) t = 64;
-  return (unsigned)t;
+/* ---- launch tuning (gsh_tune): 0 rows per band (0 = auto), 1 block shape, 2 prefetch depth */
+int g_tune[8] = {0, 1, 1, 0, 0, 0, 0, 0};
+
+struct StripCfg { dim3 grid, block; unsigned T; };
+/* rows: output rows per frame.  Bands as tall as possible while >= ~4K waves keep 256 CUs busy. */
+StripCfg strip_cfg(unsigned w, unsigned rows, unsigned n) {
+  StripCfg c;
+  const unsigned strips = (w + 15) / 16;
+  const unsigned long long waves_x = (strips + 63) / 64;
+  unsigned long long t = g_tune[0] > 0 ? (unsigned long long)g_tune[0]
+                                       : (unsigned long long)rows * waves_x * n / 4096ull;
+  if (g_tune[0] <= 0) { /* measured on MI355X: 128-row bands beat shorter ones once >= ~4K waves exist */
+    if (t < 8) t = 8;
+    if (t > 128) t = 128;
+  }
+  c.T = (unsigned)t;
+  const unsigned nb = (rows + c.T - 1) / c.T;
+  unsigned bx = 256, by = 1;
+  if (g_tune[1] == 0) bx = 64, by = 4;
+  else if (g_tune[1] == 2) bx = 128, by = 2;
+  c.block = dim3(bx, by);
+  c.grid = dim3((strips + bx - 1) / bx, (nb + by - 1) / by, n);
+  return c;
+}
+inline bool strip_ok(unsigned w, unsigned h, const void *a, const void *b) {
+  return w % 16 == 0 && (unsigned long long)w * h < 0x7fffffffull && al16(a) && al16(b);
 }
 constexpr unsigned kMaxZ = 32768; /* frames per launch (grid.z limit 65535) */
 
 /* ------------------------------------------------------------------ stencil launchers */
-void launch_sobel(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned n) {
+/* keep_cols: the strip kernel overwrites columns 0 / w-1 of rows 1..h-2 (ref never writes them);
+ * true = save and restore them around the launch, false = the caller does not care (it copies
+ * back the interior only, or zeroes the frame afterwards). */
+void launch_sobel(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned n,
+                  bool keep_cols = true) {
   if (w < 3 || h < 3 || n == 0) return;
   hipStream_t st = ctx().s();
   const size_t fb = (size_t)w * h;
@@ -163,10 +187,13 @@ void launch_sobel(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsi
     const unsigned nn = std::min(kMaxZ, n - f0);
     uint8_t *d = dst + fb * f0;
     const uint8_t *s = src + fb * f0;
-    if (w % 16 == 0 && al16(d) && al16(s)) {
-      const unsigned T = strip_rows(w, h, nn), nb = (h - 2 + T - 1) / T;
-      GS_LAUNCH(k_sobel16, dim3((w + 1023) / 1024, (nb + 3) / 4, nn), dim3(64, 4), 0, st, d, s, w,
-                h, T, fb);
+    if (strip_ok(w, h, d, s)) {
+      const StripCfg c = strip_cfg(w, h - 2, nn);
+      uint8_t *cols = keep_cols ? (uint8_t *)ctx().scratch(SL_COLS, (size_t)nn * 2 * h) : nullptr;
+      const dim3 cg((2 * h + 255) / 256, nn);
+      if (keep_cols) GS_LAUNCH(k_edge_cols, cg, dim3(256), 0, st, d, cols, w, h, fb, 0);
+      GS_LAUNCH(k_sobel16, c.grid, c.block, 0, st, d, s, w, h, c.T, fb);
+      if (keep_cols) GS_LAUNCH(k_edge_cols, cg, dim3(256), 0, st, d, cols, w, h, fb, 1);
     } else {
       GS_LAUNCH(k_sobel_px, grid2d(w, h, nn), dim3(64, 4), 0, st, d, s, w, h, fb);
     }
@@ -182,10 +209,9 @@ void launch_morph(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsi
     const unsigned nn = std::min(kMaxZ, n - f0);
     uint8_t *d = dst + fb * f0;
     const uint8_t *s = src + fb * f0;
-    if (w % 16 == 0 && al16(d) && al16(s)) {
-      const unsigned T = strip_rows(w, h, nn), nb = (h + T - 1) / T;
-      GS_LAUNCH(k_morph16<DILATE>, dim3((w + 1023) / 1024, (nb + 3) / 4, nn), dim3(64, 4), 0, st,
-                d, s, w, h, T, fb);
+    if (strip_ok(w, h, d, s)) {
+      const StripCfg c = strip_cfg(w, h, nn);
+      GS_LAUNCH(k_morph16<DILATE>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb);
     } else {
       GS_LAUNCH(k_morph_px<DILATE>, grid2d(w, h, nn), dim3(64, 4), 0, st, d, s, w, h, fb);
     }
@@ -226,16 +252,19 @@ void launch_blur(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsig
   if (n == 0) return;
   hipStream_t st = ctx().s();
   const size_t fb = (size_t)w * h;
-  if (radius >= 1 && radius <= 3 && w % 16 == 0 && al16(dst) && al16(src)) {
+  if (radius >= 1 && radius <= 3 && strip_ok(w, h, dst, src) && h > 2 * radius && w > 2 * radius) {
     for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
       const unsigned nn = std::min(kMaxZ, n - f0);
-      const unsigned T = strip_rows(w, h, nn), nb = (h + T - 1) / T;
-      const dim3 g((w + 1023) / 1024, (nb + 3) / 4, nn), b(64, 4);
+      const StripCfg c = strip_cfg(w, h, nn);
       uint8_t *d = dst + fb * f0;
       const uint8_t *s = src + fb * f0;
-      if (radius == 1) GS_LAUNCH(k_blur16<1>, g, b, 0, st, d, s, w, h, T, fb);
-      else if (radius == 2) GS_LAUNCH(k_blur16<2>, g, b, 0, st, d, s, w, h, T, fb);
-      else GS_LAUNCH(k_blur16<3>, g, b, 0, st, d, s, w, h, T, fb);
+      if (radius == 1) GS_LAUNCH(k_blur16<1>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb);
+      else if (radius == 2) GS_LAUNCH(k_blur16<2>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb);
+      else GS_LAUNCH(k_blur16<3>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb);
+      /* clipped-window pixels (the radius-wide frame) get their true divisor */
+      const unsigned npx = 2 * radius * w + (h - 2 * radius) * 2 * radius;
+      GS_LAUNCH(k_blur_frame_px, dim3((npx + 255) / 256, nn), dim3(256), 0, st, d, s, w, h,
+                (int)radius, fb);
     }
     return;
   }
@@ -279,8 +308,11 @@ void launch_threshold(uint8_t *img, size_t frame_bytes, unsigned n, const uint8_
 void launch_otsu(const uint8_t *img, unsigned w, unsigned h, unsigned n, unsigned *hist,
                  uint8_t *thr) {
   launch_histogram(img, (size_t)(w * h), n, hist);
-  GS_LAUNCH(k_otsu_scan, dim3((n + 63) / 64), dim3(64), 0, ctx().s(), (const unsigned *)hist,
-            w * h, n, thr);
+  for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
+    const unsigned nn = std::min(kMaxZ, n - f0);
+    GS_LAUNCH(k_otsu, dim3(nn), dim3(256), 0, ctx().s(), (const unsigned *)hist + (size_t)f0 * 256,
+              w * h, thr + f0);
+  }
 }
 
 /* ------------------------------------------------------------------ ordered compaction driver */
@@ -612,6 +644,14 @@ void gsh_set_stream(void *s) {
 }
 void *gsh_get_stream(void) { return (void *)ctx().s(); }
 void gsh_set_async(int on) { ctx().async = on != 0; }
+void gsh_tune(int key, int value) {
+  if (key >= 0 && key < 8) g_tune[key] = value;
+}
+void gsh_probe_strip_copy(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned n) {
+  GS_ASSERT(dst && src && w % 16 == 0 && al16(dst) && al16(src));
+  const StripCfg c = strip_cfg(w, h, n);
+  GS_LAUNCH(k_strip_copy, c.grid, c.block, 0, ctx().s(), dst, src, w, h, c.T, (size_t)w * h);
+}
 void gsh_sync(void) { ctx().sync(); }
 void gsh_shutdown(void) { ctx().release(); }
 void *gsh_malloc(size_t bytes) {
@@ -678,9 +718,15 @@ void gsh_edge_pipeline_batch(uint8_t *dst, uint8_t *tmp, const uint8_t *src, uns
   GS_ASSERT(dst && tmp && src && hist_scratch && thr && w > 0 && h > 0);
   const size_t fb = (size_t)w * h;
   launch_blur(tmp, src, w, h, n, radius);
-  /* sobel never writes its 1-px frame (ref :308-309): config 2 runs it into a zeroed image */
-  GS_HIP(hipMemsetAsync(dst, 0, fb * n, ctx().s()));
-  launch_sobel(dst, tmp, w, h, n);
+  /* sobel never writes its 1-px frame (ref :308-309); config 2 runs it into a zeroed image, so
+   * only that frame needs zeroing (the interior is overwritten) -- after the sobel launch,
+   * which then need not preserve columns 0 / w-1 */
+  if (w < 3 || h < 3) GS_HIP(hipMemsetAsync(dst, 0, fb * n, ctx().s()));
+  launch_sobel(dst, tmp, w, h, n, false);
+  if (w >= 3 && h >= 3)
+    for (unsigned f0 = 0; f0 < n; f0 += kMaxZ)
+      GS_LAUNCH(k_zero_frame, dim3((2 * w + 2 * h + 255) / 256, std::min(kMaxZ, n - f0)), dim3(256), 0,
+                ctx().s(), dst + fb * f0, w, h, fb);
   launch_otsu(dst, w, h, n, hist_scratch, thr);
   launch_threshold(dst, fb, n, thr, 0);
 }
@@ -884,7 +930,7 @@ void gs_sobel(struct gs_image dst, struct gs_image src) { /* ref :306 */
   const uint8_t *s = (const uint8_t *)stage_in(src.data, nb, SL_IN);
   const bool dhost = !is_dev(dst.data);
   uint8_t *d = dhost ? (uint8_t *)ctx().scratch(SL_OUT, nb) : dst.data;
-  launch_sobel(d, s, w, h, 1);
+  launch_sobel(d, s, w, h, 1, !dhost);
   /* the 1-px frame of dst is never written (ref :308-309): copy back the interior only */
   if (dhost)
     GS_HIP(hipMemcpy2DAsync(dst.data + w + 1, w, d + w + 1, w, w - 2, h - 2, hipMemcpyDeviceToHost,

@@ -102,30 +102,74 @@ __global__ __launch_bounds__(256) void k_hist_reduce(const unsigned *partial, un
   hist[(size_t)blockIdx.x * 256u + threadIdx.x] = s;
 }
 
-/* ref :205-223 -- the 256-step float32 scan, one thread per frame, same expression order,
- * no FMA contraction (IEEE add/mul/div are correctly rounded on gfx950 as on x86-64). */
-__global__ void k_otsu_scan(const unsigned *hist, unsigned npix, unsigned n, uint8_t *thr) {
+/* ref :205-223.  The reference's scan is a chain of float32 adds (sum / sumB) followed, per t,
+ * by an expression of (wb, sumB_t, sum) only.  So: every thread forms its product
+ * (float)t*hist[t] (same rounding as the reference's), ONE thread runs the sequential add chain
+ * once (prefix p[t] == the reference's sumB after step t, and p[255] == its `sum`: same values,
+ * same order), then all 256 between-class variances are evaluated in parallel and reduced with
+ * "greater wins, first index on ties" == the reference's strict `>` update.  No FMA contraction;
+ * IEEE add/mul/div are correctly rounded on gfx950 as on x86-64.  grid n frames, block 256. */
+__global__ __launch_bounds__(256) void k_otsu(const unsigned *hist, unsigned npix, uint8_t *thr) {
 #ifndef GS_EMU
 #pragma clang fp contract(off)
 #endif
-  const unsigned f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= n) return;
-  const unsigned *hg = hist + (size_t)f * 256u;
-  unsigned wb = 0, wf = 0, best = 0;
-  float sum = 0, sumB = 0, varMax = -1.0f;
-  for (unsigned i = 0; i < 256; i++) sum += (float)i * (float)hg[i];
-  for (unsigned t = 0; t < 256; t++) {
-    wb += hg[t];
-    if (wb == 0) continue;
-    wf = npix - wb;
-    if (wf == 0) break;
-    sumB += (float)t * (float)hg[t];
+  __shared__ float prod[256];
+  __shared__ float pre[256];
+  __shared__ unsigned wsum[4];
+  __shared__ float bv[4];
+  __shared__ unsigned bt[4];
+  const unsigned t = threadIdx.x, lane = t & 63u, wv = t >> 6;
+  const unsigned hv = hist[(size_t)blockIdx.x * 256u + t];
+  prod[t] = (float)t * (float)hv;
+  const unsigned inc = wave_incl_scan(hv);
+  if (lane == 63) wsum[wv] = inc;
+  __syncthreads();
+  if (t == 0) {
+    float s = 0;
+    for (int i = 0; i < 256; i++) {
+      s += prod[i];
+      pre[i] = s;
+    }
+  }
+  unsigned wb = inc;
+  for (unsigned k = 0; k < wv; k++) wb += wsum[k];
+  __syncthreads();
+  const float sum = pre[255], sumB = pre[t];
+  const unsigned wf = npix - wb;
+  float var = -2.0f; /* below the reference's initial varMax = -1: never selected */
+  if (wb != 0 && wf != 0) {
     const float mB = sumB / (float)wb;
     const float mF = (sum - sumB) / (float)wf;
-    const float between = (float)wb * (float)wf * (mB - mF) * (mB - mF);
-    if (between > varMax) varMax = between, best = t;
+    var = (float)wb * (float)wf * (mB - mF) * (mB - mF);
   }
-  thr[f] = (uint8_t)best;
+  /* wf == 0 can only hold from some t on (break, ref :215); wb == 0 only up to some t (continue) */
+  float v = var;
+  unsigned a = t;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const float ov = __builtin_bit_cast(float, shfl(__builtin_bit_cast(uint32_t, v), (int)(lane ^ (unsigned)d)));
+    const unsigned oa = shfl(a, (int)(lane ^ (unsigned)d));
+    if (ov > v || (ov == v && oa < a)) v = ov, a = oa;
+  }
+  if (lane == 0) bv[wv] = v, bt[wv] = a;
+  __syncthreads();
+  if (t == 0) {
+    for (int k = 1; k < 4; k++)
+      if (bv[k] > v || (bv[k] == v && bt[k] < a)) v = bv[k], a = bt[k];
+    thr[blockIdx.x] = (uint8_t)(v > -1.0f ? a : 0u);
+  }
+}
+
+/* the 1-px frame of every image := 0 (what "gs_sobel into a zeroed image" leaves there).
+ * grid (ceil((2w+2h)/256), n frames) */
+__global__ __launch_bounds__(256) void k_zero_frame(uint8_t *img, unsigned w, unsigned h,
+                                                    size_t frame_bytes) {
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  uint8_t *f = img + (size_t)blockIdx.y * frame_bytes;
+  if (i < w) f[i] = 0;
+  else if (i < 2 * w) f[(size_t)(h - 1) * w + (i - w)] = 0;
+  else if (i < 2 * w + h) f[(size_t)(i - 2 * w) * w] = 0;
+  else if (i < 2 * w + 2 * h) f[(size_t)(i - 2 * w - h) * w + (w - 1)] = 0;
 }
 
 /* sums[f] += sum over bytes of (index+1)*(byte+1) mod 2^64 (order independent). */

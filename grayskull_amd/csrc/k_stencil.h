@@ -28,8 +28,6 @@
 
 namespace gs {
 
-struct alignas(16) U4 { uint32_t x, y, z, w; };
-
 template <int N, class F> GS_DEV void static_for(F &&f) {
   if constexpr (N > 0) {
     static_for<N - 1>(f);
@@ -38,32 +36,51 @@ template <int N, class F> GS_DEV void static_for(F &&f) {
 }
 
 /* ------------------------------------------------------------------ strip helpers */
-struct RawRow { U4 v; uint32_t hl, hr; };
+struct RawRow { U4 v; uint32_t hh; };
 
-/* Row y of a frame, this lane's 16 B plus (lanes 0 / 63 only) the 4 B left / right of the
- * wave's 1 KiB; anything outside the image reads as FILL bytes. */
-template <uint32_t FILL4>
-GS_DEV RawRow strip_load(const uint8_t *frame, unsigned w, unsigned h, int y, unsigned x0,
-                         unsigned lane) {
-  RawRow r;
-  r.v = U4{FILL4, FILL4, FILL4, FILL4};
-  r.hl = FILL4;
-  r.hr = FILL4;
-  if (y >= 0 && y < (int)h) { /* wave-uniform */
-    const uint8_t *rp = frame + (size_t)y * w;
-    if (x0 < w) {
-      r.v = *(const U4 *)(rp + x0);
-      if (lane == 0 && x0 > 0) r.hl = *(const uint32_t *)(rp + x0 - 4);
-      if (lane == 63 && x0 + 16 < w) r.hr = *(const uint32_t *)(rp + x0 + 16);
-    }
+/* One lane's view of a frame pair.  The block shape is free: blockDim.x is a multiple of 64 (a
+ * wave's lanes are 64 consecutive strips of one band), blockDim.y stacks further bands.
+ * INVERT complements in-image bytes on the way in and all bytes on the way out
+ * (erode == ~dilate(~x)): the hardware's zero fill then acts as the 255 fill erosion needs. */
+template <bool INVERT = false> struct Strip {
+  BufRsrc src, dst;
+  unsigned w, h, x0, lane, band;
+  GS_DEV Strip(const uint8_t *s, uint8_t *d, unsigned w_, unsigned h_, size_t frame_bytes)
+      : src(make_buf(s + (size_t)blockIdx.z * frame_bytes, frame_bytes)),
+        dst(make_buf(d + (size_t)blockIdx.z * frame_bytes, frame_bytes)), w(w_), h(h_) {
+    lane = threadIdx.x & 63u;
+    x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 16u;
+    band = blockIdx.y * blockDim.y + threadIdx.y;
   }
-  return r;
-}
+  /* row y: this lane's 16 B; lane 0 also fetches the 4 B left of the wave's 1 KiB, lane 63 the
+   * 4 B right of it (one shared instruction).  Everything outside the image reads 0. */
+  GS_DEV RawRow load(int y) const {
+    const bool ok = (unsigned)y < h && x0 < w;
+    const uint32_t base = (uint32_t)y * w + x0;
+    RawRow r;
+    r.v = buf_load16(src, ok ? base : kOOB);
+    uint32_t ho = kOOB;
+    if (lane == 0 && x0 > 0) ho = base - 4;
+    if (lane == 63 && x0 + 16 < w) ho = base + 16;
+    r.hh = buf_load4(src, ok ? ho : kOOB);
+    if (INVERT) { /* complement in-image bytes only: out-of-range stays 0 in the inverted domain */
+      const uint32_t m = ok ? 0xffffffffu : 0u, hm = (ok && ho != kOOB) ? 0xffffffffu : 0u;
+      r.v = U4{r.v.x ^ m, r.v.y ^ m, r.v.z ^ m, r.v.w ^ m};
+      r.hh ^= hm;
+    }
+    return r;
+  }
+  /* whole 16 B of row y (dropped when !ok or the lane is outside the image) */
+  GS_DEV void store(int y, bool ok, U4 o) const {
+    if (INVERT) o = U4{~o.x, ~o.y, ~o.z, ~o.w};
+    buf_store16(dst, (ok && x0 < w) ? (uint32_t)y * w + x0 : kOOB, o);
+  }
+};
 
 /* 24 bytes = cols x0-4 .. x0+19 as 12 dwords of u16 pairs: U[j] = (px 2j-4, px 2j-3). */
 GS_DEV void strip_unpack(const RawRow &r, uint32_t (&U)[12]) {
-  uint32_t L = wave_shr1(r.v.w, r.hl); /* left neighbour's last dword  */
-  uint32_t R = wave_shl1(r.v.x, r.hr); /* right neighbour's first dword */
+  const uint32_t L = wave_shr1(r.v.w, r.hh); /* left neighbour's last dword (lane 0: halo)   */
+  const uint32_t R = wave_shl1(r.v.x, r.hh); /* right neighbour's first dword (lane 63: halo) */
   U[0] = unpack_lo(L), U[1] = unpack_hi(L);
   U[2] = unpack_lo(r.v.x), U[3] = unpack_hi(r.v.x);
   U[4] = unpack_lo(r.v.y), U[5] = unpack_hi(r.v.y);
@@ -72,96 +89,119 @@ GS_DEV void strip_unpack(const RawRow &r, uint32_t (&U)[12]) {
   U[10] = unpack_lo(R), U[11] = unpack_hi(R);
 }
 
-GS_DEV void store_bytes(uint8_t *p, const U4 &v, int lo, int hi) { /* bytes [lo,hi) of v */
-  const uint32_t d[4] = {v.x, v.y, v.z, v.w};
-  for (int i = lo; i < hi; i++) p[i] = (uint8_t)(d[i >> 2] >> (8 * (i & 3)));
+/* Row loop shared by the strip kernels.  Per output row i of the band:
+ *     wait for row i's raw data -> unpack (raw registers die) -> store row i-1's result ->
+ *     issue the load of the next input row -> arithmetic for row i.
+ * So the store and the next load are in flight during the arithmetic and the single
+ * s_waitcnt at the top of the next row finds them (nearly) complete.  RING rows are unrolled
+ * so the vertical window is indexed at compile time. */
+template <int RING, bool INVERT, class Body>
+GS_DEV void strip_rows(const Strip<INVERT> &S, int y0, int nrows, int lead, RawRow first, Body &&body) {
+  RawRow raw = first; /* = load(y0 + lead): the newest input row output row 0 needs */
+  U4 o_prev{0, 0, 0, 0};
+  for (int base = 0; base < nrows; base += RING) {
+    static_for<RING>([&](auto I) {
+      const int i = base + decltype(I)::value;
+      if (i >= nrows) return; /* wave-uniform */
+      uint32_t U[12];
+      strip_unpack(raw, U);
+      S.store(y0 + i - 1, i > 0, o_prev);
+      raw = S.load(y0 + i + lead + 1);
+      o_prev = body(I, i, U);
+    });
+  }
+  S.store(y0 + nrows - 1, nrows > 0, o_prev);
 }
 
 /* ------------------------------------------------------------------ sobel, strips */
-/* ref grayskull.h:306-320: interior only, (|gx|+|gy|)/2 clamped to 255. */
-__global__ __launch_bounds__(256) void k_sobel16(uint8_t *dst, const uint8_t *src, unsigned w,
-                                                 unsigned h, unsigned T, size_t frame_bytes) {
-  const unsigned lane = threadIdx.x;
-  const unsigned x0 = (blockIdx.x * 64u + lane) * 16u;
-  const unsigned band = blockIdx.y * blockDim.y + threadIdx.y;
-  const int y0 = 1 + (int)(band * T);
-  if (y0 >= (int)h - 1) return; /* whole wave */
-  const int nrows = ((int)h - 1 - y0) < (int)T ? ((int)h - 1 - y0) : (int)T;
-  const uint8_t *sf = src + (size_t)blockIdx.z * frame_bytes;
-  uint8_t *df = dst + (size_t)blockIdx.z * frame_bytes;
-
-  uint32_t ring[3][12];
-  strip_unpack(strip_load<0u>(sf, w, h, y0 - 1, x0, lane), ring[0]);
-  strip_unpack(strip_load<0u>(sf, w, h, y0, x0, lane), ring[1]);
-  RawRow nxt = strip_load<0u>(sf, w, h, y0 + 1, x0, lane);
-
-  for (int base = 0; base < nrows; base += 3) {
-    static_for<3>([&](auto I) {
-      constexpr int ia = I, ib = (I + 1) % 3, ic = (I + 2) % 3;
-      const int i = base + ia;
-      if (i >= nrows) return; /* wave-uniform */
-      const int y = y0 + i;
-      strip_unpack(nxt, ring[ic]);
-      if (i + 1 < nrows) nxt = strip_load<0u>(sf, w, h, y + 2, x0, lane);
-      const uint32_t(&a)[12] = ring[ia];
-      const uint32_t(&b)[12] = ring[ib];
-      const uint32_t(&c)[12] = ring[ic];
-      /* vertical pass on px -2..17 (U[1..10]): S = a+2b+c, D = c-a */
-      uint32_t S[10], D[10];
+/* ref grayskull.h:306-320: (|gx|+|gy|)/2 clamped to 255 on rows 1..h-2.
+ * Horizontal pass once per input row (kept in a 3-row register ring):
+ *   H1[x] = r[x-1] + 2 r[x] + r[x+1]      H2[x] = r[x+1] - r[x-1]
+ * vertical pass per output row:  gx = H2a + 2 H2b + H2c,  gy = H1c - H1a.
+ * The kernel writes whole 16-byte groups, i.e. it also overwrites columns 0 and w-1 of rows
+ * 1..h-2, which the reference never writes: the launcher saves and restores those two columns
+ * (or the caller zeroes the frame afterwards). */
+GS_DEV void sobel_hpass(const uint32_t (&U)[12], uint32_t (&H1)[8], uint32_t (&H2)[8]) {
+  uint32_t A[11];
 #pragma unroll
-      for (int j = 0; j < 10; j++) {
-        S[j] = pk_add_u16(pk_add_u16(a[j + 1], c[j + 1]), pk_shl_u16(b[j + 1], 1));
-        D[j] = pk_sub_u16(c[j + 1], a[j + 1]);
-      }
-      /* odd-aligned pairs: SA[j] = (S px 2j-3, 2j-2) relative to own px 0 */
-      uint32_t SA[9], DA[9];
+  for (int j = 1; j <= 9; j++) A[j] = alignbit(U[j + 1], U[j], 16); /* (px 2j-3, 2j-2) */
 #pragma unroll
-      for (int j = 0; j < 9; j++) {
-        SA[j] = alignbit(S[j + 1], S[j], 16);
-        DA[j] = alignbit(D[j + 1], D[j], 16);
-      }
-      uint32_t M[8];
-#pragma unroll
-      for (int k = 0; k < 8; k++) { /* own pair k = px (2k, 2k+1) = S[k+1] */
-        uint32_t gx = pk_sub_u16(SA[k + 1], SA[k]);
-        uint32_t gy = pk_add_u16(pk_add_u16(DA[k], DA[k + 1]), pk_shl_u16(D[k + 1], 1));
-        uint32_t m = pk_shr_u16(pk_add_u16(pk_abs_i16(gx), pk_abs_i16(gy)), 1);
-        M[k] = pk_min_u16(m, 0x00ff00ffu);
-      }
-      U4 o{pack_lohi(M[0], M[1]), pack_lohi(M[2], M[3]), pack_lohi(M[4], M[5]),
-           pack_lohi(M[6], M[7])};
-      if (x0 < w) {
-        uint8_t *op = df + (size_t)y * w + x0;
-        const bool first = x0 == 0, last = x0 + 16 >= w;
-        if (!first && !last) *(U4 *)op = o;
-        else store_bytes(op, o, first ? 1 : 0, last ? 15 : 16); /* never touch x=0 / x=w-1 */
-      }
-    });
+  for (int k = 0; k < 8; k++) {
+    H2[k] = pk_sub_u16(A[k + 2], A[k + 1]);
+    H1[k] = pk_mad2_u16(U[k + 2], pk_add_u16(A[k + 1], A[k + 2]));
   }
 }
 
+__global__ __launch_bounds__(256) void k_sobel16(uint8_t *dst, const uint8_t *src, unsigned w,
+                                                 unsigned h, unsigned T, size_t frame_bytes) {
+  const Strip<> S(src, dst, w, h, frame_bytes);
+  const int y0 = 1 + (int)(S.band * T);
+  if (y0 >= (int)h - 1) return; /* whole wave */
+  const int nrows = ((int)h - 1 - y0) < (int)T ? ((int)h - 1 - y0) : (int)T;
+  uint32_t R1[3][8], R2[3][8];
+  {
+    uint32_t U[12];
+    strip_unpack(S.load(y0 - 1), U);
+    sobel_hpass(U, R1[0], R2[0]);
+    strip_unpack(S.load(y0), U);
+    sobel_hpass(U, R1[1], R2[1]);
+  }
+  strip_rows<3>(S, y0, nrows, 1, S.load(y0 + 1), [&](auto I, int, const uint32_t(&U)[12]) {
+    constexpr int ia = decltype(I)::value, ib = (ia + 1) % 3, ic = (ia + 2) % 3;
+    sobel_hpass(U, R1[ic], R2[ic]);
+    uint32_t M[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const uint32_t gx = pk_mad2_u16(R2[ib][k], pk_add_u16(R2[ia][k], R2[ic][k]));
+      const uint32_t gy = pk_sub_u16(R1[ic][k], R1[ia][k]);
+      const uint32_t m = pk_shr_u16(pk_add_u16(pk_abs_i16(gx), pk_abs_i16(gy)), 1);
+      M[k] = pk_min_u16(m, 0x00ff00ffu);
+    }
+    return U4{pack_lohi(M[0], M[1]), pack_lohi(M[2], M[3]), pack_lohi(M[4], M[5]),
+              pack_lohi(M[6], M[7])};
+  });
+}
+
+/* columns 0 and w-1 of rows 1..h-2: save (dir 0) to / restore (dir 1) from `cols`
+ * (n frames x 2 x h bytes).  grid (ceil(2h/256), n), block 256 */
+__global__ __launch_bounds__(256) void k_edge_cols(uint8_t *img, uint8_t *cols, unsigned w,
+                                                   unsigned h, size_t frame_bytes, int dir) {
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= 2 * h) return;
+  const unsigned y = i >> 1;
+  if (y < 1 || y + 1 >= h) return;
+  uint8_t *p = img + (size_t)blockIdx.y * frame_bytes + (size_t)y * w + ((i & 1) ? w - 1 : 0);
+  uint8_t *c = cols + (size_t)blockIdx.y * 2 * h + i;
+  if (dir) *p = *c;
+  else *c = *p;
+}
+
 /* ------------------------------------------------------------------ box blur, strips */
-/* ref grayskull.h:268-283.  Zero fill outside the image makes the clipped window sum equal
- * the padded one; the divisor is (#cols in image) x (#rows in image).  Interior pixels use
- * floor(s/d) == (s*MAGIC)>>SHIFT (exact for s <= 255*d, checked at compile time in tests);
- * frame pixels take the generic u32 division. */
+/* ref grayskull.h:268-283.  Zero fill outside the image makes the clipped window sum equal the
+ * padded one.  The strip kernel divides every pixel by the interior divisor d = (2R+1)^2 with
+ * floor(s/d) == (s*MUL) >> 24 (exact for s <= 255*d; the quotient is the top byte of the 32-bit
+ * product, so four of them pack with v_perm_b32).  Pixels whose window is clipped (the R-wide
+ * frame) have a smaller divisor; k_blur_frame_px rewrites exactly those afterwards. */
 template <int R> struct BlurMagic;
-template <> struct BlurMagic<1> { static constexpr uint32_t mul = 7282, shift = 16; };  /* /9  */
-template <> struct BlurMagic<2> { static constexpr uint32_t mul = 5243, shift = 17; };  /* /25 */
-template <> struct BlurMagic<3> { static constexpr uint32_t mul = 2675, shift = 17; };  /* /49 */
+template <> struct BlurMagic<1> { static constexpr uint32_t mul = 1864136; };  /* ceil(2^24/9)  */
+template <> struct BlurMagic<2> { static constexpr uint32_t mul = 671089; };   /* ceil(2^24/25) */
+template <> struct BlurMagic<3> { static constexpr uint32_t mul = 342393; };   /* ceil(2^24/49) */
 
 template <int R>
 GS_DEV void blur_hsum(const uint32_t (&U)[12], uint32_t (&H)[8]) {
-  uint32_t A[11]; /* A[j] = pair starting one px after U[j] */
+  uint32_t A[11], P[11];
+  constexpr int jlo = R >= 3 ? 0 : 1, jhi = R >= 3 ? 10 : 9;
 #pragma unroll
-  for (int j = 0; j < 11; j++) A[j] = alignbit(U[j + 1], U[j], 16);
+  for (int j = jlo; j <= jhi; j++) {
+    A[j] = alignbit(U[j + 1], U[j], 16); /* pair starting one px after U[j] */
+    P[j] = pk_add_u16(U[j], A[j]);       /* 2-px sums (x, x+1) for both halves */
+  }
 #pragma unroll
   for (int k = 0; k < 8; k++) {
-    const int j = k + 2;
-    uint32_t s = pk_add_u16(pk_add_u16(A[j - 1], U[j]), A[j]);
-    if constexpr (R >= 2) s = pk_add_u16(pk_add_u16(s, U[j - 1]), U[j + 1]);
-    if constexpr (R >= 3) s = pk_add_u16(pk_add_u16(s, A[j - 2]), A[j + 1]);
-    H[k] = s;
+    const int j = k + 2; /* U[j] = own pair k */
+    if constexpr (R == 1) H[k] = pk_add_u16(A[j - 1], P[j]);
+    else if constexpr (R == 2) H[k] = pk_add_u16(pk_add_u16(P[j - 1], P[j]), U[j + 1]);
+    else H[k] = pk_add_u16(pk_add_u16(pk_add_u16(A[j - 2], P[j - 1]), P[j]), P[j + 1]);
   }
 }
 
@@ -169,121 +209,119 @@ template <int R>
 __global__ __launch_bounds__(256) void k_blur16(uint8_t *dst, const uint8_t *src, unsigned w,
                                                 unsigned h, unsigned T, size_t frame_bytes) {
   constexpr int N = 2 * R + 1;
-  const unsigned lane = threadIdx.x;
-  const unsigned x0 = (blockIdx.x * 64u + lane) * 16u;
-  const unsigned band = blockIdx.y * blockDim.y + threadIdx.y;
-  const int y0 = (int)(band * T);
+  const Strip<> S(src, dst, w, h, frame_bytes);
+  const int y0 = (int)(S.band * T);
   if (y0 >= (int)h) return;
   const int nrows = ((int)h - y0) < (int)T ? ((int)h - y0) : (int)T;
-  const uint8_t *sf = src + (size_t)blockIdx.z * frame_bytes;
-  uint8_t *df = dst + (size_t)blockIdx.z * frame_bytes;
-  const bool edge_lane = x0 == 0 || x0 + 16 >= w;
-
   uint32_t ring[N][8], V[8];
 #pragma unroll
   for (int k = 0; k < 8; k++) V[k] = 0, ring[N - 1][k] = 0;
-  {
+#pragma unroll
+  for (int r = 0; r < N - 1; r++) { /* image rows y0-R .. y0+R-1 */
     uint32_t U[12];
+    strip_unpack(S.load(y0 - R + r), U);
+    blur_hsum<R>(U, ring[r]);
 #pragma unroll
-    for (int r = 0; r < N - 1; r++) { /* image rows y0-R .. y0+R-1 */
-      strip_unpack(strip_load<0u>(sf, w, h, y0 - R + r, x0, lane), U);
-      blur_hsum<R>(U, ring[r]);
+    for (int k = 0; k < 8; k++) V[k] = pk_add_u16(V[k], ring[r][k]);
+  }
+  strip_rows<N>(S, y0, nrows, R, S.load(y0 + R), [&](auto I, int, const uint32_t(&U)[12]) {
+    constexpr int slot = (decltype(I)::value + N - 1) % N; /* row i-1 leaves, row i+2R enters */
+    uint32_t Hn[8], p[16];
+    blur_hsum<R>(U, Hn);
 #pragma unroll
-      for (int k = 0; k < 8; k++) V[k] = pk_add_u16(V[k], ring[r][k]);
+    for (int k = 0; k < 8; k++) {
+      V[k] = pk_sub_u16(pk_add_u16(V[k], Hn[k]), ring[slot][k]);
+      ring[slot][k] = Hn[k];
+      p[2 * k] = (V[k] & 0xffffu) * BlurMagic<R>::mul; /* quotient = byte 3 */
+      p[2 * k + 1] = (V[k] >> 16) * BlurMagic<R>::mul;
     }
-  }
-  RawRow nxt = strip_load<0u>(sf, w, h, y0 + R, x0, lane);
+    U4 o;
+    o.x = perm_b32(p[3], perm_b32(p[2], perm_b32(p[1], p[0], 0x0c0c0703u), 0x0c070100u), 0x07020100u);
+    o.y = perm_b32(p[7], perm_b32(p[6], perm_b32(p[5], p[4], 0x0c0c0703u), 0x0c070100u), 0x07020100u);
+    o.z = perm_b32(p[11], perm_b32(p[10], perm_b32(p[9], p[8], 0x0c0c0703u), 0x0c070100u), 0x07020100u);
+    o.w = perm_b32(p[15], perm_b32(p[14], perm_b32(p[13], p[12], 0x0c0c0703u), 0x0c070100u), 0x07020100u);
+    return o;
+  });
+}
 
-  for (int base = 0; base < nrows; base += N) {
-    static_for<N>([&](auto I) {
-      constexpr int slot = (I + N - 1) % N; /* holds row i-1 (outgoing), receives row i+2R */
-      const int i = base + I;
-      if (i >= nrows) return;
-      const int y = y0 + i;
-      uint32_t U[12], Hn[8];
-      strip_unpack(nxt, U);
-      if (i + 1 < nrows) nxt = strip_load<0u>(sf, w, h, y + R + 1, x0, lane);
-      blur_hsum<R>(U, Hn);
-#pragma unroll
-      for (int k = 0; k < 8; k++) {
-        V[k] = pk_sub_u16(pk_add_u16(V[k], Hn[k]), ring[slot][k]);
-        ring[slot][k] = Hn[k];
-      }
-      uint32_t q[16];
-      const bool edge_row = y < R || y + R >= (int)h;
-      if (!edge_row && !edge_lane) {
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-          q[2 * k] = ((V[k] & 0xffffu) * BlurMagic<R>::mul) >> BlurMagic<R>::shift;
-          q[2 * k + 1] = ((V[k] >> 16) * BlurMagic<R>::mul) >> BlurMagic<R>::shift;
-        }
-      } else {
-        const int ya = y - R < 0 ? 0 : y - R, yb = y + R > (int)h - 1 ? (int)h - 1 : y + R;
-        const unsigned cy = (unsigned)(yb - ya + 1);
-#pragma unroll
-        for (int p = 0; p < 16; p++) {
-          const int x = (int)x0 + p;
-          const int xa = x - R < 0 ? 0 : x - R, xb = x + R > (int)w - 1 ? (int)w - 1 : x + R;
-          const unsigned cnt = cy * (unsigned)(xb - xa + 1);
-          const unsigned s = (p & 1) ? (V[p >> 1] >> 16) : (V[p >> 1] & 0xffffu);
-          q[p] = x < (int)w ? s / cnt : 0u;
-        }
-      }
-      U4 o;
-      o.x = q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24);
-      o.y = q[4] | (q[5] << 8) | (q[6] << 16) | (q[7] << 24);
-      o.z = q[8] | (q[9] << 8) | (q[10] << 16) | (q[11] << 24);
-      o.w = q[12] | (q[13] << 8) | (q[14] << 16) | (q[15] << 24);
-      if (x0 < w) *(U4 *)(df + (size_t)y * w + x0) = o;
-    });
+/* The R-wide frame of each image, where the window is clipped and the divisor is the number of
+ * in-image taps (ref :275-281).  One thread per frame pixel: rows [0,R) and [h-R,h) in full,
+ * columns [0,R) and [w-R,w) of the rows in between.  grid (ceil(npx/256), n frames). */
+__global__ __launch_bounds__(256) void k_blur_frame_px(uint8_t *dst, const uint8_t *src, unsigned w,
+                                                       unsigned h, int R, size_t frame_bytes) {
+  const unsigned nrow_px = 2u * (unsigned)R * w;             /* needs h > 2R, w > 2R */
+  const unsigned mid = h - 2u * (unsigned)R;
+  const unsigned total = nrow_px + mid * 2u * (unsigned)R;
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= total) return;
+  int x, y;
+  if (i < nrow_px) {
+    const unsigned ry = i / w;
+    x = (int)(i - ry * w);
+    y = ry < (unsigned)R ? (int)ry : (int)(h - 2u * R + ry);
+  } else {
+    const unsigned j = i - nrow_px, ry = j / (2u * R), cx = j - ry * 2u * R;
+    y = R + (int)ry;
+    x = cx < (unsigned)R ? (int)cx : (int)(w - 2u * R + cx);
   }
+  const uint8_t *f = src + (size_t)blockIdx.y * frame_bytes;
+  const int xa = x - R < 0 ? 0 : x - R, xb = x + R > (int)w - 1 ? (int)w - 1 : x + R;
+  const int ya = y - R < 0 ? 0 : y - R, yb = y + R > (int)h - 1 ? (int)h - 1 : y + R;
+  unsigned sum = 0;
+  for (int yy = ya; yy <= yb; yy++)
+    for (int xx = xa; xx <= xb; xx++) sum += f[(size_t)yy * w + xx];
+  const unsigned cnt = (unsigned)((xb - xa + 1) * (yb - ya + 1));
+  dst[(size_t)blockIdx.y * frame_bytes + (size_t)y * w + x] = (uint8_t)(sum / cnt);
 }
 
 /* ------------------------------------------------------------------ 3x3 erode / dilate, strips */
-/* ref grayskull.h:285-304: min/max over in-image taps == min/max with 255/0 fill. */
+/* ref grayskull.h:285-304: max over in-image taps == max with 0 fill; erode runs as
+ * ~dilate(~x) (Strip<INVERT>), i.e. min with 255 fill. */
 template <bool DILATE>
 __global__ __launch_bounds__(256) void k_morph16(uint8_t *dst, const uint8_t *src, unsigned w,
                                                  unsigned h, unsigned T, size_t frame_bytes) {
-  constexpr uint32_t FILL = DILATE ? 0u : 0xffffffffu;
-  const unsigned lane = threadIdx.x;
-  const unsigned x0 = (blockIdx.x * 64u + lane) * 16u;
-  const unsigned band = blockIdx.y * blockDim.y + threadIdx.y;
-  const int y0 = (int)(band * T);
+  const Strip<!DILATE> S(src, dst, w, h, frame_bytes);
+  const int y0 = (int)(S.band * T);
   if (y0 >= (int)h) return;
   const int nrows = ((int)h - y0) < (int)T ? ((int)h - y0) : (int)T;
-  const uint8_t *sf = src + (size_t)blockIdx.z * frame_bytes;
-  uint8_t *df = dst + (size_t)blockIdx.z * frame_bytes;
-
-  auto op = [](uint32_t a, uint32_t b) { return DILATE ? pk_max_u16(a, b) : pk_min_u16(a, b); };
-  auto hpass = [&](const RawRow &rr, uint32_t(&H)[8]) {
-    uint32_t U[12];
-    strip_unpack(rr, U);
+  auto hpass = [](const uint32_t(&U)[12], uint32_t(&H)[8]) {
 #pragma unroll
     for (int k = 0; k < 8; k++) {
       const int j = k + 2;
-      H[k] = op(op(alignbit(U[j], U[j - 1], 16), U[j]), alignbit(U[j + 1], U[j], 16));
+      H[k] = pk_max_u16(pk_max_u16(alignbit(U[j], U[j - 1], 16), U[j]), alignbit(U[j + 1], U[j], 16));
     }
   };
   uint32_t ring[3][8];
-  hpass(strip_load<FILL>(sf, w, h, y0 - 1, x0, lane), ring[0]);
-  hpass(strip_load<FILL>(sf, w, h, y0, x0, lane), ring[1]);
-  RawRow nxt = strip_load<FILL>(sf, w, h, y0 + 1, x0, lane);
-
-  for (int base = 0; base < nrows; base += 3) {
-    static_for<3>([&](auto I) {
-      constexpr int ia = I, ib = (I + 1) % 3, ic = (I + 2) % 3;
-      const int i = base + ia;
-      if (i >= nrows) return;
-      const int y = y0 + i;
-      hpass(nxt, ring[ic]);
-      if (i + 1 < nrows) nxt = strip_load<FILL>(sf, w, h, y + 2, x0, lane);
-      uint32_t M[8];
+  {
+    uint32_t U[12];
+    strip_unpack(S.load(y0 - 1), U);
+    hpass(U, ring[0]);
+    strip_unpack(S.load(y0), U);
+    hpass(U, ring[1]);
+  }
+  strip_rows<3>(S, y0, nrows, 1, S.load(y0 + 1), [&](auto I, int, const uint32_t(&U)[12]) {
+    constexpr int ia = decltype(I)::value, ib = (ia + 1) % 3, ic = (ia + 2) % 3;
+    hpass(U, ring[ic]);
+    uint32_t M[8];
 #pragma unroll
-      for (int k = 0; k < 8; k++) M[k] = op(op(ring[ia][k], ring[ib][k]), ring[ic][k]);
-      U4 o{pack_lohi(M[0], M[1]), pack_lohi(M[2], M[3]), pack_lohi(M[4], M[5]),
-           pack_lohi(M[6], M[7])};
-      if (x0 < w) *(U4 *)(df + (size_t)y * w + x0) = o;
-    });
+    for (int k = 0; k < 8; k++) M[k] = pk_max_u16(pk_max_u16(ring[ia][k], ring[ib][k]), ring[ic][k]);
+    return U4{pack_lohi(M[0], M[1]), pack_lohi(M[2], M[3]), pack_lohi(M[4], M[5]),
+              pack_lohi(M[6], M[7])};
+  });
+}
+
+/* diagnostic: same traffic pattern as the strip kernels, no arithmetic (access-pattern ceiling) */
+__global__ __launch_bounds__(256) void k_strip_copy(uint8_t *dst, const uint8_t *src, unsigned w,
+                                                    unsigned h, unsigned T, size_t frame_bytes) {
+  const Strip<> S(src, dst, w, h, frame_bytes);
+  const int y0 = (int)(S.band * T);
+  if (y0 >= (int)h) return;
+  const int nrows = ((int)h - y0) < (int)T ? ((int)h - y0) : (int)T;
+  RawRow raw = S.load(y0);
+  for (int i = 0; i < nrows; i++) {
+    const U4 cur = raw.v;
+    raw = S.load(y0 + i + 1);
+    S.store(y0 + i, true, cur);
   }
 }
 

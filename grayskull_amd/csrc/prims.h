@@ -25,6 +25,15 @@ namespace gs {
 
 constexpr int kWave = 64; /* CDNA wavefront */
 
+struct alignas(16) U4 { uint32_t x, y, z, w; };
+
+/* Raw buffer access (buffer_load/store ... offen through a 128-bit V#): the per-lane byte offset
+ * is range-checked by the hardware against the frame size, out-of-range lanes load 0 and drop
+ * their stores.  That makes every strip-kernel memory op branch-free (no exec-mask diamonds, so
+ * hipcc can keep loads in flight across the arithmetic with counted waits) and gives the zero
+ * fill outside the image for free.  kOOB is an offset no frame (< 2 GiB) can contain. */
+constexpr uint32_t kOOB = 0x80000000u;
+
 #ifdef GS_EMU
 /* ------------------------------------------------------------------ emulation */
 GS_DEV unsigned lane_id() { return emu::lane_id(); }
@@ -66,10 +75,35 @@ GS_DEV uint32_t perm_b32(uint32_t hi, uint32_t lo, uint32_t sel) { /* v_perm_b32
 GS_DEV uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { /* v_alignbit_b32 */
   return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31));
 }
+struct BufRsrc { uint8_t *base; uint32_t n; };
+GS_DEV BufRsrc make_buf(const void *base, size_t bytes) {
+  return BufRsrc{(uint8_t *)base, (uint32_t)(bytes > 0x7fffffffu ? 0x7fffffffu : bytes)};
+}
+GS_DEV void emu_buf_check(const BufRsrc &b, uint32_t off, uint32_t sz) {
+  if (off < b.n && off + sz > b.n) { fprintf(stderr, "emu: partially out-of-range buffer access\n"); abort(); }
+}
+GS_DEV U4 buf_load16(const BufRsrc &b, uint32_t off) {
+  U4 v{0, 0, 0, 0};
+  emu_buf_check(b, off, 16);
+  if (off < b.n) memcpy(&v, b.base + off, 16);
+  return v;
+}
+GS_DEV uint32_t buf_load4(const BufRsrc &b, uint32_t off) {
+  uint32_t v = 0;
+  emu_buf_check(b, off, 4);
+  if (off < b.n) memcpy(&v, b.base + off, 4);
+  return v;
+}
+GS_DEV void buf_store16(const BufRsrc &b, uint32_t off, const U4 &v) {
+  emu_buf_check(b, off, 16);
+  if (off < b.n) memcpy(b.base + off, &v, 16);
+}
 #define GS_PK2(expr_lo, expr_hi) ((uint32_t)((expr_lo) & 0xffffu) | ((uint32_t)((expr_hi) & 0xffffu) << 16))
 GS_DEV uint32_t pk_add_u16(uint32_t a, uint32_t b) { return GS_PK2((a & 0xffff) + (b & 0xffff), (a >> 16) + (b >> 16)); }
 GS_DEV uint32_t pk_sub_u16(uint32_t a, uint32_t b) { return GS_PK2((a & 0xffff) - (b & 0xffff), (a >> 16) - (b >> 16)); }
 GS_DEV uint32_t pk_mul_u16(uint32_t a, uint32_t b) { return GS_PK2((a & 0xffff) * (b & 0xffff), (a >> 16) * (b >> 16)); }
+GS_DEV uint32_t pk_mad_u16(uint32_t a, uint32_t b, uint32_t c) { return GS_PK2((a & 0xffff) * (b & 0xffff) + (c & 0xffff), (a >> 16) * (b >> 16) + (c >> 16)); }
+GS_DEV uint32_t pk_mad2_u16(uint32_t a, uint32_t c) { return GS_PK2(2 * (a & 0xffff) + (c & 0xffff), 2 * (a >> 16) + (c >> 16)); }
 GS_DEV uint32_t pk_shl_u16(uint32_t a, unsigned s) { return GS_PK2((a & 0xffff) << s, (a >> 16) << s); }
 GS_DEV uint32_t pk_shr_u16(uint32_t a, unsigned s) { return GS_PK2((a & 0xffff) >> s, (a >> 16) >> s); }
 GS_DEV uint32_t pk_min_u16(uint32_t a, uint32_t b) {
@@ -102,6 +136,30 @@ GS_DEV uint32_t shfl(uint32_t x, int src) { /* ds_bpermute_b32 */
 GS_DEV uint32_t perm_b32(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 GS_DEV uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
 
+/* cache-policy bits of the strip kernels' buffer ops (aux: 1 = sc0, 2 = nt, 16 = sc1) */
+#ifndef GS_LOAD_AUX
+#define GS_LOAD_AUX 0
+#endif
+#ifndef GS_STORE_AUX
+#define GS_STORE_AUX 2 /* nt: results are streamed out, never re-read by this kernel; measured
+                          -4 % (sobel) ... -9 % (blur) kernel time vs default policy on MI355X */
+#endif
+typedef unsigned int gs_u32x4 __attribute__((ext_vector_type(4)));
+struct BufRsrc { __amdgpu_buffer_rsrc_t r; };
+/* base/bytes must be wave-uniform (kernel arguments, blockIdx): the V# then lives in SGPRs */
+GS_DEV BufRsrc make_buf(const void *base, size_t bytes) {
+  return BufRsrc{__builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)(bytes > 0x7fffffffu ? 0x7fffffffu : bytes), 0x00020000)};
+}
+GS_DEV U4 buf_load16(const BufRsrc &b, uint32_t off) { /* buffer_load_dwordx4 offen */
+  const gs_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(b.r, (int)off, 0, GS_LOAD_AUX);
+  return U4{v.x, v.y, v.z, v.w};
+}
+GS_DEV uint32_t buf_load4(const BufRsrc &b, uint32_t off) { /* buffer_load_dword offen */
+  return __builtin_amdgcn_raw_buffer_load_b32(b.r, (int)off, 0, GS_LOAD_AUX);
+}
+GS_DEV void buf_store16(const BufRsrc &b, uint32_t off, const U4 &v) { /* buffer_store_dwordx4 offen */
+  __builtin_amdgcn_raw_buffer_store_b128(gs_u32x4{v.x, v.y, v.z, v.w}, b.r, (int)off, 0, GS_STORE_AUX);
+}
 typedef unsigned short gs_u16x2 __attribute__((ext_vector_type(2)));
 typedef short gs_i16x2 __attribute__((ext_vector_type(2)));
 #define GS_U2(x) __builtin_bit_cast(gs_u16x2, (uint32_t)(x))
@@ -110,6 +168,18 @@ typedef short gs_i16x2 __attribute__((ext_vector_type(2)));
 GS_DEV uint32_t pk_add_u16(uint32_t a, uint32_t b) { return GS_R((gs_u16x2)(GS_U2(a) + GS_U2(b))); }  /* v_pk_add_u16 */
 GS_DEV uint32_t pk_sub_u16(uint32_t a, uint32_t b) { return GS_R((gs_u16x2)(GS_U2(a) - GS_U2(b))); }  /* v_pk_sub_u16 */
 GS_DEV uint32_t pk_mul_u16(uint32_t a, uint32_t b) { return GS_R((gs_u16x2)(GS_U2(a) * GS_U2(b))); }  /* v_pk_mul_lo_u16 */
+GS_DEV uint32_t pk_mad_u16(uint32_t a, uint32_t b, uint32_t c) { return GS_R((gs_u16x2)(GS_U2(a) * GS_U2(b) + GS_U2(c))); } /* v_pk_mad_u16 */
+/* 2*a + c per half in ONE v_pk_mad_u16 (hipcc strength-reduces a*2+c into shift+add, so spell it;
+ * pure VALU register op: no memory, no hazard beyond what hipcc pads around asm) */
+GS_DEV uint32_t pk_mad2_u16(uint32_t a, uint32_t c) {
+#ifdef GS_NO_MAD
+  return GS_R((gs_u16x2)(GS_U2(a) + GS_U2(a) + GS_U2(c)));
+#else
+  uint32_t d;
+  asm("v_pk_mad_u16 %0, %1, 2, %2 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(c));
+  return d;
+#endif
+}
 GS_DEV uint32_t pk_shl_u16(uint32_t a, unsigned s) { return GS_R((gs_u16x2)(GS_U2(a) << (unsigned short)s)); } /* v_pk_lshlrev_b16 */
 GS_DEV uint32_t pk_shr_u16(uint32_t a, unsigned s) { return GS_R((gs_u16x2)(GS_U2(a) >> (unsigned short)s)); } /* v_pk_lshrrev_b16 */
 GS_DEV uint32_t pk_min_u16(uint32_t a, uint32_t b) { return GS_R(__builtin_elementwise_min(GS_U2(a), GS_U2(b))); } /* v_pk_min_u16 */

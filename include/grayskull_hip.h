@@ -33,6 +33,11 @@ void *gsh_get_stream(void);
 void gsh_set_async(int on);               /* drop-in gs_* calls on device pointers skip
                                              the final stream sync when on             */
 void gsh_sync(void);                      /* hipStreamSynchronize(current stream)       */
+/* launch tuning of the strip kernels: key 0 rows per band (0 = auto), 1 block shape
+ * (0: 64x4, 1: 256x1, 2: 128x2), 2 row-prefetch depth (1..3).  Results never change. */
+void gsh_tune(int key, int value);
+/* diagnostic: strip-kernel traffic pattern with no arithmetic (access-pattern ceiling) */
+void gsh_probe_strip_copy(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned n);
 void gsh_shutdown(void);                  /* free this thread's scratch + stream        */
 
 void *gsh_malloc(size_t bytes);           /* hipMalloc; aborts on failure               */

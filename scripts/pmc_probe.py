@@ -1,0 +1,15 @@
+#!/usr/bin/env python3
+"""small fixed workload for rocprofv3 --pmc passes: each strip kernel a few times on 64 4K frames"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, grayskull_amd as gs
+g = gs.lib(); g.use_torch_stream()
+F, H, W = 64, 2160, 3840
+src = torch.empty((F, H, W), dtype=torch.uint8, device="cuda"); g.synth_batch(src, 1000)
+dst = torch.zeros_like(src); tmp = torch.zeros_like(src)
+hist = torch.zeros((F, 256), dtype=torch.int32, device="cuda"); thr = torch.zeros(F, dtype=torch.uint8, device="cuda")
+for _ in range(3):
+    g.probe_strip_copy(dst, src); g.blur_batch(tmp, src, 2); g.sobel_batch(dst, tmp); g.erode_batch(dst, src)
+    g.otsu_batch(dst, hist, thr); g.threshold_batch(dst, thr)
+torch.cuda.synchronize()
+print("algorithmic bytes per launch: copy/blur/erode/threshold %d, sobel %d, hist %d" % (2*F*H*W, F*(H*W+(H-2)*(W-2)), F*H*W))

@@ -77,9 +77,11 @@ def test_c99_dropin_program_against_emulated_kernels(tmp_path, emu):
 
 
 def test_blur_magic_divisions_are_exact():
-    """(s*MUL)>>SHIFT == s // d over the whole reachable range (k_stencil.h BlurMagic)"""
-    for r, mul, shift in ((1, 7282, 16), (2, 5243, 17), (3, 2675, 17)):
+    """(s*MUL) >> 24 == s // d over the whole reachable range, product < 2^32, MUL < 2^24
+    (k_stencil.h BlurMagic: the quotient is the top byte of a v_mul_u32_u24 product)"""
+    for r, mul in ((1, 1864136), (2, 671089), (3, 342393)):
         d = (2 * r + 1) ** 2
+        assert mul < 2 ** 24
         for s in range(0, 255 * d + 1):
-            assert (s * mul) >> shift == s // d
+            assert (s * mul) >> 24 == s // d
             assert s * mul < 2 ** 32

@@ -124,3 +124,16 @@ def test_batch_entry_points(emu, oracle):
     idx = np.arange(1, 67 * 45 + 1, dtype=np.uint64)
     for i in range(2):
         assert sums[i] == np.sum(idx * (gen[i].reshape(-1).astype(np.uint64) + 1), dtype=np.uint64)
+
+
+@pytest.mark.parametrize("geom", [0, 1, 2])
+@pytest.mark.parametrize("pf", [1, 2, 3])
+def test_strip_launch_tuning_never_changes_results(emu, oracle, geom, pf):
+    """gsh_tune: block shape x prefetch depth x rows-per-band, incl. bands of 1 row"""
+    try:
+        for T in (0, 1, 5):
+            emu.tune(0, T), emu.tune(1, geom), emu.tune(2, pf)
+            for (w, h) in ((2064, 11), (64, 23), (4112, 4)):
+                pc.stencils(emu, oracle, Oracle.synth(w, h, w + h + T), MEM, radii=(1, 2, 3))
+    finally:
+        emu.tune(0, 0), emu.tune(1, 1), emu.tune(2, 2)
