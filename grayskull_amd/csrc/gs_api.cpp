@@ -52,7 +52,7 @@ namespace {
 /* ------------------------------------------------------------------ per-thread context */
 enum Slot { SL_IN = 0, SL_OUT, SL_AUX, SL_AUX2, SL_II, SL_PAD, SL_MASK, SL_CNT, SL_PFX, SL_TOT,
             SL_HISTP, SL_HIST, SL_THR, SL_KPS, SL_MOM, SL_KIN, SL_DESC, SL_TAB, SL_JUMP, SL_LEV,
-            SL_BEST, SL_COLS, SL_COUNT };
+            SL_BEST, SL_COUNT };
 
 struct Ctx {
   int device = 0;
@@ -175,9 +175,9 @@ inline bool strip_ok(unsigned w, unsigned h, const void *a, const void *b) {
 constexpr unsigned kMaxZ = 32768; /* frames per launch (grid.z limit 65535) */
 
 /* ------------------------------------------------------------------ stencil launchers */
-/* keep_cols: the strip kernel overwrites columns 0 / w-1 of rows 1..h-2 (ref never writes them);
- * true = save and restore them around the launch, false = the caller does not care (it copies
- * back the interior only, or zeroes the frame afterwards). */
+/* keep_cols: true = columns 0 / w-1 keep dst's bytes like the reference (the kernel re-writes
+ * them unchanged); false = the caller does not care (it copies back the interior only, or zeroes
+ * the frame afterwards), which saves one dword load per row in the two edge lanes. */
 void launch_sobel(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned n,
                   bool keep_cols = true) {
   if (w < 3 || h < 3 || n == 0) return;
@@ -187,13 +187,10 @@ void launch_sobel(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsi
     const unsigned nn = std::min(kMaxZ, n - f0);
     uint8_t *d = dst + fb * f0;
     const uint8_t *s = src + fb * f0;
-    if (strip_ok(w, h, d, s)) {
+    if (strip_ok(w, h, d, s) && w >= 32) {
       const StripCfg c = strip_cfg(w, h - 2, nn);
-      uint8_t *cols = keep_cols ? (uint8_t *)ctx().scratch(SL_COLS, (size_t)nn * 2 * h) : nullptr;
-      const dim3 cg((2 * h + 255) / 256, nn);
-      if (keep_cols) GS_LAUNCH(k_edge_cols, cg, dim3(256), 0, st, d, cols, w, h, fb, 0);
-      GS_LAUNCH(k_sobel16, c.grid, c.block, 0, st, d, s, w, h, c.T, fb);
-      if (keep_cols) GS_LAUNCH(k_edge_cols, cg, dim3(256), 0, st, d, cols, w, h, fb, 1);
+      if (keep_cols) GS_LAUNCH(k_sobel16<true>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb);
+      else GS_LAUNCH(k_sobel16<false>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb);
     } else {
       GS_LAUNCH(k_sobel_px, grid2d(w, h, nn), dim3(64, 4), 0, st, d, s, w, h, fb);
     }
@@ -261,9 +258,8 @@ void launch_blur(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsig
       if (radius == 1) GS_LAUNCH(k_blur16<1>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb);
       else if (radius == 2) GS_LAUNCH(k_blur16<2>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb);
       else GS_LAUNCH(k_blur16<3>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb);
-      /* clipped-window pixels (the radius-wide frame) get their true divisor */
-      const unsigned npx = 2 * radius * w + (h - 2 * radius) * 2 * radius;
-      GS_LAUNCH(k_blur_frame_px, dim3((npx + 255) / 256, nn), dim3(256), 0, st, d, s, w, h,
+      /* the 2*radius vertically clipped rows of each frame get their true divisors */
+      GS_LAUNCH(k_blur_edge_rows, dim3((w + 255) / 256, 2 * radius, nn), dim3(256), 0, st, d, s, w, h,
                 (int)radius, fb);
     }
     return;

@@ -95,22 +95,29 @@ GS_DEV void strip_unpack(const RawRow &r, uint32_t (&U)[12]) {
  * So the store and the next load are in flight during the arithmetic and the single
  * s_waitcnt at the top of the next row finds them (nearly) complete.  RING rows are unrolled
  * so the vertical window is indexed at compile time. */
-template <int RING, bool INVERT, class Body>
-GS_DEV void strip_rows(const Strip<INVERT> &S, int y0, int nrows, int lead, RawRow first, Body &&body) {
+struct NoFin {
+  GS_DEV U4 operator()(const U4 &o, int) const { return o; } /* called right before row y's store */
+  GS_DEV void prefetch(int) {}                              /* called when row y's loads issue   */
+};
+template <int RING, bool INVERT, class Body, class Fin = NoFin>
+GS_DEV void strip_rows(const Strip<INVERT> &S, int y0, int nrows, int lead, RawRow first, Body &&body,
+                       Fin fin = Fin()) {
   RawRow raw = first; /* = load(y0 + lead): the newest input row output row 0 needs */
   U4 o_prev{0, 0, 0, 0};
+  fin.prefetch(y0);
   for (int base = 0; base < nrows; base += RING) {
     static_for<RING>([&](auto I) {
       const int i = base + decltype(I)::value;
       if (i >= nrows) return; /* wave-uniform */
       uint32_t U[12];
       strip_unpack(raw, U);
-      S.store(y0 + i - 1, i > 0, o_prev);
+      S.store(y0 + i - 1, i > 0, fin(o_prev, y0 + i - 1));
       raw = S.load(y0 + i + lead + 1);
+      fin.prefetch(y0 + i);
       o_prev = body(I, i, U);
     });
   }
-  S.store(y0 + nrows - 1, nrows > 0, o_prev);
+  S.store(y0 + nrows - 1, nrows > 0, fin(o_prev, y0 + nrows - 1));
 }
 
 /* ------------------------------------------------------------------ sobel, strips */
@@ -118,9 +125,10 @@ GS_DEV void strip_rows(const Strip<INVERT> &S, int y0, int nrows, int lead, RawR
  * Horizontal pass once per input row (kept in a 3-row register ring):
  *   H1[x] = r[x-1] + 2 r[x] + r[x+1]      H2[x] = r[x+1] - r[x-1]
  * vertical pass per output row:  gx = H2a + 2 H2b + H2c,  gy = H1c - H1a.
- * The kernel writes whole 16-byte groups, i.e. it also overwrites columns 0 and w-1 of rows
- * 1..h-2, which the reference never writes: the launcher saves and restores those two columns
- * (or the caller zeroes the frame afterwards). */
+ * The reference never writes columns 0 and w-1 (ref :309).  The kernel stores whole 16-byte
+ * groups, so with KEEP_COLS the lane holding column 0 (w-1) fetches dst's own first (last) dword
+ * of the row one iteration ahead and writes that byte back unchanged.  KEEP_COLS=false is for
+ * callers that do not care (interior-only copy back, or frame zeroed afterwards). */
 GS_DEV void sobel_hpass(const uint32_t (&U)[12], uint32_t (&H1)[8], uint32_t (&H2)[8]) {
   uint32_t A[11];
 #pragma unroll
@@ -132,6 +140,28 @@ GS_DEV void sobel_hpass(const uint32_t (&U)[12], uint32_t (&H1)[8], uint32_t (&H
   }
 }
 
+struct SobelKeepCols { /* Fin functor of strip_rows */
+  BufRsrc dst;
+  unsigned w, x0;
+  bool first, last;
+  uint32_t e_next = 0, e_cur = 0; /* dst dword holding the protected byte: rows y+1 and y */
+  GS_DEV SobelKeepCols(const Strip<> &S) : dst(S.dst), w(S.w), x0(S.x0) {
+    first = x0 == 0, last = x0 + 16 == w; /* launcher guarantees w >= 32: never both */
+  }
+  GS_DEV void prefetch(int y) {
+    e_cur = e_next;
+    const uint32_t row = (uint32_t)y * w + x0;
+    e_next = buf_load4(dst, first ? row : last ? row + 12 : kOOB);
+  }
+  GS_DEV U4 operator()(U4 o, int) const {
+    /* operator() for row y runs after prefetch(y+1): row y's dword is e_cur */
+    o.x = first ? perm_b32(o.x, e_cur, 0x07060500u) : o.x; /* byte 0 <- dst */
+    o.w = last ? perm_b32(o.w, e_cur, 0x03060504u) : o.w;  /* byte 3 <- dst */
+    return o;
+  }
+};
+
+template <bool KEEP_COLS>
 __global__ __launch_bounds__(256) void k_sobel16(uint8_t *dst, const uint8_t *src, unsigned w,
                                                  unsigned h, unsigned T, size_t frame_bytes) {
   const Strip<> S(src, dst, w, h, frame_bytes);
@@ -146,7 +176,7 @@ __global__ __launch_bounds__(256) void k_sobel16(uint8_t *dst, const uint8_t *sr
     strip_unpack(S.load(y0), U);
     sobel_hpass(U, R1[1], R2[1]);
   }
-  strip_rows<3>(S, y0, nrows, 1, S.load(y0 + 1), [&](auto I, int, const uint32_t(&U)[12]) {
+  auto body = [&](auto I, int, const uint32_t(&U)[12]) {
     constexpr int ia = decltype(I)::value, ib = (ia + 1) % 3, ic = (ia + 2) % 3;
     sobel_hpass(U, R1[ic], R2[ic]);
     uint32_t M[8];
@@ -159,29 +189,20 @@ __global__ __launch_bounds__(256) void k_sobel16(uint8_t *dst, const uint8_t *sr
     }
     return U4{pack_lohi(M[0], M[1]), pack_lohi(M[2], M[3]), pack_lohi(M[4], M[5]),
               pack_lohi(M[6], M[7])};
-  });
-}
-
-/* columns 0 and w-1 of rows 1..h-2: save (dir 0) to / restore (dir 1) from `cols`
- * (n frames x 2 x h bytes).  grid (ceil(2h/256), n), block 256 */
-__global__ __launch_bounds__(256) void k_edge_cols(uint8_t *img, uint8_t *cols, unsigned w,
-                                                   unsigned h, size_t frame_bytes, int dir) {
-  const unsigned i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= 2 * h) return;
-  const unsigned y = i >> 1;
-  if (y < 1 || y + 1 >= h) return;
-  uint8_t *p = img + (size_t)blockIdx.y * frame_bytes + (size_t)y * w + ((i & 1) ? w - 1 : 0);
-  uint8_t *c = cols + (size_t)blockIdx.y * 2 * h + i;
-  if (dir) *p = *c;
-  else *c = *p;
+  };
+  if constexpr (KEEP_COLS) strip_rows<3>(S, y0, nrows, 1, S.load(y0 + 1), body, SobelKeepCols(S));
+  else strip_rows<3>(S, y0, nrows, 1, S.load(y0 + 1), body);
 }
 
 /* ------------------------------------------------------------------ box blur, strips */
 /* ref grayskull.h:268-283.  Zero fill outside the image makes the clipped window sum equal the
  * padded one.  The strip kernel divides every pixel by the interior divisor d = (2R+1)^2 with
  * floor(s/d) == (s*MUL) >> 24 (exact for s <= 255*d; the quotient is the top byte of the 32-bit
- * product, so four of them pack with v_perm_b32).  Pixels whose window is clipped (the R-wide
- * frame) have a smaller divisor; k_blur_frame_px rewrites exactly those afterwards. */
+ * product, so four of them pack with v_perm_b32).  Where the window is clipped the divisor is
+ * the number of in-image taps (ref :275-281): the R leftmost / rightmost columns get their own
+ * per-lane multipliers ceil(2^24 / (N * cols_in_image)) (selects, no branch; exact: for d <= N*N,
+ * e = MUL*d - 2^24 < d and s*e <= 255*d*d < 2^24), and the R top / bottom rows -- 2R rows per
+ * frame -- are rewritten by k_blur_edge_rows with a true division. */
 template <int R> struct BlurMagic;
 template <> struct BlurMagic<1> { static constexpr uint32_t mul = 1864136; };  /* ceil(2^24/9)  */
 template <> struct BlurMagic<2> { static constexpr uint32_t mul = 671089; };   /* ceil(2^24/25) */
@@ -210,6 +231,7 @@ __global__ __launch_bounds__(256) void k_blur16(uint8_t *dst, const uint8_t *src
                                                 unsigned h, unsigned T, size_t frame_bytes) {
   constexpr int N = 2 * R + 1;
   const Strip<> S(src, dst, w, h, frame_bytes);
+  const bool first = S.x0 == 0, last = S.x0 + 16 == w;
   const int y0 = (int)(S.band * T);
   if (y0 >= (int)h) return;
   const int nrows = ((int)h - y0) < (int)T ? ((int)h - y0) : (int)T;
@@ -226,52 +248,57 @@ __global__ __launch_bounds__(256) void k_blur16(uint8_t *dst, const uint8_t *src
   }
   strip_rows<N>(S, y0, nrows, R, S.load(y0 + R), [&](auto I, int, const uint32_t(&U)[12]) {
     constexpr int slot = (decltype(I)::value + N - 1) % N; /* row i-1 leaves, row i+2R enters */
-    uint32_t Hn[8], p[16];
+    uint32_t Hn[8];
     blur_hsum<R>(U, Hn);
+    /* per-pixel multipliers: interior constant, except the R columns next to an image edge
+     * (compile-time constants behind one select each; rows clipped vertically are rewritten by
+     * k_blur_edge_rows afterwards) */
+    uint32_t mL[R], mR[R];
+    constexpr uint32_t mC = BlurMagic<R>::mul;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-      V[k] = pk_sub_u16(pk_add_u16(V[k], Hn[k]), ring[slot][k]);
-      ring[slot][k] = Hn[k];
-      p[2 * k] = (V[k] & 0xffffu) * BlurMagic<R>::mul; /* quotient = byte 3 */
-      p[2 * k + 1] = (V[k] >> 16) * BlurMagic<R>::mul;
+    for (int q = 0; q < R; q++) {
+      mL[q] = first ? (0x1000000u + N * (R + 1 + q) - 1u) / (N * (R + 1 + q)) : mC;
+      mR[q] = last ? (0x1000000u + N * (2 * R - q) - 1u) / (N * (2 * R - q)) : mC;
     }
-    U4 o;
-    o.x = perm_b32(p[3], perm_b32(p[2], perm_b32(p[1], p[0], 0x0c0c0703u), 0x0c070100u), 0x07020100u);
-    o.y = perm_b32(p[7], perm_b32(p[6], perm_b32(p[5], p[4], 0x0c0c0703u), 0x0c070100u), 0x07020100u);
-    o.z = perm_b32(p[11], perm_b32(p[10], perm_b32(p[9], p[8], 0x0c0c0703u), 0x0c070100u), 0x07020100u);
-    o.w = perm_b32(p[15], perm_b32(p[14], perm_b32(p[13], p[12], 0x0c0c0703u), 0x0c070100u), 0x07020100u);
+    uint32_t od[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) { /* 4 pixels = 2 pairs -> one output dword */
+      uint32_t p[4];
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        const int k = 2 * g + t;
+        V[k] = pk_sub_u16(pk_add_u16(V[k], Hn[k]), ring[slot][k]);
+        ring[slot][k] = Hn[k];
+#pragma unroll
+        for (int hlf = 0; hlf < 2; hlf++) { /* quotient = byte 3 of the product */
+          const int q = 2 * k + hlf;
+          const uint32_t sv = hlf ? (V[k] >> 16) : (V[k] & 0xffffu);
+          const uint32_t m = q < R ? mL[q < R ? q : 0] : q >= 16 - R ? mR[q >= 16 - R ? q - (16 - R) : 0] : mC;
+          p[2 * t + hlf] = sv * m;
+        }
+      }
+      od[g] = perm_b32(p[3], perm_b32(p[2], perm_b32(p[1], p[0], 0x0c0c0703u), 0x0c070100u), 0x07020100u);
+    }
+    U4 o{od[0], od[1], od[2], od[3]};
     return o;
   });
 }
 
-/* The R-wide frame of each image, where the window is clipped and the divisor is the number of
- * in-image taps (ref :275-281).  One thread per frame pixel: rows [0,R) and [h-R,h) in full,
- * columns [0,R) and [w-R,w) of the rows in between.  grid (ceil(npx/256), n frames). */
-__global__ __launch_bounds__(256) void k_blur_frame_px(uint8_t *dst, const uint8_t *src, unsigned w,
-                                                       unsigned h, int R, size_t frame_bytes) {
-  const unsigned nrow_px = 2u * (unsigned)R * w;             /* needs h > 2R, w > 2R */
-  const unsigned mid = h - 2u * (unsigned)R;
-  const unsigned total = nrow_px + mid * 2u * (unsigned)R;
-  const unsigned i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= total) return;
-  int x, y;
-  if (i < nrow_px) {
-    const unsigned ry = i / w;
-    x = (int)(i - ry * w);
-    y = ry < (unsigned)R ? (int)ry : (int)(h - 2u * R + ry);
-  } else {
-    const unsigned j = i - nrow_px, ry = j / (2u * R), cx = j - ry * 2u * R;
-    y = R + (int)ry;
-    x = cx < (unsigned)R ? (int)cx : (int)(w - 2u * R + cx);
-  }
-  const uint8_t *f = src + (size_t)blockIdx.y * frame_bytes;
+/* rows [0,R) and [h-R,h): the window is clipped vertically, divisor = in-image taps
+ * (ref :275-281).  One thread per pixel, coalesced along x.  grid (ceil(w/256), 2R, n frames). */
+__global__ __launch_bounds__(256) void k_blur_edge_rows(uint8_t *dst, const uint8_t *src, unsigned w,
+                                                        unsigned h, int R, size_t frame_bytes) {
+  const int x = (int)(blockIdx.x * 256u + threadIdx.x);
+  if (x >= (int)w) return;
+  const int ry = (int)blockIdx.y, y = ry < R ? ry : (int)h - 2 * R + ry;
+  const uint8_t *f = src + (size_t)blockIdx.z * frame_bytes;
   const int xa = x - R < 0 ? 0 : x - R, xb = x + R > (int)w - 1 ? (int)w - 1 : x + R;
   const int ya = y - R < 0 ? 0 : y - R, yb = y + R > (int)h - 1 ? (int)h - 1 : y + R;
   unsigned sum = 0;
   for (int yy = ya; yy <= yb; yy++)
     for (int xx = xa; xx <= xb; xx++) sum += f[(size_t)yy * w + xx];
   const unsigned cnt = (unsigned)((xb - xa + 1) * (yb - ya + 1));
-  dst[(size_t)blockIdx.y * frame_bytes + (size_t)y * w + x] = (uint8_t)(sum / cnt);
+  dst[(size_t)blockIdx.z * frame_bytes + (size_t)y * w + x] = (uint8_t)(sum / cnt);
 }
 
 /* ------------------------------------------------------------------ 3x3 erode / dilate, strips */
