@@ -291,7 +291,7 @@ class Grayskull:
 
     def edge_pipeline_batch(self, dst, tmp, src, radius, hist_scratch, thr):
         n, h, w = self._nhw(src)
-        self.c.gsh_edge_pipeline_batch(_ptr(dst), _ptr(tmp), _ptr(src), w, h, n, radius,
+        self.c.gsh_edge_pipeline_batch(_ptr(dst), _ptr(tmp) if tmp is not None else None, _ptr(src), w, h, n, radius,
                                        _ptr(hist_scratch), _ptr(thr))
 
     def integral_batch(self, src, ii):

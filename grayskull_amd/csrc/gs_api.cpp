@@ -286,7 +286,7 @@ void launch_histogram(const uint8_t *img, size_t frame_bytes, unsigned n, unsign
     GS_LAUNCH(k_hist_partial, dim3(bpf, nn), dim3(256), 0, st, img + frame_bytes * f0, frame_bytes,
               partial);
     GS_LAUNCH(k_hist_reduce, dim3(nn), dim3(256), 0, st, (const unsigned *)partial, bpf,
-              hist + (size_t)f0 * 256);
+              hist + (size_t)f0 * 256, 0u);
   }
 }
 void launch_threshold(uint8_t *img, size_t frame_bytes, unsigned n, const uint8_t *thr_dev,
@@ -711,18 +711,45 @@ void gsh_threshold_batch_dev(uint8_t *img, unsigned w, unsigned h, unsigned n, c
 }
 void gsh_edge_pipeline_batch(uint8_t *dst, uint8_t *tmp, const uint8_t *src, unsigned w, unsigned h,
                              unsigned n, unsigned radius, unsigned *hist_scratch, uint8_t *thr) {
-  GS_ASSERT(dst && tmp && src && hist_scratch && thr && w > 0 && h > 0);
+  GS_ASSERT(dst && src && hist_scratch && thr && w > 0 && h > 0);
   const size_t fb = (size_t)w * h;
-  launch_blur(tmp, src, w, h, n, radius);
+  hipStream_t st = ctx().s();
+  auto zero_frame = [&]() { /* gs_sobel ran "into a zeroed image": only its 1-px frame is left */
+    for (unsigned f0 = 0; f0 < n; f0 += kMaxZ)
+      GS_LAUNCH(k_zero_frame, dim3((2 * w + 2 * h + 255) / 256, std::min(kMaxZ, n - f0)), dim3(256), 0,
+                st, dst + fb * f0, w, h, fb);
+  };
+  if (!tmp && g_tune[3] == 0 && radius >= 1 && radius <= 3 && strip_ok(w, h, dst, src) && w >= 32 &&
+      h >= 3 && h > 2 * radius) { /* every window is clipped on at most one side per axis */
+    /* fused: the blurred image only ever exists in registers (1 R + 1 W per pixel) */
+    for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
+      const unsigned nn = std::min(kMaxZ, n - f0);
+      const StripCfg c = strip_cfg(w, h - 2, nn);
+      const unsigned bpf = c.grid.x * c.grid.y;
+      unsigned *partial = (unsigned *)ctx().scratch(SL_HISTP, (size_t)nn * bpf * 256 * 4);
+      uint8_t *d = dst + fb * f0;
+      const uint8_t *s = src + fb * f0;
+      if (radius == 1) GS_LAUNCH(k_blur_sobel_hist16<1>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb, partial);
+      else if (radius == 2) GS_LAUNCH(k_blur_sobel_hist16<2>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb, partial);
+      else GS_LAUNCH(k_blur_sobel_hist16<3>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb, partial);
+      /* the 2w + 2(h-2) frame pixels are 0 in the result and were not counted by the kernel */
+      GS_LAUNCH(k_hist_reduce, dim3(nn), dim3(256), 0, st, (const unsigned *)partial, bpf,
+                hist_scratch + (size_t)f0 * 256, 2 * w + 2 * (h - 2));
+      GS_LAUNCH(k_otsu, dim3(nn), dim3(256), 0, st, (const unsigned *)hist_scratch + (size_t)f0 * 256,
+                w * h, thr + f0);
+    }
+    zero_frame();
+    launch_threshold(dst, fb, n, thr, 0);
+    return;
+  }
+  uint8_t *t = tmp ? tmp : (uint8_t *)ctx().scratch(SL_AUX, fb * n);
+  launch_blur(t, src, w, h, n, radius);
   /* sobel never writes its 1-px frame (ref :308-309); config 2 runs it into a zeroed image, so
    * only that frame needs zeroing (the interior is overwritten) -- after the sobel launch,
    * which then need not preserve columns 0 / w-1 */
-  if (w < 3 || h < 3) GS_HIP(hipMemsetAsync(dst, 0, fb * n, ctx().s()));
-  launch_sobel(dst, tmp, w, h, n, false);
-  if (w >= 3 && h >= 3)
-    for (unsigned f0 = 0; f0 < n; f0 += kMaxZ)
-      GS_LAUNCH(k_zero_frame, dim3((2 * w + 2 * h + 255) / 256, std::min(kMaxZ, n - f0)), dim3(256), 0,
-                ctx().s(), dst + fb * f0, w, h, fb);
+  if (w < 3 || h < 3) GS_HIP(hipMemsetAsync(dst, 0, fb * n, st));
+  launch_sobel(dst, t, w, h, n, false);
+  if (w >= 3 && h >= 3) zero_frame();
   launch_otsu(dst, w, h, n, hist_scratch, thr);
   launch_threshold(dst, fb, n, thr, 0);
 }

@@ -95,9 +95,9 @@ __global__ __launch_bounds__(256) void k_hist_partial(const uint8_t *img, size_t
 
 /* grid n frames, block 256 */
 __global__ __launch_bounds__(256) void k_hist_reduce(const unsigned *partial, unsigned bpf,
-                                                     unsigned *hist) {
+                                                     unsigned *hist, unsigned extra0) {
   const unsigned *p = partial + (size_t)blockIdx.x * bpf * 256u + threadIdx.x;
-  unsigned s = 0;
+  unsigned s = threadIdx.x == 0 ? extra0 : 0u; /* pixels known to be 0 that nobody counted */
   for (unsigned b = 0; b < bpf; b++) s += p[(size_t)b * 256u];
   hist[(size_t)blockIdx.x * 256u + threadIdx.x] = s;
 }

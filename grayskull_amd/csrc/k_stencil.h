@@ -122,9 +122,9 @@ GS_DEV void strip_rows(const Strip<INVERT> &S, int y0, int nrows, int lead, RawR
 
 /* ------------------------------------------------------------------ sobel, strips */
 /* ref grayskull.h:306-320: (|gx|+|gy|)/2 clamped to 255 on rows 1..h-2.
- * Horizontal pass once per input row (kept in a 3-row register ring):
+ * Horizontal pass once per input row:
  *   H1[x] = r[x-1] + 2 r[x] + r[x+1]      H2[x] = r[x+1] - r[x-1]
- * vertical pass per output row:  gx = H2a + 2 H2b + H2c,  gy = H1c - H1a.
+ * vertical pass per output row:  gx = H2a + 2 H2b + H2c,  gy = H1c - H1a  (SobelState).
  * The reference never writes columns 0 and w-1 (ref :309).  The kernel stores whole 16-byte
  * groups, so with KEEP_COLS the lane holding column 0 (w-1) fetches dst's own first (last) dword
  * of the row one iteration ahead and writes that byte back unchanged.  KEEP_COLS=false is for
@@ -161,6 +161,49 @@ struct SobelKeepCols { /* Fin functor of strip_rows */
   }
 };
 
+/* vertical state of the sobel recurrence, one new input row b per step (output row y = b-1):
+ *   gx(y) = H2(b-2) + 2 H2(b-1) + H2(b) = Pa + H2(b),   Pa' = H2(b-1) + 2 H2(b),
+ *   gy(y) = H1(b) - H1(b-2).
+ * 32 registers instead of a 3-row ring of (H1,H2) = 48, and only a 2-step static rotation. */
+struct SobelState {
+  uint32_t Pa[8], Hp[8], H1[2][8];
+  /* prime with input rows y0-1 (r0) and y0 (r1) */
+  GS_DEV void init(const uint32_t (&U0)[12], const uint32_t (&U1)[12]) {
+    uint32_t h1[8], h2[8];
+    sobel_hpass(U0, H1[0], h2);
+    sobel_hpass(U1, h1, Hp);
+#pragma unroll
+    for (int k = 0; k < 8; k++) H1[1][k] = h1[k], Pa[k] = pk_mad2_u16(Hp[k], h2[k]);
+  }
+  /* PAR = parity of the step: H1[PAR] holds row b-2 and receives row b */
+  template <int PAR> GS_DEV U4 step(const uint32_t (&U)[12]) {
+    uint32_t H1n[8], H2n[8], M[8];
+    sobel_hpass(U, H1n, H2n);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const uint32_t gx = pk_add_u16(Pa[k], H2n[k]);
+      const uint32_t gy = pk_sub_u16(H1n[k], H1[PAR][k]);
+      Pa[k] = pk_mad2_u16(H2n[k], Hp[k]);
+      Hp[k] = H2n[k];
+      H1[PAR][k] = H1n[k];
+      const uint32_t m = pk_shr_u16(pk_add_u16(pk_abs_i16(gx), pk_abs_i16(gy)), 1);
+      M[k] = pk_min_u16(m, 0x00ff00ffu);
+    }
+    return U4{pack_lohi(M[0], M[1]), pack_lohi(M[2], M[3]), pack_lohi(M[4], M[5]),
+              pack_lohi(M[6], M[7])};
+  }
+  /* same, H1 history shifted instead of alternated (for callers whose unroll period is odd) */
+  GS_DEV U4 step_shift(const uint32_t (&U)[12]) {
+    const U4 o = step<0>(U); /* H1[0] (row b-2) consumed and overwritten with row b */
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const uint32_t t = H1[0][k];
+      H1[0][k] = H1[1][k], H1[1][k] = t;
+    }
+    return o;
+  }
+};
+
 template <bool KEEP_COLS>
 __global__ __launch_bounds__(256) void k_sobel16(uint8_t *dst, const uint8_t *src, unsigned w,
                                                  unsigned h, unsigned T, size_t frame_bytes) {
@@ -168,30 +211,16 @@ __global__ __launch_bounds__(256) void k_sobel16(uint8_t *dst, const uint8_t *sr
   const int y0 = 1 + (int)(S.band * T);
   if (y0 >= (int)h - 1) return; /* whole wave */
   const int nrows = ((int)h - 1 - y0) < (int)T ? ((int)h - 1 - y0) : (int)T;
-  uint32_t R1[3][8], R2[3][8];
+  SobelState st;
   {
-    uint32_t U[12];
-    strip_unpack(S.load(y0 - 1), U);
-    sobel_hpass(U, R1[0], R2[0]);
-    strip_unpack(S.load(y0), U);
-    sobel_hpass(U, R1[1], R2[1]);
+    uint32_t U0[12], U1[12];
+    strip_unpack(S.load(y0 - 1), U0);
+    strip_unpack(S.load(y0), U1);
+    st.init(U0, U1);
   }
-  auto body = [&](auto I, int, const uint32_t(&U)[12]) {
-    constexpr int ia = decltype(I)::value, ib = (ia + 1) % 3, ic = (ia + 2) % 3;
-    sobel_hpass(U, R1[ic], R2[ic]);
-    uint32_t M[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const uint32_t gx = pk_mad2_u16(R2[ib][k], pk_add_u16(R2[ia][k], R2[ic][k]));
-      const uint32_t gy = pk_sub_u16(R1[ic][k], R1[ia][k]);
-      const uint32_t m = pk_shr_u16(pk_add_u16(pk_abs_i16(gx), pk_abs_i16(gy)), 1);
-      M[k] = pk_min_u16(m, 0x00ff00ffu);
-    }
-    return U4{pack_lohi(M[0], M[1]), pack_lohi(M[2], M[3]), pack_lohi(M[4], M[5]),
-              pack_lohi(M[6], M[7])};
-  };
-  if constexpr (KEEP_COLS) strip_rows<3>(S, y0, nrows, 1, S.load(y0 + 1), body, SobelKeepCols(S));
-  else strip_rows<3>(S, y0, nrows, 1, S.load(y0 + 1), body);
+  auto body = [&](auto I, int, const uint32_t(&U)[12]) { return st.template step<decltype(I)::value>(U); };
+  if constexpr (KEEP_COLS) strip_rows<2>(S, y0, nrows, 1, S.load(y0 + 1), body, SobelKeepCols(S));
+  else strip_rows<2>(S, y0, nrows, 1, S.load(y0 + 1), body);
 }
 
 /* ------------------------------------------------------------------ box blur, strips */
@@ -299,6 +328,136 @@ __global__ __launch_bounds__(256) void k_blur_edge_rows(uint8_t *dst, const uint
     for (int xx = xa; xx <= xb; xx++) sum += f[(size_t)yy * w + xx];
   const unsigned cnt = (unsigned)((xb - xa + 1) * (yb - ya + 1));
   dst[(size_t)blockIdx.z * frame_bytes + (size_t)y * w + x] = (uint8_t)(sum / cnt);
+}
+
+/* ------------------------------------------------------------------ fused blur -> sobel -> histogram */
+/* The config-2 chain (gs_blur(R); gs_sobel; histogram for gs_otsu_threshold) in ONE pass over the
+ * frame: 1 B/px read + 1 B/px written instead of 2+2+1.  Per source row the lane forms the
+ * (2R+1)-tap horizontal sums for pixels -2..17, keeps their running vertical sum, divides (exact
+ * 2^24 multipliers, chosen per pixel / per row where the window is clipped: every divisor is
+ * rows_in_image * cols_in_image, ref :275-281), and feeds the blurred row -- never written to
+ * memory -- straight into the sobel recurrence.  The sobel bytes go to dst and into an
+ * LDS-privatised histogram (32 bank-spread copies, see k_hist_partial); each block leaves 256
+ * partial counts for k_hist_reduce.  Bit-identical to the separate calls (tests).  Columns 0 and
+ * w-1 of dst receive junk here; the launcher zeroes the 1-px frame afterwards (config 2 runs
+ * gs_sobel into a zeroed image), and the histogram counts those frame pixels as 0 analytically. */
+constexpr uint32_t blur_k24(unsigned cx, unsigned cy) { return (0x1000000u + cx * cy - 1u) / (cx * cy); }
+
+template <int R, unsigned CX>
+GS_DEV uint32_t blur_mul_for_rows(unsigned cy) { /* cy in [R+1, 2R+1], wave-uniform */
+  uint32_t m = blur_k24(CX, 2 * R + 1);
+#pragma unroll
+  for (unsigned c = R + 1; c < 2 * R + 1; c++) m = cy == c ? blur_k24(CX, c) : m;
+  return m;
+}
+
+template <int R>
+GS_DEV void blur_hsum10(const uint32_t (&U)[12], uint32_t (&H)[10]) { /* pairs = px -2..17 */
+  uint32_t A[13]; /* A[j+1] = pair starting one px after U[j], j = -1..11 (ends zero-extended) */
+  A[0] = alignbit(U[0], 0u, 16);
+#pragma unroll
+  for (int j = 0; j <= 10; j++) A[j + 1] = alignbit(U[j + 1], U[j], 16);
+  A[12] = alignbit(0u, U[11], 16);
+#pragma unroll
+  for (int k = 0; k < 10; k++) {
+    const int j = k + 1; /* U[j] = pair k */
+    uint32_t s = pk_add_u16(pk_add_u16(A[j], U[j]), A[j + 1]);            /* -1, 0, +1 */
+    if constexpr (R >= 2) s = pk_add_u16(pk_add_u16(s, U[j - 1]), U[j + 1]); /* -2, +2 */
+    if constexpr (R >= 3) s = pk_add_u16(pk_add_u16(s, A[j - 1]), A[j + 2]); /* -3, +3 */
+    H[k] = s;
+  }
+}
+
+/* grid like the strip kernels; partial: [frame][blockIdx.y * gridDim.x + blockIdx.x][256] */
+template <int R>
+__global__ __launch_bounds__(256) void k_blur_sobel_hist16(uint8_t *dst, const uint8_t *src,
+                                                           unsigned w, unsigned h, unsigned T,
+                                                           size_t frame_bytes, unsigned *partial) {
+  constexpr int N = 2 * R + 1;
+  __shared__ unsigned lh[256 * 32];
+  const unsigned tid = threadIdx.y * blockDim.x + threadIdx.x, copy = tid & 31u;
+  for (unsigned i = tid; i < 256 * 32; i += 256) lh[i] = 0;
+  __syncthreads();
+  const Strip<> S(src, dst, w, h, frame_bytes);
+  const int y0 = 1 + (int)(S.band * T);
+  if (y0 < (int)h - 1) { /* wave-uniform; no early return: every wave reaches the barrier */
+    const int nrows = ((int)h - 1 - y0) < (int)T ? ((int)h - 1 - y0) : (int)T;
+    const bool first = S.x0 == 0, last = S.x0 + 16 == w, inimg = S.x0 < w;
+    uint32_t ring[N][10], V[10];
+    SobelState st;
+    /* blurred row b as u16 pairs for pixels -2..17, placed where sobel_hpass expects U[1..10] */
+    auto blurred = [&](int b, uint32_t(&UB)[12]) {
+      const int ya = b - R < 0 ? 0 : b - R, yb = b + R > (int)h - 1 ? (int)h - 1 : b + R;
+      const unsigned cy = (unsigned)(yb - ya + 1);
+      const uint32_t mC = blur_mul_for_rows<R, N>(cy);
+      uint32_t mL[R], mR[R];
+      static_for<R>([&](auto Q) {
+        constexpr int q = decltype(Q)::value;
+        mL[q] = first ? blur_mul_for_rows<R, R + 1 + q>(cy) : mC;
+        mR[q] = last ? blur_mul_for_rows<R, 2 * R - q>(cy) : mC;
+      });
+      UB[0] = 0, UB[11] = 0;
+#pragma unroll
+      for (int k = 0; k < 10; k++) { /* pair k = own pixels (2k-2, 2k-1) */
+        uint32_t pr[2];
+#pragma unroll
+        for (int hlf = 0; hlf < 2; hlf++) {
+          const int q = 2 * k - 2 + hlf; /* own pixel index -2..17 */
+          const uint32_t sv = hlf ? (V[k] >> 16) : (V[k] & 0xffffu);
+          const uint32_t m = (q >= 0 && q < R) ? mL[(q >= 0 && q < R) ? q : 0]
+                             : (q >= 16 - R && q < 16) ? mR[(q >= 16 - R && q < 16) ? q - (16 - R) : 0]
+                                                       : mC;
+          pr[hlf] = sv * m; /* quotient = byte 3 */
+        }
+        UB[k + 1] = perm_b32(pr[1], pr[0], 0x0c070c03u);
+      }
+    };
+    /* prologue: source rows y0-1-R .. y0+R give blurred rows y0-1 and y0 */
+#pragma unroll
+    for (int k = 0; k < 10; k++) V[k] = 0;
+    uint32_t UB0[12], UB1[12];
+    static_for<N>([&](auto K) {
+      constexpr int kk = decltype(K)::value;
+      uint32_t U[12];
+      strip_unpack(S.load(y0 - 1 - R + kk), U);
+      blur_hsum10<R>(U, ring[kk]);
+#pragma unroll
+      for (int k = 0; k < 10; k++) V[k] = pk_add_u16(V[k], ring[kk][k]);
+    });
+    blurred(y0 - 1, UB0);
+    {
+      uint32_t U[12], Hn[10];
+      strip_unpack(S.load(y0 + R), U);
+      blur_hsum10<R>(U, Hn);
+#pragma unroll
+      for (int k = 0; k < 10; k++) V[k] = pk_sub_u16(pk_add_u16(V[k], Hn[k]), ring[0][k]), ring[0][k] = Hn[k];
+    }
+    blurred(y0, UB1);
+    st.init(UB0, UB1);
+
+    strip_rows<N>(S, y0, nrows, R + 1, S.load(y0 + R + 1), [&](auto I, int i, const uint32_t(&U)[12]) {
+      constexpr int slot = (decltype(I)::value + 1) % N; /* oldest row of the vertical window */
+      uint32_t Hn[10], UB[12];
+      blur_hsum10<R>(U, Hn);
+#pragma unroll
+      for (int k = 0; k < 10; k++) V[k] = pk_sub_u16(pk_add_u16(V[k], Hn[k]), ring[slot][k]), ring[slot][k] = Hn[k];
+      blurred(y0 + i + 1, UB);
+      const U4 o = st.step_shift(UB);
+      const uint32_t od[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        const bool ok = inimg && !(first && q == 0) && !(last && q == 15);
+        if (ok) atomicAdd(&lh[((od[q >> 2] >> (8 * (q & 3))) & 0xffu) * 32u + copy], 1u);
+      }
+      return o;
+    });
+  }
+  __syncthreads();
+  unsigned acc = 0;
+#pragma unroll 8
+  for (unsigned k = 0; k < 32; k++) acc += lh[tid * 32u + ((k + tid) & 31u)];
+  const size_t blk = (size_t)blockIdx.z * gridDim.x * gridDim.y + (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+  partial[blk * 256u + tid] = acc;
 }
 
 /* ------------------------------------------------------------------ 3x3 erode / dilate, strips */

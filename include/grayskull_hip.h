@@ -34,7 +34,8 @@ void gsh_set_async(int on);               /* drop-in gs_* calls on device pointe
                                              the final stream sync when on             */
 void gsh_sync(void);                      /* hipStreamSynchronize(current stream)       */
 /* launch tuning of the strip kernels: key 0 rows per band (0 = auto), 1 block shape
- * (0: 64x4, 1: 256x1, 2: 128x2), 2 row-prefetch depth (1..3).  Results never change. */
+ * (0: 64x4, 1: 256x1, 2: 128x2), 3 set to 1 to disable the fused pipeline kernel.
+ * Results never change. */
 void gsh_tune(int key, int value);
 /* diagnostic: strip-kernel traffic pattern with no arithmetic (access-pattern ceiling) */
 void gsh_probe_strip_copy(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned n);
@@ -63,7 +64,9 @@ void gsh_threshold_batch(uint8_t *img, unsigned w, unsigned h, unsigned n, uint8
 void gsh_threshold_batch_dev(uint8_t *img, unsigned w, unsigned h, unsigned n, const uint8_t *thr);
 
 /* config-2 chain per frame: blur(radius) -> sobel (dst frame pre-zeroed) -> otsu -> threshold.
- * tmp and dst are n*w*h bytes each; thr receives the n Otsu thresholds. */
+ * dst: n*w*h bytes, thr: the n Otsu thresholds.  tmp: n*w*h bytes that receive the blurred
+ * frames, or NULL when the caller does not need them -- then blur, sobel and the histogram run
+ * as ONE fused kernel and the blurred image never touches memory (same dst / thr bytes). */
 void gsh_edge_pipeline_batch(uint8_t *dst, uint8_t *tmp, const uint8_t *src, unsigned w, unsigned h,
                              unsigned n, unsigned radius, unsigned *hist_scratch, uint8_t *thr);
 

@@ -137,3 +137,25 @@ def test_strip_launch_tuning_never_changes_results(emu, oracle, geom, pf):
                 pc.stencils(emu, oracle, Oracle.synth(w, h, w + h + T), MEM, radii=(1, 2, 3))
     finally:
         emu.tune(0, 0), emu.tune(1, 1), emu.tune(2, 2)
+
+
+@pytest.mark.parametrize("radius", [1, 2, 3])
+@pytest.mark.parametrize("shape", [(64, 23), (2064, 9), (4112, 5), (32, 3), (48, 4)])
+def test_fused_edge_pipeline_equals_separate_calls(emu, oracle, radius, shape):
+    """gsh_edge_pipeline_batch(tmp=NULL): fused blur->sobel->histogram kernel vs the oracle chain"""
+    w, h = shape
+    n = 2
+    src = np.stack([Oracle.synth(w, h, 300 + w + i) for i in range(n)])
+    for T in (0, 1, 3):
+        emu.tune(0, T)
+        out = np.full_like(src, 7)
+        hist = np.zeros((n, 256), np.uint32)
+        thr = np.zeros(n, np.uint8)
+        emu.edge_pipeline_batch(out, None, src, radius, hist, thr)
+        for i in range(n):
+            s = oracle.sobel(oracle.blur(src[i], radius))
+            t = oracle.otsu_threshold(s)
+            assert np.array_equal(hist[i], oracle.histogram(s)), "histogram of the sobel image"
+            assert thr[i] == t
+            assert np.array_equal(out[i], oracle.threshold(s, t))
+    emu.tune(0, 0)

@@ -175,6 +175,13 @@ def test_kat_synth_config2_chain(hip, kat, idx):
     thr = torch.zeros(1, dtype=torch.uint8, device="cuda")
     hip.edge_pipeline_batch(out, tmp, src, 2, hist, thr)
     assert int(thr[0]) == k["otsu"] and fnv(out[0].cpu().numpy()) == k["thr"]
+    assert fnv(tmp[0].cpu().numpy()) == k["blur2"]
+    # ... and so must the single fused kernel (tmp=NULL: the blurred image stays in registers)
+    out2, thr2 = torch.full_like(src, 5), torch.zeros(1, dtype=torch.uint8, device="cuda")
+    hist2 = torch.zeros((1, 256), dtype=torch.int32, device="cuda")
+    hip.edge_pipeline_batch(out2, None, src, 2, hist2, thr2)
+    assert int(thr2[0]) == k["otsu"] and fnv(out2[0].cpu().numpy()) == k["thr"]
+    assert bool((hist2 == hist).all()), "fused histogram == histogram of the sobel image"
 
 
 @pytest.mark.parametrize("idx", [2, 3, 4])
@@ -256,6 +263,14 @@ def test_batch_4k_properties(hip, oracle):
         t = oracle.otsu_threshold(s)
         assert int(thr[f]) == t
         assert_same(once[f].cpu().numpy(), oracle.threshold(s, t), "edge pipeline frame %d" % f)
+    # fused kernel path over the whole batch, every radius it supports, == the unfused path
+    for r in (1, 2, 3):
+        a, b = torch.full_like(src, 1), torch.full_like(src, 2)
+        ha, hb = torch.zeros_like(hist), torch.zeros_like(hist)
+        ta, tb = torch.zeros_like(thr), torch.zeros_like(thr)
+        hip.edge_pipeline_batch(a, tmp, src, r, ha, ta)
+        hip.edge_pipeline_batch(b, None, src, r, hb, tb)
+        assert bool((a == b).all()) and bool((ha == hb).all()) and bool((ta == tb).all()), "fused r=%d" % r
 
 
 def test_batch_integral_lbp_fast(hip, oracle, cascade):
