@@ -352,7 +352,7 @@ void launch_fast(const uint8_t *img, uint8_t *score, unsigned w, unsigned h, uns
 }  // namespace
 
 struct gsh_cascade {
-  unsigned window_w, window_h, nfeatures, nweaks, nstages;
+  unsigned window_w, window_h, nfeatures, nweaks, nstages, nsub = 0;
   std::vector<int8_t> features;
   std::vector<uint16_t> weak_feature_idx;
   LbpWeak *d_weak = nullptr;
@@ -403,7 +403,7 @@ void build_scales(const gsh_cascade &c, unsigned iw, unsigned ih, float scale_fa
       if (fw < 1) fw = 1;
       if (fh < 1) fh = 1;
       if (fx < 0 || fy < 0 || fx + 3 * fw > win_w || fy + 3 * fh > win_h) guard = true;
-      geom.push_back(LbpGeom{fy * (int)S + fx, fw, fh * (int)S, 0});
+      geom.push_back(LbpGeom{(fy * (int)S + fx) * 4, fw * 4, fh * (int)S * 4, 0});
     }
     scales.push_back(sc);
     if (scales.size() >= 4096 || !(scale_factor > 1.0f)) break; /* the reference would not terminate */
@@ -455,21 +455,48 @@ void launch_lbp_padded(gsh_cascade *dc, const unsigned *padded, unsigned iw, uns
   const unsigned nch = dc->total_chunks;
   unsigned long long *mask =
       (unsigned long long *)ctx().scratch(SL_MASK, (size_t)n * nch * kChunkWords * 8);
-  unsigned *cnt = (unsigned *)ctx().scratch(SL_CNT, (size_t)n * nch * 4);
-  GS_HIP(hipMemsetAsync(cnt, 0, (size_t)n * nch * 4, st));
+  unsigned *cnt = (unsigned *)ctx().scratch(SL_CNT, (size_t)n * nch * 4); /* every chunk is written */
   LbpArgs a;
   a.padded = padded;
   a.frame_stride = (size_t)(iw + 1) * (ih + 1);
   a.S = iw + 1;
-  a.limit = a.frame_stride - 1;
+  a.limit_bytes = (unsigned)((a.frame_stride - 1) * 4);
   a.step = step;
-  a.nweaks = dc->nweaks, a.nstages = dc->nstages;
+  a.nweaks = dc->nweaks, a.nstages = dc->nstages, a.nsub = dc->nsub;
   a.scales = dc->d_scales, a.geom = dc->d_geom, a.weak = dc->d_weak, a.stage = dc->d_stage;
   a.subsets = dc->d_subsets;
   a.mask = mask, a.chunk_count = cnt, a.total_chunks = nch;
-  const dim3 g(dc->max_chunks, (unsigned)dc->scales.size(), n);
-  if (dc->guard) GS_LAUNCH(k_lbp_cascade<true>, g, dim3(256), 0, st, a);
-  else GS_LAUNCH(k_lbp_cascade<false>, g, dim3(256), 0, st, a);
+  const unsigned nsc = (unsigned)dc->scales.size();
+  const dim3 g(dc->max_chunks, nsc, n);
+  const size_t lds = (size_t)dc->nstages * sizeof(LbpStage) +
+                     (size_t)dc->nweaks * (sizeof(LbpWeak) + sizeof(LbpGeom)) + (size_t)dc->nsub * 4;
+  GS_ASSERT(lds <= 60 * 1024 && "cascade tables must fit the block's LDS");
+  /* phases of the block-local survivor re-packing: g_tune[4] selects a preset */
+  LbpPhases ph;
+  {
+    static const unsigned presets[8][kLbpMaxPhases] = {
+        {2, 5, 99, 99, 99, 99, 99, 99},   /* 0 default (measured best on MI355X, frontalface) */
+        {99, 99, 99, 99, 99, 99, 99, 99}, /* 1: single dense phase (no re-packing) */
+        {1, 2, 4, 6, 9, 13, 99, 99},
+        {1, 2, 3, 4, 6, 8, 12, 99},
+        {1, 2, 5, 99, 99, 99, 99, 99},
+        {2, 4, 7, 99, 99, 99, 99, 99},
+        {2, 6, 99, 99, 99, 99, 99, 99},
+        {3, 7, 99, 99, 99, 99, 99, 99}};
+    const unsigned *pr = presets[(g_tune[4] >= 0 && g_tune[4] < 8) ? g_tune[4] : 0];
+    ph.n = 0;
+    unsigned prev = 0;
+    for (unsigned i = 0; i < kLbpMaxPhases && prev < dc->nstages; i++) {
+      const unsigned e = (i + 1 == kLbpMaxPhases) ? dc->nstages : std::min(pr[i], dc->nstages);
+      if (e <= prev) continue;
+      ph.end[ph.n++] = e, prev = e;
+    }
+    if (ph.n == 0) ph.n = 1, ph.end[0] = dc->nstages;
+    ph.end[ph.n - 1] = dc->nstages;
+  }
+  const size_t lds_all = ((lds + 15) & ~(size_t)15) + 2 * kChunkItems * 2 + 64 * 4 + 16;
+  if (dc->guard) GS_LAUNCH(k_lbp_cascade<true>, g, dim3(256), lds_all, st, a, ph);
+  else GS_LAUNCH(k_lbp_cascade<false>, g, dim3(256), lds_all, st, a, ph);
   run_compaction(mask, cnt, nch, n, max_rects, counts,
                  LbpEmit{dc->d_scales, (unsigned)dc->scales.size(), step, rects, max_rects});
 }
@@ -498,7 +525,11 @@ __global__ void k_lbp_single(LbpArgs a, const LbpGeom *geom, unsigned *out) {
 #ifndef GS_EMU
 #pragma clang fp contract(off)
 #endif
-  if (threadIdx.x == 0) out[0] = lbp_window_pass<true>(a, a.padded, 0, geom) ? 1u : 0u;
+  GS_DYN_LDS(smem);
+  const LbpLds t = lbp_stage_tables(smem, a, geom, threadIdx.x, 64u);
+  __syncthreads();
+  if (threadIdx.x == 0)
+    out[0] = lbp_window_stages<true>(t, make_buf(a.padded, a.frame_stride * 4), a.padded, 0u, a.limit_bytes, 0u, a.nstages) ? 1u : 0u;
 }
 
 /* ------------------------------------------------------------------ ORB host logic */
@@ -778,6 +809,7 @@ gsh_cascade *gsh_cascade_create(const struct gs_lbp_cascade *c) {
   std::vector<LbpStage> stg(c->nstages);
   for (unsigned i = 0; i < c->nstages; i++)
     stg[i] = LbpStage{c->stage_weak_start[i], c->stage_nweaks[i], c->stage_threshold[i], 0.0f};
+  dc->nsub = nsub;
   GS_HIP(hipMalloc((void **)&dc->d_weak, std::max<size_t>(1, wk.size()) * sizeof(LbpWeak)));
   GS_HIP(hipMalloc((void **)&dc->d_stage, std::max<size_t>(1, stg.size()) * sizeof(LbpStage)));
   GS_HIP(hipMalloc((void **)&dc->d_subsets, std::max<size_t>(1, nsub) * 4));
@@ -1095,17 +1127,19 @@ unsigned gs_lbp_window(const struct gs_lbp_cascade *c, const unsigned *ii, unsig
     int fw = (int)((int)dc->features[fi * 4 + 2] * scale), fh = (int)((int)dc->features[fi * 4 + 3] * scale);
     if (fw < 1) fw = 1;
     if (fh < 1) fh = 1;
-    geom[wi] = LbpGeom{fy * (int)S + fx, fw, fh * (int)S, 0};
+    geom[wi] = LbpGeom{(fy * (int)S + fx) * 4, fw * 4, fh * (int)S * 4, 0};
   }
   LbpGeom *dg = (LbpGeom *)ctx().scratch(SL_TAB, std::max<size_t>(1, geom.size()) * sizeof(LbpGeom));
   GS_HIP(hipMemcpyAsync(dg, geom.data(), geom.size() * sizeof(LbpGeom), hipMemcpyHostToDevice, st));
   unsigned *dout = (unsigned *)ctx().scratch(SL_TOT, 16);
   LbpArgs a;
   memset(&a, 0, sizeof a);
-  a.padded = tab, a.frame_stride = (size_t)S * R, a.S = S, a.limit = (size_t)S * R - 1, a.step = 1;
-  a.nweaks = dc->nweaks, a.nstages = dc->nstages;
+  a.padded = tab, a.frame_stride = (size_t)S * R, a.S = S, a.limit_bytes = (unsigned)(((size_t)S * R - 1) * 4), a.step = 1;
+  a.nweaks = dc->nweaks, a.nstages = dc->nstages, a.nsub = dc->nsub;
   a.weak = dc->d_weak, a.stage = dc->d_stage, a.subsets = dc->d_subsets;
-  GS_LAUNCH(k_lbp_single, dim3(1), dim3(64), 0, st, a, (const LbpGeom *)dg, dout);
+  const size_t lds = (size_t)dc->nstages * sizeof(LbpStage) +
+                     (size_t)dc->nweaks * (sizeof(LbpWeak) + sizeof(LbpGeom)) + (size_t)dc->nsub * 4;
+  GS_LAUNCH(k_lbp_single, dim3(1), dim3(64), lds, st, a, (const LbpGeom *)dg, dout);
   unsigned r = 0;
   GS_HIP(hipMemcpyAsync(&r, dout, 4, hipMemcpyDeviceToHost, st));
   ctx().sync();

@@ -26,7 +26,7 @@ struct LbpScale {          /* one entry per visited scale (host-computed, float3
   unsigned chunk_base;     /* first chunk of this scale in the frame's chunk array */
   unsigned nchunks;
 };
-struct LbpGeom { int off0, fw, fh_stride, pad; };      /* per (scale, weak): padded-table offsets */
+struct LbpGeom { int off0, fw, fh_stride, pad; };      /* per (scale, weak): BYTE offsets in the padded table */
 struct LbpWeak { float left, right; unsigned sub_off, nsub; };
 struct LbpStage { unsigned first, count; float threshold, pad; };
 
@@ -34,11 +34,11 @@ struct LbpArgs {
   const unsigned *padded;       /* n frames of (iw+1)*(ih+1) u32 */
   size_t frame_stride;          /* (iw+1)*(ih+1) */
   unsigned S;                   /* iw + 1 */
-  size_t limit;                 /* frame_stride - 1 (GUARD clamp) */
+  unsigned limit_bytes;         /* (frame_stride - 1) * 4 (GUARD clamp) */
   int step;
-  unsigned nweaks, nstages;
+  unsigned nweaks, nstages, nsub;
   const LbpScale *scales;
-  const LbpGeom *geom;          /* [nscales][nweaks] */
+  const LbpGeom *geom;          /* [nscales][nweaks], BYTE offsets into the padded table */
   const LbpWeak *weak;
   const LbpStage *stage;
   const int32_t *subsets;
@@ -47,34 +47,88 @@ struct LbpArgs {
   unsigned total_chunks;
 };
 
+/* cascade tables of one scale, staged in LDS by the block: every lane of every wave evaluates
+ * the same weak classifier of the same scale, so these reads are same-address broadcasts
+ * (low latency, no bank conflicts); only the subset word is a per-lane LDS read */
+struct LbpLds {
+  const LbpStage *stage;
+  const LbpWeak *weak;
+  const LbpGeom *geom;
+  const int32_t *subsets;
+};
+GS_DEV size_t lbp_lds_bytes(unsigned nstages, unsigned nweaks, unsigned nsub) {
+  return (size_t)nstages * sizeof(LbpStage) + (size_t)nweaks * (sizeof(LbpWeak) + sizeof(LbpGeom)) +
+         (size_t)nsub * 4;
+}
+GS_DEV LbpLds lbp_stage_tables(char *smem, const LbpArgs &a, const LbpGeom *geom_scale,
+                               unsigned tid, unsigned nthreads) {
+  uint32_t *d = (uint32_t *)smem;
+  const unsigned n0 = a.nstages * 4, n1 = a.nweaks * 4, n3 = a.nsub;
+  for (unsigned i = tid; i < n0; i += nthreads) d[i] = ((const uint32_t *)a.stage)[i];
+  for (unsigned i = tid; i < n1; i += nthreads) d[n0 + i] = ((const uint32_t *)a.weak)[i];
+  for (unsigned i = tid; i < n1; i += nthreads) d[n0 + n1 + i] = ((const uint32_t *)geom_scale)[i];
+  for (unsigned i = tid; i < n3; i += nthreads) d[n0 + 2 * n1 + i] = ((const uint32_t *)a.subsets)[i];
+  LbpLds t;
+  t.stage = (const LbpStage *)d;
+  t.weak = (const LbpWeak *)(d + n0);
+  t.geom = (const LbpGeom *)(d + n0 + n1);
+  t.subsets = (const int32_t *)(d + n0 + 2 * n1);
+  return t;
+}
+
+/* stages [s0, s1) of the cascade for the window whose top-left padded-table BYTE offset is
+ * `origin`; returns false as soon as a stage sum falls below its threshold (ref :794-811).
+ * The 16 corner loads are buffer gathers: the per-lane part of the address is the window origin
+ * (constant for the whole cascade), the per-feature part is wave-uniform and travels in the
+ * SGPR soffset -- no vector ALU for addressing.  Cells are formed from column differences
+ * (21 instead of 27 add/sub).  GUARD (feature rectangles that can stick out of the window, only
+ * with scale < 1 after the clamp of ref :803-804): explicit clamped vector address instead; the
+ * reference reads out of bounds there, so no particular value is "right". */
+#ifndef GS_LBP_BUFFER_GATHER
+#define GS_LBP_BUFFER_GATHER 0 /* measured on MI355X: plain global gathers 17.7 Gwin/s dense vs 11.6 */
+#endif
 template <bool GUARD>
-GS_DEV bool lbp_window_pass(const LbpArgs &a, const unsigned *P, size_t origin,
-                            const LbpGeom *geom) {
-  /* GUARD: a scale whose (clamped, ref :803-804) feature rectangles can stick out of the
-   * window reads clamped addresses instead of faulting; the reference reads out of bounds
-   * there, so no particular value is "right". */
-  auto ld = [&](long off) -> unsigned {
-    size_t idx = origin + (size_t)off;
-    if (GUARD) idx = idx > a.limit ? a.limit : idx;
-    return P[idx];
-  };
-  for (unsigned s = 0; s < a.nstages; s++) {
-    const LbpStage st = a.stage[s];
+GS_DEV bool lbp_window_stages(const LbpLds &t, const BufRsrc &P, const unsigned *Pg, unsigned origin,
+                              unsigned limit, unsigned s0, unsigned s1) {
+  for (unsigned s = s0; s < s1; s++) {
+    const LbpStage st = t.stage[s];
+    const unsigned first = uniform(st.first), count = uniform(st.count);
     float sum = 0.0f;
-    for (unsigned k = 0; k < st.count; k++) {
-      const unsigned wi = st.first + k;
-      const LbpGeom g = geom[wi];
-      const LbpWeak wk = a.weak[wi];
+    for (unsigned k = 0; k < count; k++) {
+      const unsigned wi = first + k;
+      const LbpGeom g = t.geom[wi];
+      const LbpWeak wk = t.weak[wi];
+      const unsigned off0 = uniform((unsigned)g.off0), fw = uniform((unsigned)g.fw),
+                     fhs = uniform((unsigned)g.fh_stride);
       unsigned G[4][4];
 #pragma unroll
       for (int j = 0; j < 4; j++)
 #pragma unroll
-        for (int i = 0; i < 4; i++) G[j][i] = ld((long)g.off0 + (long)j * g.fh_stride + i * g.fw);
-      unsigned c[3][3];
+        for (int i = 0; i < 4; i++) {
+          const unsigned so = off0 + (unsigned)j * fhs + (unsigned)i * fw;
+#if GS_LBP_BUFFER_GATHER
+          if (GUARD) {
+            unsigned idx = origin + so;
+            idx = idx > limit ? limit : idx;
+            G[j][i] = buf_load4(P, idx);
+          } else {
+            G[j][i] = buf_gather4(P, origin, so);
+          }
+#else
+          unsigned idx = origin + so;
+          if (GUARD) idx = idx > limit ? limit : idx;
+          G[j][i] = *(const unsigned *)((const char *)Pg + idx);
+#endif
+        }
+      unsigned D[3][4], c[3][3];
 #pragma unroll
       for (int j = 0; j < 3; j++)
 #pragma unroll
-        for (int i = 0; i < 3; i++) c[j][i] = G[j + 1][i + 1] + G[j][i] - G[j][i + 1] - G[j + 1][i];
+        for (int i = 0; i < 4; i++) D[j][i] = G[j + 1][i] - G[j][i];
+#pragma unroll
+      for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int i = 0; i < 3; i++) c[j][i] = D[j][i + 1] - D[j][i];
       const unsigned ctr = c[1][1];
       const unsigned code = ((c[0][0] >= ctr) << 7) | ((c[0][1] >= ctr) << 6) |
                             ((c[0][2] >= ctr) << 5) | ((c[1][2] >= ctr) << 4) |
@@ -82,7 +136,7 @@ GS_DEV bool lbp_window_pass(const LbpArgs &a, const unsigned *P, size_t origin,
                             ((c[2][0] >= ctr) << 1) | ((c[1][0] >= ctr) << 0);
       const unsigned word = code >> 5, bit = code & 31u;
       bool hit = false;
-      if (word < wk.nsub) hit = ((uint32_t)a.subsets[wk.sub_off + word] >> bit) & 1u;
+      if (word < wk.nsub) hit = ((uint32_t)t.subsets[wk.sub_off + word] >> bit) & 1u;
       sum += hit ? wk.left : wk.right;
     }
     if (sum < st.threshold) return false;
@@ -90,28 +144,99 @@ GS_DEV bool lbp_window_pass(const LbpArgs &a, const unsigned *P, size_t origin,
   return true;
 }
 
-/* grid (max chunks per scale, nscales, n frames), block 256: 8 windows per thread */
+GS_DEV unsigned lbp_origin(const LbpArgs &a, const LbpScale &sc, unsigned idx) {
+  const unsigned yi = idx / sc.nx, xi = idx - yi * sc.nx;
+  return ((yi * (unsigned)a.step) * a.S + xi * (unsigned)a.step) * 4u;
+}
+
+/* 63 % of windows die in stage 0 and ~99 % by stage 4, but a wave keeps executing while ANY of
+ * its 64 lanes is alive: run densely, a wave executes ~35 weak classifiers for an average of ~6
+ * per window.  So a block works through its chunk (2048 consecutive windows of one scale) in
+ * PHASES of a few stages each: phase 0 evaluates every window, survivors are re-packed into an
+ * LDS queue (one ds_add per wave), the next phase runs only over the queue, 64 survivors to a
+ * wave, and so on until the last phase sets the window's bit in a 2048-bit LDS mask.  Survivors
+ * of one chunk sit within a row or two of the integral image, so the re-packed gathers still hit
+ * lines the dense phase just pulled into L1/L2 (a global survivor list loses exactly that and
+ * measured 3-4x SLOWER).  The finished mask words and their popcount go to the ordered
+ * compaction (k_compact.h) -- same bits as publishing ballots, no atomics on global memory. */
+constexpr unsigned kLbpMaxPhases = 8;
+struct LbpPhases { unsigned n; unsigned end[kLbpMaxPhases]; }; /* phase p = stages [end[p-1], end[p]) */
+
+/* grid (max chunks per scale, nscales, n frames), block 256;
+ * dynamic LDS = lbp_lds_bytes(...) + 2 queues x 2048 u16 + 64 mask words + 2 counters */
+GS_DEV size_t lbp_block_lds_bytes(unsigned nstages, unsigned nweaks, unsigned nsub) {
+  return lbp_lds_bytes(nstages, nweaks, nsub) + 2 * kChunkItems * 2 + 64 * 4 + 16;
+}
+
 template <bool GUARD>
-__global__ __launch_bounds__(256) void k_lbp_cascade(LbpArgs a) {
+__global__ __launch_bounds__(256) void k_lbp_cascade(LbpArgs a, LbpPhases ph) {
 #ifndef GS_EMU
 #pragma clang fp contract(off)
 #endif
+  GS_DYN_LDS(smem);
   const LbpScale sc = a.scales[blockIdx.y];
-  if (blockIdx.x >= sc.nchunks) return;
-  const unsigned tid = threadIdx.x, wv = tid >> 6;
-  const unsigned nwin = sc.nx * sc.ny;
-  const unsigned *P = a.padded + (size_t)blockIdx.z * a.frame_stride;
-  const LbpGeom *geom = a.geom + (size_t)blockIdx.y * a.nweaks;
-  const size_t chunk = (size_t)blockIdx.z * a.total_chunks + sc.chunk_base + blockIdx.x;
-  for (unsigned k = 0; k < kChunkItems / 256u; k++) {
-    const unsigned idx = blockIdx.x * kChunkItems + k * 256u + tid;
-    bool pass = false;
-    if (idx < nwin) {
-      const unsigned yi = idx / sc.nx, xi = idx - yi * sc.nx;
-      const size_t origin = (size_t)(yi * (unsigned)a.step) * a.S + xi * (unsigned)a.step;
-      pass = lbp_window_pass<GUARD>(a, P, origin, geom);
+  if (blockIdx.x >= sc.nchunks) return; /* whole block */
+  const unsigned tid = threadIdx.x;
+  const LbpLds t = lbp_stage_tables(smem, a, a.geom + (size_t)blockIdx.y * a.nweaks, tid, 256u);
+  char *extra = smem + ((lbp_lds_bytes(a.nstages, a.nweaks, a.nsub) + 15) & ~(size_t)15);
+  uint16_t *queue = (uint16_t *)extra;                       /* [2][kChunkItems] */
+  uint32_t *bits = (uint32_t *)(extra + 2 * kChunkItems * 2); /* [64] */
+  unsigned *qn = (unsigned *)(bits + 64);                     /* [2] */
+  if (tid < 64) bits[tid] = 0;
+  if (tid < 2) qn[tid] = 0;
+  __syncthreads();
+  const unsigned nwin = sc.nx * sc.ny, first = blockIdx.x * kChunkItems;
+  const unsigned *Pg = a.padded + (size_t)blockIdx.z * a.frame_stride;
+  const BufRsrc P = make_buf(Pg, a.frame_stride * 4);
+  unsigned n_in = nwin - first < kChunkItems ? nwin - first : kChunkItems;
+  unsigned cur = 0;
+  for (unsigned p = 0; p < ph.n; p++) {
+    const unsigned s0 = p ? ph.end[p - 1] : 0u, s1 = ph.end[p];
+    const bool lastp = p + 1 == ph.n;
+    const uint16_t *qin = queue + cur * kChunkItems;
+    uint16_t *qout = queue + (cur ^ 1u) * kChunkItems;
+    for (unsigned i0 = 0; i0 < n_in; i0 += 256u) { /* block-uniform trip count */
+      const unsigned i = i0 + tid;
+      bool pass = false;
+      unsigned local = 0;
+      if (i < n_in) {
+        local = p ? qin[i] : i;
+        pass = lbp_window_stages<GUARD>(t, P, Pg, lbp_origin(a, sc, first + local), a.limit_bytes, s0, s1);
+      }
+      if (lastp) {
+        if (pass) atomicOr(&bits[local >> 5], 1u << (local & 31u));
+      } else { /* re-pack survivors: one LDS atomic per wave */
+        const uint64_t m = ballot(pass);
+        if (m) {
+          const unsigned lane = lane_id();
+          unsigned base = 0;
+          if (lane == 0) base = atomicAdd(&qn[cur ^ 1u], (unsigned)__popcll(m));
+          base = readlane0(base);
+          if (pass) qout[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)local;
+        }
+      }
     }
-    publish_flags(pass, a.mask, a.chunk_count, chunk * kChunkWords + k * 4u + wv);
+    __syncthreads();
+    if (!lastp) {
+      n_in = qn[cur ^ 1u];
+      __syncthreads();
+      if (tid == 0) qn[cur] = 0; /* becomes the output counter of the phase after next */
+      cur ^= 1u;
+      if (n_in == 0) break; /* block-uniform */
+    }
+  }
+  __syncthreads();
+  /* publish this chunk: 32 words of 64 bits + their total */
+  const size_t chunk = (size_t)blockIdx.z * a.total_chunks + sc.chunk_base + blockIdx.x;
+  if (tid < 64) { /* one wave */
+    unsigned c = 0;
+    if (tid < kChunkWords) {
+      const unsigned long long wv = (unsigned long long)bits[2 * tid] | ((unsigned long long)bits[2 * tid + 1] << 32);
+      a.mask[chunk * kChunkWords + tid] = wv;
+      c = (unsigned)__popcll(wv);
+    }
+    c = wave_sum(c);
+    if (tid == 0) a.chunk_count[chunk] = c;
   }
 }
 

@@ -98,6 +98,9 @@ GS_DEV void buf_store16(const BufRsrc &b, uint32_t off, const U4 &v) {
   emu_buf_check(b, off, 16);
   if (off < b.n) memcpy(b.base + off, &v, 16);
 }
+/* dword gather: per-lane byte offset + wave-uniform byte offset (SGPR soffset on the GPU) */
+GS_DEV uint32_t buf_gather4(const BufRsrc &b, uint32_t voff, uint32_t soff) { return buf_load4(b, voff + soff); }
+GS_DEV uint32_t uniform(uint32_t x) { return x; } /* v_readfirstlane_b32 on the GPU */
 #define GS_PK2(expr_lo, expr_hi) ((uint32_t)((expr_lo) & 0xffffu) | ((uint32_t)((expr_hi) & 0xffffu) << 16))
 GS_DEV uint32_t pk_add_u16(uint32_t a, uint32_t b) { return GS_PK2((a & 0xffff) + (b & 0xffff), (a >> 16) + (b >> 16)); }
 GS_DEV uint32_t pk_sub_u16(uint32_t a, uint32_t b) { return GS_PK2((a & 0xffff) - (b & 0xffff), (a >> 16) - (b >> 16)); }
@@ -157,6 +160,13 @@ GS_DEV U4 buf_load16(const BufRsrc &b, uint32_t off) { /* buffer_load_dwordx4 of
 GS_DEV uint32_t buf_load4(const BufRsrc &b, uint32_t off) { /* buffer_load_dword offen */
   return __builtin_amdgcn_raw_buffer_load_b32(b.r, (int)off, 0, GS_LOAD_AUX);
 }
+/* buffer_load_dword v, voff, s[rsrc], soff offen: the wave-uniform part of the address rides in
+ * an SGPR, so a gather whose lanes differ only by a fixed per-lane origin needs NO vector ALU
+ * for addressing (cascade corner loads). Default cache policy. */
+GS_DEV uint32_t buf_gather4(const BufRsrc &b, uint32_t voff, uint32_t soff) {
+  return __builtin_amdgcn_raw_buffer_load_b32(b.r, (int)voff, (int)soff, 0);
+}
+GS_DEV uint32_t uniform(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 GS_DEV void buf_store16(const BufRsrc &b, uint32_t off, const U4 &v) { /* buffer_store_dwordx4 offen */
   __builtin_amdgcn_raw_buffer_store_b128(gs_u32x4{v.x, v.y, v.z, v.w}, b.r, (int)off, 0, GS_STORE_AUX);
 }

@@ -34,7 +34,8 @@ void gsh_set_async(int on);               /* drop-in gs_* calls on device pointe
                                              the final stream sync when on             */
 void gsh_sync(void);                      /* hipStreamSynchronize(current stream)       */
 /* launch tuning of the strip kernels: key 0 rows per band (0 = auto), 1 block shape
- * (0: 64x4, 1: 256x1, 2: 128x2), 3 set to 1 to disable the fused pipeline kernel.
+ * (0: 64x4, 1: 256x1, 2: 128x2), 3 set to 1 to disable the fused pipeline kernel, 4 preset of
+ * the cascade stages at which gs_lbp_detect re-packs survivors (1: never).
  * Results never change. */
 void gsh_tune(int key, int value);
 /* diagnostic: strip-kernel traffic pattern with no arithmetic (access-pattern ceiling) */

@@ -159,3 +159,17 @@ def test_fused_edge_pipeline_equals_separate_calls(emu, oracle, radius, shape):
             assert thr[i] == t
             assert np.array_equal(out[i], oracle.threshold(s, t))
     emu.tune(0, 0)
+
+
+@pytest.mark.parametrize("preset", [0, 1, 2, 3])
+def test_lbp_survivor_repacking_never_changes_results(emu, oracle, cascade, preset):
+    """gsh_tune 4: dense single phase vs block-local survivor re-packing at various stage splits"""
+    try:
+        emu.tune(4, preset)
+        pc.lbp(emu, oracle, Oracle.synth(96, 80, 7), MEM, cascade, params=((4096, 1.1, 1.0, 4.0, 1),))
+        pc.lbp(emu, oracle, Oracle.synth(64, 48, 9), MEM, random_cascade(1),
+               params=((4096, 1.25, 1.0, 2.0, 2), (37, 1.25, 1.0, 2.0, 1)))
+        pc.lbp(emu, oracle, Oracle.synth(80, 60, 11), MEM, random_cascade(4, nstages=6, weaks_per_stage=2),
+               params=((500, 1.2, 1.0, 2.5, 1),))
+    finally:
+        emu.tune(4, 0)
