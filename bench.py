@@ -146,12 +146,26 @@ def main():
     ktab[fk] = {"ms": round(fms, 4), "GB/s": round(2.0 * npx / fms / 1e6, 1),
                 "frac": round(2.0 * npx / fms / 1e6 / HBM_PEAK_GBS, 4), "bytes": 2.0 * npx,
                 "note": "step minus threshold pass; replaces blur+sobel+histogram (5 B/px unfused)"}
-    chain = [k for k in ktab if "erode" not in k and k != fk and "gs_blur" not in k and "gs_sobel" not in k and "histogram" not in k] + [fk]
-    dom = max(chain, key=lambda k: ktab[k]["ms"])
-    roof = {"bound": "hbm", "kernel": dom, "achieved": ktab[dom]["GB/s"], "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": ktab[dom]["frac"], "traffic": None,
-            "algorithmic_bytes_per_launch": ktab[dom]["bytes"], "avg_launch_ms": ktab[dom]["ms"],
-            "frac_of_measured_copy_ceiling_6290": round(ktab[dom]["GB/s"] / 6290.0, 4)}
+    # dominant kernel of the timed step = the fused kernel.  SURVEY.md 8(d): a fused kernel is
+    # reported against the UNFUSED per-call sum of the calls it performs (gs_blur 2 + gs_sobel 2 +
+    # gs_histogram 1 = 5 B/px), with the bytes it really moves (1 R + 1 W) stated beside it.
+    percall = 5.0 * npx
+    pmc = None
+    try:
+        pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if (w, h, F) == (3840, 2160, 64):
+            pmc = pt["per_launch"].get("gs::k_blur_sobel_hist16<2>", {}).get("total_bytes")
+    except Exception:
+        pass
+    roof = {"bound": "hbm", "kernel": "k_blur_sobel_hist16<2> (gs_blur r=2 + gs_sobel + gs_histogram in one launch)",
+            "achieved": round(percall / fms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(percall / fms / 1e6 / HBM_PEAK_GBS, 4), "traffic": pmc,
+            "accounting": "unfused per-call sum, 5 B/px (SURVEY 8d); the launch itself reads 1 and writes 1 B/px",
+            "algorithmic_bytes_per_launch": percall, "avg_launch_ms": round(fms, 4),
+            "actual_io": {"bytes_per_px": 2, "GB/s": ktab[fk]["GB/s"], "frac": ktab[fk]["frac"],
+                          "note": "VALU-bound at this point (~260 lane-ops per 16 px + 16 LDS atomics)"},
+            "per_call_kernels": {k: ktab[k]["frac"] for k in ktab if k != fk},
+            "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc, corrected per MI355X_MICROARCH.md)" if pmc else None}
 
     # north-star shape: gs_sobel alone on 4096x4096, rotating over 64 distinct frames (1 GiB/plane)
     ns = None

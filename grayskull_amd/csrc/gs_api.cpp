@@ -455,8 +455,13 @@ void launch_lbp_padded(gsh_cascade *dc, const unsigned *padded, unsigned iw, uns
   const unsigned nch = dc->total_chunks;
   unsigned long long *mask =
       (unsigned long long *)ctx().scratch(SL_MASK, (size_t)n * nch * kChunkWords * 8);
-  unsigned *cnt = (unsigned *)ctx().scratch(SL_CNT, (size_t)n * nch * 4); /* every chunk is written */
+  const unsigned nsc0 = (unsigned)dc->scales.size();
+  unsigned *cnt = (unsigned *)ctx().scratch(SL_CNT, ((size_t)n * nch + (size_t)n * nsc0) * 4);
+  GS_HIP(hipMemsetAsync(cnt, 0, ((size_t)n * nch + (size_t)n * nsc0) * 4, st));
+  GS_HIP(hipMemsetAsync(mask, 0, (size_t)n * nch * kChunkWords * 8, st));
   LbpArgs a;
+  a.scale_hits = cnt + (size_t)n * nch;
+  a.nscales = nsc0, a.cap = max_rects;
   a.padded = padded;
   a.frame_stride = (size_t)(iw + 1) * (ih + 1);
   a.S = iw + 1;

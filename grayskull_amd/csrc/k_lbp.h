@@ -42,9 +42,11 @@ struct LbpArgs {
   const LbpWeak *weak;
   const LbpStage *stage;
   const int32_t *subsets;
-  unsigned long long *mask;     /* n frames x total_chunks*kChunkWords */
-  unsigned *chunk_count;        /* n frames x total_chunks */
+  unsigned long long *mask;     /* n frames x total_chunks*kChunkWords (pre-zeroed) */
+  unsigned *chunk_count;        /* n frames x total_chunks (pre-zeroed) */
   unsigned total_chunks;
+  unsigned *scale_hits;         /* n frames x nscales: detections counted so far in EARLIER scales */
+  unsigned nscales, cap;        /* cap = max_rects */
 };
 
 /* cascade tables of one scale, staged in LDS by the block: every lane of every wave evaluates
@@ -177,6 +179,12 @@ __global__ __launch_bounds__(256) void k_lbp_cascade(LbpArgs a, LbpPhases ph) {
   const LbpScale sc = a.scales[blockIdx.y];
   if (blockIdx.x >= sc.nchunks) return; /* whole block */
   const unsigned tid = threadIdx.x;
+  /* The reference stops scanning once max_rects detections exist (ref :819-823), and the output is
+   * the FIRST max_rects hits in (scale, y, x) order.  Hits already counted in earlier scales can
+   * only grow, so if they reach the cap no window of this scale can be among the first max_rects:
+   * skip the block (its mask words and counter stay zero).  A stale (smaller) read only skips
+   * less. */
+  if (atomicAdd(&a.scale_hits[(size_t)blockIdx.z * a.nscales + blockIdx.y], 0u) >= a.cap) return;
   const LbpLds t = lbp_stage_tables(smem, a, a.geom + (size_t)blockIdx.y * a.nweaks, tid, 256u);
   char *extra = smem + ((lbp_lds_bytes(a.nstages, a.nweaks, a.nsub) + 15) & ~(size_t)15);
   uint16_t *queue = (uint16_t *)extra;                       /* [2][kChunkItems] */
@@ -236,7 +244,12 @@ __global__ __launch_bounds__(256) void k_lbp_cascade(LbpArgs a, LbpPhases ph) {
       c = (unsigned)__popcll(wv);
     }
     c = wave_sum(c);
-    if (tid == 0) a.chunk_count[chunk] = c;
+    if (tid == 0 && c) {
+      a.chunk_count[chunk] = c;
+      /* scale_hits[s] = hits counted so far in scales < s (hits are rare: few atomics) */
+      for (unsigned q = blockIdx.y + 1; q < a.nscales; q++)
+        atomicAdd(&a.scale_hits[(size_t)blockIdx.z * a.nscales + q], c);
+    }
   }
 }
 

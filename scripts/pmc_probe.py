@@ -11,5 +11,6 @@ hist = torch.zeros((F, 256), dtype=torch.int32, device="cuda"); thr = torch.zero
 for _ in range(3):
     g.probe_strip_copy(dst, src); g.blur_batch(tmp, src, 2); g.sobel_batch(dst, tmp); g.erode_batch(dst, src)
     g.otsu_batch(dst, hist, thr); g.threshold_batch(dst, thr)
+    g.edge_pipeline_batch(dst, None, src, 2, hist, thr)
 torch.cuda.synchronize()
 print("algorithmic bytes per launch: copy/blur/erode/threshold %d, sobel %d, hist %d" % (2*F*H*W, F*(H*W+(H-2)*(W-2)), F*H*W))

@@ -173,3 +173,11 @@ def test_lbp_survivor_repacking_never_changes_results(emu, oracle, cascade, pres
                params=((500, 1.2, 1.0, 2.5, 1),))
     finally:
         emu.tune(4, 0)
+
+
+def test_lbp_cap_reached_in_early_scales(emu, oracle, cascade):
+    """config-5 style input (sobel edge map): many hits, max_rects reached before the last scale --
+    later scales are skipped on the GPU exactly because they cannot contribute (ref :819-823)"""
+    edges = oracle.sobel(oracle.blur(Oracle.synth(160, 120, 1000), 2))
+    pc.lbp(emu, oracle, edges, MEM, cascade, params=((4096, 1.1, 1.0, 4.0, 1), (5, 1.1, 1.0, 4.0, 1), (60, 1.2, 1.0, 3.0, 2)))
+    pc.lbp(emu, oracle, Oracle.synth(64, 48, 9), MEM, random_cascade(1), params=((3, 1.25, 1.0, 2.0, 1), (200, 1.1, 1.0, 2.0, 1)))

@@ -115,6 +115,9 @@ def test_lbp(hip, oracle, cascade, mem):
            params=((4096, 1.25, 1.0, 2.0, 2), (37, 1.25, 1.0, 2.0, 1), (1, 1.5, 1.0, 1.6, 1), (100000, 1.2, 1.0, 3.0, 1)),
            windows=((0, 0, 1.0), (1, 0, 1.0), (0, 1, 1.5), (40, 24, 1.0)))
     pc.lbp(hip, oracle, Oracle.synth(640, 480, 3), mem, cascade, params=((4096, 1.2, 1.0, 4.0, 2),))
+    # config-5 style input (sobel edge map): thousands of hits, max_rects reached in early scales
+    edges = oracle.sobel(oracle.blur(Oracle.synth(960, 540, 1000), 2))
+    pc.lbp(hip, oracle, edges, mem, cascade, params=((4096, 1.1, 1.0, 4.0, 1), (100, 1.1, 1.0, 4.0, 1), (100000, 1.3, 1.0, 3.0, 3)))
 
 
 # ---- golden vectors generated by the unmodified reference, at the BASELINE.json sizes --------
