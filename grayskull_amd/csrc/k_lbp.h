@@ -119,7 +119,12 @@ GS_DEV bool lbp_window_stages(const LbpLds &t, const BufRsrc &P, const unsigned 
 #else
           unsigned idx = origin + so;
           if (GUARD) idx = idx > limit ? limit : idx;
+#ifdef GS_LBP_EXPERIMENT_FEWER_GATHERS /* WRONG RESULTS: bound-finding experiment only */
+          if (i == 0) G[j][i] = *(const unsigned *)((const char *)Pg + idx);
+          else G[j][i] = G[j][0] * (unsigned)(i + 3) + so;
+#else
           G[j][i] = *(const unsigned *)((const char *)Pg + idx);
+#endif
 #endif
         }
       unsigned D[3][4], c[3][3];

@@ -241,11 +241,20 @@ __global__ __launch_bounds__(256) void k_synth_pixels(uint8_t *dst, const uint8_
   uint32_t s = xs_jump(J, seed ? seed : 1u, (uint64_t)nlev + i0);
   const uint8_t *lv = levels + (size_t)f * nlev;
   uint8_t *out = dst + (size_t)f * npx;
+  /* i0 is a multiple of 256 and frames are whole dwords apart when w*h % 4 == 0: dword stores */
+  const bool aligned = (((uintptr_t)out) & 3) == 0;
+  uint32_t packed = 0;
   for (size_t i = i0; i < i0 + kSynthRun && i < npx; i++) {
     s = xs32(s);
     const unsigned x = (unsigned)(i % w), y = (unsigned)(i / w);
     int v = (int)lv[(y / 32) * bw + x / 32] + (int)(s & 15u) - 8;
-    out[i] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+    const uint32_t b = (uint32_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+    if (aligned && i0 + kSynthRun <= npx) {
+      packed |= b << (8 * (i & 3));
+      if ((i & 3) == 3) *(uint32_t *)(out + i - 3) = packed, packed = 0;
+    } else {
+      out[i] = (uint8_t)b;
+    }
   }
 }
 

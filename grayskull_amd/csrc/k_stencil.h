@@ -204,8 +204,14 @@ struct SobelState {
   }
 };
 
+#ifndef GS_SOBEL_MINWAVES
+#define GS_SOBEL_MINWAVES 1
+#endif
+#ifndef GS_BLUR_MINWAVES
+#define GS_BLUR_MINWAVES 1
+#endif
 template <bool KEEP_COLS>
-__global__ __launch_bounds__(256) void k_sobel16(uint8_t *dst, const uint8_t *src, unsigned w,
+__global__ __launch_bounds__(256, GS_SOBEL_MINWAVES) void k_sobel16(uint8_t *dst, const uint8_t *src, unsigned w,
                                                  unsigned h, unsigned T, size_t frame_bytes) {
   const Strip<> S(src, dst, w, h, frame_bytes);
   const int y0 = 1 + (int)(S.band * T);
@@ -256,7 +262,7 @@ GS_DEV void blur_hsum(const uint32_t (&U)[12], uint32_t (&H)[8]) {
 }
 
 template <int R>
-__global__ __launch_bounds__(256) void k_blur16(uint8_t *dst, const uint8_t *src, unsigned w,
+__global__ __launch_bounds__(256, GS_BLUR_MINWAVES) void k_blur16(uint8_t *dst, const uint8_t *src, unsigned w,
                                                 unsigned h, unsigned T, size_t frame_bytes) {
   constexpr int N = 2 * R + 1;
   const Strip<> S(src, dst, w, h, frame_bytes);

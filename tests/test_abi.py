@@ -85,3 +85,19 @@ def test_blur_magic_divisions_are_exact():
         for s in range(0, 255 * d + 1):
             assert (s * mul) >> 24 == s // d
             assert s * mul < 2 ** 32
+
+
+def test_precondition_failures_abort_like_gs_assert(emu, tmp_path):
+    """reference behaviour (grayskull.h:94-98): message 'Assertion failed: <cond>' on stderr + abort()"""
+    import sys
+    prog = tmp_path / "bad.py"
+    prog.write_text('''
+import sys, numpy as np
+sys.path.insert(0, %r)
+import grayskull_amd as G
+g = G.Grayskull(%r)
+g.blur(np.zeros((4, 4), np.uint8), np.zeros((5, 4), np.uint8), 1)   # dst/src size mismatch
+''' % (ROOT, os.path.join(ROOT, "tests", "emu", "libgs_kernel_emu.so")))
+    r = subprocess.run([sys.executable, str(prog)], capture_output=True)
+    assert r.returncode == -6, r  # SIGABRT
+    assert b"Assertion failed:" in r.stderr and b"dst.w == src.w" in r.stderr
