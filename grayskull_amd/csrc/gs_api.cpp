@@ -149,16 +149,23 @@ inline bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 int g_tune[8] = {0, 1, 1, 0, 0, 0, 0, 0};
 
 struct StripCfg { dim3 grid, block; unsigned T; };
-/* rows: output rows per frame.  Bands as tall as possible while >= ~4K waves keep 256 CUs busy. */
-StripCfg strip_cfg(unsigned w, unsigned rows, unsigned n) {
+/* rows: output rows per frame.  One wave per (1024-px column block, band, frame).  Measured on
+ * MI355X (profiles/r01d_ubench_T_fine.log): fastest when every wave of the launch is resident
+ * at once and bands divide the rows evenly -- ~5 waves per SIMD x 1024 SIMDs = 5120 waves
+ * (64 x 4K frames: 20 bands of 108 rows; 128-row bands leave a ragged 17th band: +10 % time). */
+StripCfg strip_cfg(unsigned w, unsigned rows, unsigned n, unsigned waves_per_simd = 5) {
   StripCfg c;
   const unsigned strips = (w + 15) / 16;
   const unsigned long long waves_x = (strips + 63) / 64;
-  unsigned long long t = g_tune[0] > 0 ? (unsigned long long)g_tune[0]
-                                       : (unsigned long long)rows * waves_x * n / 4096ull;
-  if (g_tune[0] <= 0) { /* measured on MI355X: 128-row bands beat shorter ones once >= ~4K waves exist */
-    if (t < 8) t = 8;
-    if (t > 128) t = 128;
+  unsigned long long t;
+  if (g_tune[0] > 0) {
+    t = (unsigned long long)g_tune[0];
+  } else {
+    unsigned long long nb = 1024ull * waves_per_simd / (waves_x * n); /* bands per frame */
+    const unsigned long long nb_max = rows / 8 ? rows / 8 : 1; /* bands of >= 8 rows */
+    if (nb < 1) nb = 1;
+    if (nb > nb_max) nb = nb_max;
+    t = (rows + nb - 1) / nb;
   }
   c.T = (unsigned)t;
   const unsigned nb = (rows + c.T - 1) / c.T;
@@ -760,7 +767,7 @@ void gsh_edge_pipeline_batch(uint8_t *dst, uint8_t *tmp, const uint8_t *src, uns
     /* fused: the blurred image only ever exists in registers (1 R + 1 W per pixel) */
     for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
       const unsigned nn = std::min(kMaxZ, n - f0);
-      const StripCfg c = strip_cfg(w, h - 2, nn);
+      const StripCfg c = strip_cfg(w, h - 2, nn, 3); /* 167 VGPRs: 3 waves per SIMD */
       const unsigned bpf = c.grid.x * c.grid.y;
       unsigned *partial = (unsigned *)ctx().scratch(SL_HISTP, (size_t)nn * bpf * 256 * 4);
       uint8_t *d = dst + fb * f0;
@@ -990,11 +997,20 @@ void gs_sobel(struct gs_image dst, struct gs_image src) { /* ref :306 */
   const uint8_t *s = (const uint8_t *)stage_in(src.data, nb, SL_IN);
   const bool dhost = !is_dev(dst.data);
   uint8_t *d = dhost ? (uint8_t *)ctx().scratch(SL_OUT, nb) : dst.data;
-  launch_sobel(d, s, w, h, 1, !dhost);
-  /* the 1-px frame of dst is never written (ref :308-309): copy back the interior only */
+  if (dhost) {
+    /* The 1-px frame of dst is never written (ref :308-309).  Rows 0 / h-1 are simply not copied
+     * back; columns 0 / w-1 of the other rows are planted into the device copy (2h bytes up) so
+     * rows 1..h-2 can come back as ONE contiguous copy (a pitched interior copy is 3x slower). */
+    std::vector<uint8_t> cols(2 * (size_t)h);
+    for (unsigned y = 1; y + 1 < h; y++) cols[2 * y] = dst.data[(size_t)y * w], cols[2 * y + 1] = dst.data[(size_t)y * w + w - 1];
+    uint8_t *dc = (uint8_t *)ctx().scratch(SL_AUX2, 2 * (size_t)h);
+    GS_HIP(hipMemcpyAsync(dc, cols.data(), 2 * (size_t)h, hipMemcpyHostToDevice, ctx().s()));
+    GS_LAUNCH(k_put_cols, dim3((2 * h + 255) / 256), dim3(256), 0, ctx().s(), d, (const uint8_t *)dc, w, h);
+    ctx().sync(); /* cols is a local */
+  }
+  launch_sobel(d, s, w, h, 1, true);
   if (dhost)
-    GS_HIP(hipMemcpy2DAsync(dst.data + w + 1, w, d + w + 1, w, w - 2, h - 2, hipMemcpyDeviceToHost,
-                            ctx().s()));
+    GS_HIP(hipMemcpyAsync(dst.data + w, d + w, (size_t)w * (h - 2), hipMemcpyDeviceToHost, ctx().s()));
   finish(dhost);
 }
 

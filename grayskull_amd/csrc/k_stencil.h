@@ -229,6 +229,18 @@ __global__ __launch_bounds__(256, GS_SOBEL_MINWAVES) void k_sobel16(uint8_t *dst
   else strip_rows<2>(S, y0, nrows, 1, S.load(y0 + 1), body);
 }
 
+/* host-staged gs_sobel: columns 0 and w-1 of rows 1..h-2 of the caller's dst, gathered on the
+ * host into cols[2*h] (cols[2y], cols[2y+1]), are planted into the device copy so the kernel can
+ * preserve them and whole rows can be copied back.  grid ceil(2h/256), block 256 */
+__global__ __launch_bounds__(256) void k_put_cols(uint8_t *img, const uint8_t *cols, unsigned w,
+                                                  unsigned h) {
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= 2 * h) return;
+  const unsigned y = i >> 1;
+  if (y < 1 || y + 1 >= h) return;
+  img[(size_t)y * w + ((i & 1) ? w - 1 : 0)] = cols[i];
+}
+
 /* ------------------------------------------------------------------ box blur, strips */
 /* ref grayskull.h:268-283.  Zero fill outside the image makes the clipped window sum equal the
  * padded one.  The strip kernel divides every pixel by the interior divisor d = (2R+1)^2 with
