@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST, DEV = pc.Mem("host"), pc.Mem("device")
+SENT = pc.SENTINEL
 
 SHAPES = [(67, 45), (64, 40), (16, 16), (1040, 7), (2064, 5), (33, 3), (1, 1), (3, 3), (16, 1),
           (640, 480), (1280, 720), (1001, 333), (4095, 9), (4097, 5), (4112, 6)]
@@ -318,3 +319,90 @@ def test_c99_dropin_program_on_gpu(tmp_path):
                            "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.check_output([str(exe)]).decode()
     assert "all passed" in out
+
+
+# ---- limits and odd call patterns ---------------------------------------------------------------
+def test_large_frame_8192(hip, oracle):
+    """one 8192x8192 frame (67 MB): strip kernels with 8 column blocks, tall bands"""
+    import torch
+    img = Oracle.synth(8192, 8192, 77)
+    s = torch.from_numpy(img).cuda()
+    d = torch.full_like(s, SENT)
+    hip.sobel(d, s)
+    assert_same(d.cpu().numpy(), oracle.sobel(img, np.full_like(img, SENT)), "sobel 8192^2")
+    hip.blur(d, s, 2)
+    assert_same(d.cpu().numpy(), oracle.blur(img, 2), "blur 8192^2")
+    hip.erode(d, s)
+    assert_same(d.cpu().numpy(), oracle.erode(img), "erode 8192^2")
+    assert_same(hip.histogram(s), oracle.histogram(img), "histogram 8192^2")
+    assert hip.otsu_threshold(s) == oracle.otsu_threshold(img)
+
+
+def test_integral_wraps_mod_2_32_like_the_reference(hip, oracle):
+    """255 * 4200 * 4200 > 2^32: the reference's `unsigned` table wraps (grayskull.h:744-752)"""
+    img = np.full((4200, 4200), 255, np.uint8)
+    ii = hip.integral(img)
+    exp = oracle.integral(img)
+    assert_same(ii, exp, "integral wrap")
+    assert int(exp[-1, -1]) == (255 * 4200 * 4200) % 2 ** 32
+
+
+def test_more_frames_than_grid_z(hip, oracle):
+    """40000 tiny frames in one batch call: launches are split at the grid.z limit"""
+    import torch
+    n, h, w = 40000, 16, 32
+    rs = np.random.RandomState(3)
+    frames = rs.randint(0, 256, (n, h, w)).astype(np.uint8)
+    src = torch.from_numpy(frames).cuda()
+    dst = torch.zeros_like(src)
+    hip.sobel_batch(dst, src)
+    got = dst.cpu().numpy()
+    for f in (0, 32767, 32768, 39999):
+        assert_same(got[f], oracle.sobel(frames[f]), "sobel frame %d" % f)
+    hip.blur_batch(dst, src, 1)
+    got = dst.cpu().numpy()
+    for f in (0, 32767, 32768, 39999):
+        assert_same(got[f], oracle.blur(frames[f], 1), "blur frame %d" % f)
+    hist = torch.zeros((n, 256), dtype=torch.int32, device="cuda")
+    thr = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    hip.otsu_batch(src, hist, thr)
+    t = thr.cpu().numpy()
+    for f in (0, 32767, 32768, 39999):
+        assert int(t[f]) == oracle.otsu_threshold(frames[f])
+
+
+def test_mixed_host_and_device_arguments(hip, oracle):
+    """dst on the host, src on the device and vice versa"""
+    import torch
+    img = Oracle.synth(640, 480, 8)
+    dev = torch.from_numpy(img).cuda()
+    out = np.full_like(img, SENT)
+    hip.blur(out, dev, 3)
+    assert_same(out, oracle.blur(img, 3), "host dst, device src")
+    dout = torch.full_like(dev, SENT)
+    hip.sobel(dout, img)
+    assert_same(dout.cpu().numpy(), oracle.sobel(img, np.full_like(img, SENT)), "device dst, host src")
+    out = np.full_like(img, SENT)
+    hip.sobel(out, dev)
+    assert_same(out, oracle.sobel(img, np.full_like(img, SENT)), "host dst (frame kept), device src")
+
+
+def test_user_stream_and_async_mode(hip, oracle):
+    """gsh_set_stream / gsh_set_async: calls enqueue on the caller's stream without a host sync"""
+    import torch
+    img = Oracle.synth(1280, 720, 4)
+    s = torch.cuda.Stream()
+    try:
+        with torch.cuda.stream(s):
+            hip.set_stream(s.cuda_stream)
+            hip.set_async(True)
+            d = torch.from_numpy(img).cuda()
+            a, b = torch.zeros_like(d), torch.zeros_like(d)
+            for _ in range(5):
+                hip.blur(a, d, 2)
+                hip.sobel(b, a)
+            s.synchronize()
+        assert_same(b.cpu().numpy(), oracle.sobel(oracle.blur(img, 2)), "async chain on a user stream")
+    finally:
+        hip.set_async(False)
+        hip.set_stream(None)
