@@ -180,6 +180,52 @@ def main():
               "frac_hbm_peak": round(by / ms / 1e6 / HBM_PEAK_GBS, 4), "frames": n4}
         del a4, b4
 
+    # ---- the other single-GPU configs of BASELINE.json, for the record (not the headline metric) --
+    other = None
+    if sh.world == 1:
+        from grayskull_amd.cascade import Cascade
+        from oracle.pyoracle import Oracle as _O
+        other = {}
+        casc = Cascade.from_blob(os.path.join(ROOT, "tests", "golden", "frontalface_cascade.bin"))
+        n3, h3, w3 = 8, 1080, 1920
+        s3 = torch.empty((n3, h3, w3), dtype=torch.uint8, device="cuda")
+        g.synth_batch(s3, 3)
+        ii3 = torch.zeros((n3, h3, w3), dtype=torch.int32, device="cuda")
+        rc = torch.zeros((n3, 4096, 4), dtype=torch.int32, device="cuda")
+        cn = torch.zeros(n3, dtype=torch.int32, device="cuda")
+        dc = g.cascade_create(casc)
+        ms_ii = time_stream(torch, lambda: g.integral_batch(s3, ii3), 5)
+        ms_lbp = time_stream(torch, lambda: g.lbp_detect_batch(dc, ii3, rc, cn, 4096, 1.1, 1.0, 4.0, 1), 3)
+        nwin = g.lbp_window_count(casc, w3, h3, 1.1, 1.0, 4.0, 1)
+        other["configs[2] gs_integral + gs_lbp_detect(frontalface) 1920x1080 sf=1.1 scales 1..4 step 1"] = {
+            "frames": n3, "integral_ms_per_frame": round(ms_ii / n3, 4), "lbp_ms_per_frame": round(ms_lbp / n3, 3),
+            "windows_per_frame": nwin, "Gwindows/s": round(nwin * n3 / ms_lbp / 1e6, 2),
+            "detections_frame0": int(cn[0]), "expected_frame0 (reference KAT)": 158,
+            "bound": "texture-addresser gather rate (TA busy 94 %), not HBM",
+            "reference_1core": "5.98 s/frame, 4.83 Mwin/s (BASELINE.md)"}
+        dc.close()
+        A = _O.synth(1280, 720, 4)
+        B = np.zeros_like(A)
+        B[:717, :1275] = A[3:, 5:]
+        dA, dB = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
+        sm = torch.zeros_like(dA)
+        ka = g.orb_extract_dev(dA, sm, 500, 20)
+        t1 = time.perf_counter()
+        for _ in range(10):
+            ka = g.orb_extract_dev(dA, sm, 500, 20)
+        t_orb = (time.perf_counter() - t1) / 10
+        kb = g.orb_extract_dev(dB, sm, 500, 20)
+        t1 = time.perf_counter()
+        for _ in range(10):
+            mm = g.match_orb(ka, kb, 2500, 60.0)
+        t_match = (time.perf_counter() - t1) / 10
+        other["configs[3] gs_orb_extract x2 + gs_match_orb 1280x720 threshold=20 nkps=500"] = {
+            "orb_extract_ms": round(t_orb * 1e3, 3), "keypoints": int(len(ka)), "match_ms": round(t_match * 1e3, 3),
+            "matches": int(len(mm)), "expected_matches (reference KAT)": 337,
+            "note": "wall time incl. the host round trips (host libm atan2f/sinf, stable sort)",
+            "reference_1core": "70 ms extract, 48.6 ms match (BASELINE.md)"}
+        del s3, ii3, rc, cn
+
     # ---- verification against the oracle (outside the timed region) -------------------------
     parity = "skipped"
     if not args.no_verify and sh.rank == 0:
@@ -210,7 +256,7 @@ def main():
                   "hbm_bytes_per_px": 4, "note": "blur+sobel+histogram in one kernel, then threshold"},
         "unfused": {"ms_per_step": round(ms_unfused, 4), "Mpix/s": round(npx / ms_unfused / 1e3, 1),
                     "hbm_bytes_per_px": 7, "note": "separate gs_blur, gs_sobel, histogram, threshold kernels"},
-        "roofline": roof, "kernels": ktab, "sobel_4096x4096": ns, "parity": parity,
+        "roofline": roof, "kernels": ktab, "sobel_4096x4096": ns, "other_configs": other, "parity": parity,
         "otsu_thresholds_gathered": int(thr_all.numel()),
     }
     if sh.rank == 0 and sh.world == 1 and not args.no_cpu:

@@ -226,10 +226,23 @@ void launch_integral(const uint8_t *src, unsigned w, unsigned h, unsigned n, uns
   if (n == 0) return;
   hipStream_t st = ctx().s();
   const size_t fp = (size_t)w * h;
+  const bool banded = g_tune[6] == 0 && w % 16 == 0 && w <= 4096 && fp * 4 < 0x7fffffffull && al16(src) && al16(ii);
   for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
     const unsigned nn = std::min(kMaxZ, n - f0);
-    GS_LAUNCH(k_integral_rows, dim3(h, nn), dim3(256), 0, st, src + fp * f0, w, h, ii + fp * f0);
-    GS_LAUNCH(k_integral_cols, dim3((w + 255) / 256, nn), dim3(256), 0, st, ii + fp * f0, w, h);
+    if (banded) {
+      unsigned nb = std::max(1u, 2048u / nn);               /* ~2K blocks in flight */
+      nb = std::min(nb, std::max(1u, h / 8));
+      const unsigned BH = (h + nb - 1) / nb;
+      nb = (h + BH - 1) / BH;
+      unsigned *cs = (unsigned *)ctx().scratch(SL_HISTP, (size_t)nn * nb * w * 4);
+      GS_LAUNCH(k_integral_colsum, dim3(1, nb, nn), dim3(256), 0, st, src + fp * f0, w, h, BH, nb, cs);
+      GS_LAUNCH(k_integral_colbase, dim3((w + 255) / 256, nn), dim3(256), 0, st, cs, w, nb);
+      GS_LAUNCH(k_integral_band, dim3(1, nb, nn), dim3(256), 0, st, src + fp * f0, w, h, BH, nb,
+                (const unsigned *)cs, ii + fp * f0);
+    } else {
+      GS_LAUNCH(k_integral_rows, dim3(h, nn), dim3(256), 0, st, src + fp * f0, w, h, ii + fp * f0);
+      GS_LAUNCH(k_integral_cols, dim3((w + 255) / 256, nn), dim3(256), 0, st, ii + fp * f0, w, h);
+    }
   }
 }
 

@@ -98,6 +98,7 @@ GS_DEV void buf_store16(const BufRsrc &b, uint32_t off, const U4 &v) {
   emu_buf_check(b, off, 16);
   if (off < b.n) memcpy(b.base + off, &v, 16);
 }
+GS_DEV void buf_store16_wb(const BufRsrc &b, uint32_t off, const U4 &v) { buf_store16(b, off, v); }
 /* dword gather: per-lane byte offset + wave-uniform byte offset (SGPR soffset on the GPU) */
 GS_DEV uint32_t buf_gather4(const BufRsrc &b, uint32_t voff, uint32_t soff) { return buf_load4(b, voff + soff); }
 GS_DEV uint32_t uniform(uint32_t x) { return x; } /* v_readfirstlane_b32 on the GPU */
@@ -169,6 +170,12 @@ GS_DEV uint32_t buf_gather4(const BufRsrc &b, uint32_t voff, uint32_t soff) {
 GS_DEV uint32_t uniform(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 GS_DEV void buf_store16(const BufRsrc &b, uint32_t off, const U4 &v) { /* buffer_store_dwordx4 offen */
   __builtin_amdgcn_raw_buffer_store_b128(gs_u32x4{v.x, v.y, v.z, v.w}, b.r, (int)off, 0, GS_STORE_AUX);
+}
+/* default (write-back) policy: for stores that fill a cache line piecewise (a lane's 64 B of an
+ * integral-image row go out as four 16-B stores interleaved with its neighbours') -- nt there
+ * would push partial lines to memory */
+GS_DEV void buf_store16_wb(const BufRsrc &b, uint32_t off, const U4 &v) {
+  __builtin_amdgcn_raw_buffer_store_b128(gs_u32x4{v.x, v.y, v.z, v.w}, b.r, (int)off, 0, 0);
 }
 typedef unsigned short gs_u16x2 __attribute__((ext_vector_type(2)));
 typedef short gs_i16x2 __attribute__((ext_vector_type(2)));

@@ -17,17 +17,20 @@ def timeit(fn, reps=5):
 out = {}
 # ---- config 3: integral + lbp_detect on 1080p (and 4K), sf=1.1, scales 1..4, step 1
 for (w, h, n, seed) in ((1920, 1080, 8, 3), (3840, 2160, 4, 1000)):
-    src = torch.empty((n, h, w), dtype=torch.uint8, device="cuda"); g.synth_batch(src, seed)
-    ii = torch.zeros((n, h, w), dtype=torch.int32, device="cuda")
-    ms_int = timeit(lambda: g.integral_batch(src, ii))
-    dc = g.cascade_create(casc)
-    rects = torch.zeros((n, 4096, 4), dtype=torch.int32, device="cuda"); counts = torch.zeros(n, dtype=torch.int32, device="cuda")
-    nwin = g.lbp_window_count(casc, w, h, 1.1, 1.0, 4.0, 1)
-    ms_lbp = timeit(lambda: g.lbp_detect_batch(dc, ii, rects, counts, 4096, 1.1, 1.0, 4.0, 1), 3)
-    out["cfg3_%dx%d" % (w, h)] = {"frames": n, "integral_ms_per_frame": round(ms_int / n, 4), "integral_GBs_5Bpx": round(5.0 * n * w * h / ms_int / 1e6, 1),
-                                 "lbp_ms_per_frame": round(ms_lbp / n, 3), "windows_per_frame": nwin, "Mwin/s": round(nwin * n / ms_lbp / 1e3, 1),
-                                 "detections": counts.cpu().tolist()}
-    dc.close()
+  for variant in (0, 1):
+      g.tune(6, variant)
+      src = torch.empty((n, h, w), dtype=torch.uint8, device="cuda"); g.synth_batch(src, seed)
+      ii = torch.zeros((n, h, w), dtype=torch.int32, device="cuda")
+      ms_int = timeit(lambda: g.integral_batch(src, ii))
+      dc = g.cascade_create(casc)
+      rects = torch.zeros((n, 4096, 4), dtype=torch.int32, device="cuda"); counts = torch.zeros(n, dtype=torch.int32, device="cuda")
+      nwin = g.lbp_window_count(casc, w, h, 1.1, 1.0, 4.0, 1)
+      ms_lbp = timeit(lambda: g.lbp_detect_batch(dc, ii, rects, counts, 4096, 1.1, 1.0, 4.0, 1), 3)
+      out["cfg3_%dx%d_%s" % (w, h, "generic" if variant else "banded")] = {"frames": n, "integral_ms_per_frame": round(ms_int / n, 4), "integral_GBs_5Bpx": round(5.0 * n * w * h / ms_int / 1e6, 1),
+                                   "lbp_ms_per_frame": round(ms_lbp / n, 3), "windows_per_frame": nwin, "Mwin/s": round(nwin * n / ms_lbp / 1e3, 1),
+                                   "detections": counts.cpu().tolist()}
+      dc.close()
+g.tune(6, 0)
 # ---- config 4: ORB extract + match on a 1280x720 pair
 from oracle.pyoracle import Oracle
 A = Oracle.synth(1280, 720, 4); B = np.zeros_like(A); B[:717, :1275] = A[3:, 5:]
