@@ -500,12 +500,12 @@ void launch_lbp_padded(gsh_cascade *dc, const unsigned *padded, unsigned iw, uns
   LbpPhases ph;
   {
     static const unsigned presets[8][kLbpMaxPhases] = {
-        {2, 5, 99, 99, 99, 99, 99, 99},   /* 0 default (measured best on MI355X, frontalface) */
+        {2, 4, 7, 99, 99, 99, 99, 99},    /* 0 default (measured best on MI355X, frontalface) */
         {99, 99, 99, 99, 99, 99, 99, 99}, /* 1: single dense phase (no re-packing) */
         {1, 2, 4, 6, 9, 13, 99, 99},
         {1, 2, 3, 4, 6, 8, 12, 99},
         {1, 2, 5, 99, 99, 99, 99, 99},
-        {2, 4, 7, 99, 99, 99, 99, 99},
+        {2, 5, 99, 99, 99, 99, 99, 99},
         {2, 6, 99, 99, 99, 99, 99, 99},
         {3, 7, 99, 99, 99, 99, 99, 99}};
     const unsigned *pr = presets[(g_tune[4] >= 0 && g_tune[4] < 8) ? g_tune[4] : 0];
@@ -824,16 +824,23 @@ gsh_cascade *gsh_cascade_create(const struct gs_lbp_cascade *c) {
   dc->nfeatures = c->nfeatures, dc->nweaks = c->nweaks, dc->nstages = c->nstages;
   dc->features.assign(c->features, c->features + (size_t)c->nfeatures * 4);
   dc->weak_feature_idx.assign(c->weak_feature_idx, c->weak_feature_idx + c->nweaks);
-  std::vector<LbpWeak> wk(c->nweaks);
-  unsigned nsub = 0;
-  for (unsigned i = 0; i < c->nweaks; i++) {
-    wk[i] = LbpWeak{c->weak_left_val[i], c->weak_right_val[i], c->weak_subset_offset[i],
-                    c->weak_num_subsets[i]};
-    nsub = std::max(nsub, (unsigned)c->weak_subset_offset[i] + c->weak_num_subsets[i]);
-  }
+  /* device tables in EVALUATION order: stage by stage, so a stage range is one contiguous run of
+   * weak classifiers (the reference indexes through stage_weak_start, ref :795-798) */
+  std::vector<LbpWeak> wk;
   std::vector<LbpStage> stg(c->nstages);
-  for (unsigned i = 0; i < c->nstages; i++)
-    stg[i] = LbpStage{c->stage_weak_start[i], c->stage_nweaks[i], c->stage_threshold[i], 0.0f};
+  dc->weak_feature_idx.clear();
+  unsigned nsub = 0;
+  for (unsigned si = 0; si < c->nstages; si++) {
+    stg[si] = LbpStage{(unsigned)wk.size(), c->stage_nweaks[si], c->stage_threshold[si], 0.0f};
+    for (unsigned k = 0; k < c->stage_nweaks[si]; k++) {
+      const unsigned i = (unsigned)c->stage_weak_start[si] + k;
+      wk.push_back(LbpWeak{c->weak_left_val[i], c->weak_right_val[i], c->weak_subset_offset[i],
+                           c->weak_num_subsets[i]});
+      dc->weak_feature_idx.push_back(c->weak_feature_idx[i]);
+      nsub = std::max(nsub, (unsigned)c->weak_subset_offset[i] + c->weak_num_subsets[i]);
+    }
+  }
+  dc->nweaks = (unsigned)wk.size(); /* classifiers actually reachable through the stages */
   dc->nsub = nsub;
   GS_HIP(hipMalloc((void **)&dc->d_weak, std::max<size_t>(1, wk.size()) * sizeof(LbpWeak)));
   GS_HIP(hipMalloc((void **)&dc->d_stage, std::max<size_t>(1, stg.size()) * sizeof(LbpStage)));

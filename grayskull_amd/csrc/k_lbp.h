@@ -86,52 +86,48 @@ GS_DEV LbpLds lbp_stage_tables(char *smem, const LbpArgs &a, const LbpGeom *geom
  * (21 instead of 27 add/sub).  GUARD (feature rectangles that can stick out of the window, only
  * with scale < 1 after the clamp of ref :803-804): explicit clamped vector address instead; the
  * reference reads out of bounds there, so no particular value is "right". */
-#ifndef GS_LBP_BUFFER_GATHER
-#define GS_LBP_BUFFER_GATHER 0 /* measured on MI355X: plain global gathers 17.7 Gwin/s dense vs 11.6 */
-#endif
+/* The 16 corner gathers of the NEXT weak classifier are issued before the current one's
+ * arithmetic (they do not depend on it; only a stage end does), so L2 latency overlaps the ~70
+ * lane-ops of cell/code/lookup work.  Tables are in evaluation order (stage by stage), so the
+ * classifiers of stages [s0, s1) are the contiguous range [stage[s0].first, end of stage s1-1). */
+struct LbpCorners { unsigned G[4][4]; };
 template <bool GUARD>
-GS_DEV bool lbp_window_stages(const LbpLds &t, const BufRsrc &P, const unsigned *Pg, unsigned origin,
+GS_DEV LbpCorners lbp_gather(const LbpLds &t, const unsigned *Pg, unsigned origin, unsigned limit,
+                             unsigned wi) {
+  const LbpGeom g = t.geom[wi];
+  const unsigned off0 = uniform((unsigned)g.off0), fw = uniform((unsigned)g.fw),
+                 fhs = uniform((unsigned)g.fh_stride);
+  LbpCorners c;
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      unsigned idx = origin + off0 + (unsigned)j * fhs + (unsigned)i * fw;
+      if (GUARD) idx = idx > limit ? limit : idx;
+      c.G[j][i] = *(const unsigned *)((const char *)Pg + idx);
+    }
+  return c;
+}
+
+template <bool GUARD>
+GS_DEV bool lbp_window_stages(const LbpLds &t, const BufRsrc &, const unsigned *Pg, unsigned origin,
                               unsigned limit, unsigned s0, unsigned s1) {
+  const unsigned wend = uniform(t.stage[s1 - 1].first) + uniform(t.stage[s1 - 1].count);
+  unsigned wi = uniform(t.stage[s0].first);
+  LbpCorners nxt = lbp_gather<GUARD>(t, Pg, origin, limit, wi);
   for (unsigned s = s0; s < s1; s++) {
     const LbpStage st = t.stage[s];
-    const unsigned first = uniform(st.first), count = uniform(st.count);
+    const unsigned count = uniform(st.count);
     float sum = 0.0f;
-    for (unsigned k = 0; k < count; k++) {
-      const unsigned wi = first + k;
-      const LbpGeom g = t.geom[wi];
+    for (unsigned k = 0; k < count; k++, wi++) {
+      const LbpCorners cur = nxt;
       const LbpWeak wk = t.weak[wi];
-      const unsigned off0 = uniform((unsigned)g.off0), fw = uniform((unsigned)g.fw),
-                     fhs = uniform((unsigned)g.fh_stride);
-      unsigned G[4][4];
-#pragma unroll
-      for (int j = 0; j < 4; j++)
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const unsigned so = off0 + (unsigned)j * fhs + (unsigned)i * fw;
-#if GS_LBP_BUFFER_GATHER
-          if (GUARD) {
-            unsigned idx = origin + so;
-            idx = idx > limit ? limit : idx;
-            G[j][i] = buf_load4(P, idx);
-          } else {
-            G[j][i] = buf_gather4(P, origin, so);
-          }
-#else
-          unsigned idx = origin + so;
-          if (GUARD) idx = idx > limit ? limit : idx;
-#ifdef GS_LBP_EXPERIMENT_FEWER_GATHERS /* WRONG RESULTS: bound-finding experiment only */
-          if (i == 0) G[j][i] = *(const unsigned *)((const char *)Pg + idx);
-          else G[j][i] = G[j][0] * (unsigned)(i + 3) + so;
-#else
-          G[j][i] = *(const unsigned *)((const char *)Pg + idx);
-#endif
-#endif
-        }
+      if (wi + 1 < wend) nxt = lbp_gather<GUARD>(t, Pg, origin, limit, wi + 1); /* wave-uniform */
       unsigned D[3][4], c[3][3];
 #pragma unroll
       for (int j = 0; j < 3; j++)
 #pragma unroll
-        for (int i = 0; i < 4; i++) D[j][i] = G[j + 1][i] - G[j][i];
+        for (int i = 0; i < 4; i++) D[j][i] = cur.G[j + 1][i] - cur.G[j][i];
 #pragma unroll
       for (int j = 0; j < 3; j++)
 #pragma unroll
