@@ -567,19 +567,20 @@ unsigned orb_candidates(const uint8_t *img_dev, unsigned w, unsigned h, uint8_t 
   unsigned *kps = (unsigned *)ctx().scratch(SL_KPS, (size_t)cap * 48 + 16);
   unsigned *cnt = (unsigned *)ctx().scratch(SL_TOT, 16);
   launch_fast(img_dev, score_dev, w, h, 1, kps, cnt, cap, threshold);
+  /* moments of every candidate slot (blocks beyond the device-side count exit), then ONE
+   * round trip for count + records + moments */
+  int *mom = (int *)ctx().scratch(SL_MOM, (size_t)cap * 8);
+  GS_LAUNCH(k_orient_moments, dim3(cap), dim3(64), 0, st, img_dev, w, h, (const unsigned *)kps, 12u,
+            15u, mom, (const unsigned *)cnt);
+  std::vector<unsigned> hk((size_t)cap * 12);
+  std::vector<int> hm((size_t)cap * 2);
   unsigned n = 0;
   GS_HIP(hipMemcpyAsync(&n, cnt, 4, hipMemcpyDeviceToHost, st));
+  GS_HIP(hipMemcpyAsync(hk.data(), kps, (size_t)cap * 48, hipMemcpyDeviceToHost, st));
+  GS_HIP(hipMemcpyAsync(hm.data(), mom, (size_t)cap * 8, hipMemcpyDeviceToHost, st));
   ctx().sync();
   out.resize(n);
   if (!n) return 0;
-  int *mom = (int *)ctx().scratch(SL_MOM, (size_t)n * 8);
-  GS_LAUNCH(k_orient_moments, dim3(n), dim3(64), 0, st, img_dev, w, h, (const unsigned *)kps, 12u,
-            15u, mom);
-  std::vector<unsigned> hk((size_t)n * 12);
-  std::vector<int> hm((size_t)n * 2);
-  GS_HIP(hipMemcpyAsync(hk.data(), kps, (size_t)n * 48, hipMemcpyDeviceToHost, st));
-  GS_HIP(hipMemcpyAsync(hm.data(), mom, (size_t)n * 8, hipMemcpyDeviceToHost, st));
-  ctx().sync();
   for (unsigned i = 0; i < n; i++)
     out[i] = Cand{hk[i * 12], hk[i * 12 + 1], hk[i * 12 + 2], hm[2 * i], hm[2 * i + 1]};
   return n;
@@ -624,7 +625,7 @@ void launch_match(const uint32_t *k1, unsigned n1, const uint32_t *k2, unsigned 
     GS_HIP(hipMemsetAsync(count, 0, 4, st));
     return;
   }
-  const unsigned blocks = (n1 + 255) / 256, words = blocks * 4;
+  const unsigned blocks = (n1 + 3) / 4, words = (n1 + 63) / 64;
   const unsigned nchunks = (words + kChunkWords - 1) / kChunkWords;
   unsigned long long *mask =
       (unsigned long long *)ctx().scratch(SL_MASK, (size_t)nchunks * kChunkWords * 8);
@@ -1238,7 +1239,7 @@ float gs_compute_orientation(struct gs_image img, unsigned x, unsigned y, unsign
   int *dm = (int *)ctx().scratch(SL_MOM, 16);
   GS_HIP(hipMemcpyAsync(dp, pt, 8, hipMemcpyHostToDevice, st));
   GS_LAUNCH(k_orient_moments, dim3(1), dim3(64), 0, st, patch, 2 * r + 1, 2 * r + 1,
-            (const unsigned *)dp, 2u, r, dm);
+            (const unsigned *)dp, 2u, r, dm, (const unsigned *)nullptr);
   int m[2];
   GS_HIP(hipMemcpyAsync(m, dm, 8, hipMemcpyDeviceToHost, st));
   ctx().sync();

@@ -10,7 +10,8 @@
  *  k_brief           rotated BRIEF-256 given host-computed sin/cos (ref :623-637): float32, no
  *                    FMA contraction, truncation toward zero, out-of-image taps read 0.
  *  k_match           brute-force Hamming NN + ratio test (ref :680-699) with XOR + popcount;
- *                    one thread per query, train descriptors via wave-uniform (scalar) loads.
+ *                    one wave per query, lanes stride over the train descriptors, butterfly
+ *                    merge of (best, second, first-argmin).
  */
 #ifndef GS_K_ORB_H
 #define GS_K_ORB_H
@@ -29,10 +30,12 @@ GS_CONST_TABLE int8_t k_brief_pattern[1024] = {
 
 struct KpIn { unsigned x, y; float sin_a, cos_a; }; /* host -> device per keypoint */
 
-/* grid nkp, block 64.  pts: (x,y) pairs; out: (m01, m10) int pairs */
+/* grid nkp (or an upper bound, with the true count in *count_dev), block 64.
+ * pts: (x,y) pairs; out: (m01, m10) int pairs */
 __global__ __launch_bounds__(64) void k_orient_moments(const uint8_t *img, unsigned w, unsigned h,
                                                        const unsigned *pts, unsigned pt_stride,
-                                                       unsigned r, int *out) {
+                                                       unsigned r, int *out, const unsigned *count_dev) {
+  if (count_dev && blockIdx.x >= *count_dev) return;
   const unsigned x = pts[(size_t)blockIdx.x * pt_stride], y = pts[(size_t)blockIdx.x * pt_stride + 1];
   const int side = 2 * (int)r + 1, total = side * side, rr = (int)(r * r);
   int m01 = 0, m10 = 0;
@@ -76,34 +79,55 @@ __global__ __launch_bounds__(256) void k_brief(const uint8_t *img, unsigned w, u
 }
 
 /* keypoint record = 12 dwords, descriptor at dword 4 (grayskull.h:42-47).
- * grid ceil(n1/256), block 256.  best_idx / best_dist per query + accept flags (compaction). */
+ * One WAVE per query: the 64 lanes stride over the train descriptors, each keeping the
+ * reference's (best, second, first-argmin) state; states merge with
+ *   best = min(b1,b2), second = min(max(b1,b2), s1, s2), arg = arg of the smaller best (lower
+ *   index on ties)
+ * which is the sequential loop's result for any visiting order (ref :686-694: two smallest of
+ * the multiset {init, init, d_0, d_1, ...} with strict '<', first index attaining the minimum).
+ * grid ceil(n1/4), block 256.  mask / chunk_count pre-zeroed; bit i of the mask = query i accepted. */
 __global__ __launch_bounds__(256) void k_match(const uint32_t *k1, unsigned n1, const uint32_t *k2,
                                                unsigned n2, float max_distance, unsigned *best_idx,
                                                unsigned *best_dist, unsigned long long *mask,
                                                unsigned *chunk_count) {
-  const unsigned i = blockIdx.x * 256u + threadIdx.x;
-  bool accept = false;
-  if (i < n1) {
-    uint32_t d1[8];
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned i = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (i >= n1) return; /* whole wave */
+  uint32_t d1[8];
 #pragma unroll
-    for (int q = 0; q < 8; q++) d1[q] = k1[(size_t)i * 12u + 4 + q];
-    float best = max_distance + 1, second = max_distance + 1;
-    unsigned arg = 0;
-    for (unsigned j = 0; j < n2; j++) {
-      const uint32_t *d2 = k2 + (size_t)j * 12u + 4; /* wave-uniform address */
-      unsigned bits = 0;
+  for (int q = 0; q < 8; q++) d1[q] = k1[(size_t)i * 12u + 4 + q];
+  float best = max_distance + 1, second = max_distance + 1;
+  unsigned arg = 0;
+  for (unsigned j = lane; j < n2; j += 64u) {
+    const uint32_t *d2 = k2 + (size_t)j * 12u + 4;
+    unsigned bits = 0;
 #pragma unroll
-      for (int q = 0; q < 8; q++) bits += (unsigned)__popc(d1[q] ^ d2[q]);
-      const float d = (float)bits;
-      if (d < best) second = best, best = d, arg = j;
-      else if (d < second) second = d;
-    }
-    accept = best <= max_distance && best < 0.8f * second;
+    for (int q = 0; q < 8; q++) bits += (unsigned)__popc(d1[q] ^ d2[q]);
+    const float d = (float)bits;
+    if (d < best) second = best, best = d, arg = j;
+    else if (d < second) second = d;
+  }
+#pragma unroll
+  for (int sft = 32; sft >= 1; sft >>= 1) { /* butterfly merge of the 64 lane states */
+    const int src = (int)(lane ^ (unsigned)sft);
+    const float ob = __builtin_bit_cast(float, shfl(__builtin_bit_cast(uint32_t, best), src));
+    const float os = __builtin_bit_cast(float, shfl(__builtin_bit_cast(uint32_t, second), src));
+    const unsigned oa = shfl(arg, src);
+    const float hi = ob > best ? ob : best; /* the larger of the two bests */
+    float s2 = os < second ? os : second;
+    s2 = hi < s2 ? hi : s2;
+    if (ob < best || (ob == best && oa < arg)) arg = oa;
+    best = ob < best ? ob : best;
+    second = s2;
+  }
+  if (lane == 0) {
     best_idx[i] = arg;
     best_dist[i] = (unsigned)best;
+    if (best <= max_distance && best < 0.8f * second) {
+      atomicOr(&mask[i >> 6], 1ull << (i & 63u));
+      atomicAdd(&chunk_count[(i >> 6) / kChunkWords], 1u);
+    }
   }
-  /* item = query index; words of 64 queries; chunk counters as everywhere */
-  publish_flags(accept, mask, chunk_count, i >> 6);
 }
 
 /* compaction functor: query i -> gs_match {i, best_idx, distance} (ref :696) */
