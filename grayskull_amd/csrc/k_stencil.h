@@ -50,7 +50,7 @@ template <bool INVERT = false> struct Strip {
         dst(make_buf(d + (size_t)blockIdx.z * frame_bytes, frame_bytes)), w(w_), h(h_) {
     lane = threadIdx.x & 63u;
     x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 16u;
-    band = blockIdx.y * blockDim.y + threadIdx.y;
+    band = uniform(blockIdx.y * blockDim.y + threadIdx.y); /* same for the wave's 64 lanes: SGPR */
   }
   /* row y: this lane's 16 B; lane 0 also fetches the 4 B left of the wave's 1 KiB, lane 63 the
    * 4 B right of it (one shared instruction).  Everything outside the image reads 0. */
@@ -99,25 +99,42 @@ struct NoFin {
   GS_DEV U4 operator()(const U4 &o, int) const { return o; } /* called right before row y's store */
   GS_DEV void prefetch(int) {}                              /* called when row y's loads issue   */
 };
-template <int RING, bool INVERT, class Body, class Fin = NoFin>
+/* EXITS: leave the unrolled group at the first row >= nrows (true), or always run whole groups of
+ * RING rows (false): then the group is one basic block -- register rotation resolves at compile
+ * time with nothing to copy at block boundaries -- and rows i >= nrows of the last group are
+ * computed and dropped (stores predicated off; their loads are in-frame rows of the next band or
+ * out-of-range zero fill).  false costs registers; it pays for the VALU-heavy fused kernel only.
+ * DEPTH: how many rows ahead the input is requested (1 or 2). */
+template <int RING, bool INVERT, bool EXITS = true, int DEPTH = 1, class Body, class Fin = NoFin>
 GS_DEV void strip_rows(const Strip<INVERT> &S, int y0, int nrows, int lead, RawRow first, Body &&body,
                        Fin fin = Fin()) {
   RawRow raw = first; /* = load(y0 + lead): the newest input row output row 0 needs */
+  RawRow raw2 = first;
+  if constexpr (DEPTH == 2) raw2 = S.load(y0 + lead + 1);
   U4 o_prev{0, 0, 0, 0};
   fin.prefetch(y0);
-  for (int base = 0; base < nrows; base += RING) {
+  int base = 0;
+  for (; base < nrows; base += RING) {
     static_for<RING>([&](auto I) {
       const int i = base + decltype(I)::value;
-      if (i >= nrows) return; /* wave-uniform */
+      if constexpr (EXITS) {
+        if (i >= nrows) return; /* wave-uniform */
+      }
       uint32_t U[12];
       strip_unpack(raw, U);
-      S.store(y0 + i - 1, i > 0, fin(o_prev, y0 + i - 1));
-      raw = S.load(y0 + i + lead + 1);
+      S.store(y0 + i - 1, i > 0 && i <= nrows, fin(o_prev, y0 + i - 1));
+      if constexpr (DEPTH == 2) {
+        raw = raw2;
+        raw2 = S.load(y0 + i + lead + 2);
+      } else {
+        raw = S.load(y0 + i + lead + 1);
+      }
       fin.prefetch(y0 + i);
       o_prev = body(I, i, U);
     });
   }
-  S.store(y0 + nrows - 1, nrows > 0, fin(o_prev, y0 + nrows - 1));
+  if constexpr (EXITS) S.store(y0 + nrows - 1, nrows > 0, fin(o_prev, y0 + nrows - 1));
+  else S.store(y0 + base - 1, base == nrows && nrows > 0, fin(o_prev, y0 + base - 1));
 }
 
 /* ------------------------------------------------------------------ sobel, strips */
@@ -177,7 +194,12 @@ struct SobelState {
   }
   /* PAR = parity of the step: H1[PAR] holds row b-2 and receives row b */
   template <int PAR> GS_DEV U4 step(const uint32_t (&U)[12]) {
-    uint32_t H1n[8], H2n[8], M[8];
+    uint32_t M[8];
+    return step<PAR>(U, M);
+  }
+  /* M: the 16 results as u16 pairs (before packing to bytes) */
+  template <int PAR> GS_DEV U4 step(const uint32_t (&U)[12], uint32_t (&M)[8]) {
+    uint32_t H1n[8], H2n[8];
     sobel_hpass(U, H1n, H2n);
 #pragma unroll
     for (int k = 0; k < 8; k++) {
@@ -193,8 +215,8 @@ struct SobelState {
               pack_lohi(M[6], M[7])};
   }
   /* same, H1 history shifted instead of alternated (for callers whose unroll period is odd) */
-  GS_DEV U4 step_shift(const uint32_t (&U)[12]) {
-    const U4 o = step<0>(U); /* H1[0] (row b-2) consumed and overwritten with row b */
+  GS_DEV U4 step_shift(const uint32_t (&U)[12], uint32_t (&M)[8]) {
+    const U4 o = step<0>(U, M); /* H1[0] (row b-2) consumed and overwritten with row b */
 #pragma unroll
     for (int k = 0; k < 8; k++) {
       const uint32_t t = H1[0][k];
@@ -225,8 +247,8 @@ __global__ __launch_bounds__(256, GS_SOBEL_MINWAVES) void k_sobel16(uint8_t *dst
     st.init(U0, U1);
   }
   auto body = [&](auto I, int, const uint32_t(&U)[12]) { return st.template step<decltype(I)::value>(U); };
-  if constexpr (KEEP_COLS) strip_rows<2>(S, y0, nrows, 1, S.load(y0 + 1), body, SobelKeepCols(S));
-  else strip_rows<2>(S, y0, nrows, 1, S.load(y0 + 1), body);
+  if constexpr (KEEP_COLS) strip_rows<2, false>(S, y0, nrows, 1, S.load(y0 + 1), body, SobelKeepCols(S));
+  else strip_rows<2, false>(S, y0, nrows, 1, S.load(y0 + 1), body);
 }
 
 /* host-staged gs_sobel: columns 0 and w-1 of rows 1..h-2 of the caller's dst, gathered on the
@@ -293,7 +315,7 @@ __global__ __launch_bounds__(256, GS_BLUR_MINWAVES) void k_blur16(uint8_t *dst, 
 #pragma unroll
     for (int k = 0; k < 8; k++) V[k] = pk_add_u16(V[k], ring[r][k]);
   }
-  strip_rows<N>(S, y0, nrows, R, S.load(y0 + R), [&](auto I, int, const uint32_t(&U)[12]) {
+  strip_rows<N, false>(S, y0, nrows, R, S.load(y0 + R), [&](auto I, int, const uint32_t(&U)[12]) {
     constexpr int slot = (decltype(I)::value + N - 1) % N; /* row i-1 leaves, row i+2R enters */
     uint32_t Hn[8];
     blur_hsum<R>(U, Hn);
@@ -372,17 +394,23 @@ GS_DEV uint32_t blur_mul_for_rows(unsigned cy) { /* cy in [R+1, 2R+1], wave-unif
 template <int R>
 GS_DEV void blur_hsum10(const uint32_t (&U)[12], uint32_t (&H)[10]) { /* pairs = px -2..17 */
   uint32_t A[13]; /* A[j+1] = pair starting one px after U[j], j = -1..11 (ends zero-extended) */
-  A[0] = alignbit(U[0], 0u, 16);
+  if constexpr (R >= 3) A[0] = alignbit(U[0], 0u, 16), A[12] = alignbit(0u, U[11], 16);
 #pragma unroll
   for (int j = 0; j <= 10; j++) A[j + 1] = alignbit(U[j + 1], U[j], 16);
-  A[12] = alignbit(0u, U[11], 16);
+  if constexpr (R == 1) {
 #pragma unroll
-  for (int k = 0; k < 10; k++) {
-    const int j = k + 1; /* U[j] = pair k */
-    uint32_t s = pk_add_u16(pk_add_u16(A[j], U[j]), A[j + 1]);            /* -1, 0, +1 */
-    if constexpr (R >= 2) s = pk_add_u16(pk_add_u16(s, U[j - 1]), U[j + 1]); /* -2, +2 */
-    if constexpr (R >= 3) s = pk_add_u16(pk_add_u16(s, A[j - 1]), A[j + 2]); /* -3, +3 */
-    H[k] = s;
+    for (int k = 0; k < 10; k++) H[k] = pk_add_u16(pk_add_u16(A[k + 1], U[k + 1]), A[k + 2]);
+  } else {
+    uint32_t Q[11]; /* Q[j] = U[j] + A[j+1]: the 2-px sums starting at both pixels of pair j */
+#pragma unroll
+    for (int j = 0; j <= 10; j++) Q[j] = pk_add_u16(U[j], A[j + 1]);
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+      const int j = k + 1; /* U[j] = pair k */
+      uint32_t t = pk_add_u16(pk_add_u16(Q[j - 1], Q[j]), U[j + 1]);        /* -2 .. +2 */
+      if constexpr (R >= 3) t = pk_add_u16(pk_add_u16(t, A[j - 1]), A[j + 2]); /* -3, +3 */
+      H[k] = t;
+    }
   }
 }
 
@@ -401,7 +429,11 @@ __global__ __launch_bounds__(256) void k_blur_sobel_hist16(uint8_t *dst, const u
   if (y0 < (int)h - 1) { /* wave-uniform; no early return: every wave reaches the barrier */
     const int nrows = ((int)h - 1 - y0) < (int)T ? ((int)h - 1 - y0) : (int)T;
     const bool first = S.x0 == 0, last = S.x0 + 16 == w, inimg = S.x0 < w;
-    uint32_t ring[N][10], V[10];
+    /* N+1 ring slots: the new row lands in the free slot and the unroll period N+1 is even, so
+     * the sobel history alternates (step<parity>) without register moves */
+    constexpr bool SPARE = R <= 2; /* R = 3: the 8th slot would cost the third wave per SIMD */
+    constexpr int NS = SPARE ? N + 1 : N, P0 = SPARE ? 1 : 0; /* P0: slot of the first prologue row */
+    uint32_t ring[NS][10], V[10];
     SobelState st;
     /* blurred row b as u16 pairs for pixels -2..17, placed where sobel_hpass expects U[1..10] */
     auto blurred = [&](int b, uint32_t(&UB)[12]) {
@@ -438,34 +470,50 @@ __global__ __launch_bounds__(256) void k_blur_sobel_hist16(uint8_t *dst, const u
       constexpr int kk = decltype(K)::value;
       uint32_t U[12];
       strip_unpack(S.load(y0 - 1 - R + kk), U);
-      blur_hsum10<R>(U, ring[kk]);
+      blur_hsum10<R>(U, ring[kk + P0]);
 #pragma unroll
-      for (int k = 0; k < 10; k++) V[k] = pk_add_u16(V[k], ring[kk][k]);
+      for (int k = 0; k < 10; k++) V[k] = pk_add_u16(V[k], ring[kk + P0][k]);
     });
     blurred(y0 - 1, UB0);
     {
       uint32_t U[12], Hn[10];
       strip_unpack(S.load(y0 + R), U);
-      blur_hsum10<R>(U, Hn);
+      blur_hsum10<R>(U, Hn); /* enters slot 0 (SPARE: the free slot); the oldest row (slot P0) leaves */
 #pragma unroll
-      for (int k = 0; k < 10; k++) V[k] = pk_sub_u16(pk_add_u16(V[k], Hn[k]), ring[0][k]), ring[0][k] = Hn[k];
+      for (int k = 0; k < 10; k++) V[k] = pk_sub_u16(pk_add_u16(V[k], Hn[k]), ring[P0][k]), ring[0][k] = Hn[k];
     }
     blurred(y0, UB1);
     st.init(UB0, UB1);
+    const uint32_t cb2 = (copy << 2) * 0x10001u; /* this lane's histogram copy, as a pair of byte offsets */
 
-    strip_rows<N>(S, y0, nrows, R + 1, S.load(y0 + R + 1), [&](auto I, int i, const uint32_t(&U)[12]) {
-      constexpr int slot = (decltype(I)::value + 1) % N; /* oldest row of the vertical window */
-      uint32_t Hn[10], UB[12];
+#ifndef GS_FUSED_DEPTH
+#define GS_FUSED_DEPTH 1
+#endif
+#ifndef GS_FUSED_EXITS
+#define GS_FUSED_EXITS false
+#endif
+    strip_rows<NS, false, GS_FUSED_EXITS, GS_FUSED_DEPTH>(S, y0, nrows, R + 1, S.load(y0 + R + 1), [&](auto I, int i, const uint32_t(&U)[12]) {
+      /* iteration I, SPARE: slot I+1 is free (its row left last iteration), slot I+2 holds the
+       * oldest row; otherwise the new row replaces the oldest (slot I+1) */
+      constexpr int fr = (decltype(I)::value + 1) % NS, old = (decltype(I)::value + 1 + P0) % NS;
+      uint32_t UB[12], M[8], Hn[10];
       blur_hsum10<R>(U, Hn);
 #pragma unroll
-      for (int k = 0; k < 10; k++) V[k] = pk_sub_u16(pk_add_u16(V[k], Hn[k]), ring[slot][k]), ring[slot][k] = Hn[k];
+      for (int k = 0; k < 10; k++) V[k] = pk_sub_u16(pk_add_u16(V[k], Hn[k]), ring[old][k]), ring[fr][k] = Hn[k];
       blurred(y0 + i + 1, UB);
-      const U4 o = st.step_shift(UB);
-      const uint32_t od[4] = {o.x, o.y, o.z, o.w};
+      U4 o;
+      if constexpr (NS % 2 == 0) o = st.template step<decltype(I)::value & 1>(UB, M);
+      else o = st.step_shift(UB, M);
+      /* histogram, branch-free: lanes outside the image, the two frame columns and the dropped
+       * rows of the last group add 0.  LDS byte offsets bin*128 + copy*4 for both pixels of a
+       * pair come from one v_pk_mad_u16. */
+      const unsigned inc = (inimg && i < nrows) ? 1u : 0u;
+      const unsigned inc0 = first ? 0u : inc, inc15 = last ? 0u : inc;
 #pragma unroll
-      for (int q = 0; q < 16; q++) {
-        const bool ok = inimg && !(first && q == 0) && !(last && q == 15);
-        if (ok) atomicAdd(&lh[((od[q >> 2] >> (8 * (q & 3))) & 0xffu) * 32u + copy], 1u);
+      for (int k = 0; k < 8; k++) {
+        const uint32_t a2 = pk_mad_u16_s(M[k], 0x00800080u, cb2);
+        atomicAdd((unsigned *)((char *)lh + (a2 & 0xffffu)), k == 0 ? inc0 : inc);
+        atomicAdd((unsigned *)((char *)lh + (a2 >> 16)), k == 7 ? inc15 : inc);
       }
       return o;
     });
@@ -503,7 +551,7 @@ __global__ __launch_bounds__(256) void k_morph16(uint8_t *dst, const uint8_t *sr
     strip_unpack(S.load(y0), U);
     hpass(U, ring[1]);
   }
-  strip_rows<3>(S, y0, nrows, 1, S.load(y0 + 1), [&](auto I, int, const uint32_t(&U)[12]) {
+  strip_rows<3, !DILATE>(S, y0, nrows, 1, S.load(y0 + 1), [&](auto I, int, const uint32_t(&U)[12]) {
     constexpr int ia = decltype(I)::value, ib = (ia + 1) % 3, ic = (ia + 2) % 3;
     hpass(U, ring[ic]);
     uint32_t M[8];

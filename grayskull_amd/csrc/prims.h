@@ -108,6 +108,7 @@ GS_DEV uint32_t pk_sub_u16(uint32_t a, uint32_t b) { return GS_PK2((a & 0xffff) 
 GS_DEV uint32_t pk_mul_u16(uint32_t a, uint32_t b) { return GS_PK2((a & 0xffff) * (b & 0xffff), (a >> 16) * (b >> 16)); }
 GS_DEV uint32_t pk_mad_u16(uint32_t a, uint32_t b, uint32_t c) { return GS_PK2((a & 0xffff) * (b & 0xffff) + (c & 0xffff), (a >> 16) * (b >> 16) + (c >> 16)); }
 GS_DEV uint32_t pk_mad2_u16(uint32_t a, uint32_t c) { return GS_PK2(2 * (a & 0xffff) + (c & 0xffff), 2 * (a >> 16) + (c >> 16)); }
+GS_DEV uint32_t pk_mad_u16_s(uint32_t a, uint32_t b, uint32_t c) { return pk_mad_u16(a, b, c); }
 GS_DEV uint32_t pk_shl_u16(uint32_t a, unsigned s) { return GS_PK2((a & 0xffff) << s, (a >> 16) << s); }
 GS_DEV uint32_t pk_shr_u16(uint32_t a, unsigned s) { return GS_PK2((a & 0xffff) >> s, (a >> 16) >> s); }
 GS_DEV uint32_t pk_min_u16(uint32_t a, uint32_t b) {
@@ -196,6 +197,13 @@ GS_DEV uint32_t pk_mad2_u16(uint32_t a, uint32_t c) {
   asm("v_pk_mad_u16 %0, %1, 2, %2 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(c));
   return d;
 #endif
+}
+/* a*b + c per half with a wave-uniform multiplier pair b (SGPR): kept as one v_pk_mad_u16 even
+ * when b is a power of two */
+GS_DEV uint32_t pk_mad_u16_s(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t d;
+  asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b), "v"(c));
+  return d;
 }
 GS_DEV uint32_t pk_shl_u16(uint32_t a, unsigned s) { return GS_R((gs_u16x2)(GS_U2(a) << (unsigned short)s)); } /* v_pk_lshlrev_b16 */
 GS_DEV uint32_t pk_shr_u16(uint32_t a, unsigned s) { return GS_R((gs_u16x2)(GS_U2(a) >> (unsigned short)s)); } /* v_pk_lshrrev_b16 */

@@ -22,8 +22,11 @@ ops = os.environ.get("UB_OPS", "copy,erode,sobel,blur2").split(",")
 def call(g, op):
     return {"copy": lambda: g.probe_strip_copy(dst, src), "erode": lambda: g.erode_batch(dst, src),
             "sobel": lambda: g.sobel_batch(dst, src), "blur2": lambda: g.blur_batch(dst, src, 2),
-            "thr": lambda: g.threshold_batch(dst, 100), "hist": lambda: g.histogram_batch(src, hist)}[op]
+            "thr": lambda: g.threshold_batch(dst, 100), "dilate": lambda: g.dilate_batch(dst, src),
+            "blur1": lambda: g.blur_batch(dst, src, 1), "blur3": lambda: g.blur_batch(dst, src, 3),
+            "fused": lambda: g.edge_pipeline_batch(dst, None, src, 2, hist, thr), "hist": lambda: g.histogram_batch(src, hist)}[op]
 hist = torch.zeros((F, 256), dtype=torch.int32, device="cuda")
+thr = torch.zeros((F,), dtype=torch.uint8, device="cuda")
 res = {}
 for rnd in range(int(os.environ.get("AB_ROUNDS", 5))):
     for op in ops:
