@@ -105,6 +105,9 @@ struct NoFin {
  * computed and dropped (stores predicated off; their loads are in-frame rows of the next band or
  * out-of-range zero fill).  false costs registers; it pays for the VALU-heavy fused kernel only.
  * DEPTH: how many rows ahead the input is requested (1 or 2). */
+#ifndef GS_FENCE
+#define GS_FENCE 2
+#endif
 template <int RING, bool INVERT, bool EXITS = true, int DEPTH = 1, class Body, class Fin = NoFin>
 GS_DEV void strip_rows(const Strip<INVERT> &S, int y0, int nrows, int lead, RawRow first, Body &&body,
                        Fin fin = Fin()) {
@@ -120,6 +123,7 @@ GS_DEV void strip_rows(const Strip<INVERT> &S, int y0, int nrows, int lead, RawR
       if constexpr (EXITS) {
         if (i >= nrows) return; /* wave-uniform */
       }
+      if constexpr (!EXITS && GS_FENCE >= 2) sched_fence(); /* the next row's unpack (= its vmcnt wait) stays down here */
       uint32_t U[12];
       strip_unpack(raw, U);
       S.store(y0 + i - 1, i > 0 && i <= nrows, fin(o_prev, y0 + i - 1));
@@ -130,6 +134,7 @@ GS_DEV void strip_rows(const Strip<INVERT> &S, int y0, int nrows, int lead, RawR
         raw = S.load(y0 + i + lead + 1);
       }
       fin.prefetch(y0 + i);
+      if constexpr (!EXITS && GS_FENCE >= 1) sched_fence(); /* one big block: keep the loads ahead of the arithmetic */
       o_prev = body(I, i, U);
     });
   }

@@ -109,6 +109,7 @@ GS_DEV uint32_t pk_mul_u16(uint32_t a, uint32_t b) { return GS_PK2((a & 0xffff) 
 GS_DEV uint32_t pk_mad_u16(uint32_t a, uint32_t b, uint32_t c) { return GS_PK2((a & 0xffff) * (b & 0xffff) + (c & 0xffff), (a >> 16) * (b >> 16) + (c >> 16)); }
 GS_DEV uint32_t pk_mad2_u16(uint32_t a, uint32_t c) { return GS_PK2(2 * (a & 0xffff) + (c & 0xffff), 2 * (a >> 16) + (c >> 16)); }
 GS_DEV uint32_t pk_mad_u16_s(uint32_t a, uint32_t b, uint32_t c) { return pk_mad_u16(a, b, c); }
+GS_DEV void sched_fence() {}
 GS_DEV uint32_t pk_shl_u16(uint32_t a, unsigned s) { return GS_PK2((a & 0xffff) << s, (a >> 16) << s); }
 GS_DEV uint32_t pk_shr_u16(uint32_t a, unsigned s) { return GS_PK2((a & 0xffff) >> s, (a >> 16) >> s); }
 GS_DEV uint32_t pk_min_u16(uint32_t a, uint32_t b) {
@@ -198,6 +199,8 @@ GS_DEV uint32_t pk_mad2_u16(uint32_t a, uint32_t c) {
   return d;
 #endif
 }
+/* the instruction scheduler moves nothing across this point (keeps a prefetch where it was put) */
+GS_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 /* a*b + c per half with a wave-uniform multiplier pair b (SGPR): kept as one v_pk_mad_u16 even
  * when b is a power of two */
 GS_DEV uint32_t pk_mad_u16_s(uint32_t a, uint32_t b, uint32_t c) {

@@ -6,7 +6,7 @@ import numpy as np, torch
 import grayskull_amd as gs
 from grayskull_amd.cascade import Cascade
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-g = gs.lib(); g.use_torch_stream()
+g = gs.Grayskull(os.environ["UB_LIB"]) if os.environ.get("UB_LIB") else gs.lib(); g.use_torch_stream()
 casc = Cascade.from_blob(os.path.join(ROOT, "tests/golden/frontalface_cascade.bin"))
 def timeit(fn, reps=5):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
