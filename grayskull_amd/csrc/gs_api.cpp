@@ -781,7 +781,7 @@ void gsh_edge_pipeline_batch(uint8_t *dst, uint8_t *tmp, const uint8_t *src, uns
     /* fused: the blurred image only ever exists in registers (1 R + 1 W per pixel) */
     for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
       const unsigned nn = std::min(kMaxZ, n - f0);
-      const StripCfg c = strip_cfg(w, h - 2, nn, 3); /* 167 VGPRs: 3 waves per SIMD */
+      const StripCfg c = strip_cfg(w, h - 2, nn, 3); /* <= 168 VGPRs: 3 waves per SIMD */
       const unsigned bpf = c.grid.x * c.grid.y;
       unsigned *partial = (unsigned *)ctx().scratch(SL_HISTP, (size_t)nn * bpf * 256 * 4);
       uint8_t *d = dst + fb * f0;
