@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--frames", type=int, default=64, help="frames per GPU (64 x 8.3 MB = 531 MB/plane >> 256 MiB L3)")
+    ap.add_argument("--frames", type=int, default=256, help="frames per GPU (256 x 8.3 MB = 2.1 GB/plane >> 256 MiB L3; 3 planes resident)")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--radius", type=int, default=2)
@@ -86,11 +86,14 @@ def main():
     import grayskull_amd as gs
     from grayskull_amd.shard import Sharder
 
-    sh = Sharder()
+    # GS_BENCH_BACKEND=gloo GS_BENCH_DEVICE=0: rehearse the N>1 code path on a 1-GPU box (ranks
+    # share the GPU, so the number means nothing); the driver's runs use neither.
+    sh = Sharder(backend=os.environ.get("GS_BENCH_BACKEND") or None)
     assert sh.world == args.gpus or sh.world == 1, "WORLD_SIZE must match --gpus"
-    torch.cuda.set_device(sh.local_rank)
+    device = int(os.environ.get("GS_BENCH_DEVICE", sh.local_rank))
+    torch.cuda.set_device(device)
     g = gs.lib()
-    g.set_device(sh.local_rank)
+    g.set_device(device)
     g.use_torch_stream()
 
     w, h, F, r = args.width, args.height, args.frames, args.radius
@@ -127,7 +130,6 @@ def main():
     ms_unfused = time_stream(torch, step_unfused, reps)
     ms_fused = time_stream(torch, step, reps)
     kernels = {
-        "fused blur+sobel+hist k_blur_sobel_hist16": (lambda: g.edge_pipeline_batch(dst, None, src, r, hist, thr), 2.0 * npx),
         "gs_blur(r=%d) k_blur16" % r: (lambda: g.blur_batch(tmp, src, r), 2.0 * npx),
         "gs_sobel k_sobel16": (lambda: g.sobel_batch(dst, tmp), float(F * (w * h + (w - 2) * (h - 2)))),
         "gs_histogram+otsu": (lambda: g.otsu_batch(dst, hist, thr), 1.0 * npx),
@@ -139,29 +141,40 @@ def main():
         ms = time_stream(torch, fn, reps)
         ktab[name] = {"ms": round(ms, 4), "GB/s": round(nbytes / ms / 1e6, 1),
                       "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4), "bytes": nbytes}
-    # the fused row times the whole fused step (4 launches); subtract the threshold pass to get the
-    # fused kernel itself (+ its two tiny followers), 2 B/px algorithmic (1 R + 1 W)
+    # The fused kernel itself: the library brackets each of its launches with HIP events on the
+    # stream it is launched on (gsh_profile) while the SAME step function runs `reps` more times.
+    # A step launches it once per 32-frame chunk; chunk i's threshold pass runs on a side stream
+    # under chunk i+1's fused kernel, so these durations include that sharing.
     fk = "fused blur+sobel+hist k_blur_sobel_hist16"
-    fms = max(ktab[fk]["ms"] - ktab["gs_threshold k_threshold"]["ms"], 1e-6)
-    ktab[fk] = {"ms": round(fms, 4), "GB/s": round(2.0 * npx / fms / 1e6, 1),
-                "frac": round(2.0 * npx / fms / 1e6 / HBM_PEAK_GBS, 4), "bytes": 2.0 * npx,
-                "note": "step minus threshold pass; replaces blur+sobel+histogram (5 B/px unfused)"}
+    g.profile(True)
+    for _ in range(reps):
+        step()
+    nl, tot_ms = g.profile_read()
+    g.profile(False)
+    fms = tot_ms / max(nl, 1)
+    fpl = F * reps / max(nl, 1)           # frames per launch
+    lpx = fpl * w * h                     # pixels per launch
+    ktab[fk] = {"ms": round(fms, 4), "GB/s": round(2.0 * lpx / fms / 1e6, 1),
+                "frac": round(2.0 * lpx / fms / 1e6 / HBM_PEAK_GBS, 4), "bytes": 2.0 * lpx,
+                "frames_per_launch": fpl, "launches_timed": nl,
+                "note": "per launch, HIP events on the launch stream; replaces blur+sobel+histogram (5 B/px unfused)"}
     # dominant kernel of the timed step = the fused kernel.  SURVEY.md 8(d): a fused kernel is
     # reported against the UNFUSED per-call sum of the calls it performs (gs_blur 2 + gs_sobel 2 +
     # gs_histogram 1 = 5 B/px), with the bytes it really moves (1 R + 1 W) stated beside it.
-    percall = 5.0 * npx
+    percall = 5.0 * lpx
     pmc = None
     try:
         pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        if (w, h, F) == (3840, 2160, 64):
-            pmc = pt["per_launch"].get("gs::k_blur_sobel_hist16<2>", {}).get("total_bytes")
+        kname = "gs::k_blur_sobel_hist16<2>"
+        if (w, h, r) == (3840, 2160, 2) and pt.get("frames_per_launch", {}).get(kname) == fpl:
+            pmc = pt["per_launch"].get(kname, {}).get("total_bytes")
     except Exception:
         pass
     roof = {"bound": "hbm", "kernel": "k_blur_sobel_hist16<2> (gs_blur r=2 + gs_sobel + gs_histogram in one launch)",
             "achieved": round(percall / fms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(percall / fms / 1e6 / HBM_PEAK_GBS, 4), "traffic": pmc,
             "accounting": "unfused per-call sum, 5 B/px (SURVEY 8d); the launch itself reads 1 and writes 1 B/px",
-            "algorithmic_bytes_per_launch": percall, "avg_launch_ms": round(fms, 4),
+            "algorithmic_bytes_per_launch": percall, "avg_launch_ms": round(fms, 4), "frames_per_launch": fpl,
             "actual_io": {"bytes_per_px": 2, "GB/s": ktab[fk]["GB/s"], "frac": ktab[fk]["frac"],
                           "note": "VALU-bound (266 lane-ops per 16 px + 16 LDS atomics; VALU busy 86 %, profiles/r01e_fused_sq_counters.txt)"},
             "per_call_kernels": {k: ktab[k]["frac"] for k in ktab if k != fk},
@@ -234,12 +247,13 @@ def main():
         step()
         torch.cuda.synchronize()
         ok = True
-        for f in (0, F - 1):
+        vf = sorted({0, min(31, F - 1), min(32, F - 1), F - 1})  # both sides of a chunk boundary
+        for f in vf:
             img = Oracle.synth(w, h, 1000 + lo + f)
             s = o.sobel(o.blur(img, r))
             t = o.otsu_threshold(s)
             ok &= int(thr[f]) == t and np.array_equal(dst[f].cpu().numpy(), o.threshold(s, t))
-        parity = "bit-exact vs oracle on frames 0 and %d" % (F - 1) if ok else "MISMATCH"
+        parity = "bit-exact vs oracle on frames %s" % vf if ok else "MISMATCH"
     thr_all = sh.all_gather_frames(thr, F * sh.world)  # KB-scale result exchange (RCCL when N>1)
 
     out = {
@@ -253,7 +267,7 @@ def main():
                    "frames_per_gpu": F, "global_frames": F * sh.world, "sharding": "by frame, no data-path collective",
                    "chain_algorithmic_bytes_per_px_unfused": 7, "hbm_peak_GBs": HBM_PEAK_GBS},
         "fused": {"ms_per_step": round(ms_fused, 4), "Mpix/s": round(npx / ms_fused / 1e3, 1),
-                  "hbm_bytes_per_px": 4, "note": "blur+sobel+histogram in one kernel, then threshold"},
+                  "hbm_bytes_per_px": 4, "note": "blur+sobel+histogram in one kernel per 32-frame chunk; each chunk's threshold pass runs under the next chunk's fused kernel"},
         "unfused": {"ms_per_step": round(ms_unfused, 4), "Mpix/s": round(npx / ms_unfused / 1e3, 1),
                     "hbm_bytes_per_px": 7, "note": "separate gs_blur, gs_sobel, histogram, threshold kernels"},
         "roofline": roof, "kernels": ktab, "sobel_4096x4096": ns, "other_configs": other, "parity": parity,

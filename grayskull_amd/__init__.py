@@ -81,6 +81,8 @@ _SIGS = {
     "gsh_set_async": (None, [C.c_int]),
     "gsh_sync": (None, []),
     "gsh_tune": (None, [C.c_int, C.c_int]),
+    "gsh_profile": (None, [C.c_int]),
+    "gsh_profile_read": (C.c_uint, [C.POINTER(C.c_double)]),
     "gsh_probe_strip_copy": (None, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint]),
     "gsh_shutdown": (None, []),
     "gsh_malloc": (C.c_void_p, [C.c_size_t]),
@@ -165,6 +167,15 @@ class Grayskull:
 
     def tune(self, key, value):
         self.c.gsh_tune(int(key), int(value))
+
+    def profile(self, on):
+        self.c.gsh_profile(1 if on else 0)
+
+    def profile_read(self):
+        """(launches bracketed since the last read, their summed duration in ms)"""
+        ms = C.c_double(0.0)
+        n = self.c.gsh_profile_read(C.byref(ms))
+        return int(n), float(ms.value)
 
     def probe_strip_copy(self, dst, src):
         n, h, w = self._nhw(src)

@@ -54,12 +54,37 @@ enum Slot { SL_IN = 0, SL_OUT, SL_AUX, SL_AUX2, SL_II, SL_PAD, SL_MASK, SL_CNT, 
             SL_HISTP, SL_HIST, SL_THR, SL_KPS, SL_MOM, SL_KIN, SL_DESC, SL_TAB, SL_JUMP, SL_LEV,
             SL_BEST, SL_COUNT };
 
+/* gsh_edge_pipeline_batch: frames per chunk (measured best for 64..512-frame batches of 4K frames:
+ * profiles/r01f_chunk_overlap.log) and the most chunks per call */
+constexpr unsigned kChunkFrames = 32, kMaxChunks = 64;
 struct Ctx {
   int device = 0;
   bool device_set = false;
   hipStream_t stream = nullptr;
   bool own_stream = false, user_stream = false, async = false;
   struct Buf { void *p = nullptr; size_t cap = 0; } slot[SL_COUNT];
+#ifndef GS_EMU
+  /* gsh_profile: events bracketing the pipeline's fused-kernel launches on their stream */
+  static constexpr int kProfPairs = 512;
+  bool prof_on = false;
+  hipEvent_t prof_ev[2 * kProfPairs] = {};
+  unsigned prof_n = 0;
+  void prof_mark(int which, hipStream_t on) { /* which: 0 before, 1 after the launch */
+    if (!prof_on || prof_n >= (unsigned)kProfPairs) return;
+    hipEvent_t &e = prof_ev[2 * prof_n + which];
+    if (!e) GS_HIP(hipEventCreate(&e));
+    GS_HIP(hipEventRecord(e, on));
+    if (which) prof_n++;
+  }
+  hipStream_t side = nullptr; /* chunk overlap inside gsh_edge_pipeline_batch */
+  hipEvent_t ev_join = nullptr, ev_chunk[kMaxChunks] = {};
+  void ensure_side() {
+    if (side) return;
+    GS_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    GS_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    for (auto &e : ev_chunk) GS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+#endif
 
   void ensure_device() {
     if (device_set) return;
@@ -105,6 +130,13 @@ struct Ctx {
       if (b.p) (void)hipFree(b.p);
       b.p = nullptr, b.cap = 0;
     }
+#ifndef GS_EMU
+    if (side) {
+      (void)hipStreamDestroy(side), (void)hipEventDestroy(ev_join);
+      for (auto &e : ev_chunk) (void)hipEventDestroy(e), e = nullptr;
+      side = nullptr, ev_join = nullptr;
+    }
+#endif
     if (own_stream) (void)hipStreamDestroy(stream);
     own_stream = false;
     if (!user_stream) stream = nullptr;
@@ -310,9 +342,9 @@ void launch_histogram(const uint8_t *img, size_t frame_bytes, unsigned n, unsign
   }
 }
 void launch_threshold(uint8_t *img, size_t frame_bytes, unsigned n, const uint8_t *thr_dev,
-                      unsigned thr_const) {
+                      unsigned thr_const, hipStream_t on = nullptr) {
   if (n == 0) return;
-  hipStream_t st = ctx().s();
+  hipStream_t st = on ? on : ctx().s();
   const size_t chunks = frame_bytes / 16 + 2;
   const unsigned bx = (unsigned)std::max<size_t>(1, std::min<size_t>((chunks + 255) / 256, 2048));
   for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
@@ -697,6 +729,33 @@ void gsh_set_stream(void *s) {
 }
 void *gsh_get_stream(void) { return (void *)ctx().s(); }
 void gsh_set_async(int on) { ctx().async = on != 0; }
+void gsh_profile(int on) {
+#ifndef GS_EMU
+  Ctx &c = ctx();
+  c.prof_on = on != 0;
+  c.prof_n = 0;
+#else
+  (void)on;
+#endif
+}
+unsigned gsh_profile_read(double *total_ms) {
+  unsigned n = 0;
+  double sum = 0;
+#ifndef GS_EMU
+  Ctx &c = ctx();
+  c.sync();
+  for (unsigned i = 0; i < c.prof_n; i++) {
+    float ms = 0;
+    GS_HIP(hipEventSynchronize(c.prof_ev[2 * i + 1]));
+    GS_HIP(hipEventElapsedTime(&ms, c.prof_ev[2 * i], c.prof_ev[2 * i + 1]));
+    sum += ms;
+  }
+  n = c.prof_n;
+  c.prof_n = 0;
+#endif
+  if (total_ms) *total_ms = sum;
+  return n;
+}
 void gsh_tune(int key, int value) {
   if (key >= 0 && key < 8) g_tune[key] = value;
 }
@@ -778,25 +837,78 @@ void gsh_edge_pipeline_batch(uint8_t *dst, uint8_t *tmp, const uint8_t *src, uns
   };
   if (!tmp && g_tune[3] == 0 && radius >= 1 && radius <= 3 && strip_ok(w, h, dst, src) && w >= 32 &&
       h >= 3 && h > 2 * radius) { /* every window is clipped on at most one side per axis */
-    /* fused: the blurred image only ever exists in registers (1 R + 1 W per pixel) */
-    for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
-      const unsigned nn = std::min(kMaxZ, n - f0);
-      const StripCfg c = strip_cfg(w, h - 2, nn, 3); /* <= 168 VGPRs: 3 waves per SIMD */
-      const unsigned bpf = c.grid.x * c.grid.y;
-      unsigned *partial = (unsigned *)ctx().scratch(SL_HISTP, (size_t)nn * bpf * 256 * 4);
-      uint8_t *d = dst + fb * f0;
-      const uint8_t *s = src + fb * f0;
-      if (radius == 1) GS_LAUNCH(k_blur_sobel_hist16<1>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb, partial);
-      else if (radius == 2) GS_LAUNCH(k_blur_sobel_hist16<2>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb, partial);
-      else GS_LAUNCH(k_blur_sobel_hist16<3>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb, partial);
-      /* the 2w + 2(h-2) frame pixels are 0 in the result and were not counted by the kernel */
-      GS_LAUNCH(k_hist_reduce, dim3(nn), dim3(256), 0, st, (const unsigned *)partial, bpf,
-                hist_scratch + (size_t)f0 * 256, 2 * w + 2 * (h - 2));
-      GS_LAUNCH(k_otsu, dim3(nn), dim3(256), 0, st, (const unsigned *)hist_scratch + (size_t)f0 * 256,
-                w * h, thr + f0);
+    /* fused: the blurred image only ever exists in registers (1 R + 1 W per pixel).
+     * The fused kernel is VALU-bound (~40 % of HBM peak) and the passes after it HBM-bound with
+     * an idle VALU.  A batch larger than kChunkFrames is cut into chunks: the fused kernels run
+     * back to back on the caller's stream, each chunk's histogram reduce / Otsu / frame zeroing /
+     * threshold pass on a side stream behind one event, i.e. under the next chunk's fused kernel.
+     * gsh_tune key 5: frames per chunk (0 = default, negative = never split). */
+    const int tune_chunk = g_tune[5];
+    const unsigned per = tune_chunk < 0 ? n : tune_chunk > 0 ? (unsigned)tune_chunk : kChunkFrames;
+    const StripCfg c = strip_cfg(w, h - 2, std::min(std::min(kMaxZ, n), per), 3); /* <= 168 VGPRs: 3 waves per SIMD */
+    const unsigned bpf = c.grid.x * c.grid.y;
+    unsigned *partial = (unsigned *)ctx().scratch(SL_HISTP, (size_t)n * bpf * 256 * 4);
+    auto run_fused = [&](hipStream_t on, unsigned f0, unsigned nn) {
+      for (unsigned g0 = f0; g0 < f0 + nn; g0 += kMaxZ) {
+        const unsigned m = std::min(kMaxZ, f0 + nn - g0);
+        const dim3 grid(c.grid.x, c.grid.y, m);
+        uint8_t *d = dst + fb * g0;
+        const uint8_t *sp = src + fb * g0;
+        unsigned *pp = partial + (size_t)g0 * bpf * 256;
+#ifndef GS_EMU
+        ctx().prof_mark(0, on);
+#endif
+        if (radius == 1) GS_LAUNCH(k_blur_sobel_hist16<1>, grid, c.block, 0, on, d, sp, w, h, c.T, fb, pp);
+        else if (radius == 2) GS_LAUNCH(k_blur_sobel_hist16<2>, grid, c.block, 0, on, d, sp, w, h, c.T, fb, pp);
+        else GS_LAUNCH(k_blur_sobel_hist16<3>, grid, c.block, 0, on, d, sp, w, h, c.T, fb, pp);
+#ifndef GS_EMU
+        ctx().prof_mark(1, on);
+#endif
+      }
+    };
+    auto run_rest = [&](hipStream_t on, unsigned f0, unsigned nn) {
+      for (unsigned g0 = f0; g0 < f0 + nn; g0 += kMaxZ) {
+        const unsigned m = std::min(kMaxZ, f0 + nn - g0);
+        const unsigned *pp = partial + (size_t)g0 * bpf * 256;
+        /* the 2w + 2(h-2) frame pixels are 0 in the result and were not counted by the kernel */
+        GS_LAUNCH(k_hist_reduce, dim3(m), dim3(256), 0, on, pp, bpf, hist_scratch + (size_t)g0 * 256,
+                  2 * w + 2 * (h - 2));
+        GS_LAUNCH(k_otsu, dim3(m), dim3(256), 0, on, (const unsigned *)hist_scratch + (size_t)g0 * 256,
+                  w * h, thr + g0);
+        /* gs_sobel ran "into a zeroed image": only its 1-px frame is left to zero */
+        GS_LAUNCH(k_zero_frame, dim3((2 * w + 2 * h + 255) / 256, m), dim3(256), 0, on, dst + fb * g0, w, h, fb);
+      }
+      launch_threshold(dst + fb * f0, fb, nn, thr + f0, 0, on);
+    };
+    const unsigned chunks = (n + per - 1) / per;
+#ifdef GS_EMU
+    const bool split = false;
+#else
+    const bool split = chunks > 1 && chunks <= kMaxChunks;
+#endif
+    if (!split) {
+      run_fused(st, 0, n);
+      run_rest(st, 0, n);
+      return;
     }
-    zero_frame();
-    launch_threshold(dst, fb, n, thr, 0);
+#ifndef GS_EMU
+    Ctx &cx = ctx();
+    cx.ensure_side();
+    unsigned i = 0;
+    for (unsigned f0 = 0; f0 < n; f0 += per, i++) {
+      const unsigned nn = std::min(per, n - f0);
+      run_fused(st, f0, nn);
+      if (f0 + per >= n) { /* last chunk: nothing left to hide it under; rejoin the caller's stream */
+        GS_HIP(hipEventRecord(cx.ev_join, cx.side));
+        GS_HIP(hipStreamWaitEvent(st, cx.ev_join, 0));
+        run_rest(st, f0, nn);
+      } else {
+        GS_HIP(hipEventRecord(cx.ev_chunk[i], st));
+        GS_HIP(hipStreamWaitEvent(cx.side, cx.ev_chunk[i], 0));
+        run_rest(cx.side, f0, nn);
+      }
+    }
+#endif
     return;
   }
   uint8_t *t = tmp ? tmp : (uint8_t *)ctx().scratch(SL_AUX, fb * n);

@@ -70,15 +70,15 @@ class Sharder:
         if not self.dist:
             return local[:total].clone()
         per = (total + self.world - 1) // self.world
-        pad = torch.zeros(per, dtype=local.dtype, device=local.device)
-        pad[:local.numel()] = local
+        pad = torch.zeros(per, dtype=local.dtype, device=self._dev())  # gloo gathers on the host
+        pad[:local.numel()] = local.to(pad.device)
         out = [torch.zeros_like(pad) for _ in range(self.world)]
         self.dist.all_gather(out, pad)
         parts = []
         for r in range(self.world):
             lo, hi = frame_range(r, self.world, total)
             parts.append(out[r][:hi - lo])
-        return torch.cat(parts)
+        return torch.cat(parts).to(local.device)
 
     def close(self):
         if self.dist and self.dist.is_initialized():

@@ -35,9 +35,16 @@ void gsh_set_async(int on);               /* drop-in gs_* calls on device pointe
 void gsh_sync(void);                      /* hipStreamSynchronize(current stream)       */
 /* launch tuning of the strip kernels: key 0 rows per band (0 = auto), 1 block shape
  * (0: 64x4, 1: 256x1, 2: 128x2), 3 set to 1 to disable the fused pipeline kernel, 4 preset of
- * the cascade stages at which gs_lbp_detect re-packs survivors (1: never).
- * Results never change. */
+ * the cascade stages at which gs_lbp_detect re-packs survivors (1: never), 5 frames per chunk of
+ * gsh_edge_pipeline_batch's internal overlap (0 = default 32, negative = never split),
+ * 6 set to 1 for the generic two-pass gs_integral.  Results never change. */
 void gsh_tune(int key, int value);
+/* measurement aid for bench.py: while on, gsh_edge_pipeline_batch brackets every launch of its
+ * fused blur+sobel+histogram kernel with HIP events on the stream it is launched on (up to 512
+ * launches); gsh_profile_read synchronises, returns how many launches were bracketed since the
+ * last read and their summed duration in milliseconds. */
+void gsh_profile(int on);
+unsigned gsh_profile_read(double *total_ms);
 /* diagnostic: strip-kernel traffic pattern with no arithmetic (access-pattern ceiling) */
 void gsh_probe_strip_copy(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned n);
 void gsh_shutdown(void);                  /* free this thread's scratch + stream        */

@@ -27,14 +27,18 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     acc = collections.defaultdict(list)
     with open(files[0]) as f:
         for row in csv.DictReader(f):
-            if row.get("Counter_Name") == c:
-                acc[row["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(row["Counter_Value"]))
+            if row.get("Counter_Name") == c:  # launches of one kernel with different grids are different workloads
+                acc[(row["Kernel_Name"].split("(")[0].replace("void ", ""), row.get("Grid_Size", "?"))].append(float(row["Counter_Value"]))
     for k, v in acc.items(): vals.setdefault(k, {})[c] = sum(v) / len(v)
-for k, v in vals.items():
+ngrids = collections.Counter(k for k, _ in vals)
+for (k, grid), v in vals.items():
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v and k.startswith("gs::"):
-        traffic[k] = {"read_bytes": round(2 * v["FETCH_SIZE"] * 1024), "write_bytes": round(v["WRITE_SIZE"] * 1024),
-                      "total_bytes": round((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)}
-out = {"workload": "64 frames 3840x2160 (scripts/pmc_probe.py)", "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes; read = 2 x FETCH_SIZE KB (gfx950), write = WRITE_SIZE KB",
+        traffic[k if ngrids[k] == 1 else "%s@grid%s" % (k, grid)] = {
+            "read_bytes": round(2 * v["FETCH_SIZE"] * 1024), "write_bytes": round(v["WRITE_SIZE"] * 1024),
+            "total_bytes": round((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024), "grid_threads": grid}
+out = {"workload": "64 frames 3840x2160 (scripts/pmc_probe.py); the pipeline call launches its fused kernel per 32-frame chunk",
+       "frames_per_launch": {"default": 64, "gs::k_blur_sobel_hist16<2>": 32},
+       "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes; read = 2 x FETCH_SIZE KB (gfx950), write = WRITE_SIZE KB",
        "per_launch": traffic}
 json.dump(out, open(os.path.join(root, "pmc_traffic.json"), "w"), indent=1)
 print("wrote", os.path.join(root, "pmc_traffic.json"))

@@ -277,6 +277,49 @@ def test_batch_4k_properties(hip, oracle):
         assert bool((a == b).all()) and bool((ha == hb).all()) and bool((ta == tb).all()), "fused r=%d" % r
 
 
+def test_pipeline_chunk_overlap(hip, oracle):
+    """gsh_edge_pipeline_batch cuts big batches into chunks whose threshold pass runs on a side
+    stream under the next chunk's fused kernel: same bytes for every chunking, ragged last chunk,
+    repeated calls (side stream rejoined each time), also on a caller-provided stream."""
+    import torch
+    n, h, w = 23, 96, 256
+    src = torch.empty((n, h, w), dtype=torch.uint8, device="cuda")
+    hip.synth_batch(src, 4242)
+    hist = torch.zeros((n, 256), dtype=torch.int32, device="cuda")
+    ref, tref = torch.zeros_like(src), torch.zeros(n, dtype=torch.uint8, device="cuda")
+    try:
+        hip.tune(5, -1)  # never split
+        hip.edge_pipeline_batch(ref, None, src, 2, hist, tref)
+        hip.sync()
+        href = hist.clone()
+        for f in (0, 7, 8, n - 1):
+            s = oracle.sobel(oracle.blur(src[f].cpu().numpy(), 2))
+            t = oracle.otsu_threshold(s)
+            assert int(tref[f]) == t
+            assert_same(ref[f].cpu().numpy(), oracle.threshold(s, t), "unsplit pipeline frame %d" % f)
+        for per in (1, 4, 8, 22, 0):
+            hip.tune(5, per)
+            for rep in range(2):
+                out, thr = torch.full_like(src, 7), torch.zeros(n, dtype=torch.uint8, device="cuda")
+                hist.zero_()
+                hip.edge_pipeline_batch(out, None, src, 2, hist, thr)
+                hip.sync()
+                assert bool((out == ref).all()) and bool((thr == tref).all()) and bool((hist == href).all()), \
+                    "chunk size %d, call %d" % (per, rep)
+        hip.tune(5, 4)
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            hip.use_torch_stream()
+            out, thr = torch.full_like(src, 3), torch.zeros(n, dtype=torch.uint8, device="cuda")
+            hip.edge_pipeline_batch(out, None, src, 2, hist, thr)
+            after = out.clone()  # stream-ordered consumer on the caller's stream, no host sync
+        st.synchronize()
+        assert bool((after == ref).all()) and bool((thr == tref).all())
+    finally:
+        hip.tune(5, 0)
+        hip.use_torch_stream()
+
+
 def test_batch_integral_lbp_fast(hip, oracle, cascade):
     import torch
     n, h, w = 3, 480, 640
