@@ -45,6 +45,11 @@
     }                                                                                  \
   } while (0)
 
+namespace gs { /* gs_fused.cpp */
+void launch_blur_sobel_hist(unsigned radius, dim3 grid, dim3 block, hipStream_t st, uint8_t *dst,
+                            const uint8_t *src, unsigned w, unsigned h, unsigned T, size_t frame_bytes,
+                            unsigned *partial);
+}
 using namespace gs;
 
 namespace {
@@ -258,7 +263,7 @@ void launch_integral(const uint8_t *src, unsigned w, unsigned h, unsigned n, uns
   if (n == 0) return;
   hipStream_t st = ctx().s();
   const size_t fp = (size_t)w * h;
-  const bool banded = g_tune[6] == 0 && w % 16 == 0 && w <= 4096 && fp * 4 < 0x7fffffffull && al16(src) && al16(ii);
+  const bool banded = g_tune[6] != 1 && w % 16 == 0 && w <= 4096 && fp * 4 < 0x7fffffffull && al16(src) && al16(ii);
   for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
     const unsigned nn = std::min(kMaxZ, n - f0);
     if (banded) {
@@ -269,8 +274,15 @@ void launch_integral(const uint8_t *src, unsigned w, unsigned h, unsigned n, uns
       unsigned *cs = (unsigned *)ctx().scratch(SL_HISTP, (size_t)nn * nb * w * 4);
       GS_LAUNCH(k_integral_colsum, dim3(1, nb, nn), dim3(256), 0, st, src + fp * f0, w, h, BH, nb, cs);
       GS_LAUNCH(k_integral_colbase, dim3((w + 255) / 256, nn), dim3(256), 0, st, cs, w, nb);
-      GS_LAUNCH(k_integral_band, dim3(1, nb, nn), dim3(256), 0, st, src + fp * f0, w, h, BH, nb,
-                (const unsigned *)cs, ii + fp * f0);
+      if (g_tune[6] == 2) /* the block-per-band form (one barrier per row), kept for comparison */
+        GS_LAUNCH(k_integral_band, dim3(1, nb, nn), dim3(256), 0, st, src + fp * f0, w, h, BH, nb,
+                  (const unsigned *)cs, ii + fp * f0);
+      else if (w <= 2048)
+        GS_LAUNCH(k_integral_wave<8>, dim3(1, (nb + 3) / 4, nn), dim3(256), 0, st, src + fp * f0, w, h, BH,
+                  nb, (const unsigned *)cs, ii + fp * f0);
+      else
+        GS_LAUNCH(k_integral_wave<16>, dim3(1, (nb + 3) / 4, nn), dim3(256), 0, st, src + fp * f0, w, h, BH,
+                  nb, (const unsigned *)cs, ii + fp * f0);
     } else {
       GS_LAUNCH(k_integral_rows, dim3(h, nn), dim3(256), 0, st, src + fp * f0, w, h, ii + fp * f0);
       GS_LAUNCH(k_integral_cols, dim3((w + 255) / 256, nn), dim3(256), 0, st, ii + fp * f0, w, h);
@@ -858,9 +870,7 @@ void gsh_edge_pipeline_batch(uint8_t *dst, uint8_t *tmp, const uint8_t *src, uns
 #ifndef GS_EMU
         ctx().prof_mark(0, on);
 #endif
-        if (radius == 1) GS_LAUNCH(k_blur_sobel_hist16<1>, grid, c.block, 0, on, d, sp, w, h, c.T, fb, pp);
-        else if (radius == 2) GS_LAUNCH(k_blur_sobel_hist16<2>, grid, c.block, 0, on, d, sp, w, h, c.T, fb, pp);
-        else GS_LAUNCH(k_blur_sobel_hist16<3>, grid, c.block, 0, on, d, sp, w, h, c.T, fb, pp);
+        launch_blur_sobel_hist(radius, grid, c.block, on, d, sp, w, h, c.T, fb, pp);
 #ifndef GS_EMU
         ctx().prof_mark(1, on);
 #endif

@@ -1,0 +1,168 @@
+/*
+ * k_fused.h -- the config-2 pipeline kernel: gs_blur(R) -> gs_sobel -> histogram in one pass
+ * (reference semantics grayskull.h:268-283, :306-320, :199-203).  Built by gs_fused.cpp.
+ */
+#ifndef GS_K_FUSED_H
+#define GS_K_FUSED_H
+#include "k_strip.h"
+
+namespace gs {
+
+/* ------------------------------------------------------------------ fused blur -> sobel -> histogram */
+/* The config-2 chain (gs_blur(R); gs_sobel; histogram for gs_otsu_threshold) in ONE pass over the
+ * frame: 1 B/px read + 1 B/px written instead of 2+2+1.  Per source row the lane forms the
+ * (2R+1)-tap horizontal sums for pixels -2..17, keeps their running vertical sum, divides (exact
+ * 2^24 multipliers, chosen per pixel / per row where the window is clipped: every divisor is
+ * rows_in_image * cols_in_image, ref :275-281), and feeds the blurred row -- never written to
+ * memory -- straight into the sobel recurrence.  The sobel bytes go to dst and into an
+ * LDS-privatised histogram (32 bank-spread copies, see k_hist_partial); each block leaves 256
+ * partial counts for k_hist_reduce.  Bit-identical to the separate calls (tests).  Columns 0 and
+ * w-1 of dst receive junk here; the launcher zeroes the 1-px frame afterwards (config 2 runs
+ * gs_sobel into a zeroed image), and the histogram counts those frame pixels as 0 analytically. */
+constexpr uint32_t blur_k24(unsigned cx, unsigned cy) { return (0x1000000u + cx * cy - 1u) / (cx * cy); }
+
+template <int R, unsigned CX>
+GS_DEV uint32_t blur_mul_for_rows(unsigned cy) { /* cy in [R+1, 2R+1], wave-uniform */
+  uint32_t m = blur_k24(CX, 2 * R + 1);
+#pragma unroll
+  for (unsigned c = R + 1; c < 2 * R + 1; c++) m = cy == c ? blur_k24(CX, c) : m;
+  return m;
+}
+
+template <int R>
+GS_DEV void blur_hsum10(const uint32_t (&U)[12], uint32_t (&H)[10]) { /* pairs = px -2..17 */
+  uint32_t A[13]; /* A[j+1] = pair starting one px after U[j], j = -1..11 (ends zero-extended) */
+  if constexpr (R >= 3) A[0] = alignbit(U[0], 0u, 16), A[12] = alignbit(0u, U[11], 16);
+#pragma unroll
+  for (int j = 0; j <= 10; j++) A[j + 1] = alignbit(U[j + 1], U[j], 16);
+  if constexpr (R == 1) {
+#pragma unroll
+    for (int k = 0; k < 10; k++) H[k] = pk_add_u16(pk_add_u16(A[k + 1], U[k + 1]), A[k + 2]);
+  } else {
+    uint32_t Q[11]; /* Q[j] = U[j] + A[j+1]: the 2-px sums starting at both pixels of pair j */
+#pragma unroll
+    for (int j = 0; j <= 10; j++) Q[j] = pk_add_u16(U[j], A[j + 1]);
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+      const int j = k + 1; /* U[j] = pair k */
+      uint32_t t = pk_add_u16(pk_add_u16(Q[j - 1], Q[j]), U[j + 1]);        /* -2 .. +2 */
+      if constexpr (R >= 3) t = pk_add_u16(pk_add_u16(t, A[j - 1]), A[j + 2]); /* -3, +3 */
+      H[k] = t;
+    }
+  }
+}
+
+/* grid like the strip kernels; partial: [frame][blockIdx.y * gridDim.x + blockIdx.x][256] */
+template <int R>
+__global__ __launch_bounds__(256) void k_blur_sobel_hist16(uint8_t *dst, const uint8_t *src,
+                                                           unsigned w, unsigned h, unsigned T,
+                                                           size_t frame_bytes, unsigned *partial) {
+  constexpr int N = 2 * R + 1;
+  __shared__ unsigned lh[256 * 32];
+  const unsigned tid = threadIdx.y * blockDim.x + threadIdx.x, copy = tid & 31u;
+  for (unsigned i = tid; i < 256 * 32; i += 256) lh[i] = 0;
+  __syncthreads();
+  const Strip<> S(src, dst, w, h, frame_bytes);
+  const int y0 = 1 + (int)(S.band * T);
+  if (y0 < (int)h - 1) { /* wave-uniform; no early return: every wave reaches the barrier */
+    const int nrows = ((int)h - 1 - y0) < (int)T ? ((int)h - 1 - y0) : (int)T;
+    const bool first = S.x0 == 0, last = S.x0 + 16 == w, inimg = S.x0 < w;
+    /* N+1 ring slots: the new row lands in the free slot and the unroll period N+1 is even, so
+     * the sobel history alternates (step<parity>) without register moves */
+    constexpr bool SPARE = R <= 2; /* R = 3: the 8th slot would cost the third wave per SIMD */
+    constexpr int NS = SPARE ? N + 1 : N, P0 = SPARE ? 1 : 0; /* P0: slot of the first prologue row */
+    uint32_t ring[NS][10], V[10];
+    SobelState st;
+    /* blurred row b as u16 pairs for pixels -2..17, placed where sobel_hpass expects U[1..10] */
+    auto blurred = [&](int b, uint32_t(&UB)[12]) {
+      const int ya = b - R < 0 ? 0 : b - R, yb = b + R > (int)h - 1 ? (int)h - 1 : b + R;
+      const unsigned cy = (unsigned)(yb - ya + 1);
+      const uint32_t mC = blur_mul_for_rows<R, N>(cy);
+      uint32_t mL[R], mR[R];
+      static_for<R>([&](auto Q) {
+        constexpr int q = decltype(Q)::value;
+        mL[q] = first ? blur_mul_for_rows<R, R + 1 + q>(cy) : mC;
+        mR[q] = last ? blur_mul_for_rows<R, 2 * R - q>(cy) : mC;
+      });
+      UB[0] = 0, UB[11] = 0;
+#pragma unroll
+      for (int k = 0; k < 10; k++) { /* pair k = own pixels (2k-2, 2k-1) */
+        uint32_t pr[2];
+#pragma unroll
+        for (int hlf = 0; hlf < 2; hlf++) {
+          const int q = 2 * k - 2 + hlf; /* own pixel index -2..17 */
+          const uint32_t sv = hlf ? (V[k] >> 16) : (V[k] & 0xffffu);
+          const uint32_t m = (q >= 0 && q < R) ? mL[(q >= 0 && q < R) ? q : 0]
+                             : (q >= 16 - R && q < 16) ? mR[(q >= 16 - R && q < 16) ? q - (16 - R) : 0]
+                                                       : mC;
+          pr[hlf] = sv * m; /* quotient = byte 3 */
+        }
+        UB[k + 1] = perm_b32(pr[1], pr[0], 0x0c070c03u);
+      }
+    };
+    /* prologue: source rows y0-1-R .. y0+R give blurred rows y0-1 and y0 */
+#pragma unroll
+    for (int k = 0; k < 10; k++) V[k] = 0;
+    uint32_t UB0[12], UB1[12];
+    static_for<N>([&](auto K) {
+      constexpr int kk = decltype(K)::value;
+      uint32_t U[12];
+      strip_unpack(S.load(y0 - 1 - R + kk), U);
+      blur_hsum10<R>(U, ring[kk + P0]);
+#pragma unroll
+      for (int k = 0; k < 10; k++) V[k] = pk_add_u16(V[k], ring[kk + P0][k]);
+    });
+    blurred(y0 - 1, UB0);
+    {
+      uint32_t U[12], Hn[10];
+      strip_unpack(S.load(y0 + R), U);
+      blur_hsum10<R>(U, Hn); /* enters slot 0 (SPARE: the free slot); the oldest row (slot P0) leaves */
+#pragma unroll
+      for (int k = 0; k < 10; k++) V[k] = pk_sub_u16(pk_add_u16(V[k], Hn[k]), ring[P0][k]), ring[0][k] = Hn[k];
+    }
+    blurred(y0, UB1);
+    st.init(UB0, UB1);
+    const uint32_t cb2 = (copy << 2) * 0x10001u; /* this lane's histogram copy, as a pair of byte offsets */
+
+#ifndef GS_FUSED_DEPTH
+#define GS_FUSED_DEPTH 1
+#endif
+#ifndef GS_FUSED_EXITS
+#define GS_FUSED_EXITS false
+#endif
+    strip_rows<NS, false, GS_FUSED_EXITS, GS_FUSED_DEPTH>(S, y0, nrows, R + 1, S.load(y0 + R + 1), [&](auto I, int i, const uint32_t(&U)[12]) {
+      /* iteration I, SPARE: slot I+1 is free (its row left last iteration), slot I+2 holds the
+       * oldest row; otherwise the new row replaces the oldest (slot I+1) */
+      constexpr int fr = (decltype(I)::value + 1) % NS, old = (decltype(I)::value + 1 + P0) % NS;
+      uint32_t UB[12], M[8], Hn[10];
+      blur_hsum10<R>(U, Hn);
+#pragma unroll
+      for (int k = 0; k < 10; k++) V[k] = pk_sub_u16(pk_add_u16(V[k], Hn[k]), ring[old][k]), ring[fr][k] = Hn[k];
+      blurred(y0 + i + 1, UB);
+      U4 o;
+      if constexpr (NS % 2 == 0) o = st.template step<decltype(I)::value & 1>(UB, M);
+      else o = st.step_shift(UB, M);
+      /* histogram, branch-free: lanes outside the image, the two frame columns and the dropped
+       * rows of the last group add 0.  LDS byte offsets bin*128 + copy*4 for both pixels of a
+       * pair come from one v_pk_mad_u16. */
+      const unsigned inc = (inimg && i < nrows) ? 1u : 0u;
+      const unsigned inc0 = first ? 0u : inc, inc15 = last ? 0u : inc;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const uint32_t a2 = pk_mad_u16_s(M[k], 0x00800080u, cb2);
+        atomicAdd((unsigned *)((char *)lh + (a2 & 0xffffu)), k == 0 ? inc0 : inc);
+        atomicAdd((unsigned *)((char *)lh + (a2 >> 16)), k == 7 ? inc15 : inc);
+      }
+      return o;
+    });
+  }
+  __syncthreads();
+  unsigned acc = 0;
+#pragma unroll 8
+  for (unsigned k = 0; k < 32; k++) acc += lh[tid * 32u + ((k + tid) & 31u)];
+  const size_t blk = (size_t)blockIdx.z * gridDim.x * gridDim.y + (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+  partial[blk * 256u + tid] = acc;
+}
+
+}  // namespace gs
+#endif

@@ -7,6 +7,8 @@
  * across columns -- 13 B/px of traffic for 5 B/px algorithmic (1 R + 4 W).  Fast path
  * (k_integral_colsum / _colbase / _band below): 6 B/px.
  *
+ * k_integral_wave: barrier-free replacement of k_integral_band (one wave per band).
+ *
  * k_integral_pad: copies an unpadded w x h table into the (w+1) x (h+1) zero-bordered layout
  * the cascade kernel reads (turns the x>0 / y>0 guards of gs_integral_sum, ref :754-763, into
  * plain loads).
@@ -175,6 +177,57 @@ __global__ __launch_bounds__(256) void k_integral_band(const uint8_t *src, unsig
 #pragma unroll
     for (int q = 0; q < 4; q++)
       buf_store16_wb(D, ob + 16u * q, U4{off + P[4 * q], off + P[4 * q + 1], off + P[4 * q + 2], off + P[4 * q + 3]});
+  }
+}
+
+/* Barrier-free form of step (3): one WAVE per band spans the whole row.  The row is cut into TILES
+ * tiles of 256 px; in tile t the lane owns the 4 px at t*256 + 4*lane, so every load is one
+ * coalesced 256-B dword row per wave and every store one coalesced 1-KiB dwordx4 row.  Running
+ * column sums V[TILES][4] live in registers; per row: in-lane prefix of 4, one DPP wave scan per
+ * tile, and the tile totals chain through a scalar carry (v_readlane).  No LDS, no barrier, the
+ * next row's TILES dwords are in flight during the arithmetic.
+ * grid (1, ceil(nbands/4), n frames), block 256 = 4 waves = 4 bands.  w <= TILES*256, w % 4 == 0. */
+template <int TILES>
+__global__ __launch_bounds__(256) void k_integral_wave(const uint8_t *src, unsigned w, unsigned h,
+                                                       unsigned BH, unsigned nbands,
+                                                       const unsigned *colbase, unsigned *ii) {
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned band = uniform(blockIdx.y * 4u + (threadIdx.x >> 6));
+  if (band >= nbands) return; /* whole wave */
+  const size_t fb = (size_t)w * h;
+  const BufRsrc S = make_buf(src + (size_t)blockIdx.z * fb, fb);
+  const BufRsrc D = make_buf(ii + (size_t)blockIdx.z * fb, fb * 4);
+  const BufRsrc C = make_buf(colbase + ((size_t)blockIdx.z * nbands + band) * w, (size_t)w * 4);
+  const unsigned y0 = band * BH, y1 = y0 + BH < h ? y0 + BH : h;
+  unsigned V[TILES][4];
+  uint32_t xo[TILES], nxt[TILES]; /* per-tile byte offset of the lane's 4 px inside a row, or OOB */
+#pragma unroll
+  for (int t = 0; t < TILES; t++) {
+    const unsigned x = (unsigned)t * 256u + lane * 4u;
+    xo[t] = x < w ? x : kOOB;
+    const U4 b = buf_load16(C, x < w ? x * 4u : kOOB); /* zero beyond w */
+    V[t][0] = b.x, V[t][1] = b.y, V[t][2] = b.z, V[t][3] = b.w;
+    nxt[t] = buf_load4(S, x < w ? y0 * w + x : kOOB);
+  }
+  for (unsigned y = y0; y < y1; y++) { /* wave-uniform trip count */
+    uint32_t cur[TILES];
+    const bool more = y + 1 < y1;
+#pragma unroll
+    for (int t = 0; t < TILES; t++) {
+      cur[t] = nxt[t];
+      nxt[t] = buf_load4(S, (more && xo[t] != kOOB) ? (y + 1) * w + xo[t] : kOOB);
+    }
+    unsigned carry = 0; /* sum of the tiles to the left, wave-uniform */
+#pragma unroll
+    for (int t = 0; t < TILES; t++) {
+      const uint32_t d = cur[t];
+      V[t][0] += d & 0xffu, V[t][1] += (d >> 8) & 0xffu, V[t][2] += (d >> 16) & 0xffu, V[t][3] += d >> 24;
+      const unsigned p0 = V[t][0], p1 = p0 + V[t][1], p2 = p1 + V[t][2], p3 = p2 + V[t][3];
+      const unsigned inc = wave_incl_scan(p3);
+      const unsigned off = carry + inc - p3;
+      buf_store16_wb(D, xo[t] != kOOB ? (y * w + xo[t]) * 4u : kOOB, U4{off + p0, off + p1, off + p2, off + p3});
+      carry += readlane_last(inc);
+    }
   }
 }
 

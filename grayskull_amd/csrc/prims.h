@@ -218,8 +218,11 @@ GS_DEV uint32_t pk_abs_i16(uint32_t a) { return GS_R(__builtin_elementwise_abs(G
 /* ------------------------------------------------------------------ common */
 GS_DEV uint32_t readlane0(uint32_t x) { return shfl(x, 0); }
 
-/* inclusive add-scan across the wave (Hillis-Steele over wave_shr-style shuffles) */
+/* inclusive add-scan across the wave.  gfx950: six DPP adds -- row_shr 1/2/4/8 inside each row of
+ * 16 lanes, then row_bcast15 / row_bcast31 carry the row totals across (no LDS crossbar);
+ * emulator: Hillis-Steele over shuffles. */
 GS_DEV uint32_t wave_incl_scan(uint32_t v) {
+#ifdef GS_EMU
   unsigned l = lane_id();
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -227,6 +230,23 @@ GS_DEV uint32_t wave_incl_scan(uint32_t v) {
     if ((int)l >= d) v += t;
   }
   return v;
+#else
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); /* row_shr:1 */
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); /* row_shr:2 */
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); /* row_shr:4 */
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); /* row_shr:8 */
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); /* row_bcast:15 -> rows 1, 3 */
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); /* row_bcast:31 -> rows 2, 3 */
+  return v;
+#endif
+}
+/* lane 63's value, wave-uniform (v_readlane_b32 -> SGPR on the GPU) */
+GS_DEV uint32_t readlane_last(uint32_t x) {
+#ifdef GS_EMU
+  return shfl(x, 63);
+#else
+  return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+#endif
 }
 GS_DEV uint32_t wave_sum(uint32_t v) {
 #pragma unroll

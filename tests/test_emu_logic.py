@@ -31,7 +31,7 @@ def test_stencils_extremes(emu, oracle):
     pc.stencils(emu, oracle, Oracle.synth(20, 9, 3), MEM, radii=(0, 20, 1000))  # radius >= image
 
 
-@pytest.mark.parametrize("shape", [(67, 45), (64, 40), (1, 1), (5, 1), (1031, 3), (48, 33)])
+@pytest.mark.parametrize("shape", [(67, 45), (64, 40), (1, 1), (5, 1), (1031, 3), (48, 33), (2064, 4), (4096, 3), (272, 70)])
 def test_pointwise_and_integral(emu, oracle, shape):
     w, h = shape
     img = Oracle.synth(w, h, 11 + w)
