@@ -273,7 +273,7 @@ void launch_integral(const uint8_t *src, unsigned w, unsigned h, unsigned n, uns
       nb = (h + BH - 1) / BH;
       unsigned *cs = (unsigned *)ctx().scratch(SL_HISTP, (size_t)nn * nb * w * 4);
       GS_LAUNCH(k_integral_colsum, dim3(1, nb, nn), dim3(256), 0, st, src + fp * f0, w, h, BH, nb, cs);
-      GS_LAUNCH(k_integral_colbase, dim3((w + 255) / 256, nn), dim3(256), 0, st, cs, w, nb);
+      GS_LAUNCH(k_integral_colbase, dim3((w + 63) / 64, nn), dim3(64, 16), 0, st, cs, w, nb);
       if (g_tune[6] == 2) /* the block-per-band form (one barrier per row), kept for comparison */
         GS_LAUNCH(k_integral_band, dim3(1, nb, nn), dim3(256), 0, st, src + fp * f0, w, h, BH, nb,
                   (const unsigned *)cs, ii + fp * f0);
@@ -383,7 +383,7 @@ void run_compaction(unsigned long long *mask, unsigned *cnt, unsigned nchunks, u
   unsigned *pfx = (unsigned *)ctx().scratch(SL_PFX, (size_t)n * nchunks * 4);
   GS_LAUNCH(k_chunk_scan, dim3(n), dim3(1024), 0, st, (const unsigned *)cnt, nchunks, pfx,
             totals_dev, cap);
-  GS_LAUNCH(k_emit<F>, dim3((nchunks + 255) / 256, n), dim3(256), 0, st,
+  GS_LAUNCH(k_emit<F>, dim3((nchunks + 3) / 4, n), dim3(256), 0, st,
             (const unsigned long long *)mask, (const unsigned *)cnt, (const unsigned *)pfx, nchunks,
             cap, emit);
 }

@@ -121,13 +121,45 @@ __global__ __launch_bounds__(256) void k_integral_colsum(const uint8_t *src, uns
   }
 }
 
-/* in place: colsum[b][x] <- sum of colsum[b'][x] for b' < b.  grid (ceil(w/256), n), block 256 */
-__global__ __launch_bounds__(256) void k_integral_colbase(unsigned *colsum, unsigned w, unsigned nbands) {
-  const unsigned x = blockIdx.x * 256u + threadIdx.x;
-  if (x >= w) return;
+/* in place: colsum[b][x] <- sum of colsum[b'][x] for b' < b.  grid (ceil(w/64), n), block (64,16):
+ * a wave owns 64 columns of one sixteenth of the bands -- sums it, the 16 partial sums meet in
+ * LDS, then it rewrites its bands as running sums (a few hundred bands walked by one thread per
+ * column is 30 us of dependent latency; this is 5). */
+__global__ __launch_bounds__(1024) void k_integral_colbase(unsigned *colsum, unsigned w, unsigned nbands) {
+  __shared__ unsigned part[16][64];
+  const unsigned x = blockIdx.x * 64u + threadIdx.x, g = threadIdx.y;
+  const unsigned per = (nbands + 15u) / 16u;
+  const unsigned b0 = g * per < nbands ? g * per : nbands, b1 = b0 + per < nbands ? b0 + per : nbands;
   unsigned *p = colsum + (size_t)blockIdx.y * nbands * w + x;
+  unsigned sum = 0;
+  if (x < w) {
+    unsigned b = b0;
+    for (; b + 8 <= b1; b += 8) {
+      unsigned v[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) v[k] = p[(size_t)(b + k) * w];
+#pragma unroll
+      for (int k = 0; k < 8; k++) sum += v[k];
+    }
+    for (; b < b1; b++) sum += p[(size_t)b * w];
+  }
+  part[g][threadIdx.x] = sum;
+  __syncthreads();
+  if (x >= w) return;
   unsigned acc = 0;
-  for (unsigned b = 0; b < nbands; b++) {
+  for (unsigned k = 0; k < g; k++) acc += part[k][threadIdx.x];
+  unsigned b = b0;
+  for (; b + 8 <= b1; b += 8) {
+    unsigned v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = p[(size_t)(b + k) * w];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      p[(size_t)(b + k) * w] = acc;
+      acc += v[k];
+    }
+  }
+  for (; b < b1; b++) {
     const unsigned v = p[(size_t)b * w];
     p[(size_t)b * w] = acc;
     acc += v;

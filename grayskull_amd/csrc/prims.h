@@ -240,6 +240,14 @@ GS_DEV uint32_t wave_incl_scan(uint32_t v) {
   return v;
 #endif
 }
+/* lane k's value for a wave-uniform k (v_readlane_b32 with an SGPR lane select) */
+GS_DEV uint32_t readlane_at(uint32_t x, unsigned k) {
+#ifdef GS_EMU
+  return shfl(x, (int)k);
+#else
+  return (uint32_t)__builtin_amdgcn_readlane((int)x, (int)k);
+#endif
+}
 /* lane 63's value, wave-uniform (v_readlane_b32 -> SGPR on the GPU) */
 GS_DEV uint32_t readlane_last(uint32_t x) {
 #ifdef GS_EMU
