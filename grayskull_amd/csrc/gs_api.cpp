@@ -406,8 +406,12 @@ void launch_fast(const uint8_t *img, uint8_t *score, unsigned w, unsigned h, uns
       (unsigned long long *)ctx().scratch(SL_MASK, (size_t)n * nchunks * kChunkWords * 8);
   unsigned *cnt = (unsigned *)ctx().scratch(SL_CNT, (size_t)n * nchunks * 4);
   GS_HIP(hipMemsetAsync(cnt, 0, (size_t)n * nchunks * 4, st));
+  /* row = item / (w-6) by multiplication where the magic fits (see div_by) */
+  const unsigned iw = w - 6;
+  const unsigned magic = (iw > 256 && iw <= 8192 && (unsigned long long)iw * (h - 6) <= (1ull << 26))
+                             ? (unsigned)(((1ull << 40) + iw - 1) / iw) : 0u;
   GS_LAUNCH(k_fast_nms, dim3(nchunks, n), dim3(256), 0, st, (const uint8_t *)score, w, h, fb, mask,
-            cnt, nchunks);
+            cnt, nchunks, magic);
   run_compaction(mask, cnt, nchunks, n, nkps, counts,
                  FastEmit{score, w, fb, kps, nkps});
 }

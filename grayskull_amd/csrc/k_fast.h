@@ -26,8 +26,16 @@ GS_DEV bool ring_has_run9(unsigned m) {
   return (r & 0xffffu) != 0;
 }
 
-/* score of the pixel whose centre value is p and ring values are v[0..15] (ref :491-513) */
-GS_DEV unsigned fast_score(unsigned p, const unsigned (&v)[16], unsigned threshold) {
+/* score of the pixel whose centre value is p and ring values are v[0..15] (ref :491-513).
+ * The kernel is VALU-bound, so the class masks are gathered from SIGN bits: hi - v < 0 <=> brighter,
+ * v - lo < 0 <=> darker, and one v_alignbit_b32 shifts a sign bit into the mask
+ * (acc = {acc, s} >> 31): 2 lane-ops per ring pixel and class instead of compare + select + or.
+ * The masks come out bit-reversed (ring pixel 0 in bit 15), which a circular-run test cannot see.
+ * When p < threshold the reference's unsigned `p - t` wraps and every non-brighter pixel is
+ * "darker" (ref :496-498): that case is one select on the finished masks.  |v - p| is one
+ * v_sad_u16 and the 16-way minimum folds into v_min3_u32. */
+/* literal form of ref :491-513 in u32 arithmetic, for thresholds so large that p + t itself wraps */
+GS_DEV unsigned fast_score_u32(unsigned p, const unsigned (&v)[16], unsigned threshold) {
   const unsigned hi = p + threshold, lo = p - threshold; /* u32 wrap-around on purpose */
   unsigned bright = 0, dark = 0, mind = 255;
 #pragma unroll
@@ -36,10 +44,26 @@ GS_DEV unsigned fast_score(unsigned p, const unsigned (&v)[16], unsigned thresho
     const bool d = !b && v[j] < lo;
     bright |= (unsigned)b << j;
     dark |= (unsigned)d << j;
-    const int df = (int)v[j] - (int)p;
-    const unsigned ad = (unsigned)(df < 0 ? -df : df);
-    mind = ad < mind ? ad : mind;
+    mind = umin(mind, absdiff_u16(v[j], p));
   }
+  return (ring_has_run9(bright) || ring_has_run9(dark)) ? mind : 0u;
+}
+
+GS_DEV unsigned fast_score(unsigned p, const unsigned (&v)[16], unsigned threshold) {
+  if (threshold > 0xffffff00u) return fast_score_u32(p, v, threshold); /* kernel argument: uniform */
+  /* v, p <= 255; t in [256, 2^32-256] behaves like 256 (never brighter, p - t wraps): clamp so the
+   * signed differences below cannot overflow */
+  const int t = (int)(threshold < 256u ? threshold : 256u), hi = (int)p + t, lo = (int)p - t;
+  uint32_t bright = 0, dark = 0;
+  unsigned mind = 255;
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    bright = alignbit(bright, (uint32_t)(hi - (int)v[j]), 31); /* sign set <=> v > p + t */
+    dark = alignbit(dark, (uint32_t)((int)v[j] - lo), 31);     /* sign set <=> v < p - t (no wrap) */
+    mind = umin(mind, absdiff_u16(v[j], p));
+  }
+  bright &= 0xffffu, dark &= 0xffffu;
+  if (lo < 0) dark = bright ^ 0xffffu; /* unsigned wrap of p - t in the reference */
   return (ring_has_run9(bright) || ring_has_run9(dark)) ? mind : 0u;
 }
 
@@ -59,11 +83,18 @@ __global__ __launch_bounds__(256) void k_fast_score_px(const uint8_t *img, uint8
       (uint8_t)fast_score(c[0], v, threshold);
 }
 
+/* idx / d for idx < 2^26 with the host's magic = ceil(2^40 / d) (needs d > 256 to fit 32 bits; the
+ * error term idx * (magic*d - 2^40) < 2^26 * 2^13 stays below 2^40); magic 0: plain division */
+GS_DEV unsigned div_by(unsigned idx, unsigned d, unsigned magic) {
+  return magic ? (unsigned)(((unsigned long long)idx * magic) >> 40) : idx / d;
+}
+
 /* pass 2: NMS flags over the interior in raster order, item = (y-3)*(w-6) + (x-3).
  * grid (nchunks, n frames), block 256, 8 items per thread (one chunk per block). */
 __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t *score, unsigned w, unsigned h,
                                                   size_t frame_bytes, unsigned long long *mask,
-                                                  unsigned *chunk_count, unsigned nchunks) {
+                                                  unsigned *chunk_count, unsigned nchunks,
+                                                  unsigned div_magic) {
   const unsigned iw = w - 6, nitems = iw * (h - 6);
   const uint8_t *sf = score + (size_t)blockIdx.y * frame_bytes;
   const unsigned tid = threadIdx.x, wv = tid >> 6;
@@ -72,7 +103,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t *score, unsigned
     const unsigned idx = blockIdx.x * kChunkItems + k * 256u + tid;
     bool kp = false;
     if (idx < nitems) {
-      const unsigned yy = idx / iw, x = 3 + (idx - yy * iw), y = 3 + yy;
+      const unsigned yy = div_by(idx, iw, div_magic), x = 3 + (idx - yy * iw), y = 3 + yy;
       const uint8_t *c = sf + (size_t)y * w + x;
       const unsigned s = c[0];
       if (s) {

@@ -216,6 +216,15 @@ GS_DEV uint32_t pk_abs_i16(uint32_t a) { return GS_R(__builtin_elementwise_abs(G
 #endif
 
 /* ------------------------------------------------------------------ common */
+GS_DEV unsigned umin(unsigned a, unsigned b) { return a < b ? a : b; }
+/* |a - b| for a, b < 65536 (v_sad_u16 with zero high halves on the GPU) */
+GS_DEV unsigned absdiff_u16(unsigned a, unsigned b) {
+#ifdef GS_EMU
+  return a > b ? a - b : b - a;
+#else
+  return __builtin_amdgcn_sad_u16(a, b, 0u);
+#endif
+}
 GS_DEV uint32_t readlane0(uint32_t x) { return shfl(x, 0); }
 
 /* inclusive add-scan across the wave.  gfx950: six DPP adds -- row_shr 1/2/4/8 inside each row of

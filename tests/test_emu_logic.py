@@ -54,13 +54,16 @@ def test_next_rows(emu, oracle, shape):
     pc.next_rows(emu, oracle, Oracle.synth(w, h, 21), MEM)
 
 
-@pytest.mark.parametrize("shape", [(67, 45), (96, 80), (7, 7), (6, 30), (40, 8)])
+@pytest.mark.parametrize("shape", [(67, 45), (96, 80), (7, 7), (6, 30), (40, 8), (300, 12)])
 def test_fast(emu, oracle, shape):
     w, h = shape
     pc.fast(emu, oracle, Oracle.synth(w, h, 5), MEM)
     rs = np.random.RandomState(1)
     pc.fast(emu, oracle, rs.randint(0, 256, (h, w)).astype(np.uint8), MEM, threshold=5, caps=(5000, 1))
     pc.fast(emu, oracle, rs.randint(0, 40, (h, w)).astype(np.uint8), MEM, threshold=30)  # p < t everywhere
+    img = rs.randint(0, 256, (h, w)).astype(np.uint8)
+    for t in (0, 1, 255, 256, 300, 0x7fffffff, 0x80000000, 0xffffff00, 0xffffff01, 0xfffffff0, 0xffffffff):
+        pc.fast(emu, oracle, img, MEM, threshold=t, caps=(5000,))  # incl. thresholds where p + t wraps
 
 
 def test_fast_quirk(emu, oracle):
