@@ -136,6 +136,11 @@ struct Ctx {
       b.p = nullptr, b.cap = 0;
     }
 #ifndef GS_EMU
+    for (auto &e : prof_ev) {
+      if (e) (void)hipEventDestroy(e);
+      e = nullptr;
+    }
+    prof_n = 0;
     if (side) {
       (void)hipStreamDestroy(side), (void)hipEventDestroy(ev_join);
       for (auto &e : ev_chunk) (void)hipEventDestroy(e), e = nullptr;
