@@ -113,6 +113,9 @@ _SIGS = {
                               C.c_void_p, C.c_uint, C.c_uint]),
     "gsh_orb_extract": (C.c_uint, [C.c_void_p, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p,
                                    C.c_uint, C.c_uint]),
+    "gsh_orb_pyramid_buffer_bytes": (C.c_size_t, [C.c_uint, C.c_uint, C.c_uint]),
+    "gsh_orb_extract_pyramid": (C.c_uint, [C.c_void_p, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p,
+                                           C.c_uint, C.c_uint, C.c_uint]),
     "gsh_match_orb_dev": (None, [C.c_void_p, C.c_uint, C.c_void_p, C.c_uint, C.c_void_p,
                                  C.c_void_p, C.c_uint, C.c_float]),
     "gsh_adaptive_threshold_batch": (None, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint,
@@ -331,6 +334,17 @@ class Grayskull:
         h, w = int(img.shape[0]), int(img.shape[1])
         kps = np.zeros(max(nkps, 1), KEYPOINT_DTYPE)
         n = self.c.gsh_orb_extract(_ptr(img), w, h, _ptr(scoremap), kps.ctypes.data, nkps, threshold)
+        return kps[:n].copy()
+
+    def orb_pyramid_buffer_bytes(self, w, h, n_levels):
+        return int(self.c.gsh_orb_pyramid_buffer_bytes(w, h, n_levels))
+
+    def orb_extract_pyramid_dev(self, img, buffer, nkps, threshold, n_levels):
+        """nanomagick.c:245-290 on a device image; buffer: device bytes (levels + scoremaps)"""
+        h, w = int(img.shape[0]), int(img.shape[1])
+        kps = np.zeros(max(nkps, 1), KEYPOINT_DTYPE)
+        n = self.c.gsh_orb_extract_pyramid(_ptr(img), w, h, _ptr(buffer), kps.ctypes.data, nkps, threshold,
+                                           n_levels)
         return kps[:n].copy()
 
     def match_orb_dev(self, k1, n1, k2, n2, matches, count, max_matches, max_distance):

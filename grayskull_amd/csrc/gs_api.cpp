@@ -611,64 +611,91 @@ __global__ void k_lbp_single(LbpArgs a, const LbpGeom *geom, unsigned *out) {
 }
 
 /* ------------------------------------------------------------------ ORB host logic */
-struct Cand { unsigned x, y, response; int m01, m10; };
 
-/* FAST candidates + moments of every candidate on the device; returns them on the host */
-unsigned orb_candidates(const uint8_t *img_dev, unsigned w, unsigned h, uint8_t *score_dev,
-                        unsigned cap, unsigned threshold, std::vector<Cand> &out) {
-  hipStream_t st = ctx().s();
-  unsigned *kps = (unsigned *)ctx().scratch(SL_KPS, (size_t)cap * 48 + 16);
-  unsigned *cnt = (unsigned *)ctx().scratch(SL_TOT, 16);
-  launch_fast(img_dev, score_dev, w, h, 1, kps, cnt, cap, threshold);
-  /* moments of every candidate slot (blocks beyond the device-side count exit), then ONE
-   * round trip for count + records + moments */
-  int *mom = (int *)ctx().scratch(SL_MOM, (size_t)cap * 8);
-  GS_LAUNCH(k_orient_moments, dim3(cap), dim3(64), 0, st, img_dev, w, h, (const unsigned *)kps, 12u,
-            15u, mom, (const unsigned *)cnt);
-  std::vector<unsigned> hk((size_t)cap * 12);
-  std::vector<int> hm((size_t)cap * 2);
-  unsigned n = 0;
-  GS_HIP(hipMemcpyAsync(&n, cnt, 4, hipMemcpyDeviceToHost, st));
-  GS_HIP(hipMemcpyAsync(hk.data(), kps, (size_t)cap * 48, hipMemcpyDeviceToHost, st));
-  GS_HIP(hipMemcpyAsync(hm.data(), mom, (size_t)cap * 8, hipMemcpyDeviceToHost, st));
-  ctx().sync();
-  out.resize(n);
-  if (!n) return 0;
-  for (unsigned i = 0; i < n; i++)
-    out[i] = Cand{hk[i * 12], hk[i * 12 + 1], hk[i * 12 + 2], hm[2 * i], hm[2 * i + 1]};
-  return n;
-}
+/* gs_orb_extract (ref :651-669) for up to 4 independent images (pyramid levels) with TWO host round
+ * trips in total: (1) FAST + NMS + ordered emit + disc moments of every candidate slot, per level,
+ * then one copy-back of counts + records + moments; host: stable sort (desc response, ref :639),
+ * 15-px border filter, atan2f / sinf from libm (ref :100-101); (2) BRIEF for the kept keypoints of
+ * all levels, one copy-back of the descriptors. */
+struct OrbLevel {
+  const uint8_t *img;
+  unsigned w, h;
+  uint8_t *score;
+  gs_keypoint *out; /* host */
+  unsigned nkps;    /* wanted */
+  unsigned got;
+};
 
-/* ref :651-669 after FAST: stable sort (desc response), 15-px border filter, angle, BRIEF */
-unsigned orb_finish(const uint8_t *img_dev, unsigned w, unsigned h, std::vector<Cand> &cand,
-                    gs_keypoint *kps_host, unsigned nkps) {
+void orb_extract_levels(OrbLevel *L, unsigned nl, unsigned threshold) {
   hipStream_t st = ctx().s();
-  std::stable_sort(cand.begin(), cand.end(),
-                   [](const Cand &a, const Cand &b) { return a.response > b.response; });
-  const unsigned r = 15;
-  std::vector<KpIn> kin;
-  unsigned n = 0;
-  for (size_t i = 0; i < cand.size() && n < nkps; i++) {
-    const Cand &c = cand[i];
-    if (c.x >= r && c.y >= r && c.x < w - r && c.y < h - r) {
-      gs_keypoint &k = kps_host[n];
-      k.pt.x = c.x, k.pt.y = c.y, k.response = c.response;
-      k.angle = atan2f((float)c.m01, (float)c.m10); /* ref :620, :100 */
-      const float angle = k.angle;
-      kin.push_back(KpIn{c.x, c.y, sinf(angle), sinf((float)(angle + 1.57079f))}); /* ref :626 */
-      n++;
-    }
+  unsigned cap[4], coff[4], ctot = 0;
+  for (unsigned l = 0; l < nl; l++) {
+    cap[l] = (L[l].nkps && L[l].w >= 7 && L[l].h >= 7) ? std::min(L[l].nkps * 4u, 5000u) : 0u;
+    coff[l] = ctot, ctot += cap[l], L[l].got = 0;
   }
-  if (!n) return 0;
-  KpIn *dk = (KpIn *)ctx().scratch(SL_KIN, (size_t)n * sizeof(KpIn));
-  uint32_t *dd = (uint32_t *)ctx().scratch(SL_DESC, (size_t)n * 32);
-  GS_HIP(hipMemcpyAsync(dk, kin.data(), (size_t)n * sizeof(KpIn), hipMemcpyHostToDevice, st));
-  GS_LAUNCH(k_brief, dim3(n), dim3(256), 0, st, img_dev, w, h, (const KpIn *)dk, dd);
-  std::vector<uint32_t> hd((size_t)n * 8);
-  GS_HIP(hipMemcpyAsync(hd.data(), dd, (size_t)n * 32, hipMemcpyDeviceToHost, st));
+  if (!ctot) return;
+  unsigned *kps = (unsigned *)ctx().scratch(SL_KPS, (size_t)ctot * 48 + 16);
+  unsigned *cnt = (unsigned *)ctx().scratch(SL_TOT, 16);
+  int *mom = (int *)ctx().scratch(SL_MOM, (size_t)ctot * 8);
+  for (unsigned l = 0; l < nl; l++) {
+    if (!cap[l]) continue;
+    launch_fast(L[l].img, L[l].score, L[l].w, L[l].h, 1, kps + (size_t)coff[l] * 12, cnt + l, cap[l], threshold);
+    /* moments of every candidate slot (blocks beyond the device-side count exit) */
+    GS_LAUNCH(k_orient_moments, dim3(cap[l]), dim3(64), 0, st, L[l].img, L[l].w, L[l].h,
+              (const unsigned *)(kps + (size_t)coff[l] * 12), 12u, 15u, mom + (size_t)coff[l] * 2,
+              (const unsigned *)(cnt + l));
+  }
+  std::vector<unsigned> hk((size_t)ctot * 12);
+  std::vector<int> hm((size_t)ctot * 2);
+  unsigned hn[4] = {0, 0, 0, 0};
+  GS_HIP(hipMemcpyAsync(hn, cnt, 16, hipMemcpyDeviceToHost, st));
+  GS_HIP(hipMemcpyAsync(hk.data(), kps, (size_t)ctot * 48, hipMemcpyDeviceToHost, st));
+  GS_HIP(hipMemcpyAsync(hm.data(), mom, (size_t)ctot * 8, hipMemcpyDeviceToHost, st));
   ctx().sync();
-  for (unsigned i = 0; i < n; i++) memcpy(kps_host[i].descriptor, &hd[(size_t)i * 8], 32);
-  return n;
+  /* host half of ref :657-667 */
+  struct Cand { unsigned x, y, response; int m01, m10; };
+  std::vector<KpIn> kin;
+  unsigned koff[4], ktot = 0;
+  const unsigned r = 15;
+  for (unsigned l = 0; l < nl; l++) {
+    koff[l] = ktot;
+    if (!cap[l]) continue;
+    const unsigned n = std::min(hn[l], cap[l]);
+    std::vector<Cand> cand(n);
+    for (unsigned i = 0; i < n; i++) {
+      const size_t q = (size_t)coff[l] + i;
+      cand[i] = Cand{hk[q * 12], hk[q * 12 + 1], hk[q * 12 + 2], hm[2 * q], hm[2 * q + 1]};
+    }
+    std::stable_sort(cand.begin(), cand.end(),
+                     [](const Cand &a, const Cand &b) { return a.response > b.response; });
+    unsigned kept = 0;
+    for (size_t i = 0; i < cand.size() && kept < L[l].nkps; i++) {
+      const Cand &c = cand[i];
+      if (c.x >= r && c.y >= r && c.x < L[l].w - r && c.y < L[l].h - r) {
+        gs_keypoint &k = L[l].out[kept];
+        k.pt.x = c.x, k.pt.y = c.y, k.response = c.response;
+        k.angle = atan2f((float)c.m01, (float)c.m10); /* ref :620, :100 */
+        const float angle = k.angle;
+        kin.push_back(KpIn{c.x, c.y, sinf(angle), sinf((float)(angle + 1.57079f))}); /* ref :626 */
+        kept++;
+      }
+    }
+    L[l].got = kept, ktot += kept;
+  }
+  if (!ktot) return;
+  KpIn *dk = (KpIn *)ctx().scratch(SL_KIN, (size_t)ktot * sizeof(KpIn));
+  uint32_t *dd = (uint32_t *)ctx().scratch(SL_DESC, (size_t)ktot * 32);
+  GS_HIP(hipMemcpyAsync(dk, kin.data(), (size_t)ktot * sizeof(KpIn), hipMemcpyHostToDevice, st));
+  for (unsigned l = 0; l < nl; l++)
+    if (L[l].got)
+      GS_LAUNCH(k_brief, dim3(L[l].got), dim3(256), 0, st, L[l].img, L[l].w, L[l].h,
+                (const KpIn *)(dk + koff[l]), dd + (size_t)koff[l] * 8);
+  std::vector<uint32_t> hd((size_t)ktot * 8);
+  GS_HIP(hipMemcpyAsync(hd.data(), dd, (size_t)ktot * 32, hipMemcpyDeviceToHost, st));
+  ctx().sync();
+  for (unsigned l = 0; l < nl; l++)
+    for (unsigned i = 0; i < L[l].got; i++)
+      memcpy(L[l].out[i].descriptor, &hd[((size_t)koff[l] + i) * 8], 32);
 }
 
 void launch_match(const uint32_t *k1, unsigned n1, const uint32_t *k2, unsigned n2,
@@ -1018,9 +1045,69 @@ void gsh_fast_batch(const uint8_t *img, uint8_t *scoremap, unsigned w, unsigned 
 unsigned gsh_orb_extract(const uint8_t *img_dev, unsigned w, unsigned h, uint8_t *scoremap_dev,
                          struct gs_keypoint *kps_host, unsigned nkps, unsigned threshold) {
   GS_ASSERT(img_dev && scoremap_dev && kps_host && nkps > 0 && w > 0 && h > 0);
-  std::vector<Cand> cand;
-  orb_candidates(img_dev, w, h, scoremap_dev, std::min(nkps * 4u, 5000u), threshold, cand);
-  return orb_finish(img_dev, w, h, cand, kps_host, nkps);
+  OrbLevel L{img_dev, w, h, scoremap_dev, kps_host, nkps, 0};
+  orb_extract_levels(&L, 1, threshold);
+  return L.got;
+}
+size_t gsh_orb_pyramid_buffer_bytes(unsigned w, unsigned h, unsigned n_levels) {
+  if (n_levels > 4) n_levels = 4;
+  size_t levels = 0, maps = (size_t)w * h;
+  for (unsigned l = 1; l < n_levels; l++) {
+    w /= 2, h /= 2;
+    if (w < 32 || h < 32) break;
+    levels += (size_t)w * h, maps += (size_t)w * h;
+  }
+  return levels + maps;
+}
+/* ref examples/nanomagick/nanomagick.c:245-290 with every level resident on the device */
+unsigned gsh_orb_extract_pyramid(const uint8_t *img_dev, unsigned w, unsigned h, uint8_t *buffer_dev,
+                                 struct gs_keypoint *kps_host, unsigned nkps, unsigned threshold,
+                                 unsigned n_levels) {
+  GS_ASSERT(img_dev && buffer_dev && kps_host && w > 0 && h > 0);
+  if (n_levels > 4) n_levels = 4;
+  const uint8_t *lev[4];
+  unsigned lw[4], lh[4], total = 0;
+  size_t off = 0;
+  lev[0] = img_dev, lw[0] = w, lh[0] = h;
+  for (unsigned l = 1; l < n_levels; l++) {
+    const unsigned nw = lw[l - 1] / 2, nh = lh[l - 1] / 2;
+    if (nw < 32 || nh < 32) {
+      n_levels = l;
+      break;
+    }
+    uint8_t *d = buffer_dev + off;
+    off += (size_t)nw * nh;
+    gsh_downsample_batch(d, lev[l - 1], lw[l - 1], lh[l - 1], 1);
+    lev[l] = d, lw[l] = nw, lh[l] = nh;
+  }
+  /* per-level quotas depend on how many keypoints the earlier levels produced only for the last
+   * level ("the remainder", nanomagick.c:275): run the first n_levels-1 levels as one batch, then
+   * the last one */
+  OrbLevel L[4];
+  uint8_t *sm[4];
+  for (unsigned l = 0; l < n_levels; l++) {
+    sm[l] = buffer_dev + off;
+    off += (size_t)lw[l] * lh[l];
+  }
+  const unsigned per = nkps / n_levels;
+  for (unsigned l = 0; l + 1 < n_levels; l++) L[l] = OrbLevel{lev[l], lw[l], lh[l], sm[l], kps_host + (size_t)l * per, per, 0};
+  if (n_levels > 1) orb_extract_levels(L, n_levels - 1, threshold);
+  for (unsigned l = 0; l + 1 < n_levels; l++) {
+    /* levels write at l*per; the reference packs them back to back (total_kps) */
+    if (L[l].got && total != l * per) memmove(kps_host + total, kps_host + (size_t)l * per, (size_t)L[l].got * sizeof(gs_keypoint));
+    for (unsigned i = total; i < total + L[l].got; i++) kps_host[i].pt.x <<= l, kps_host[i].pt.y <<= l;
+    total += L[l].got;
+  }
+  {
+    const unsigned l = n_levels - 1, want = nkps - total;
+    if (want) {
+      L[l] = OrbLevel{lev[l], lw[l], lh[l], sm[l], kps_host + total, want, 0};
+      orb_extract_levels(&L[l], 1, threshold);
+      for (unsigned i = total; i < total + L[l].got; i++) kps_host[i].pt.x <<= l, kps_host[i].pt.y <<= l;
+      total += L[l].got;
+    }
+  }
+  return total;
 }
 void gsh_match_orb_dev(const struct gs_keypoint *k1, unsigned n1, const struct gs_keypoint *k2,
                        unsigned n2, struct gs_match *matches, unsigned *count,
@@ -1407,9 +1494,6 @@ unsigned gs_orb_extract(struct gs_image img, struct gs_keypoint *kps, unsigned n
   const bool mhost = !is_dev(scoremap_buffer);
   uint8_t *dm = mhost ? (uint8_t *)ctx().scratch(SL_AUX, nb) : scoremap_buffer;
   if (mhost) GS_HIP(hipMemcpyAsync(dm, scoremap_buffer, nb, hipMemcpyHostToDevice, ctx().s()));
-  std::vector<Cand> cand;
-  orb_candidates(s, w, h, dm, std::min(nkps * 4u, 5000u), threshold, cand);
-  if (mhost) GS_HIP(hipMemcpyAsync(scoremap_buffer, dm, nb, hipMemcpyDeviceToHost, ctx().s()));
   const bool khost = !is_dev(kps);
   std::vector<gs_keypoint> tmp;
   gs_keypoint *out = kps;
@@ -1417,7 +1501,10 @@ unsigned gs_orb_extract(struct gs_image img, struct gs_keypoint *kps, unsigned n
     tmp.resize(nkps);
     out = tmp.data();
   }
-  const unsigned n = orb_finish(s, w, h, cand, out, nkps);
+  OrbLevel L{s, w, h, dm, out, nkps, 0};
+  orb_extract_levels(&L, 1, threshold);
+  const unsigned n = L.got;
+  if (mhost) GS_HIP(hipMemcpyAsync(scoremap_buffer, dm, nb, hipMemcpyDeviceToHost, ctx().s()));
   ctx().sync();
   if (!khost && n) gsh_upload(kps, out, (size_t)n * sizeof(gs_keypoint));
   return n;

@@ -108,6 +108,17 @@ void gsh_fast_batch(const uint8_t *img, uint8_t *scoremap, unsigned w, unsigned 
 unsigned gsh_orb_extract(const uint8_t *img_dev, unsigned w, unsigned h, uint8_t *scoremap_dev,
                          struct gs_keypoint *kps_host, unsigned nkps, unsigned threshold);
 
+/* The reference's ORB caller (examples/nanomagick/nanomagick.c:245-290, extract_pyramid_orb_nm) with
+ * every pyramid level resident on the device: up to 4 levels, each gs_downsample (ref :189) of the
+ * previous, stopping before a level narrower or lower than 32; nkps / n_levels keypoints per level
+ * (the last level takes the remainder); coordinates scaled back by 2^level.  buffer_dev has the
+ * reference's layout -- levels 1.. back to back, then one scoremap per level -- and its bytes are
+ * the caller's (the NMS reads the never-written 3-px scoremap frames, ref :524).  Synchronous. */
+size_t gsh_orb_pyramid_buffer_bytes(unsigned w, unsigned h, unsigned n_levels);
+unsigned gsh_orb_extract_pyramid(const uint8_t *img_dev, unsigned w, unsigned h, uint8_t *buffer_dev,
+                                 struct gs_keypoint *kps_host, unsigned nkps, unsigned threshold,
+                                 unsigned n_levels);
+
 /* All pointers device; matches: max_matches records; count: 1 u32.  Stream-ordered. */
 void gsh_match_orb_dev(const struct gs_keypoint *k1, unsigned n1, const struct gs_keypoint *k2,
                        unsigned n2, struct gs_match *matches, unsigned *count,

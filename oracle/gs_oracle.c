@@ -395,6 +395,42 @@ unsigned orc_orb_extract(const uint8_t *img, unsigned w, unsigned h, orc_keypoin
   return n;
 }
 
+/* ref examples/nanomagick/nanomagick.c:245-290 (extract_pyramid_orb_nm) -- the ORB caller of the
+ * reference: up to 4 levels, each half the size of the previous (ref grayskull.h:189-197), stop when
+ * a level would be narrower or lower than 32; `buffer` holds levels 1.. back to back and then one
+ * scoremap per level (the caller's bytes: the NMS reads their never-written 3-px frame);
+ * nkps / n_levels keypoints per level, the last level takes the remainder; coordinates scaled back
+ * by 2^level. */
+unsigned orc_orb_extract_pyramid(const uint8_t *img, unsigned w, unsigned h, orc_keypoint *kps,
+                                 unsigned nkps, unsigned threshold, uint8_t *buffer, unsigned n_levels) {
+  if (n_levels > 4) n_levels = 4;
+  const uint8_t *lev[4];
+  unsigned lw[4], lh[4], total = 0, off = 0;
+  lev[0] = img, lw[0] = w, lh[0] = h;
+  for (unsigned l = 1; l < n_levels; l++) {
+    unsigned nw = lw[l - 1] / 2, nh = lh[l - 1] / 2;
+    if (nw < 32 || nh < 32) {
+      n_levels = l;
+      break;
+    }
+    uint8_t *d = buffer + off;
+    off += nw * nh;
+    orc_downsample(d, lev[l - 1], lw[l - 1], lh[l - 1]);
+    lev[l] = d, lw[l] = nw, lh[l] = nh;
+  }
+  for (unsigned l = 0; l < n_levels; l++) {
+    uint8_t *sm = buffer + off;
+    off += lw[l] * lh[l];
+    unsigned want = nkps / n_levels;
+    if (l == n_levels - 1) want = nkps - total;
+    if (want == 0) continue;
+    unsigned got = orc_orb_extract(lev[l], lw[l], lh[l], &kps[total], want, threshold, sm);
+    for (unsigned i = total; i < total + got; i++) kps[i].x <<= l, kps[i].y <<= l;
+    total += got;
+  }
+  return total;
+}
+
 /* ref :671-699 -- brute force; best/second as float; accept iff best<=max && best<0.8*second */
 unsigned orc_match_orb(const orc_keypoint *k1, unsigned n1, const orc_keypoint *k2, unsigned n2,
                        orc_match *out, unsigned max_matches, float max_distance) {

@@ -73,6 +73,9 @@ void orc_orientation_moments(const uint8_t *img, unsigned w, unsigned h, unsigne
 void orc_brief(const uint8_t *img, unsigned w, unsigned h, orc_keypoint *kp);
 unsigned orc_orb_extract(const uint8_t *img, unsigned w, unsigned h, orc_keypoint *kps,
                          unsigned nkps, unsigned threshold, uint8_t *scoremap);
+/* ref examples/nanomagick/nanomagick.c:245-290; buffer: see orc_orb_pyramid_buffer_bytes */
+unsigned orc_orb_extract_pyramid(const uint8_t *img, unsigned w, unsigned h, orc_keypoint *kps,
+                                 unsigned nkps, unsigned threshold, uint8_t *buffer, unsigned n_levels);
 unsigned orc_match_orb(const orc_keypoint *k1, unsigned n1, const orc_keypoint *k2, unsigned n2,
                        orc_match *out, unsigned max_matches, float max_distance);
 #endif

@@ -280,6 +280,36 @@ class Oracle:
                                         _p(sm))
         return kps[:n].copy()
 
+    @staticmethod
+    def orb_pyramid_buffer_bytes(w, h, n_levels):
+        """levels 1.. back to back, then one scoremap per level (nanomagick.c:253-270)"""
+        n_levels = min(n_levels, 4)
+        dims = [(w, h)]
+        for _ in range(1, n_levels):
+            nw, nh = dims[-1][0] // 2, dims[-1][1] // 2
+            if nw < 32 or nh < 32:
+                break
+            dims.append((nw, nh))
+        return sum(a * b for a, b in dims[1:]) + sum(a * b for a, b in dims)
+
+    def orb_extract_pyramid(self, img, nkps, threshold, n_levels, buffer=None):
+        """ref examples/nanomagick/nanomagick.c:245-290; buffer = the caller's scratch bytes"""
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        nb = self.orb_pyramid_buffer_bytes(w, h, n_levels)
+        buf = np.zeros(nb + 16, np.uint8) if buffer is None else np.ascontiguousarray(buffer, np.uint8).copy()
+        assert buf.size >= nb
+        kps = np.zeros(max(nkps, 1), KEYPOINT_DTYPE)
+        if self.port:
+            n = self.lib.orc_orb_extract_pyramid(_p(img), C.c_uint(w), C.c_uint(h), _p(kps), C.c_uint(nkps),
+                                                 C.c_uint(threshold), _p(buf), C.c_uint(n_levels))
+        else:
+            nano = C.CDLL(os.path.join(HERE, "_ref", "libgs_ref_nano.so"))
+            nano.ref_extract_pyramid_orb.restype = C.c_uint
+            nano.ref_extract_pyramid_orb.argtypes = [GsImage, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p, C.c_uint]
+            n = nano.ref_extract_pyramid_orb(_img(img), _p(kps), nkps, threshold, _p(buf), n_levels)
+        return kps[:n].copy(), buf
+
     def match_orb(self, k1, k2, max_matches, max_distance):
         k1 = np.ascontiguousarray(k1, KEYPOINT_DTYPE)
         k2 = np.ascontiguousarray(k2, KEYPOINT_DTYPE)

@@ -39,6 +39,21 @@ class Mem:
         return self.put(np.full(shape, fill, dtype))
 
 
+def orb_pyramid(g, o, img, mem, nkps=90, threshold=20, levels=3, seed=1):
+    """gsh_orb_extract_pyramid (nanomagick.c:245-290 with device-resident levels) vs the oracle,
+    with a non-zero scratch buffer: pyramid levels, scoremaps and keypoints must all match"""
+    h, w = img.shape
+    nb = g.orb_pyramid_buffer_bytes(w, h, levels)
+    assert nb == o.orb_pyramid_buffer_bytes(w, h, levels)
+    buf0 = np.random.RandomState(seed).randint(0, 256, nb + 16).astype(np.uint8)
+    ko, bo = o.orb_extract_pyramid(img, nkps, threshold, levels, buf0)
+    buf = mem.put(buf0)
+    k = g.orb_extract_pyramid_dev(mem.put(img), buf, nkps, threshold, levels)
+    assert len(k) == len(ko), "pyramid ORB count %d vs %d" % (len(k), len(ko))
+    assert_same(k, ko, "pyramid ORB keypoints")
+    assert_same(mem.get(buf)[:nb], bo[:nb], "pyramid levels + scoremaps")
+
+
 def stencils(g, o, img, mem, radii=(1, 2, 3, 5)):
     s = mem.put(img)
     for r in radii:

@@ -76,6 +76,12 @@ def test_orb_and_match(emu, oracle, shape):
     pc.orb(emu, oracle, Oracle.synth(w, h, 7), MEM)
 
 
+@pytest.mark.parametrize("shape,levels,nkps", [((130, 70), 4, 50), ((96, 80), 3, 31), ((64, 64), 3, 10)])
+def test_orb_pyramid(emu, oracle, shape, levels, nkps):
+    w, h = shape
+    pc.orb_pyramid(emu, oracle, Oracle.synth(w, h, 21), MEM, nkps=nkps, levels=levels)
+
+
 def test_lbp(emu, oracle, cascade):
     img = Oracle.synth(96, 80, 7)
     pc.lbp(emu, oracle, img, MEM, cascade, params=((4096, 1.1, 1.0, 4.0, 1), (10, 1.3, 1.0, 2.0, 3)),

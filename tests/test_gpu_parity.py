@@ -277,6 +277,13 @@ def test_batch_4k_properties(hip, oracle):
         assert bool((a == b).all()) and bool((ha == hb).all()) and bool((ta == tb).all()), "fused r=%d" % r
 
 
+@pytest.mark.parametrize("shape,levels,nkps", [((1280, 720), 3, 500), ((640, 480), 4, 300), ((130, 70), 4, 50)])
+def test_orb_pyramid_device_resident(hip, oracle, shape, levels, nkps):
+    """the reference CLI's pyramid ORB driver (nanomagick.c:245-290) with all levels on the device"""
+    w, h = shape
+    pc.orb_pyramid(hip, oracle, Oracle.synth(w, h, 21), pc.Mem("device"), nkps=nkps, levels=levels)
+
+
 def test_pipeline_chunk_overlap(hip, oracle):
     """gsh_edge_pipeline_batch cuts big batches into chunks whose threshold pass runs on a side
     stream under the next chunk's fused kernel: same bytes for every chunking, ragged last chunk,
