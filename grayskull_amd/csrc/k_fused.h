@@ -124,13 +124,7 @@ __global__ __launch_bounds__(256) void k_blur_sobel_hist16(uint8_t *dst, const u
     st.init(UB0, UB1);
     const uint32_t cb2 = (copy << 2) * 0x10001u; /* this lane's histogram copy, as a pair of byte offsets */
 
-#ifndef GS_FUSED_DEPTH
-#define GS_FUSED_DEPTH 1
-#endif
-#ifndef GS_FUSED_EXITS
-#define GS_FUSED_EXITS false
-#endif
-    strip_rows<NS, false, GS_FUSED_EXITS, GS_FUSED_DEPTH>(S, y0, nrows, R + 1, S.load(y0 + R + 1), [&](auto I, int i, const uint32_t(&U)[12]) {
+    strip_rows<NS, false, /*EXITS=*/false>(S, y0, nrows, R + 1, S.load(y0 + R + 1), [&](auto I, int i, const uint32_t(&U)[12]) {
       /* iteration I, SPARE: slot I+1 is free (its row left last iteration), slot I+2 holds the
        * oldest row; otherwise the new row replaces the oldest (slot I+1) */
       constexpr int fr = (decltype(I)::value + 1) % NS, old = (decltype(I)::value + 1 + P0) % NS;

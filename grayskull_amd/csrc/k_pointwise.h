@@ -7,12 +7,6 @@
 #define GS_K_POINTWISE_H
 #include "k_stencil.h" /* U4 */
 
-/* bit 0: non-temporal loads, bit 1: non-temporal stores in k_threshold (in-place stream,
- * no reuse): 3 measured 6.6 TB/s vs 5.9 TB/s for 0 on 64 x 4K frames. */
-#ifndef GS_THR_NT
-#define GS_THR_NT 3
-#endif
-
 namespace gs {
 
 /* The 16-byte chunks of [base, base+n) are addressed relative to base rounded down to 16 B, so
@@ -52,18 +46,18 @@ __global__ __launch_bounds__(256) void k_threshold(uint8_t *img, size_t frame_by
     const size_t b0 = i * 16, b1 = b0 + 16;
     uint8_t *p = (uint8_t *)(c.a0 + b0);
     if (b0 >= c.lo && b1 <= c.hi) {
-#if defined(GS_THR_NT) && !defined(GS_EMU)
+      /* in-place stream with no reuse: non-temporal load and store (6.6 TB/s vs 5.9 TB/s) */
+#ifndef GS_EMU
       typedef unsigned int v4u __attribute__((ext_vector_type(4)));
-      v4u q = (GS_THR_NT & 1) ? __builtin_nontemporal_load((const v4u *)p) : *(const v4u *)p;
+      const v4u q = __builtin_nontemporal_load((const v4u *)p);
       U4 v{q.x, q.y, q.z, q.w};
 #else
       U4 v = *(U4 *)p;
 #endif
       v.x = swar_gt_u8(v.x, trep), v.y = swar_gt_u8(v.y, trep);
       v.z = swar_gt_u8(v.z, trep), v.w = swar_gt_u8(v.w, trep);
-#if defined(GS_THR_NT) && !defined(GS_EMU)
-      if (GS_THR_NT & 2) __builtin_nontemporal_store(v4u{v.x, v.y, v.z, v.w}, (v4u *)p);
-      else *(U4 *)p = v;
+#ifndef GS_EMU
+      __builtin_nontemporal_store(v4u{v.x, v.y, v.z, v.w}, (v4u *)p);
 #else
       *(U4 *)p = v;
 #endif

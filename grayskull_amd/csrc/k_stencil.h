@@ -27,14 +27,8 @@
 namespace gs {
 
 /* ------------------------------------------------------------------ sobel, strips (helpers: k_strip.h) */
-#ifndef GS_SOBEL_MINWAVES
-#define GS_SOBEL_MINWAVES 1
-#endif
-#ifndef GS_BLUR_MINWAVES
-#define GS_BLUR_MINWAVES 1
-#endif
 template <bool KEEP_COLS>
-__global__ __launch_bounds__(256, GS_SOBEL_MINWAVES) void k_sobel16(uint8_t *dst, const uint8_t *src, unsigned w,
+__global__ __launch_bounds__(256) void k_sobel16(uint8_t *dst, const uint8_t *src, unsigned w,
                                                  unsigned h, unsigned T, size_t frame_bytes) {
   const Strip<> S(src, dst, w, h, frame_bytes);
   const int y0 = 1 + (int)(S.band * T);
@@ -66,7 +60,7 @@ __global__ __launch_bounds__(256) void k_put_cols(uint8_t *img, const uint8_t *c
 
 /* ------------------------------------------------------------------ box blur, strips (helpers: k_strip.h) */
 template <int R>
-__global__ __launch_bounds__(256, GS_BLUR_MINWAVES) void k_blur16(uint8_t *dst, const uint8_t *src, unsigned w,
+__global__ __launch_bounds__(256) void k_blur16(uint8_t *dst, const uint8_t *src, unsigned w,
                                                 unsigned h, unsigned T, size_t frame_bytes) {
   constexpr int N = 2 * R + 1;
   const Strip<> S(src, dst, w, h, frame_bytes);

@@ -88,16 +88,11 @@ struct NoFin {
  * time with nothing to copy at block boundaries -- and rows i >= nrows of the last group are
  * computed and dropped (stores predicated off; their loads are in-frame rows of the next band or
  * out-of-range zero fill).  false costs registers; it pays for the VALU-heavy fused kernel only.
- * DEPTH: how many rows ahead the input is requested (1 or 2). */
-#ifndef GS_FENCE
-#define GS_FENCE 2
-#endif
-template <int RING, bool INVERT, bool EXITS = true, int DEPTH = 1, class Body, class Fin = NoFin>
+ * The input is requested one row ahead (two measured no better and costs 5 registers). */
+template <int RING, bool INVERT, bool EXITS = true, class Body, class Fin = NoFin>
 GS_DEV void strip_rows(const Strip<INVERT> &S, int y0, int nrows, int lead, RawRow first, Body &&body,
                        Fin fin = Fin()) {
   RawRow raw = first; /* = load(y0 + lead): the newest input row output row 0 needs */
-  RawRow raw2 = first;
-  if constexpr (DEPTH == 2) raw2 = S.load(y0 + lead + 1);
   U4 o_prev{0, 0, 0, 0};
   fin.prefetch(y0);
   int base = 0;
@@ -107,18 +102,13 @@ GS_DEV void strip_rows(const Strip<INVERT> &S, int y0, int nrows, int lead, RawR
       if constexpr (EXITS) {
         if (i >= nrows) return; /* wave-uniform */
       }
-      if constexpr (!EXITS && GS_FENCE >= 2) sched_fence(); /* the next row's unpack (= its vmcnt wait) stays down here */
+      if constexpr (!EXITS) sched_fence(); /* the next row's unpack (= its vmcnt wait) stays down here */
       uint32_t U[12];
       strip_unpack(raw, U);
       S.store(y0 + i - 1, i > 0 && i <= nrows, fin(o_prev, y0 + i - 1));
-      if constexpr (DEPTH == 2) {
-        raw = raw2;
-        raw2 = S.load(y0 + i + lead + 2);
-      } else {
-        raw = S.load(y0 + i + lead + 1);
-      }
+      raw = S.load(y0 + i + lead + 1);
       fin.prefetch(y0 + i);
-      if constexpr (!EXITS && GS_FENCE >= 1) sched_fence(); /* one big block: keep the loads ahead of the arithmetic */
+      if constexpr (!EXITS) sched_fence(); /* one big block: keep the loads ahead of the arithmetic */
       o_prev = body(I, i, U);
     });
   }

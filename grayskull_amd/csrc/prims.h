@@ -191,13 +191,9 @@ GS_DEV uint32_t pk_mad_u16(uint32_t a, uint32_t b, uint32_t c) { return GS_R((gs
 /* 2*a + c per half in ONE v_pk_mad_u16 (hipcc strength-reduces a*2+c into shift+add, so spell it;
  * pure VALU register op: no memory, no hazard beyond what hipcc pads around asm) */
 GS_DEV uint32_t pk_mad2_u16(uint32_t a, uint32_t c) {
-#ifdef GS_NO_MAD
-  return GS_R((gs_u16x2)(GS_U2(a) + GS_U2(a) + GS_U2(c)));
-#else
   uint32_t d;
   asm("v_pk_mad_u16 %0, %1, 2, %2 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(c));
   return d;
-#endif
 }
 /* the instruction scheduler moves nothing across this point (keeps a prefetch where it was put) */
 GS_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
