@@ -60,7 +60,7 @@ enum Slot { SL_IN = 0, SL_OUT, SL_AUX, SL_AUX2, SL_II, SL_PAD, SL_MASK, SL_CNT, 
             SL_BEST, SL_COUNT };
 
 /* gsh_edge_pipeline_batch: frames per chunk (measured best for 64..512-frame batches of 4K frames:
- * profiles/r01f_chunk_overlap.log) and the most chunks per call */
+ * profiles/r01g_chunk_overlap.log) and the most chunks per call */
 constexpr unsigned kChunkFrames = 32, kMaxChunks = 64;
 struct Ctx {
   int device = 0;
@@ -893,16 +893,26 @@ void gsh_edge_pipeline_batch(uint8_t *dst, uint8_t *tmp, const uint8_t *src, uns
      * gsh_tune key 5: frames per chunk (0 = default, negative = never split). */
     const int tune_chunk = g_tune[5];
     const unsigned per = tune_chunk < 0 ? n : tune_chunk > 0 ? (unsigned)tune_chunk : kChunkFrames;
-    const StripCfg c = strip_cfg(w, h - 2, std::min(std::min(kMaxZ, n), per), 3); /* <= 168 VGPRs: 3 waves per SIMD */
-    const unsigned bpf = c.grid.x * c.grid.y;
-    unsigned *partial = (unsigned *)ctx().scratch(SL_HISTP, (size_t)n * bpf * 256 * 4);
+    /* chunk sizes: `per` frames each.  (Tapering the tail -- 16, 8, 8 -- so that less of the last
+     * threshold pass is exposed measured slower: small fused launches cost more than they hide.) */
+    std::vector<unsigned> sizes;
+    for (unsigned rem = n; rem; rem -= std::min(rem, per)) sizes.push_back(std::min(rem, per));
+    /* band height per chunk size (a smaller chunk needs more bands to fill the chip) */
+    auto cfg_for = [&](unsigned nn) { return strip_cfg(w, h - 2, std::min(kMaxZ, nn), 3); /* <= 168 VGPRs: 3 waves per SIMD */ };
+    unsigned bpf_max = 0;
+    for (unsigned nn : sizes) {
+      const StripCfg c = cfg_for(nn);
+      bpf_max = std::max(bpf_max, c.grid.x * c.grid.y);
+    }
+    unsigned *partial = (unsigned *)ctx().scratch(SL_HISTP, (size_t)n * bpf_max * 256 * 4);
     auto run_fused = [&](hipStream_t on, unsigned f0, unsigned nn) {
+      const StripCfg c = cfg_for(nn);
       for (unsigned g0 = f0; g0 < f0 + nn; g0 += kMaxZ) {
         const unsigned m = std::min(kMaxZ, f0 + nn - g0);
         const dim3 grid(c.grid.x, c.grid.y, m);
         uint8_t *d = dst + fb * g0;
         const uint8_t *sp = src + fb * g0;
-        unsigned *pp = partial + (size_t)g0 * bpf * 256;
+        unsigned *pp = partial + (size_t)g0 * bpf_max * 256;
 #ifndef GS_EMU
         ctx().prof_mark(0, on);
 #endif
@@ -913,9 +923,11 @@ void gsh_edge_pipeline_batch(uint8_t *dst, uint8_t *tmp, const uint8_t *src, uns
       }
     };
     auto run_rest = [&](hipStream_t on, unsigned f0, unsigned nn) {
+      const StripCfg c = cfg_for(nn);
+      const unsigned bpf = c.grid.x * c.grid.y;
       for (unsigned g0 = f0; g0 < f0 + nn; g0 += kMaxZ) {
         const unsigned m = std::min(kMaxZ, f0 + nn - g0);
-        const unsigned *pp = partial + (size_t)g0 * bpf * 256;
+        const unsigned *pp = partial + (size_t)g0 * bpf_max * 256;
         /* the 2w + 2(h-2) frame pixels are 0 in the result and were not counted by the kernel */
         GS_LAUNCH(k_hist_reduce, dim3(m), dim3(256), 0, on, pp, bpf, hist_scratch + (size_t)g0 * 256,
                   2 * w + 2 * (h - 2));
@@ -926,11 +938,10 @@ void gsh_edge_pipeline_batch(uint8_t *dst, uint8_t *tmp, const uint8_t *src, uns
       }
       launch_threshold(dst + fb * f0, fb, nn, thr + f0, 0, on);
     };
-    const unsigned chunks = (n + per - 1) / per;
 #ifdef GS_EMU
     const bool split = false;
 #else
-    const bool split = chunks > 1 && chunks <= kMaxChunks;
+    const bool split = sizes.size() > 1 && sizes.size() <= kMaxChunks;
 #endif
     if (!split) {
       run_fused(st, 0, n);
@@ -940,11 +951,11 @@ void gsh_edge_pipeline_batch(uint8_t *dst, uint8_t *tmp, const uint8_t *src, uns
 #ifndef GS_EMU
     Ctx &cx = ctx();
     cx.ensure_side();
-    unsigned i = 0;
-    for (unsigned f0 = 0; f0 < n; f0 += per, i++) {
-      const unsigned nn = std::min(per, n - f0);
+    unsigned f0 = 0;
+    for (size_t i = 0; i < sizes.size(); i++) {
+      const unsigned nn = sizes[i];
       run_fused(st, f0, nn);
-      if (f0 + per >= n) { /* last chunk: nothing left to hide it under; rejoin the caller's stream */
+      if (i + 1 == sizes.size()) { /* last chunk: nothing left to hide it under; rejoin the caller's stream */
         GS_HIP(hipEventRecord(cx.ev_join, cx.side));
         GS_HIP(hipStreamWaitEvent(st, cx.ev_join, 0));
         run_rest(st, f0, nn);
@@ -953,6 +964,7 @@ void gsh_edge_pipeline_batch(uint8_t *dst, uint8_t *tmp, const uint8_t *src, uns
         GS_HIP(hipStreamWaitEvent(cx.side, cx.ev_chunk[i], 0));
         run_rest(cx.side, f0, nn);
       }
+      f0 += nn;
     }
 #endif
     return;

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""config-2 pipeline: batch size x frames per chunk of the side-stream overlap (gsh_tune key 5)"""
+"""config-2 pipeline: batch size x chunking of the side-stream overlap (gsh_tune key 5:
+-1 never split, N fixed N-frame chunks, 0 default = 32-frame chunks with a tapered tail)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -18,11 +19,12 @@ for F in [int(x) for x in os.environ.get("UB_F", "64,128,256,512").split(",")]:
     hist = torch.zeros((F, 256), dtype=torch.int32, device="cuda"); thr = torch.zeros((F,), dtype=torch.uint8, device="cuda")
     ref = None
     for rnd in range(2):
-        for per in [int(x) for x in os.environ.get("UB_PER", "-1,32,64,128").split(",")]:
+        for per in [int(x) for x in os.environ.get("UB_PER", "-1,32,64,0").split(",")]:
             if per > 0 and per >= F: continue
             g.tune(5, per)
             ms = timeit(lambda: g.edge_pipeline_batch(dst, None, src, 2, hist, thr))
             cs = int(dst.view(torch.int32).sum().item()) & 0xffffffff
             if ref is None: ref = cs
-            print("frames %4d per-chunk %4d  %.4f ms  %.0f Mpix/s  %s" % (F, per, ms, F * W * H / ms / 1e3, "ok" if cs == ref else "MISMATCH"))
+            print("frames %4d chunking %4d  %.4f ms  %.0f Mpix/s  %s" % (F, per, ms, F * W * H / ms / 1e3, "ok" if cs == ref else "MISMATCH"))
     del src, dst
+g.tune(5, 0)
