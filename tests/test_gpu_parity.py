@@ -284,6 +284,45 @@ def test_orb_pyramid_device_resident(hip, oracle, shape, levels, nkps):
     pc.orb_pyramid(hip, oracle, Oracle.synth(w, h, 21), pc.Mem("device"), nkps=nkps, levels=levels)
 
 
+def test_two_host_threads_share_the_library(hip, oracle):
+    """SURVEY 8(b) threading: thread-safe per calling thread (thread-local context + stream).  Two
+    host threads run different call chains at the same time on their own images."""
+    import threading
+    import torch
+    imgs = [Oracle.synth(640, 480, 300 + i) for i in range(2)]
+    out, err = [None, None], []
+
+    def work(i):
+        try:
+            src = torch.from_numpy(imgs[i]).cuda()
+            a, b = torch.zeros_like(src), torch.zeros_like(src)
+            for _ in range(20):
+                if i == 0:
+                    hip.blur(a, src, 2)
+                    hip.sobel(b, a)
+                    t = hip.otsu_threshold(b)
+                    hip.threshold(b, t)
+                else:
+                    hip.erode(a, src)
+                    hip.dilate(b, a)
+                    ii = torch.zeros((480, 640), dtype=torch.int32, device="cuda")
+                    hip.integral(b, ii)
+            hip.sync()
+            out[i] = (b.cpu().numpy(), None if i == 0 else ii.cpu().numpy().view(np.uint32))
+        except Exception as e:  # pragma: no cover
+            err.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not err, err
+    s = oracle.sobel(oracle.blur(imgs[0], 2))
+    assert_same(out[0][0], oracle.threshold(s, oracle.otsu_threshold(s)), "thread 0 chain")
+    d = oracle.dilate(oracle.erode(imgs[1]))
+    assert_same(out[1][0], d, "thread 1 chain")
+    assert_same(out[1][1], oracle.integral(d), "thread 1 integral")
+
+
 def test_pipeline_chunk_overlap(hip, oracle):
     """gsh_edge_pipeline_batch cuts big batches into chunks whose threshold pass runs on a side
     stream under the next chunk's fused kernel: same bytes for every chunking, ragged last chunk,
