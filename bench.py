@@ -176,7 +176,7 @@ def main():
             "accounting": "unfused per-call sum, 5 B/px (SURVEY 8d); the launch itself reads 1 and writes 1 B/px",
             "algorithmic_bytes_per_launch": percall, "avg_launch_ms": round(fms, 4), "frames_per_launch": fpl,
             "actual_io": {"bytes_per_px": 2, "GB/s": ktab[fk]["GB/s"], "frac": ktab[fk]["frac"],
-                          "note": "VALU-bound (266 lane-ops per 16 px + 16 LDS atomics; VALU busy 86 %, profiles/r01e_fused_sq_counters.txt)"},
+                          "note": "VALU-bound (257 lane-ops per 16 px + 16 LDS atomics; VALU busy 86 %, profiles/r01e_fused_sq_counters.txt)"},
             "per_call_kernels": {k: ktab[k]["frac"] for k in ktab if k != fk},
             "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc, corrected per MI355X_MICROARCH.md)" if pmc else None}
 

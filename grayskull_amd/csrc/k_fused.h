@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void k_blur_sobel_hist16(uint8_t *dst, const u
     }
     blurred(y0, UB1);
     st.init(UB0, UB1);
-    const uint32_t cb2 = (copy << 2) * 0x10001u; /* this lane's histogram copy, as a pair of byte offsets */
+    const uint32_t cb = copy << 2; /* byte offset of this lane's histogram copy inside a bin */
 
     strip_rows<NS, false, /*EXITS=*/false>(S, y0, nrows, R + 1, S.load(y0 + R + 1), [&](auto I, int i, const uint32_t(&U)[12]) {
       /* iteration I, SPARE: slot I+1 is free (its row left last iteration), slot I+2 holds the
@@ -137,15 +137,13 @@ __global__ __launch_bounds__(256) void k_blur_sobel_hist16(uint8_t *dst, const u
       if constexpr (NS % 2 == 0) o = st.template step<decltype(I)::value & 1>(UB, M);
       else o = st.step_shift(UB, M);
       /* histogram, branch-free: lanes outside the image, the two frame columns and the dropped
-       * rows of the last group add 0.  LDS byte offsets bin*128 + copy*4 for both pixels of a
-       * pair come from one v_pk_mad_u16. */
+       * rows of the last group add 0. */
       const unsigned inc = (inimg && i < nrows) ? 1u : 0u;
       const unsigned inc0 = first ? 0u : inc, inc15 = last ? 0u : inc;
 #pragma unroll
-      for (int k = 0; k < 8; k++) {
-        const uint32_t a2 = pk_mad_u16_s(M[k], 0x00800080u, cb2);
-        atomicAdd((unsigned *)((char *)lh + (a2 & 0xffffu)), k == 0 ? inc0 : inc);
-        atomicAdd((unsigned *)((char *)lh + (a2 >> 16)), k == 7 ? inc15 : inc);
+      for (int k = 0; k < 8; k++) { /* LDS byte offset = bin*128 + copy*4, straight from either half of the pair */
+        atomicAdd((unsigned *)((char *)lh + mad_u32_u16_lo(M[k], 128u, cb)), k == 0 ? inc0 : inc);
+        atomicAdd((unsigned *)((char *)lh + mad_u32_u16_hi(M[k], 128u, cb)), k == 7 ? inc15 : inc);
       }
       return o;
     });

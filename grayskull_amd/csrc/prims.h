@@ -109,6 +109,8 @@ GS_DEV uint32_t pk_mul_u16(uint32_t a, uint32_t b) { return GS_PK2((a & 0xffff) 
 GS_DEV uint32_t pk_mad_u16(uint32_t a, uint32_t b, uint32_t c) { return GS_PK2((a & 0xffff) * (b & 0xffff) + (c & 0xffff), (a >> 16) * (b >> 16) + (c >> 16)); }
 GS_DEV uint32_t pk_mad2_u16(uint32_t a, uint32_t c) { return GS_PK2(2 * (a & 0xffff) + (c & 0xffff), 2 * (a >> 16) + (c >> 16)); }
 GS_DEV uint32_t pk_mad_u16_s(uint32_t a, uint32_t b, uint32_t c) { return pk_mad_u16(a, b, c); }
+GS_DEV uint32_t mad_u32_u16_lo(uint32_t a, uint32_t b, uint32_t c) { return (a & 0xffffu) * (b & 0xffffu) + c; }
+GS_DEV uint32_t mad_u32_u16_hi(uint32_t a, uint32_t b, uint32_t c) { return (a >> 16) * (b & 0xffffu) + c; }
 GS_DEV void sched_fence() {}
 GS_DEV uint32_t pk_shl_u16(uint32_t a, unsigned s) { return GS_PK2((a & 0xffff) << s, (a >> 16) << s); }
 GS_DEV uint32_t pk_shr_u16(uint32_t a, unsigned s) { return GS_PK2((a & 0xffff) >> s, (a >> 16) >> s); }
@@ -202,6 +204,18 @@ GS_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 GS_DEV uint32_t pk_mad_u16_s(uint32_t a, uint32_t b, uint32_t c) {
   uint32_t d;
   asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b), "v"(c));
+  return d;
+}
+/* (low | high half of a) * (low half of the wave-uniform b) + c as a full 32-bit result: one
+ * v_mad_u32_u16 with op_sel picking the half -- no separate extraction of the u16 */
+GS_DEV uint32_t mad_u32_u16_lo(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t d;
+  asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[0,0,0,0]" : "=v"(d) : "v"(a), "s"(b), "v"(c));
+  return d;
+}
+GS_DEV uint32_t mad_u32_u16_hi(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t d;
+  asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(d) : "v"(a), "s"(b), "v"(c));
   return d;
 }
 GS_DEV uint32_t pk_shl_u16(uint32_t a, unsigned s) { return GS_R((gs_u16x2)(GS_U2(a) << (unsigned short)s)); } /* v_pk_lshlrev_b16 */
