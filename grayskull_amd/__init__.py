@@ -17,7 +17,7 @@ import os
 
 import numpy as np
 
-from ._abi import (GsImage, GsLbpCascade, KEYPOINT_DTYPE, MATCH_DTYPE, RECT_DTYPE)
+from ._abi import (GsImage, GsLbpCascade, GsPoint, GsRect, KEYPOINT_DTYPE, MATCH_DTYPE, RECT_DTYPE)
 from .cascade import Cascade
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -72,6 +72,12 @@ _SIGS = {
     "gs_adaptive_threshold": (None, [GsImage, GsImage, C.c_uint, C.c_int]),
     "gs_filter": (None, [GsImage, GsImage, GsImage, C.c_uint]),
     "gs_downsample": (None, [GsImage, GsImage]),
+    "gs_crop": (None, [GsImage, GsImage, GsRect]),
+    "gs_copy": (None, [GsImage, GsImage]),
+    "gs_resize_nn": (None, [GsImage, GsImage]),
+    "gs_resize": (None, [GsImage, GsImage]),
+    "gs_match_template": (None, [GsImage, GsImage, GsImage]),
+    "gs_find_best_match": (GsPoint, [GsImage]),
     # runtime + batch (include/grayskull_hip.h)
     "gsh_version": (C.c_char_p, []),
     "gsh_device_count": (C.c_int, []),
@@ -217,6 +223,22 @@ class Grayskull:
 
     def downsample(self, dst, src):  # grayskull.h:189
         self.c.gs_downsample(_img(dst), _img(src))
+
+    def crop(self, dst, src, x, y, w, h):  # grayskull.h:154
+        self.c.gs_crop(_img(dst), _img(src), GsRect(x, y, w, h))
+
+    def copy(self, dst, src):  # grayskull.h:160
+        self.c.gs_copy(_img(dst), _img(src))
+
+    def resize(self, dst, src, nearest=False):  # grayskull.h:171 / :164
+        (self.c.gs_resize_nn if nearest else self.c.gs_resize)(_img(dst), _img(src))
+
+    def match_template(self, img, tmpl, result):  # grayskull.h:705
+        self.c.gs_match_template(_img(img), _img(tmpl), _img(result))
+
+    def find_best_match(self, result):  # grayskull.h:726
+        p = self.c.gs_find_best_match(_img(result))
+        return int(p.x), int(p.y)
 
     def integral(self, src, ii=None):  # grayskull.h:744
         if ii is None:

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "k_fast.h"
+#include "k_geom.h"
 #include "k_integral.h"
 #include "k_lbp.h"
 #include "k_orb.h"
@@ -1306,6 +1307,77 @@ void gs_downsample(struct gs_image dst, struct gs_image src) { /* ref :189 */
   gsh_downsample_batch(d, s, src.w, src.h, 1);
   if (dhost) GS_HIP(hipMemcpyAsync(dst.data, d, db, hipMemcpyDeviceToHost, ctx().s()));
   finish(dhost);
+}
+
+/* ---- geometry + template matching ------------------------------------------ */
+void gs_crop(struct gs_image dst, struct gs_image src, struct gs_rect roi) { /* ref :154 */
+  GS_ASSERT(GS_VALID(dst) && GS_VALID(src) && roi.x + roi.w <= src.w && roi.y + roi.h <= src.h &&
+            dst.w == roi.w && dst.h == roi.h);
+  const size_t nb = (size_t)src.w * src.h, db = (size_t)dst.w * dst.h;
+  const uint8_t *s = (const uint8_t *)stage_in(src.data, nb, SL_IN);
+  const bool dhost = !is_dev(dst.data);
+  uint8_t *d = dhost ? (uint8_t *)ctx().scratch(SL_OUT, db) : dst.data;
+  GS_LAUNCH(k_crop, dim3((roi.w + 63) / 64, (roi.h + 3) / 4), dim3(64, 4), 0, ctx().s(), d, dst.w, dst.h, s,
+            src.w, src.h, roi.x, roi.y, roi.w, roi.h);
+  if (dhost) GS_HIP(hipMemcpyAsync(dst.data, d, db, hipMemcpyDeviceToHost, ctx().s()));
+  finish(dhost);
+}
+void gs_copy(struct gs_image dst, struct gs_image src) { /* ref :160 */
+  const struct gs_rect all = {0, 0, src.w, src.h};
+  gs_crop(dst, src, all);
+}
+static void resize_common(struct gs_image dst, struct gs_image src, bool nearest) {
+  const size_t nb = (size_t)src.w * src.h, db = (size_t)dst.w * dst.h;
+  const uint8_t *s = (const uint8_t *)stage_in(src.data, nb, SL_IN);
+  const bool dhost = !is_dev(dst.data);
+  uint8_t *d = dhost ? (uint8_t *)ctx().scratch(SL_OUT, db) : dst.data;
+  const dim3 g((dst.w + 63) / 64, (dst.h + 3) / 4);
+  if (nearest) GS_LAUNCH(k_resize_nn, g, dim3(64, 4), 0, ctx().s(), d, dst.w, dst.h, s, src.w, src.h);
+  else GS_LAUNCH(k_resize, g, dim3(64, 4), 0, ctx().s(), d, dst.w, dst.h, s, src.w, src.h);
+  if (dhost) GS_HIP(hipMemcpyAsync(dst.data, d, db, hipMemcpyDeviceToHost, ctx().s()));
+  finish(dhost);
+}
+void gs_resize_nn(struct gs_image dst, struct gs_image src) { /* ref :164 (asserts nothing there) */
+  GS_ASSERT(GS_VALID(dst) && GS_VALID(src));
+  resize_common(dst, src, true);
+}
+void gs_resize(struct gs_image dst, struct gs_image src) { /* ref :171 */
+  GS_ASSERT(GS_VALID(dst) && GS_VALID(src));
+  resize_common(dst, src, false);
+}
+void gs_match_template(struct gs_image img, struct gs_image tmpl, struct gs_image result) { /* ref :705 */
+  GS_ASSERT(GS_VALID(img) && GS_VALID(tmpl) && GS_VALID(result));
+  GS_ASSERT(img.w >= tmpl.w && img.h >= tmpl.h);
+  GS_ASSERT(result.w == img.w - tmpl.w + 1 && result.h == img.h - tmpl.h + 1);
+  const size_t ib = (size_t)img.w * img.h, tb = (size_t)tmpl.w * tmpl.h, rb = (size_t)result.w * result.h;
+  const uint8_t *s = (const uint8_t *)stage_in(img.data, ib, SL_IN);
+  const uint8_t *t = (const uint8_t *)stage_in(tmpl.data, tb, SL_AUX);
+  const bool dhost = !is_dev(result.data);
+  uint8_t *d = dhost ? (uint8_t *)ctx().scratch(SL_OUT, rb) : result.data;
+  GS_LAUNCH(k_match_template, dim3((result.w + 63) / 64, (result.h + 3) / 4), dim3(64, 4),
+            std::min<size_t>(tb, kTmplTile), ctx().s(), s, img.w, img.h, t, tmpl.w, tmpl.h, d, result.w,
+            result.h);
+  if (dhost) GS_HIP(hipMemcpyAsync(result.data, d, rb, hipMemcpyDeviceToHost, ctx().s()));
+  finish(dhost);
+}
+struct gs_point gs_find_best_match(struct gs_image result) { /* ref :726 */
+  GS_ASSERT(GS_VALID(result));
+  const unsigned long long n = (unsigned long long)result.w * result.h;
+  const uint8_t *s = (const uint8_t *)stage_in(result.data, (size_t)n, SL_IN);
+  const unsigned blocks = (unsigned)((n + 2047) / 2048);
+  unsigned long long *part = (unsigned long long *)ctx().scratch(SL_PFX, (size_t)blocks * 8);
+  GS_LAUNCH(k_argmax_first, dim3(blocks), dim3(256), 0, ctx().s(), s, n, part);
+  std::vector<unsigned long long> hp(blocks);
+  GS_HIP(hipMemcpyAsync(hp.data(), part, (size_t)blocks * 8, hipMemcpyDeviceToHost, ctx().s()));
+  ctx().sync();
+  unsigned long long best = 0;
+  for (unsigned long long k : hp) best = std::max(best, k);
+  struct gs_point p = {0, 0};
+  if (best >> 32) { /* a zero maximum leaves the reference's initial {0,0} */
+    const unsigned idx = 0xffffffffu - (unsigned)(best & 0xffffffffu);
+    p.x = idx % result.w, p.y = idx / result.w;
+  }
+  return p;
 }
 
 void gs_histogram(struct gs_image img, unsigned hist[256]) { /* ref :199 */

@@ -1,0 +1,129 @@
+/*
+ * k_geom.h -- SURVEY.md 8(f) rank 4: gs_crop / gs_copy (grayskull.h:154-162), gs_resize_nn (:164-169),
+ * gs_resize (:171-187), gs_match_template (:705-724), gs_find_best_match (:726-739).
+ * One thread per output pixel; byte accesses coalesce along x.  Not tuned: none of BASELINE.json's
+ * configurations is bounded by them.
+ */
+#ifndef GS_K_GEOM_H
+#define GS_K_GEOM_H
+#include "prims.h"
+
+namespace gs {
+
+/* gs_get (ref :143-145): 0 outside the image */
+GS_DEV unsigned geom_px(const uint8_t *img, unsigned w, unsigned h, unsigned x, unsigned y) {
+  return (x < w && y < h) ? img[(size_t)y * w + x] : 0u;
+}
+
+/* grid (ceil(rw/64), ceil(rh/4)), block (64,4): dst(x,y) = src(rx+x, ry+y), dropped outside dst */
+__global__ __launch_bounds__(256) void k_crop(uint8_t *dst, unsigned dw, unsigned dh, const uint8_t *src,
+                                              unsigned sw, unsigned sh, unsigned rx, unsigned ry,
+                                              unsigned rw, unsigned rh) {
+  const unsigned x = blockIdx.x * 64u + threadIdx.x, y = blockIdx.y * 4u + threadIdx.y;
+  if (x >= rw || y >= rh || x >= dw || y >= dh) return;
+  dst[(size_t)y * dw + x] = (uint8_t)geom_px(src, sw, sh, rx + x, ry + y);
+}
+
+/* NN: the reference's unsigned index arithmetic (x * sw wraps like its u32 does) */
+__global__ __launch_bounds__(256) void k_resize_nn(uint8_t *dst, unsigned dw, unsigned dh, const uint8_t *src,
+                                                   unsigned sw, unsigned sh) {
+  const unsigned x = blockIdx.x * 64u + threadIdx.x, y = blockIdx.y * 4u + threadIdx.y;
+  if (x >= dw || y >= dh) return;
+  const unsigned sx = x * sw / dw, sy = y * sh / dh;
+  dst[(size_t)y * dw + x] = (uint8_t)geom_px(src, sw, sh, sx, sy);
+}
+
+/* bilinear: float32, operation for operation like ref :173-185 (no FMA contraction: the library is
+ * built -ffp-contract=off); unsigned -> float conversions where the reference's C has them */
+__global__ __launch_bounds__(256) void k_resize(uint8_t *dst, unsigned dw, unsigned dh, const uint8_t *src,
+                                                unsigned sw, unsigned sh) {
+#ifndef GS_EMU
+#pragma clang fp contract(off)
+#endif
+  const unsigned x = blockIdx.x * 64u + threadIdx.x, y = blockIdx.y * 4u + threadIdx.y;
+  if (x >= dw || y >= dh) return;
+  float sx = ((float)x + 0.5f) * (float)sw / (float)dw - 0.5f;
+  float sy = ((float)y + 0.5f) * (float)sh / (float)dh - 0.5f;
+  const float mx = (float)sw - 1.0f, my = (float)sh - 1.0f;
+  sx = sx < mx ? sx : mx, sx = 0.0f > sx ? 0.0f : sx;
+  sy = sy < my ? sy : my, sy = 0.0f > sy ? 0.0f : sy;
+  const unsigned xi = (unsigned)sx, yi = (unsigned)sy;
+  const unsigned x1 = xi + 1 < sw - 1 ? xi + 1 : sw - 1, y1 = yi + 1 < sh - 1 ? yi + 1 : sh - 1;
+  const float dx = sx - (float)xi, dy = sy - (float)yi;
+  const int c00 = (int)geom_px(src, sw, sh, xi, yi), c01 = (int)geom_px(src, sw, sh, x1, yi);
+  const int c10 = (int)geom_px(src, sw, sh, xi, y1), c11 = (int)geom_px(src, sw, sh, x1, y1);
+  const float p = ((float)c00 * (1 - dx) * (1 - dy)) + ((float)c01 * dx * (1 - dy)) +
+                  ((float)c10 * (1 - dx) * dy) + ((float)c11 * dx * dy);
+  dst[(size_t)y * dw + x] = (uint8_t)(int)p; /* float -> uint8_t truncation (value < 256) */
+}
+
+/* SSD per offset.  grid (ceil(rw/64), ceil(rh/4)), block (64,4); the template is staged in LDS in
+ * tiles of up to 16 KiB (dynamic LDS = min(tw*th, 16384) bytes) so its reads are broadcasts.
+ * Sums: a row of up to 65535 taps of <= 65025 fits 32 bits only up to 66051 taps, so rows are
+ * accumulated in 64 bits every 4096 taps. */
+constexpr unsigned kTmplTile = 16384;
+__global__ __launch_bounds__(256) void k_match_template(const uint8_t *img, unsigned iw, unsigned ih,
+                                                        const uint8_t *tmpl, unsigned tw, unsigned th,
+                                                        uint8_t *result, unsigned rw, unsigned rh) {
+  GS_DYN_LDS(smem);
+  uint8_t *lt = (uint8_t *)smem;
+  const unsigned tid = threadIdx.y * 64u + threadIdx.x;
+  const unsigned rx = blockIdx.x * 64u + threadIdx.x, ry = blockIdx.y * 4u + threadIdx.y;
+  const bool live = rx < rw && ry < rh;
+  const unsigned long long ntaps = (unsigned long long)tw * th;
+  unsigned long long sum = 0;
+  for (unsigned long long t0 = 0; t0 < ntaps; t0 += kTmplTile) { /* block-uniform */
+    const unsigned nt = (unsigned)(ntaps - t0 < kTmplTile ? ntaps - t0 : kTmplTile);
+    __syncthreads();
+    for (unsigned i = tid; i < nt; i += 256u) lt[i] = tmpl[t0 + i];
+    __syncthreads();
+    if (live) {
+      unsigned ty = (unsigned)(t0 / tw), tx = (unsigned)(t0 - (unsigned long long)ty * tw);
+      unsigned acc = 0, run = 0;
+      for (unsigned i = 0; i < nt; i++) {
+        const int d = (int)geom_px(img, iw, ih, rx + tx, ry + ty) - (int)lt[i];
+        acc += (unsigned)(d * d);
+        if (++run == 4096u) sum += acc, acc = 0, run = 0;
+        if (++tx == tw) tx = 0, ty++;
+      }
+      sum += acc;
+    }
+  }
+  if (!live) return;
+  const unsigned long long max_diff = ntaps * 255ULL * 255ULL;
+  const unsigned long long score = sum * 255ULL / max_diff;
+  result[(size_t)ry * rw + rx] = (uint8_t)(255u - (unsigned)(score < 255ULL ? score : 255ULL));
+}
+
+/* gs_find_best_match: key = value << 32 | ~index: the maximum key is the largest value at the
+ * LOWEST raster index (the reference's strict '>' keeps the first maximum).  grid ceil(n/2048)
+ * blocks of 256, 8 items per thread; out[blockIdx.x] = block maximum; the host (or a second
+ * launch over `out`) finishes.  A zero maximum means (0,0) like the reference's initial state. */
+__global__ __launch_bounds__(256) void k_argmax_first(const uint8_t *v, unsigned long long n,
+                                                      unsigned long long *out) {
+  __shared__ unsigned long long part[4];
+  unsigned long long best = 0;
+  for (unsigned k = 0; k < 8; k++) {
+    const unsigned long long i = ((unsigned long long)blockIdx.x * 8u + k) * 256u + threadIdx.x;
+    if (i < n) {
+      const unsigned long long key = ((unsigned long long)v[i] << 32) | (0xffffffffu - (unsigned)i);
+      best = key > best ? key : best;
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const uint32_t lo = shfl((uint32_t)best, (int)(lane_id() ^ (unsigned)d));
+    const uint32_t hi = shfl((uint32_t)(best >> 32), (int)(lane_id() ^ (unsigned)d));
+    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+    best = o > best ? o : best;
+  }
+  if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int q = 1; q < 4; q++) best = part[q] > best ? part[q] : best;
+    out[blockIdx.x] = best;
+  }
+}
+
+}  // namespace gs
+#endif

@@ -130,6 +130,15 @@ GS_API void gs_filter(struct gs_image dst, struct gs_image src, struct gs_image 
                       unsigned norm);                                           /* ref :255 */
 GS_API void gs_downsample(struct gs_image dst, struct gs_image src);            /* ref :189 */
 
+/* ---- geometry helpers and template matching ----------------------- */
+GS_API void gs_crop(struct gs_image dst, struct gs_image src, struct gs_rect roi); /* ref :154 */
+GS_API void gs_copy(struct gs_image dst, struct gs_image src);                  /* ref :160 */
+GS_API void gs_resize_nn(struct gs_image dst, struct gs_image src);             /* ref :164 */
+GS_API void gs_resize(struct gs_image dst, struct gs_image src);                /* ref :171, float32 bilinear */
+GS_API void gs_match_template(struct gs_image img, struct gs_image tmpl,
+                              struct gs_image result);                          /* ref :705 */
+GS_API struct gs_point gs_find_best_match(struct gs_image result);              /* ref :726 */
+
 /* 3x3 kernels for gs_filter, as the reference spells them (ref :249-253) */
 #define gs_sharpen ((struct gs_image){3, 3, (uint8_t[]){0, -1, 0, -1, 5, -1, 0, -1, 0}})
 #define gs_emboss ((struct gs_image){3, 3, (uint8_t[]){-2, -1, 0, -1, 1, 1, 0, 1, 2}})

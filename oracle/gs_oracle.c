@@ -188,6 +188,72 @@ void orc_downsample(uint8_t *dst, const uint8_t *src, unsigned sw, unsigned sh) 
     }
 }
 
+/* ---------------------------------------------------------------- geometry + template matching */
+/* ref :154-158 -- copy the roi (gs_get: 0 outside src; gs_set: dropped outside dst) */
+void orc_crop(uint8_t *dst, unsigned dw, unsigned dh, const uint8_t *src, unsigned sw, unsigned sh,
+              unsigned rx, unsigned ry, unsigned rw, unsigned rh) {
+  for (unsigned y = 0; y < rh; y++)
+    for (unsigned x = 0; x < rw; x++)
+      if (x < dw && y < dh) dst[(size_t)y * dw + x] = px(src, sw, sh, rx + x, ry + y);
+}
+
+/* ref :164-169 -- nearest neighbour, integer index arithmetic (unsigned, may wrap for huge sizes) */
+void orc_resize_nn(uint8_t *dst, unsigned dw, unsigned dh, const uint8_t *src, unsigned sw, unsigned sh) {
+  for (unsigned y = 0; y < dh; y++)
+    for (unsigned x = 0; x < dw; x++) {
+      unsigned sx = x * sw / dw, sy = y * sh / dh;
+      dst[(size_t)y * dw + x] = px(src, sw, sh, sx, sy);
+    }
+}
+
+/* ref :171-187 -- bilinear, float32, pixel centres at +0.5; every operation is a float op in the
+ * reference's order (unsigned -> float conversions included), the result truncates to uint8 */
+void orc_resize(uint8_t *dst, unsigned dw, unsigned dh, const uint8_t *src, unsigned sw, unsigned sh) {
+  for (unsigned y = 0; y < dh; y++)
+    for (unsigned x = 0; x < dw; x++) {
+      float sx = ((float)x + 0.5f) * sw / dw - 0.5f;
+      float sy = ((float)y + 0.5f) * sh / dh - 0.5f;
+      float mx = sw - 1.0f, my = sh - 1.0f;
+      sx = sx < mx ? sx : mx, sx = 0.0f > sx ? 0.0f : sx;
+      sy = sy < my ? sy : my, sy = 0.0f > sy ? 0.0f : sy;
+      unsigned xi = (unsigned)sx, yi = (unsigned)sy;
+      unsigned x1 = xi + 1 < sw - 1 ? xi + 1 : sw - 1, y1 = yi + 1 < sh - 1 ? yi + 1 : sh - 1;
+      float dx = sx - xi, dy = sy - yi;
+      uint8_t c00 = px(src, sw, sh, xi, yi), c01 = px(src, sw, sh, x1, yi),
+              c10 = px(src, sw, sh, xi, y1), c11 = px(src, sw, sh, x1, y1);
+      uint8_t p = (c00 * (1 - dx) * (1 - dy)) + (c01 * dx * (1 - dy)) + (c10 * (1 - dx) * dy) +
+                  (c11 * dx * dy);
+      dst[(size_t)y * dw + x] = p;
+    }
+}
+
+/* ref :705-724 -- sum of squared differences per offset, normalised: 255 - min(sum*255/max, 255) */
+void orc_match_template(const uint8_t *img, unsigned iw, unsigned ih, const uint8_t *tmpl, unsigned tw,
+                        unsigned th, uint8_t *result) {
+  unsigned rw = iw - tw + 1, rh = ih - th + 1;
+  unsigned long long max_diff = (unsigned long long)tw * th * 255ULL * 255ULL;
+  for (unsigned ry = 0; ry < rh; ry++)
+    for (unsigned rx = 0; rx < rw; rx++) {
+      unsigned long long sum = 0;
+      for (unsigned ty = 0; ty < th; ty++)
+        for (unsigned tx = 0; tx < tw; tx++) {
+          int d = (int)px(img, iw, ih, rx + tx, ry + ty) - (int)tmpl[(size_t)ty * tw + tx];
+          sum += (unsigned long long)(d * d);
+        }
+      unsigned score = (unsigned)(sum * 255ULL / max_diff);
+      result[(size_t)ry * rw + rx] = (uint8_t)(255 - (score < 255 ? score : 255));
+    }
+}
+
+/* ref :726-739 -- first strict maximum in raster order; (0,0) when everything is 0 */
+void orc_find_best_match(const uint8_t *result, unsigned w, unsigned h, unsigned *bx, unsigned *by) {
+  uint8_t best = 0;
+  *bx = 0, *by = 0;
+  for (unsigned y = 0; y < h; y++)
+    for (unsigned x = 0; x < w; x++)
+      if (result[(size_t)y * w + x] > best) best = result[(size_t)y * w + x], *bx = x, *by = y;
+}
+
 /* ---------------------------------------------------------------- integral image */
 /* ref :744-752 -- inclusive, same w x h shape, u32 modular */
 void orc_integral(const uint8_t *src, unsigned w, unsigned h, unsigned *ii) {

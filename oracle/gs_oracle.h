@@ -53,6 +53,15 @@ void orc_filter(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, const 
                 unsigned kw, unsigned kh, unsigned norm);
 void orc_downsample(uint8_t *dst, const uint8_t *src, unsigned sw, unsigned sh);
 
+/* geometry + template matching */
+void orc_crop(uint8_t *dst, unsigned dw, unsigned dh, const uint8_t *src, unsigned sw, unsigned sh,
+              unsigned rx, unsigned ry, unsigned rw, unsigned rh);
+void orc_resize_nn(uint8_t *dst, unsigned dw, unsigned dh, const uint8_t *src, unsigned sw, unsigned sh);
+void orc_resize(uint8_t *dst, unsigned dw, unsigned dh, const uint8_t *src, unsigned sw, unsigned sh);
+void orc_match_template(const uint8_t *img, unsigned iw, unsigned ih, const uint8_t *tmpl, unsigned tw,
+                        unsigned th, uint8_t *result);
+void orc_find_best_match(const uint8_t *result, unsigned w, unsigned h, unsigned *bx, unsigned *by);
+
 /* integral image + LBP cascade */
 void orc_integral(const uint8_t *src, unsigned w, unsigned h, unsigned *ii);
 unsigned orc_integral_sum(const unsigned *ii, unsigned iw, unsigned x, unsigned y, unsigned w,

@@ -37,6 +37,14 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+class GsRect(C.Structure):  # grayskull.h:24
+    _fields_ = [("x", C.c_uint), ("y", C.c_uint), ("w", C.c_uint), ("h", C.c_uint)]
+
+
+class GsPoint(C.Structure):  # grayskull.h:19
+    _fields_ = [("x", C.c_uint), ("y", C.c_uint)]
+
+
 def _img(a):
     h, w = a.shape
     return GsImage(w, h, a.ctypes.data)
@@ -165,6 +173,56 @@ class Oracle:
         else:
             self.lib.gs_downsample(_img(out), _img(src))
         return out
+
+    # ---- geometry + template matching (ref :154-187, :705-739)
+    def crop(self, src, rx, ry, rw, rh):
+        src = np.ascontiguousarray(src, np.uint8)
+        h, w = src.shape
+        out = np.zeros((rh, rw), np.uint8)
+        if self.port:
+            self.lib.orc_crop(_p(out), C.c_uint(rw), C.c_uint(rh), _p(src), C.c_uint(w), C.c_uint(h),
+                              C.c_uint(rx), C.c_uint(ry), C.c_uint(rw), C.c_uint(rh))
+        else:
+            self.lib.gs_crop.argtypes = [GsImage, GsImage, GsRect]
+            self.lib.gs_crop(_img(out), _img(src), GsRect(rx, ry, rw, rh))
+        return out
+
+    def resize(self, src, dw, dh, nearest=False):
+        src = np.ascontiguousarray(src, np.uint8)
+        h, w = src.shape
+        out = np.zeros((dh, dw), np.uint8)
+        if self.port:
+            f = self.lib.orc_resize_nn if nearest else self.lib.orc_resize
+            f(_p(out), C.c_uint(dw), C.c_uint(dh), _p(src), C.c_uint(w), C.c_uint(h))
+        else:
+            f = self.lib.gs_resize_nn if nearest else self.lib.gs_resize
+            f.argtypes = [GsImage, GsImage]
+            f(_img(out), _img(src))
+        return out
+
+    def match_template(self, img, tmpl):
+        img, tmpl = np.ascontiguousarray(img, np.uint8), np.ascontiguousarray(tmpl, np.uint8)
+        (ih, iw), (th, tw) = img.shape, tmpl.shape
+        out = np.zeros((ih - th + 1, iw - tw + 1), np.uint8)
+        if self.port:
+            self.lib.orc_match_template(_p(img), C.c_uint(iw), C.c_uint(ih), _p(tmpl), C.c_uint(tw), C.c_uint(th),
+                                        _p(out))
+        else:
+            self.lib.gs_match_template.argtypes = [GsImage, GsImage, GsImage]
+            self.lib.gs_match_template(_img(img), _img(tmpl), _img(out))
+        return out
+
+    def find_best_match(self, result):
+        result = np.ascontiguousarray(result, np.uint8)
+        h, w = result.shape
+        if self.port:
+            bx, by = C.c_uint(0), C.c_uint(0)
+            self.lib.orc_find_best_match(_p(result), C.c_uint(w), C.c_uint(h), C.byref(bx), C.byref(by))
+            return int(bx.value), int(by.value)
+        self.lib.gs_find_best_match.argtypes = [GsImage]
+        self.lib.gs_find_best_match.restype = GsPoint
+        p = self.lib.gs_find_best_match(_img(result))
+        return int(p.x), int(p.y)
 
     def histogram(self, img):
         img = np.ascontiguousarray(img, np.uint8)

@@ -54,6 +54,40 @@ def orb_pyramid(g, o, img, mem, nkps=90, threshold=20, levels=3, seed=1):
     assert_same(mem.get(buf)[:nb], bo[:nb], "pyramid levels + scoremaps")
 
 
+def geometry(g, o, img, mem, seed=3):
+    """gs_crop/gs_copy, gs_resize_nn, gs_resize (float32 bilinear, bit-exact),
+    gs_match_template + gs_find_best_match"""
+    h, w = img.shape
+    s = mem.put(img)
+    rs = np.random.RandomState(seed)
+    for (rx, ry, rw, rh) in ((0, 0, w, h), (1, 0, max(w - 1, 1), h), (w // 3, h // 2, max(w // 2, 1), max(h // 3, 1))):
+        if rx + rw > w or ry + rh > h:
+            continue
+        d = mem.zeros((rh, rw), fill=SENTINEL)
+        g.crop(d, s, rx, ry, rw, rh)
+        assert_same(mem.get(d), o.crop(img, rx, ry, rw, rh), "gs_crop %s" % ((rx, ry, rw, rh),))
+    d = mem.zeros((h, w), fill=SENTINEL)
+    g.copy(d, s)
+    assert_same(mem.get(d), img, "gs_copy")
+    for (dw, dh) in ((2 * w, 2 * h), (w // 2 + 1, h // 2 + 1), (w, h), (13, 7), (3 * w + 1, 2)):
+        for nn in (False, True):
+            d = mem.zeros((dh, dw), fill=SENTINEL)
+            g.resize(d, s, nn)
+            assert_same(mem.get(d), o.resize(img, dw, dh, nn), "gs_resize%s -> %dx%d" % ("_nn" if nn else "", dw, dh))
+    tmpls = [rs.randint(0, 256, (th, tw)).astype(np.uint8) for (tw, th) in ((3, 3), (max(w // 2, 1), max(h // 2, 1)), (1, 1), (w, h))]
+    if w > 12 and h > 10:
+        tmpls.append(img[2:10, 3:11].copy())  # an exact sub-image: best match at (3, 2) unless repeated
+    for t in tmpls:
+        th, tw = t.shape
+        r = mem.zeros((h - th + 1, w - tw + 1), fill=SENTINEL)
+        g.match_template(s, mem.put(t), r)
+        ro = o.match_template(img, t)
+        assert_same(mem.get(r), ro, "gs_match_template %dx%d" % (tw, th))
+        assert g.find_best_match(r) == o.find_best_match(ro), "gs_find_best_match"
+    z = mem.zeros((5, 7), fill=0)
+    assert g.find_best_match(z) == (0, 0), "gs_find_best_match on all zeros"
+
+
 def stencils(g, o, img, mem, radii=(1, 2, 3, 5)):
     s = mem.put(img)
     for r in radii:

@@ -82,6 +82,13 @@ def test_orb_pyramid(emu, oracle, shape, levels, nkps):
     pc.orb_pyramid(emu, oracle, Oracle.synth(w, h, 21), MEM, nkps=nkps, levels=levels)
 
 
+@pytest.mark.parametrize("shape", [(67, 45), (40, 8), (5, 3), (130, 33)])
+def test_geometry_and_template_matching(emu, oracle, shape):
+    w, h = shape
+    pc.geometry(emu, oracle, Oracle.synth(w, h, 3 * w + h), MEM)
+    pc.geometry(emu, oracle, np.random.RandomState(w).randint(0, 256, (h, w)).astype(np.uint8), MEM, seed=9)
+
+
 def test_lbp(emu, oracle, cascade):
     img = Oracle.synth(96, 80, 7)
     pc.lbp(emu, oracle, img, MEM, cascade, params=((4096, 1.1, 1.0, 4.0, 1), (10, 1.3, 1.0, 2.0, 3)),

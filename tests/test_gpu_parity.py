@@ -323,6 +323,28 @@ def test_two_host_threads_share_the_library(hip, oracle):
     assert_same(out[1][1], oracle.integral(d), "thread 1 integral")
 
 
+@pytest.mark.parametrize("mem", [HOST, DEV], ids=["host", "device"])
+@pytest.mark.parametrize("shape", [(640, 480), (67, 45), (131, 20)])
+def test_geometry_and_template_matching(hip, oracle, shape, mem):
+    w, h = shape
+    pc.geometry(hip, oracle, Oracle.synth(w, h, w + h), mem)
+
+
+def test_template_matching_large(hip, oracle):
+    """a 64x64 template cut out of a 1280x720 frame: the maximum sits where it was cut"""
+    img = Oracle.synth(1280, 720, 4)
+    t = img[200:264, 500:564].copy()
+    import torch
+    r = torch.zeros((720 - 63, 1280 - 63), dtype=torch.uint8, device="cuda")
+    hip.match_template(torch.from_numpy(img).cuda(), torch.from_numpy(t).cuda(), r)
+    rn = r.cpu().numpy()
+    assert rn[200, 500] == 255, "zero SSD where the template was cut"
+    first = int(np.argmax(rn))  # numpy returns the FIRST maximum, like the reference's strict '>'
+    assert hip.find_best_match(r) == (first % rn.shape[1], first // rn.shape[1])
+    rows = oracle.match_template(img[180:300], t)  # oracle on a 120-row slab (the full frame takes a minute)
+    assert_same(rn[180:180 + rows.shape[0]], rows, "template rows 180..")
+
+
 def test_pipeline_chunk_overlap(hip, oracle):
     """gsh_edge_pipeline_batch cuts big batches into chunks whose threshold pass runs on a side
     stream under the next chunk's fused kernel: same bytes for every chunking, ragged last chunk,
