@@ -112,8 +112,13 @@ def main():
     def step_unfused():  # the same chain as separate per-call kernels (blurred frames materialised)
         g.edge_pipeline_batch(dst, tmp, src, r, hist, thr)
 
+    # the library brackets every launch of the dominant (fused) kernel with HIP events on the stream
+    # it is launched on -- during the timed steps themselves; the pairs are created beforehand
+    launches_per_step = (F + 31) // 32
+    g.profile(max(2, (args.steps + args.warmup) * launches_per_step + 8))
     for _ in range(args.warmup):
         step()
+    g.profile_read()  # drop the warm-up launches
     sh.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -122,6 +127,8 @@ def main():
     torch.cuda.synchronize()
     sh.barrier()
     dt = sh.max_over_ranks(time.perf_counter() - t0)
+    nl, tot_ms = g.profile_read()  # launches of the timed region
+    g.profile(False)
     npx = F * w * h
     value = sh.world * npx * args.steps / dt / 1e6
 
@@ -141,23 +148,18 @@ def main():
         ms = time_stream(torch, fn, reps)
         ktab[name] = {"ms": round(ms, 4), "GB/s": round(nbytes / ms / 1e6, 1),
                       "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4), "bytes": nbytes}
-    # The fused kernel itself: the library brackets each of its launches with HIP events on the
-    # stream it is launched on (gsh_profile) while the SAME step function runs `reps` more times.
-    # A step launches it once per 32-frame chunk; chunk i's threshold pass runs on a side stream
-    # under chunk i+1's fused kernel, so these durations include that sharing.
+    # The fused kernel itself: average over ALL its launches inside the timed region above (HIP events
+    # recorded by the library on the launch stream, gsh_profile).  A step launches it once per
+    # 32-frame chunk; chunk i's threshold pass runs on a side stream under chunk i+1's fused
+    # kernel, so these durations include that sharing.
     fk = "fused blur+sobel+hist k_blur_sobel_hist16"
-    g.profile(True)
-    for _ in range(reps):
-        step()
-    nl, tot_ms = g.profile_read()
-    g.profile(False)
     fms = tot_ms / max(nl, 1)
-    fpl = F * reps / max(nl, 1)           # frames per launch
+    fpl = F / launches_per_step           # frames per launch (nl may be capped at 4096 bracketed launches)
     lpx = fpl * w * h                     # pixels per launch
     ktab[fk] = {"ms": round(fms, 4), "GB/s": round(2.0 * lpx / fms / 1e6, 1),
                 "frac": round(2.0 * lpx / fms / 1e6 / HBM_PEAK_GBS, 4), "bytes": 2.0 * lpx,
                 "frames_per_launch": fpl, "launches_timed": nl,
-                "note": "per launch, HIP events on the launch stream; replaces blur+sobel+histogram (5 B/px unfused)"}
+                "note": "per launch, HIP events on the launch stream over the timed region; replaces blur+sobel+histogram (5 B/px unfused)"}
     # dominant kernel of the timed step = the fused kernel.  SURVEY.md 8(d): a fused kernel is
     # reported against the UNFUSED per-call sum of the calls it performs (gs_blur 2 + gs_sobel 2 +
     # gs_histogram 1 = 5 B/px), with the bytes it really moves (1 R + 1 W) stated beside it.

@@ -178,7 +178,8 @@ class Grayskull:
         self.c.gsh_tune(int(key), int(value))
 
     def profile(self, on):
-        self.c.gsh_profile(1 if on else 0)
+        """True / False, or an int > 1 = switch on and pre-create that many event pairs"""
+        self.c.gsh_profile(int(on))
 
     def profile_read(self):
         """(launches bracketed since the last read, their summed duration in ms)"""

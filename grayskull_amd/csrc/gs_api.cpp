@@ -71,14 +71,14 @@ struct Ctx {
   struct Buf { void *p = nullptr; size_t cap = 0; } slot[SL_COUNT];
 #ifndef GS_EMU
   /* gsh_profile: events bracketing the pipeline's fused-kernel launches on their stream */
-  static constexpr int kProfPairs = 512;
+  static constexpr int kProfPairs = 4096;
   bool prof_on = false;
   hipEvent_t prof_ev[2 * kProfPairs] = {};
   unsigned prof_n = 0;
   void prof_mark(int which, hipStream_t on) { /* which: 0 before, 1 after the launch */
     if (!prof_on || prof_n >= (unsigned)kProfPairs) return;
     hipEvent_t &e = prof_ev[2 * prof_n + which];
-    if (!e) GS_HIP(hipEventCreate(&e));
+    if (!e) GS_HIP(hipEventCreate(&e)); /* normally pre-created by gsh_profile */
     GS_HIP(hipEventRecord(e, on));
     if (which) prof_n++;
   }
@@ -792,8 +792,12 @@ void gsh_set_async(int on) { ctx().async = on != 0; }
 void gsh_profile(int on) {
 #ifndef GS_EMU
   Ctx &c = ctx();
+  c.ensure_device();
   c.prof_on = on != 0;
   c.prof_n = 0;
+  /* on > 1: create that many event pairs now, so that none is created inside a timed region */
+  for (int i = 0; on > 1 && i < 2 * std::min(on, (int)Ctx::kProfPairs); i++)
+    if (!c.prof_ev[i]) GS_HIP(hipEventCreate(&c.prof_ev[i]));
 #else
   (void)on;
 #endif

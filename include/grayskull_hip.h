@@ -40,9 +40,10 @@ void gsh_sync(void);                      /* hipStreamSynchronize(current stream
  * 6 set to 1 for the generic two-pass gs_integral.  Results never change. */
 void gsh_tune(int key, int value);
 /* measurement aid for bench.py: while on, gsh_edge_pipeline_batch brackets every launch of its
- * fused blur+sobel+histogram kernel with HIP events on the stream it is launched on (up to 512
- * launches); gsh_profile_read synchronises, returns how many launches were bracketed since the
- * last read and their summed duration in milliseconds. */
+ * fused blur+sobel+histogram kernel with HIP events on the stream it is launched on (up to 4096
+ * launches between reads; on > 1 pre-creates that many event pairs so none is created inside a
+ * timed region); gsh_profile_read synchronises, returns how many launches were bracketed since
+ * the last read and their summed duration in milliseconds. */
 void gsh_profile(int on);
 unsigned gsh_profile_read(double *total_ms);
 /* diagnostic: strip-kernel traffic pattern with no arithmetic (access-pattern ceiling) */
