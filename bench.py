@@ -292,7 +292,8 @@ def main():
                    "frames_per_gpu": F, "global_frames": F * sh.world, "sharding": "by frame, no data-path collective",
                    "chain_algorithmic_bytes_per_px_unfused": 7, "hbm_peak_GBs": HBM_PEAK_GBS},
         "fused": {"ms_per_step": round(ms_fused, 4), "Mpix/s": round(npx / ms_fused / 1e3, 1),
-                  "hbm_bytes_per_px": 4, "note": "blur+sobel+histogram in one kernel per 32-frame chunk; each chunk's threshold pass runs under the next chunk's fused kernel"},
+                  "hbm_bytes_per_px": 4, "hbm_GB/s": round(4.0 * npx / ms_fused / 1e6, 1),
+                  "hbm_frac_of_peak": round(4.0 * npx / ms_fused / 1e6 / HBM_PEAK_GBS, 4), "note": "blur+sobel+histogram in one kernel per 32-frame chunk; each chunk's threshold pass runs under the next chunk's fused kernel"},
         "unfused": {"ms_per_step": round(ms_unfused, 4), "Mpix/s": round(npx / ms_unfused / 1e3, 1),
                     "hbm_bytes_per_px": 7, "note": "separate gs_blur, gs_sobel, histogram, threshold kernels"},
         "roofline": roof, "kernels": ktab, "sobel_4096x4096": ns, "other_configs": other, "parity": parity,
