@@ -1358,9 +1358,18 @@ void gs_match_template(struct gs_image img, struct gs_image tmpl, struct gs_imag
   const uint8_t *t = (const uint8_t *)stage_in(tmpl.data, tb, SL_AUX);
   const bool dhost = !is_dev(result.data);
   uint8_t *d = dhost ? (uint8_t *)ctx().scratch(SL_OUT, rb) : result.data;
-  GS_LAUNCH(k_match_template, dim3((result.w + 63) / 64, (result.h + 3) / 4), dim3(64, 4),
-            std::min<size_t>(tb, kTmplTile), ctx().s(), s, img.w, img.h, t, tmpl.w, tmpl.h, d, result.w,
-            result.h);
+  const dim3 g((result.w + 63) / 64, (result.h + 3) / 4);
+  if (tmpl.w <= kTmplTile - 3) {
+    unsigned long long *tsq = (unsigned long long *)ctx().scratch(SL_PFX, 8);
+    GS_LAUNCH(k_sum_squares, dim3(1), dim3(256), 0, ctx().s(), t, (unsigned long long)tb, tsq);
+    const size_t twp = ((size_t)tmpl.w + 3) & ~(size_t)3;
+    const size_t lds = std::min<size_t>(twp * tmpl.h, (kTmplTile / twp) * twp);
+    GS_LAUNCH(k_match_template, g, dim3(64, 4), lds, ctx().s(), s, img.w, img.h, t, tmpl.w, tmpl.h,
+              (const unsigned long long *)tsq, d, result.w, result.h);
+  } else {
+    GS_LAUNCH(k_match_template_px, g, dim3(64, 4), 0, ctx().s(), s, img.w, img.h, t, tmpl.w, tmpl.h, d,
+              result.w, result.h);
+  }
   if (dhost) GS_HIP(hipMemcpyAsync(result.data, d, rb, hipMemcpyDeviceToHost, ctx().s()));
   finish(dhost);
 }

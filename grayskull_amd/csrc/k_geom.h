@@ -57,40 +57,90 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t *dst, unsigned dw, unsig
   dst[(size_t)y * dw + x] = (uint8_t)(int)p; /* float -> uint8_t truncation (value < 256) */
 }
 
-/* SSD per offset.  grid (ceil(rw/64), ceil(rh/4)), block (64,4); the template is staged in LDS in
- * tiles of up to 16 KiB (dynamic LDS = min(tw*th, 16384) bytes) so its reads are broadcasts.
- * Sums: a row of up to 65535 taps of <= 65025 fits 32 bits only up to 66051 taps, so rows are
- * accumulated in 64 bits every 4096 taps. */
+/* sum of squares of n bytes into *out (one block of 256; the template's constant term) */
+__global__ __launch_bounds__(256) void k_sum_squares(const uint8_t *v, unsigned long long n,
+                                                     unsigned long long *out) {
+  __shared__ unsigned long long part[4];
+  unsigned long long acc = 0;
+  for (unsigned long long i = threadIdx.x; i < n; i += 256u) acc += (unsigned long long)v[i] * v[i];
+  unsigned lo = (unsigned)acc, hi = (unsigned)(acc >> 32); /* per-thread sums fit far below 2^63 */
+  unsigned long long w = acc;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    lo = shfl((uint32_t)w, (int)(lane_id() ^ (unsigned)d)), hi = shfl((uint32_t)(w >> 32), (int)(lane_id() ^ (unsigned)d));
+    w += ((unsigned long long)hi << 32) | lo;
+  }
+  if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = w;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = part[0] + part[1] + part[2] + part[3];
+}
+
+/* gs_match_template (ref :705-724).  SSD = sum I^2 + sum T^2 - 2 sum I*T over the window: per group of
+ * four taps one unaligned dword of the image row, one LDS dword of the template and two
+ * v_dot4_u32_u8 (I.T and I.I); sum T^2 comes from k_sum_squares.  One thread per result pixel,
+ * grid (ceil(rw/64), ceil(rh/4)), block (64,4).  The template is staged in LDS as whole rows padded
+ * to a multiple of 4 bytes, up to kTmplTile bytes at a time (dynamic LDS); the tw % 4 tail taps
+ * of a row go byte by byte.  Row sums (<= tw * 65025 < 2^32 for tw <= 16384) are added to 64-bit
+ * totals after every template row.  Requires tw <= kTmplTile - 3 (wider: k_match_template_px). */
 constexpr unsigned kTmplTile = 16384;
 __global__ __launch_bounds__(256) void k_match_template(const uint8_t *img, unsigned iw, unsigned ih,
                                                         const uint8_t *tmpl, unsigned tw, unsigned th,
+                                                        const unsigned long long *tmpl_sq,
                                                         uint8_t *result, unsigned rw, unsigned rh) {
   GS_DYN_LDS(smem);
   uint8_t *lt = (uint8_t *)smem;
   const unsigned tid = threadIdx.y * 64u + threadIdx.x;
   const unsigned rx = blockIdx.x * 64u + threadIdx.x, ry = blockIdx.y * 4u + threadIdx.y;
   const bool live = rx < rw && ry < rh;
-  const unsigned long long ntaps = (unsigned long long)tw * th;
-  unsigned long long sum = 0;
-  for (unsigned long long t0 = 0; t0 < ntaps; t0 += kTmplTile) { /* block-uniform */
-    const unsigned nt = (unsigned)(ntaps - t0 < kTmplTile ? ntaps - t0 : kTmplTile);
+  const unsigned twp = (tw + 3u) & ~3u, g4 = tw >> 2;
+  const unsigned rows_per_tile = kTmplTile / twp;
+  unsigned long long s_it = 0, s_ii = 0;
+  for (unsigned t0 = 0; t0 < th; t0 += rows_per_tile) { /* block-uniform */
+    const unsigned nr = th - t0 < rows_per_tile ? th - t0 : rows_per_tile;
     __syncthreads();
-    for (unsigned i = tid; i < nt; i += 256u) lt[i] = tmpl[t0 + i];
+    for (unsigned i = tid; i < nr * twp; i += 256u) {
+      const unsigned r = i / twp, c = i - r * twp;
+      lt[i] = c < tw ? tmpl[(size_t)(t0 + r) * tw + c] : (uint8_t)0;
+    }
     __syncthreads();
     if (live) {
-      unsigned ty = (unsigned)(t0 / tw), tx = (unsigned)(t0 - (unsigned long long)ty * tw);
-      unsigned acc = 0, run = 0;
-      for (unsigned i = 0; i < nt; i++) {
-        const int d = (int)geom_px(img, iw, ih, rx + tx, ry + ty) - (int)lt[i];
-        acc += (unsigned)(d * d);
-        if (++run == 4096u) sum += acc, acc = 0, run = 0;
-        if (++tx == tw) tx = 0, ty++;
+      for (unsigned r = 0; r < nr; r++) {
+        const uint8_t *ip = img + (size_t)(ry + t0 + r) * iw + rx; /* the window lies inside the image */
+        const uint32_t *tp = (const uint32_t *)(lt + r * twp);
+        uint32_t it = 0, ii = 0;
+        for (unsigned q = 0; q < g4; q++) {
+          const uint32_t I4 = load_u32_unaligned(ip + 4u * q);
+          it = udot4(I4, tp[q], it), ii = udot4(I4, I4, ii);
+        }
+        for (unsigned c = g4 * 4u; c < tw; c++) {
+          const uint32_t a = ip[c], b = lt[r * twp + c];
+          it += a * b, ii += a * a;
+        }
+        s_it += it, s_ii += ii;
       }
-      sum += acc;
     }
   }
   if (!live) return;
+  const unsigned long long ntaps = (unsigned long long)tw * th;
+  const unsigned long long sum = s_ii + tmpl_sq[0] - 2ull * s_it; /* = sum (I - T)^2 >= 0 */
   const unsigned long long max_diff = ntaps * 255ULL * 255ULL;
+  const unsigned long long score = sum * 255ULL / max_diff;
+  result[(size_t)ry * rw + rx] = (uint8_t)(255u - (unsigned)(score < 255ULL ? score : 255ULL));
+}
+
+/* any template width: one subtract-multiply-add per tap, template read from global memory */
+__global__ __launch_bounds__(256) void k_match_template_px(const uint8_t *img, unsigned iw, unsigned ih,
+                                                           const uint8_t *tmpl, unsigned tw, unsigned th,
+                                                           uint8_t *result, unsigned rw, unsigned rh) {
+  const unsigned rx = blockIdx.x * 64u + threadIdx.x, ry = blockIdx.y * 4u + threadIdx.y;
+  if (rx >= rw || ry >= rh) return;
+  unsigned long long sum = 0;
+  for (unsigned ty = 0; ty < th; ty++)
+    for (unsigned tx = 0; tx < tw; tx++) {
+      const int d = (int)geom_px(img, iw, ih, rx + tx, ry + ty) - (int)tmpl[(size_t)ty * tw + tx];
+      sum += (unsigned long long)(d * d);
+    }
+  const unsigned long long max_diff = (unsigned long long)tw * th * 255ULL * 255ULL;
   const unsigned long long score = sum * 255ULL / max_diff;
   result[(size_t)ry * rw + rx] = (uint8_t)(255u - (unsigned)(score < 255ULL ? score : 255ULL));
 }

@@ -18,6 +18,7 @@
 #endif
 
 #include <stdint.h>
+#include <string.h>
 
 #define GS_DEV __device__ __forceinline__
 
@@ -109,6 +110,15 @@ GS_DEV uint32_t pk_mul_u16(uint32_t a, uint32_t b) { return GS_PK2((a & 0xffff) 
 GS_DEV uint32_t pk_mad_u16(uint32_t a, uint32_t b, uint32_t c) { return GS_PK2((a & 0xffff) * (b & 0xffff) + (c & 0xffff), (a >> 16) * (b >> 16) + (c >> 16)); }
 GS_DEV uint32_t pk_mad2_u16(uint32_t a, uint32_t c) { return GS_PK2(2 * (a & 0xffff) + (c & 0xffff), 2 * (a >> 16) + (c >> 16)); }
 GS_DEV uint32_t pk_mad_u16_s(uint32_t a, uint32_t b, uint32_t c) { return pk_mad_u16(a, b, c); }
+GS_DEV uint32_t udot4(uint32_t a, uint32_t b, uint32_t c) {
+  for (int i = 0; i < 4; i++) c += ((a >> (8 * i)) & 0xffu) * ((b >> (8 * i)) & 0xffu);
+  return c;
+}
+GS_DEV uint32_t load_u32_unaligned(const uint8_t *p) {
+  uint32_t v;
+  memcpy(&v, p, 4);
+  return v;
+}
 GS_DEV uint32_t mad_u32_u16_lo(uint32_t a, uint32_t b, uint32_t c) { return (a & 0xffffu) * (b & 0xffffu) + c; }
 GS_DEV uint32_t mad_u32_u16_hi(uint32_t a, uint32_t b, uint32_t c) { return (a >> 16) * (b & 0xffffu) + c; }
 GS_DEV void sched_fence() {}
@@ -205,6 +215,13 @@ GS_DEV uint32_t pk_mad_u16_s(uint32_t a, uint32_t b, uint32_t c) {
   uint32_t d;
   asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b), "v"(c));
   return d;
+}
+/* sum of the four u8 x u8 products + c (v_dot4_u32_u8) */
+GS_DEV uint32_t udot4(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_udot4(a, b, c, false); }
+/* dword at any byte address (global memory handles unaligned dwords in hardware) */
+GS_DEV uint32_t load_u32_unaligned(const uint8_t *p) {
+  typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+  return *(const u32_unaligned *)p;
 }
 /* (low | high half of a) * (low half of the wave-uniform b) + c as a full 32-bit result: one
  * v_mad_u32_u16 with op_sel picking the half -- no separate extraction of the u16 */

@@ -7,7 +7,7 @@ import pytest
 
 import parity_cases as pc
 from oracle.pyoracle import Oracle
-from util import lena, random_cascade
+from util import assert_same, lena, random_cascade
 
 MEM = pc.Mem("host")
 
@@ -87,6 +87,17 @@ def test_geometry_and_template_matching(emu, oracle, shape):
     w, h = shape
     pc.geometry(emu, oracle, Oracle.synth(w, h, 3 * w + h), MEM)
     pc.geometry(emu, oracle, np.random.RandomState(w).randint(0, 256, (h, w)).astype(np.uint8), MEM, seed=9)
+
+
+def test_template_wider_than_the_lds_tile(emu, oracle):
+    """templates wider than 16381 px take the per-tap kernel; 16380 is the widest dot4 / LDS-row case"""
+    rs = np.random.RandomState(2)
+    for (iw, ih, tw, th) in ((16420, 3, 16400, 2), (16400, 2, 16380, 2)):
+        img = rs.randint(0, 256, (ih, iw)).astype(np.uint8)
+        t = rs.randint(0, 256, (th, tw)).astype(np.uint8)
+        r = np.zeros((ih - th + 1, iw - tw + 1), np.uint8)
+        emu.match_template(img, t, r)
+        assert_same(r, oracle.match_template(img, t), "gs_match_template %dx%d" % (tw, th))
 
 
 def test_lbp(emu, oracle, cascade):
