@@ -1159,6 +1159,23 @@ void gsh_filter_batch(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, 
   GS_HIP(hipMemcpyAsync(dk, kernel_host, (size_t)kw * kh, hipMemcpyHostToDevice, st));
   ctx().sync(); /* kernel_host may be a temporary */
   const size_t fb = (size_t)w * h;
+  /* strip kernel: 3x3, every partial sum within int16 (sum |k| <= 128), norm <= 256 */
+  unsigned abs_sum = 0;
+  for (unsigned i = 0; i < kw * kh; i++) abs_sum += (unsigned)std::abs((int)kernel_host[i]);
+  if (kw == 3 && kh == 3 && abs_sum <= 128 && norm <= 256 && strip_ok(w, h, dst, src) && w >= 32) {
+    FilterK fk;
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) fk.k[r][c] = ((uint32_t)(uint16_t)(int16_t)kernel_host[r * 3 + c]) * 0x10001u;
+    fk.mul = (0x1000000u + norm - 1u) / norm;
+    fk.cap = std::min(255u * norm, 32767u) * 0x10001u;
+    fk.neg_is_255 = norm > 1 ? 0xffffffffu : 0u;
+    for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
+      const unsigned nn = std::min(kMaxZ, n - f0);
+      const StripCfg c = strip_cfg(w, h, nn, 6);
+      GS_LAUNCH(k_filter16, c.grid, c.block, 0, st, dst + fb * f0, src + fb * f0, w, h, c.T, fb, fk);
+    }
+    return;
+  }
   for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
     const unsigned nn = std::min(kMaxZ, n - f0);
     GS_LAUNCH(k_filter_px, grid2d(w, h, nn), dim3(64, 4), 0, st, dst + fb * f0, src + fb * f0, w, h,

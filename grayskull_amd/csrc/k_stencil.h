@@ -185,6 +185,65 @@ __global__ __launch_bounds__(256) void k_strip_copy(uint8_t *dst, const uint8_t 
   }
 }
 
+/* ------------------------------------------------------------------ 3x3 int8 filter, strips */
+/* ref :255-266 (gs_filter with a 3x3 kernel): zero-padded correlation, then `sum / norm` evaluated
+ * in unsigned (a negative sum with norm > 1 becomes a huge quotient -> 255; with norm == 1 it stays
+ * negative -> 0) and a clamp to 0..255.  Fast path for sum |k| <= 128 (every partial sum fits
+ * int16: <= 128*255) and norm <= 256.  Per input row the three horizontal dot products H0/H1/H2
+ * (one per kernel row) are formed with v_pk_mad_u16 (two's complement: the low 16 bits are the
+ * signed result); out(y) = H0(y-1) + H1(y) + H2(y+1) is carried in two partial-sum sets.  The
+ * quotient of the clamped non-negative sum is the top byte of sum * ceil(2^24 / norm)
+ * (exact for sum <= 255*norm, norm <= 256: 255*norm*(norm-1) < 2^24), packed like k_blur16. */
+struct FilterK { uint32_t k[3][3]; uint32_t mul, cap, neg_is_255; }; /* k: coefficient in both halves */
+
+GS_DEV void filter_hrow(const uint32_t (&U)[12], const uint32_t (&kr)[3], uint32_t (&H)[8]) {
+#pragma unroll
+  for (int p = 0; p < 8; p++) {
+    const int j = p + 2; /* U[j] = own pair p */
+    const uint32_t L = alignbit(U[j], U[j - 1], 16), R = alignbit(U[j + 1], U[j], 16);
+    H[p] = pk_mad_u16(R, kr[2], pk_mad_u16(U[j], kr[1], pk_mul_u16(L, kr[0])));
+  }
+}
+
+__global__ __launch_bounds__(256) void k_filter16(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h,
+                                                  unsigned T, size_t frame_bytes, FilterK fk) {
+  const Strip<> S(src, dst, w, h, frame_bytes);
+  const int y0 = (int)(S.band * T);
+  if (y0 >= (int)h) return;
+  const int nrows = ((int)h - y0) < (int)T ? ((int)h - y0) : (int)T;
+  uint32_t P0[8], P1[8]; /* P1 = H0(y-1) + H1(y) waits for H2(y+1); P0 = H0(y) waits for H1(y+1) */
+  {
+    uint32_t U[12], Ha[8], Hb[8];
+    strip_unpack(S.load(y0 - 1), U);
+    filter_hrow(U, fk.k[0], Ha); /* H0(y0-1) */
+    strip_unpack(S.load(y0), U);
+    filter_hrow(U, fk.k[1], Hb); /* H1(y0) */
+#pragma unroll
+    for (int p = 0; p < 8; p++) P1[p] = pk_add_u16(Ha[p], Hb[p]);
+    filter_hrow(U, fk.k[0], P0); /* H0(y0) */
+  }
+  strip_rows<1, false>(S, y0, nrows, 1, S.load(y0 + 1), [&](auto, int, const uint32_t(&U)[12]) {
+    uint32_t H0[8], H1[8], H2[8], od[4];
+    filter_hrow(U, fk.k[0], H0), filter_hrow(U, fk.k[1], H1), filter_hrow(U, fk.k[2], H2);
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      uint32_t prod[4], negm[2];
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        const int p = 2 * g + t;
+        const uint32_t sum = pk_add_u16(P1[p], H2[p]); /* int16 pair */
+        P1[p] = pk_add_u16(P0[p], H1[p]), P0[p] = H0[p];
+        negm[t] = pk_sar_i16(sum, 15);                                    /* 0xffff where negative */
+        const uint32_t c = pk_min_u16(pk_max_i16(sum, 0u), fk.cap);       /* 0 .. min(255*norm, 32767) */
+        prod[2 * t] = (c & 0xffffu) * fk.mul, prod[2 * t + 1] = (c >> 16) * fk.mul; /* quotient = byte 3 */
+      }
+      const uint32_t q = perm_b32(prod[3], perm_b32(prod[2], perm_b32(prod[1], prod[0], 0x0c0c0703u), 0x0c070100u), 0x07020100u);
+      od[g] = q | (pack_lohi(negm[0], negm[1]) & fk.neg_is_255);
+    }
+    return U4{od[0], od[1], od[2], od[3]};
+  });
+}
+
 /* ------------------------------------------------------------------ generic per-pixel kernels */
 /* grid: (ceil(w/64), ceil(h/4), n), block (64,4) */
 __global__ __launch_bounds__(256) void k_sobel_px(uint8_t *dst, const uint8_t *src, unsigned w,

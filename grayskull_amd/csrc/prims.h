@@ -136,6 +136,14 @@ GS_DEV uint32_t pk_abs_i16(uint32_t a) {
   int al = (int16_t)(a & 0xffff), ah = (int16_t)(a >> 16);
   return GS_PK2((uint32_t)(al < 0 ? -al : al), (uint32_t)(ah < 0 ? -ah : ah));
 }
+GS_DEV uint32_t pk_max_i16(uint32_t a, uint32_t b) {
+  int al = (int16_t)(a & 0xffff), ah = (int16_t)(a >> 16), bl = (int16_t)(b & 0xffff), bh = (int16_t)(b >> 16);
+  return GS_PK2((uint32_t)(al > bl ? al : bl), (uint32_t)(ah > bh ? ah : bh));
+}
+GS_DEV uint32_t pk_sar_i16(uint32_t a, unsigned s) {
+  int al = (int16_t)(a & 0xffff), ah = (int16_t)(a >> 16);
+  return GS_PK2((uint32_t)(al >> s), (uint32_t)(ah >> s));
+}
 #else
 /* ------------------------------------------------------------------ gfx950 */
 GS_DEV unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
@@ -240,6 +248,8 @@ GS_DEV uint32_t pk_shr_u16(uint32_t a, unsigned s) { return GS_R((gs_u16x2)(GS_U
 GS_DEV uint32_t pk_min_u16(uint32_t a, uint32_t b) { return GS_R(__builtin_elementwise_min(GS_U2(a), GS_U2(b))); } /* v_pk_min_u16 */
 GS_DEV uint32_t pk_max_u16(uint32_t a, uint32_t b) { return GS_R(__builtin_elementwise_max(GS_U2(a), GS_U2(b))); } /* v_pk_max_u16 */
 GS_DEV uint32_t pk_abs_i16(uint32_t a) { return GS_R(__builtin_elementwise_abs(GS_I2(a))); }           /* v_pk_sub_i16 + v_pk_max_i16 */
+GS_DEV uint32_t pk_max_i16(uint32_t a, uint32_t b) { return GS_R(__builtin_elementwise_max(GS_I2(a), GS_I2(b))); } /* v_pk_max_i16 */
+GS_DEV uint32_t pk_sar_i16(uint32_t a, unsigned s) { return GS_R((gs_i16x2)(GS_I2(a) >> (short)s)); }            /* v_pk_ashrrev_i16 */
 #endif
 
 /* ------------------------------------------------------------------ common */

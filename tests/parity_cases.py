@@ -136,7 +136,17 @@ def next_rows(g, o, img, mem):
                "box": ([[1, 1, 1], [1, 1, 1], [1, 1, 1]], 9),
                "gauss": ([[1, 2, 1], [2, 4, 2], [1, 2, 1]], 16),
                "neg_norm": ([[0, -1, 0], [-1, 2, -1], [0, -1, 0]], 3),
-               "wide": ([[1, 0, -1, 2, 1]], 2)}
+               "wide": ([[1, 0, -1, 2, 1]], 2),
+               # strip-kernel boundaries: sum |k| == 128 (largest int16-safe), 129 (falls back), norms 255/256/257
+               "abs128": ([[16, -16, 16], [-16, 0, 16], [16, -16, 16]], 7),
+               "abs129": ([[16, -16, 16], [-16, 1, 16], [16, -16, 16]], 7),
+               "all_pos_128": ([[14, 14, 14], [14, 16, 14], [14, 14, 14]], 1),
+               "norm255": ([[14, 14, 14], [14, 16, 14], [14, 14, 14]], 255),
+               "norm256": ([[14, 14, 14], [14, 16, 14], [14, 14, 14]], 256),
+               "norm257": ([[14, 14, 14], [14, 16, 14], [14, 14, 14]], 257),
+               "all_neg": ([[-1, -2, -1], [-2, -4, -2], [-1, -2, -1]], 1),
+               "all_neg_norm": ([[-1, -2, -1], [-2, -4, -2], [-1, -2, -1]], 16),
+               "min_int8": ([[0, 0, 0], [0, -128, 0], [0, 0, 0]], 2)}
     for name, (k, norm) in kernels.items():
         k = np.array(k, np.int8)
         d = mem.zeros(img.shape, fill=SENTINEL)

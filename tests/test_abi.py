@@ -101,3 +101,16 @@ g.blur(np.zeros((4, 4), np.uint8), np.zeros((5, 4), np.uint8), 1)   # dst/src si
     r = subprocess.run([sys.executable, str(prog)], capture_output=True)
     assert r.returncode == -6, r  # SIGABRT
     assert b"Assertion failed:" in r.stderr and b"dst.w == src.w" in r.stderr
+
+
+def test_filter_strip_kernel_quotient_is_exact():
+    """k_filter16 divides the clamped non-negative sum c <= min(255*norm, 32767) by norm as the top
+    byte of c * ceil(2^24 / norm); check every (norm <= 256, c) pair against integer division"""
+    import numpy as np
+    for norm in range(1, 257):
+        mul = ((1 << 24) + norm - 1) // norm
+        cap = min(255 * norm, 32767)
+        c = np.arange(cap + 1, dtype=np.uint64)
+        prod = c * np.uint64(mul)
+        assert int(prod.max()) < (1 << 32), norm
+        assert np.array_equal(prod >> np.uint64(24), np.minimum(c // np.uint64(norm), 255)), norm

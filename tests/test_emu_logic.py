@@ -48,10 +48,11 @@ def test_otsu_scan_float_order(emu, oracle):
         assert emu.otsu_threshold(img) == oracle.otsu_threshold(img)
 
 
-@pytest.mark.parametrize("shape", [(67, 45), (40, 24)])
+@pytest.mark.parametrize("shape", [(67, 45), (40, 24), (64, 40), (48, 9), (32, 3), (1040, 5), (32, 1)])
 def test_next_rows(emu, oracle, shape):
     w, h = shape
     pc.next_rows(emu, oracle, Oracle.synth(w, h, 21), MEM)
+    pc.next_rows(emu, oracle, np.random.RandomState(w + h).randint(0, 256, (h, w)).astype(np.uint8), MEM)
 
 
 @pytest.mark.parametrize("shape", [(67, 45), (96, 80), (7, 7), (6, 30), (40, 8), (300, 12)])
