@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <vector>
 
+#include "k_box.h"
 #include "k_fast.h"
 #include "k_geom.h"
 #include "k_integral.h"
@@ -315,6 +316,22 @@ void launch_box_generic(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h
   hipStream_t st = ctx().s();
   const size_t fp = (size_t)w * h;
   const unsigned r = std::min(radius, std::max(w, h)); /* larger windows clip identically */
+  if (g_tune[6] != 3 && r >= 1 && r <= 56 && w <= 4096 && strip_ok(w, h, dst, src)) {
+    /* sliding box sums straight from the source rows (k_box.h): 3-4 B/px instead of ~16; the
+     * per-band start-up grows with the radius, and from r ~ 60 the integral-image route (whose
+     * cost does not depend on r) is faster: 64 4K frames, r = 15: 0.73 vs 2.83 ms, r = 64: 2.7 vs 2.8 */
+    for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
+      const unsigned nn = std::min(kMaxZ, n - f0);
+      /* band height: ~2K blocks in flight, but at least four window heights per band (each band
+       * first sums 2r+1 rows it does not output) */
+      const unsigned want = std::max(1u, 2048u / nn);
+      const unsigned T = std::min(h, std::max(4u * (2u * r + 1u), (h + want - 1) / want));
+      const unsigned nb = (h + T - 1) / T;
+      GS_LAUNCH(k_box16<MODE>, dim3(1, nb, nn), dim3(256), 0, st, dst + fp * f0, src + fp * f0, w, h, T, fp,
+                r, c);
+    }
+    return;
+  }
   const unsigned group = (unsigned)std::max<size_t>(1, std::min<size_t>(n, (256u << 20) / (fp * 4) + 1));
   unsigned *ii = (unsigned *)ctx().scratch(SL_II, fp * 4 * group);
   for (unsigned f0 = 0; f0 < n; f0 += group) {
