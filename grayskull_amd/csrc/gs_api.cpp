@@ -1205,8 +1205,12 @@ void gsh_downsample_batch(uint8_t *dst, const uint8_t *src, unsigned sw, unsigne
   const size_t sfb = (size_t)sw * sh, dfb = (size_t)(sw / 2) * (sh / 2);
   for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
     const unsigned nn = std::min(kMaxZ, n - f0);
-    GS_LAUNCH(k_downsample_px, grid2d(sw / 2, sh / 2, nn), dim3(64, 4), 0, st, dst + dfb * f0,
-              src + sfb * f0, sw, sh);
+    if (sw % 16 == 0 && al16(src) && al16(dst) && sfb % 16 == 0 && dfb % 8 == 0)
+      GS_LAUNCH(k_downsample8, dim3((sw / 16 + 63) / 64, (sh / 2 + 3) / 4, nn), dim3(64, 4), 0, st,
+                dst + dfb * f0, src + sfb * f0, sw, sh);
+    else
+      GS_LAUNCH(k_downsample_px, grid2d(sw / 2, sh / 2, nn), dim3(64, 4), 0, st, dst + dfb * f0,
+                src + sfb * f0, sw, sh);
   }
 }
 

@@ -332,5 +332,34 @@ __global__ __launch_bounds__(256) void k_downsample_px(uint8_t *dst, const uint8
   dst[(size_t)blockIdx.z * ((size_t)dw * dh) + (size_t)y * dw + x] = (uint8_t)(s / 4);
 }
 
+/* same, 8 output px per thread: two 16-byte loads (rows 2y and 2y+1), one 8-byte store.  The 2x2
+ * sums are formed two at a time on u16 pairs.  Needs sw % 16 == 0 and 16-byte aligned frames.
+ * grid (ceil(dw/8/64), ceil(dh/4), n), block (64,4) */
+__global__ __launch_bounds__(256) void k_downsample8(uint8_t *dst, const uint8_t *src, unsigned sw,
+                                                     unsigned sh) {
+  const unsigned dw = sw / 2, dh = sh / 2;
+  const unsigned gx = blockIdx.x * 64u + threadIdx.x, y = blockIdx.y * 4u + threadIdx.y;
+  if (gx * 8u >= dw || y >= dh) return;
+  const uint8_t *f = src + (size_t)blockIdx.z * ((size_t)sw * sh) + (size_t)(2 * y) * sw + 16u * gx;
+  const U4 a = *(const U4 *)f, b = *(const U4 *)(f + sw);
+  const uint32_t ra[4] = {a.x, a.y, a.z, a.w}, rb[4] = {b.x, b.y, b.z, b.w};
+  uint32_t o[2];
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    uint32_t out = 0;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      const uint32_t da = ra[2 * q + t], db = rb[2 * q + t]; /* 4 src px of each row -> 2 outputs */
+      /* vertical sums as u16 pairs: (p0+q0, p1+q1) and (p2+q2, p3+q3) */
+      const uint32_t v01 = pk_add_u16(unpack_lo(da), unpack_lo(db)), v23 = pk_add_u16(unpack_hi(da), unpack_hi(db));
+      const uint32_t s0 = (v01 & 0xffffu) + (v01 >> 16), s1 = (v23 & 0xffffu) + (v23 >> 16);
+      out |= ((s0 >> 2) | ((s1 >> 2) << 8)) << (16 * t);
+    }
+    o[q] = out;
+  }
+  uint32_t *d = (uint32_t *)(dst + (size_t)blockIdx.z * ((size_t)dw * dh) + (size_t)y * dw + 8u * gx);
+  d[0] = o[0], d[1] = o[1];
+}
+
 }  // namespace gs
 #endif
