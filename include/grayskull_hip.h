@@ -37,7 +37,9 @@ void gsh_sync(void);                      /* hipStreamSynchronize(current stream
  * (0: 64x4, 1: 256x1, 2: 128x2), 3 set to 1 to disable the fused pipeline kernel, 4 preset of
  * the cascade stages at which gs_lbp_detect re-packs survivors (1: never), 5 frames per chunk of
  * gsh_edge_pipeline_batch's internal overlap (0 = default 32, negative = never split),
- * 6 set to 1 for the generic two-pass gs_integral.  Results never change. */
+ * 6 comparison switches: 1 = generic two-pass gs_integral, 2 = block-per-band gs_integral,
+ * 3 = integral-image route for gs_blur(radius > 3) / gs_adaptive_threshold instead of the sliding
+ * box kernel.  Results never change. */
 void gsh_tune(int key, int value);
 /* measurement aid for bench.py: while on, gsh_edge_pipeline_batch brackets every launch of its
  * fused blur+sobel+histogram kernel with HIP events on the stream it is launched on (up to 4096
