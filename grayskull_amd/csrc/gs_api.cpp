@@ -1402,8 +1402,13 @@ void gs_match_template(struct gs_image img, struct gs_image tmpl, struct gs_imag
     GS_LAUNCH(k_sum_squares, dim3(1), dim3(256), 0, ctx().s(), t, (unsigned long long)tb, tsq);
     const size_t twp = ((size_t)tmpl.w + 3) & ~(size_t)3;
     const size_t lds = std::min<size_t>(twp * tmpl.h, (kTmplTile / twp) * twp);
-    GS_LAUNCH(k_match_template, g, dim3(64, 4), lds, ctx().s(), s, img.w, img.h, t, tmpl.w, tmpl.h,
-              (const unsigned long long *)tsq, d, result.w, result.h);
+    /* four results per thread when image rows start 4-byte aligned (see k_match_template4) */
+    if (img.w % 4 == 0 && ((uintptr_t)s & 3) == 0 && (size_t)img.w * img.h < 0x7fffffffull)
+      GS_LAUNCH(k_match_template4, dim3((result.w + 255) / 256, (result.h + 3) / 4), dim3(64, 4), lds, ctx().s(),
+                s, img.w, img.h, t, tmpl.w, tmpl.h, (const unsigned long long *)tsq, d, result.w, result.h);
+    else
+      GS_LAUNCH(k_match_template, g, dim3(64, 4), lds, ctx().s(), s, img.w, img.h, t, tmpl.w, tmpl.h,
+                (const unsigned long long *)tsq, d, result.w, result.h);
   } else {
     GS_LAUNCH(k_match_template_px, g, dim3(64, 4), 0, ctx().s(), s, img.w, img.h, t, tmpl.w, tmpl.h, d,
               result.w, result.h);

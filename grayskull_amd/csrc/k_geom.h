@@ -128,6 +128,77 @@ __global__ __launch_bounds__(256) void k_match_template(const uint8_t *img, unsi
   result[(size_t)ry * rw + rx] = (uint8_t)(255u - (unsigned)(score < 255ULL ? score : 255ULL));
 }
 
+/* Register-blocked form of the same: a thread owns FOUR adjacent result pixels (rx0 = 4*k), so per
+ * group of four taps it needs image bytes rx0+4q .. rx0+4q+6: two consecutive image dwords (the second
+ * one is the next step's first), both at 4-byte-aligned offsets from the row start (when iw % 4 == 0
+ * and the frame is 4-byte aligned), coalesced across lanes.  The four shifted windows come from
+ * v_alignbyte_b32; per step: 1 load, 3 alignbyte, 8 dot4 for 16 tap-results (the one-result kernel
+ * needs 4 overlapping unaligned loads for the same work).  grid (ceil(rw/4/64), ceil(rh/4)). */
+GS_DEV uint32_t alignbyte(uint32_t hi, uint32_t lo, unsigned bytes) { return alignbit(hi, lo, 8u * bytes); }
+
+__global__ __launch_bounds__(256) void k_match_template4(const uint8_t *img, unsigned iw, unsigned ih,
+                                                         const uint8_t *tmpl, unsigned tw, unsigned th,
+                                                         const unsigned long long *tmpl_sq,
+                                                         uint8_t *result, unsigned rw, unsigned rh) {
+  GS_DYN_LDS(smem);
+  uint8_t *lt = (uint8_t *)smem;
+  const unsigned tid = threadIdx.y * 64u + threadIdx.x;
+  const unsigned rx0 = (blockIdx.x * 64u + threadIdx.x) * 4u, ry = blockIdx.y * 4u + threadIdx.y;
+  const bool live = rx0 < rw && ry < rh;
+  const unsigned twp = (tw + 3u) & ~3u, g4 = tw >> 2, rem = tw & 3u;
+  const unsigned rows_per_tile = kTmplTile / twp;
+  const uint32_t tailmask = rem ? (0xffffffffu >> (8u * (4u - rem))) : 0u; /* the tw % 4 last taps of a row */
+  /* image dwords are read up to byte rx0 + twp + 3 of a row: clamp through a buffer resource
+   * (zero beyond the frame) because the last row's tail may stick out of the allocation */
+  const BufRsrc I = make_buf(img, (size_t)iw * ih);
+  unsigned long long s_it[4] = {0, 0, 0, 0}, s_ii[4] = {0, 0, 0, 0};
+  for (unsigned t0 = 0; t0 < th; t0 += rows_per_tile) { /* block-uniform */
+    const unsigned nr = th - t0 < rows_per_tile ? th - t0 : rows_per_tile;
+    __syncthreads();
+    for (unsigned i = tid; i < nr * twp; i += 256u) {
+      const unsigned r = i / twp, c = i - r * twp;
+      lt[i] = c < tw ? tmpl[(size_t)(t0 + r) * tw + c] : (uint8_t)0;
+    }
+    __syncthreads();
+    if (live) {
+      for (unsigned r = 0; r < nr; r++) {
+        const uint32_t base = (ry + t0 + r) * iw + rx0; /* multiple of 4 */
+        const uint32_t *tp = (const uint32_t *)(lt + r * twp);
+        uint32_t it[4] = {0, 0, 0, 0}, ii[4] = {0, 0, 0, 0};
+        uint32_t lo = buf_load4(I, base);
+        const unsigned steps = g4 + (rem ? 1u : 0u);
+        for (unsigned q = 0; q < steps; q++) {
+          const uint32_t hi = buf_load4(I, base + 4u * q + 4u);
+          const uint32_t m = q < g4 ? 0xffffffffu : tailmask; /* wave-uniform */
+          const uint32_t T4 = tp[q];                           /* padded taps are 0 in LDS */
+          const uint32_t w0 = lo & m, w1 = alignbyte(hi, lo, 1) & m, w2 = alignbyte(hi, lo, 2) & m,
+                         w3 = alignbyte(hi, lo, 3) & m;
+          it[0] = udot4(w0, T4, it[0]), ii[0] = udot4(w0, w0, ii[0]);
+          it[1] = udot4(w1, T4, it[1]), ii[1] = udot4(w1, w1, ii[1]);
+          it[2] = udot4(w2, T4, it[2]), ii[2] = udot4(w2, w2, ii[2]);
+          it[3] = udot4(w3, T4, it[3]), ii[3] = udot4(w3, w3, ii[3]);
+          lo = hi;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) s_it[j] += it[j], s_ii[j] += ii[j];
+      }
+    }
+  }
+  if (!live) return;
+  const unsigned long long ntaps = (unsigned long long)tw * th, max_diff = ntaps * 255ULL * 255ULL;
+  uint32_t out = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const unsigned long long sum = s_ii[j] + tmpl_sq[0] - 2ull * s_it[j];
+    const unsigned long long score = sum * 255ULL / max_diff;
+    out |= (255u - (unsigned)(score < 255ULL ? score : 255ULL)) << (8 * j);
+  }
+  uint8_t *o = result + (size_t)ry * rw + rx0;
+  if (rx0 + 3 < rw && (((uintptr_t)o) & 3u) == 0) *(uint32_t *)o = out;
+  else
+    for (unsigned j = 0; j < 4 && rx0 + j < rw; j++) o[j] = (uint8_t)(out >> (8 * j));
+}
+
 /* any template width: one subtract-multiply-add per tap, template read from global memory */
 __global__ __launch_bounds__(256) void k_match_template_px(const uint8_t *img, unsigned iw, unsigned ih,
                                                            const uint8_t *tmpl, unsigned tw, unsigned th,
