@@ -284,6 +284,41 @@ def test_orb_pyramid_device_resident(hip, oracle, shape, levels, nkps):
     pc.orb_pyramid(hip, oracle, Oracle.synth(w, h, 21), pc.Mem("device"), nkps=nkps, levels=levels)
 
 
+def test_box_and_filter_kernels_at_frame_sizes(hip, oracle):
+    """k_box16 (sliding box sums) and k_filter16 on real frame sizes: 720p against the oracle, and on a
+    4K batch the sliding route against the independent integral-image route (gsh_tune key 6 = 3)"""
+    import torch
+    img = Oracle.synth(1280, 720, 4)
+    src = torch.from_numpy(img).cuda()
+    d = torch.zeros_like(src)
+    for r in (4, 9, 40):
+        hip.blur(d, src, r)
+        assert_same(d.cpu().numpy(), oracle.blur(img, r), "gs_blur r=%d 720p" % r)
+    hip.adaptive_threshold(d, src, 15, 5)
+    assert_same(d.cpu().numpy(), oracle.adaptive_threshold(img, 15, 5), "gs_adaptive_threshold r=15 720p")
+    for k, norm in (([[1, 2, 1], [2, 4, 2], [1, 2, 1]], 16), ([[0, -1, 0], [-1, 5, -1], [0, -1, 0]], 1), ([[-2, -1, 0], [-1, 1, 1], [0, 1, 2]], 3)):
+        k = np.array(k, np.int8)
+        hip.filter(d, src, k, norm)
+        assert_same(d.cpu().numpy(), oracle.filter(img, k, norm), "gs_filter 720p norm=%d" % norm)
+    big = torch.empty((3, 2160, 3840), dtype=torch.uint8, device="cuda")
+    hip.synth_batch(big, 77)
+    a, b = torch.zeros_like(big), torch.zeros_like(big)
+    try:
+        for r in (4, 15, 56):
+            hip.tune(6, 0)
+            hip.blur_batch(a, big, r)
+            hip.tune(6, 3)
+            hip.blur_batch(b, big, r)
+            assert bool((a == b).all()), "blur r=%d: sliding vs integral route" % r
+            hip.tune(6, 0)
+            hip.adaptive_threshold_batch(a, big, r, 7)
+            hip.tune(6, 3)
+            hip.adaptive_threshold_batch(b, big, r, 7)
+            assert bool((a == b).all()), "adaptive r=%d: sliding vs integral route" % r
+    finally:
+        hip.tune(6, 0)
+
+
 def test_two_host_threads_share_the_library(hip, oracle):
     """SURVEY 8(b) threading: thread-safe per calling thread (thread-local context + stream).  Two
     host threads run different call chains at the same time on their own images."""
