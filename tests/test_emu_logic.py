@@ -125,6 +125,14 @@ def test_lena_pipeline(emu, oracle, kat):
     c = img.copy()
     emu.threshold(c, t)
     assert fnv(c) == kat["lena"]["thr_src"]
+    # BASELINE configs[0] proper: lena resized to 512x512 (gs_resize, float32 bilinear), blur 2, sobel into a
+    # zeroed image -- SURVEY 8(c) hash of the reference's output
+    big = np.zeros((512, 512), np.uint8)
+    emu.resize(big, img)
+    a5, b5 = np.zeros_like(big), np.zeros_like(big)
+    emu.blur(a5, big, 2)
+    emu.sobel(b5, a5)
+    assert fnv(b5) == kat["lena"]["resize512_blur2_sobel"]
 
 
 def test_batch_entry_points(emu, oracle):

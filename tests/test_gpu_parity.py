@@ -144,6 +144,13 @@ def test_kat_lena(hip, kat):
     d = np.zeros_like(img)
     hip.adaptive_threshold(d, img, 15, 5)
     assert fnv(d) == k["adaptive_r15_c5"]
+    # BASELINE configs[0]: lena -> gs_resize 512x512 (float32 bilinear) -> gs_blur(2) -> gs_sobel into zeros
+    big = np.zeros((512, 512), np.uint8)
+    hip.resize(big, img)
+    a5, b5 = np.zeros_like(big), np.zeros_like(big)
+    hip.blur(a5, big, 2)
+    hip.sobel(b5, a5)
+    assert fnv(b5) == k["resize512_blur2_sobel"]
 
 
 @pytest.mark.parametrize("idx", [0, 1, 2, 3, 4])
