@@ -12,5 +12,13 @@ for _ in range(3):
     g.probe_strip_copy(dst, src); g.blur_batch(tmp, src, 2); g.sobel_batch(dst, tmp); g.erode_batch(dst, src)
     g.otsu_batch(dst, hist, thr); g.threshold_batch(dst, thr)
     g.edge_pipeline_batch(dst, None, src, 2, hist, thr)
+# the "next" rows with their own kernels + the barrier-free integral
+import numpy as np
+ii = torch.zeros((F, H, W), dtype=torch.int32, device="cuda")
+half = torch.zeros((F, H // 2, W // 2), dtype=torch.uint8, device="cuda")
+gauss = np.array([[1, 2, 1], [2, 4, 2], [1, 2, 1]], np.int8)
+for _ in range(3):
+    g.filter_batch(dst, src, gauss, 16); g.adaptive_threshold_batch(dst, src, 15, 5); g.blur_batch(dst, src, 9)
+    g.downsample_batch(half, src); g.integral_batch(src, ii)
 torch.cuda.synchronize()
 print("algorithmic bytes per launch: copy/blur/erode/threshold %d, sobel %d, hist %d" % (2*F*H*W, F*(H*W+(H-2)*(W-2)), F*H*W))
