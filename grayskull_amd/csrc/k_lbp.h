@@ -80,12 +80,13 @@ GS_DEV LbpLds lbp_stage_tables(char *smem, const LbpArgs &a, const LbpGeom *geom
 
 /* stages [s0, s1) of the cascade for the window whose top-left padded-table BYTE offset is
  * `origin`; returns false as soon as a stage sum falls below its threshold (ref :794-811).
- * The 16 corner loads are buffer gathers: the per-lane part of the address is the window origin
- * (constant for the whole cascade), the per-feature part is wave-uniform and travels in the
- * SGPR soffset -- no vector ALU for addressing.  Cells are formed from column differences
- * (21 instead of 27 add/sub).  GUARD (feature rectangles that can stick out of the window, only
- * with scale < 1 after the clamp of ref :803-804): explicit clamped vector address instead; the
- * reference reads out of bounds there, so no particular value is "right". */
+ * The 16 corner loads are global loads at origin + (wave-uniform feature offset): the per-lane
+ * part of the address is the window origin (constant for the whole cascade), the per-feature part
+ * comes from the LDS-staged geometry table via v_readfirstlane.  (Buffer gathers with the uniform
+ * part in an SGPR soffset measured slower.)  Cells are formed from column differences (21 instead
+ * of 27 add/sub).  GUARD (feature rectangles that can stick out of the window, only with
+ * scale < 1 after the clamp of ref :803-804): explicit clamped address instead; the reference
+ * reads out of bounds there, so no particular value is "right". */
 /* The 16 corner gathers of the NEXT weak classifier are issued before the current one's
  * arithmetic (they do not depend on it; only a stage end does), so L2 latency overlaps the ~70
  * lane-ops of cell/code/lookup work.  Tables are in evaluation order (stage by stage), so the
