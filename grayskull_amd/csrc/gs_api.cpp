@@ -636,7 +636,7 @@ __global__ void k_lbp_single(LbpArgs a, const LbpGeom *geom, unsigned *out) {
   const LbpLds t = lbp_stage_tables(smem, a, geom, threadIdx.x, 64u);
   __syncthreads();
   if (threadIdx.x == 0)
-    out[0] = lbp_window_stages<true>(t, make_buf(a.padded, a.frame_stride * 4), a.padded, 0u, a.limit_bytes, 0u, a.nstages) ? 1u : 0u;
+    out[0] = lbp_window_stages<true>(t, a.padded, 0u, a.limit_bytes, 0u, a.nstages) ? 1u : 0u;
 }
 
 /* ------------------------------------------------------------------ ORB host logic */

@@ -114,7 +114,7 @@ GS_DEV LbpCorners lbp_gather(const LbpLds &t, const unsigned *Pg, unsigned origi
 #define GS_LBP_PREFETCH 1 /* classifiers whose corners are in flight ahead of the arithmetic (MI355X: 1 -> 30.6, 2 -> 28.1, 3 -> 24.9 Gwin/s) */
 #endif
 template <bool GUARD>
-GS_DEV bool lbp_window_stages(const LbpLds &t, const BufRsrc &, const unsigned *Pg, unsigned origin,
+GS_DEV bool lbp_window_stages(const LbpLds &t, const unsigned *Pg, unsigned origin,
                               unsigned limit, unsigned s0, unsigned s1) {
   constexpr int PD = GS_LBP_PREFETCH;
   const unsigned wend = uniform(t.stage[s1 - 1].first) + uniform(t.stage[s1 - 1].count);
@@ -206,7 +206,6 @@ __global__ __launch_bounds__(256) void k_lbp_cascade(LbpArgs a, LbpPhases ph) {
   __syncthreads();
   const unsigned nwin = sc.nx * sc.ny, first = blockIdx.x * kChunkItems;
   const unsigned *Pg = a.padded + (size_t)blockIdx.z * a.frame_stride;
-  const BufRsrc P = make_buf(Pg, a.frame_stride * 4);
   unsigned n_in = nwin - first < kChunkItems ? nwin - first : kChunkItems;
   unsigned cur = 0;
   for (unsigned p = 0; p < ph.n; p++) {
@@ -220,7 +219,7 @@ __global__ __launch_bounds__(256) void k_lbp_cascade(LbpArgs a, LbpPhases ph) {
       unsigned local = 0;
       if (i < n_in) {
         local = p ? qin[i] : i;
-        pass = lbp_window_stages<GUARD>(t, P, Pg, lbp_origin(a, sc, first + local), a.limit_bytes, s0, s1);
+        pass = lbp_window_stages<GUARD>(t, Pg, lbp_origin(a, sc, first + local), a.limit_bytes, s0, s1);
       }
       if (lastp) {
         if (pass) atomicOr(&bits[local >> 5], 1u << (local & 31u));
