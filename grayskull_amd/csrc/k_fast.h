@@ -9,7 +9,8 @@
  * UNSIGNED arithmetic (`v > p + t`, else `v < p - t` with unsigned t): when p < t the darker
  * bound wraps and every non-brighter pixel counts as darker (ref :496-498).
  *
- * HBM-bound: 3 B/px (score pass 1 R + 1 W, NMS pass 1 R).
+ * Algorithmic traffic is 3 B/px (score pass 1 R + 1 W, NMS pass 1 R), but the score pass is
+ * VALU-bound (~140 lane-ops per pixel: 16 ring pixels x two class masks + the minimum |v - p|).
  */
 #ifndef GS_K_FAST_H
 #define GS_K_FAST_H
