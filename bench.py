@@ -137,6 +137,7 @@ def main():
     ms_unfused = time_stream(torch, step_unfused, reps)
     ms_fused = time_stream(torch, step, reps)
     kernels = {
+        "gs_blur(r=%d)+gs_sobel, one pass (gsh_blur_sobel_batch)" % r: (lambda: g.blur_sobel_batch(dst, src, r), 4.0 * npx),
         "gs_blur(r=%d) k_blur16" % r: (lambda: g.blur_batch(tmp, src, r), 2.0 * npx),
         "gs_sobel k_sobel16": (lambda: g.sobel_batch(dst, tmp), float(F * (w * h + (w - 2) * (h - 2)))),
         "gs_histogram+otsu": (lambda: g.otsu_batch(dst, hist, thr), 1.0 * npx),
@@ -296,6 +297,12 @@ def main():
                   "hbm_frac_of_peak": round(4.0 * npx / ms_fused / 1e6 / HBM_PEAK_GBS, 4), "note": "blur+sobel+histogram in one kernel per 32-frame chunk; each chunk's threshold pass runs under the next chunk's fused kernel"},
         "unfused": {"ms_per_step": round(ms_unfused, 4), "Mpix/s": round(npx / ms_unfused / 1e3, 1),
                     "hbm_bytes_per_px": 7, "note": "separate gs_blur, gs_sobel, histogram, threshold kernels"},
+        "blur_sobel_only": {  # BASELINE.json's metric names gs_sobel+gs_blur: that chain alone, one pass
+            "ms_per_step": ktab["gs_blur(r=%d)+gs_sobel, one pass (gsh_blur_sobel_batch)" % r]["ms"],
+            "Mpix/s": round(npx / ktab["gs_blur(r=%d)+gs_sobel, one pass (gsh_blur_sobel_batch)" % r]["ms"] / 1e3, 1),
+            "percall_accounting_GB/s (4 B/px)": ktab["gs_blur(r=%d)+gs_sobel, one pass (gsh_blur_sobel_batch)" % r]["GB/s"],
+            "frac_of_hbm_peak_percall_accounting": ktab["gs_blur(r=%d)+gs_sobel, one pass (gsh_blur_sobel_batch)" % r]["frac"],
+            "bytes_actually_moved_per_px": 2, "bound": "VALU"},
         "roofline": roof, "kernels": ktab, "sobel_4096x4096": ns, "other_configs": other, "parity": parity,
         "otsu_thresholds_gathered": int(thr_all.numel()),
     }

@@ -105,6 +105,7 @@ _SIGS = {
     "gsh_otsu_batch": (None, [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p]),
     "gsh_threshold_batch": (None, [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_uint8]),
     "gsh_threshold_batch_dev": (None, [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_void_p]),
+    "gsh_blur_sobel_batch": (None, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_uint]),
     "gsh_edge_pipeline_batch": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint,
                                        C.c_uint, C.c_uint, C.c_void_p, C.c_void_p]),
     "gsh_integral_batch": (None, [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_void_p]),
@@ -325,6 +326,10 @@ class Grayskull:
             self.c.gsh_threshold_batch(_ptr(img), w, h, n, t)
         else:
             self.c.gsh_threshold_batch_dev(_ptr(img), w, h, n, _ptr(t))
+
+    def blur_sobel_batch(self, dst, src, radius):
+        n, h, w = self._nhw(src)
+        self.c.gsh_blur_sobel_batch(_ptr(dst), _ptr(src), w, h, n, radius)
 
     def edge_pipeline_batch(self, dst, tmp, src, radius, hist_scratch, thr):
         n, h, w = self._nhw(src)

@@ -906,6 +906,31 @@ void gsh_threshold_batch_dev(uint8_t *img, unsigned w, unsigned h, unsigned n, c
   GS_ASSERT(img && thr && w > 0 && h > 0);
   launch_threshold(img, (size_t)(w * h), n, thr, 0);
 }
+/* gs_blur(radius) then gs_sobel into a zeroed image, per frame, in one pass (the fused kernel of
+ * the pipeline without the Otsu / threshold half) */
+void gsh_blur_sobel_batch(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned n,
+                          unsigned radius) {
+  GS_ASSERT(dst && src && w > 0 && h > 0);
+  if (n == 0) return;
+  const size_t fb = (size_t)w * h;
+  hipStream_t st = ctx().s();
+  if (g_tune[3] == 0 && radius >= 1 && radius <= 3 && strip_ok(w, h, dst, src) && w >= 32 && h >= 3 &&
+      h > 2 * radius) {
+    for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
+      const unsigned nn = std::min(kMaxZ, n - f0);
+      const StripCfg c = strip_cfg(w, h - 2, nn, 3);
+      unsigned *partial = (unsigned *)ctx().scratch(SL_HISTP, (size_t)nn * c.grid.x * c.grid.y * 256 * 4);
+      launch_blur_sobel_hist(radius, dim3(c.grid.x, c.grid.y, nn), c.block, st, dst + fb * f0, src + fb * f0, w, h,
+                             c.T, fb, partial); /* the per-block histograms are simply not used */
+      GS_LAUNCH(k_zero_frame, dim3((2 * w + 2 * h + 255) / 256, nn), dim3(256), 0, st, dst + fb * f0, w, h, fb);
+    }
+    return;
+  }
+  uint8_t *t = (uint8_t *)ctx().scratch(SL_AUX, fb * n);
+  launch_blur(t, src, w, h, n, radius);
+  GS_HIP(hipMemsetAsync(dst, 0, fb * n, st));
+  if (w >= 3 && h >= 3) launch_sobel(dst, t, w, h, n, true);
+}
 void gsh_edge_pipeline_batch(uint8_t *dst, uint8_t *tmp, const uint8_t *src, unsigned w, unsigned h,
                              unsigned n, unsigned radius, unsigned *hist_scratch, uint8_t *thr) {
   GS_ASSERT(dst && src && hist_scratch && thr && w > 0 && h > 0);

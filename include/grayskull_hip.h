@@ -74,6 +74,11 @@ void gsh_otsu_batch(const uint8_t *img, unsigned w, unsigned h, unsigned n, unsi
 void gsh_threshold_batch(uint8_t *img, unsigned w, unsigned h, unsigned n, uint8_t thresh);
 void gsh_threshold_batch_dev(uint8_t *img, unsigned w, unsigned h, unsigned n, const uint8_t *thr);
 
+/* gs_blur(src, radius) followed by gs_sobel into a zeroed dst, per frame, in one pass over the frame
+ * for radius 1..3 (the blurred image stays in registers; ref :268, :306) */
+void gsh_blur_sobel_batch(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned n,
+                          unsigned radius);
+
 /* config-2 chain per frame: blur(radius) -> sobel (dst frame pre-zeroed) -> otsu -> threshold.
  * dst: n*w*h bytes, thr: the n Otsu thresholds.  tmp: n*w*h bytes that receive the blurred
  * frames, or NULL when the caller does not need them -- then blur, sobel and the histogram run

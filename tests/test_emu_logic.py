@@ -135,6 +135,17 @@ def test_lena_pipeline(emu, oracle, kat):
     assert fnv(b5) == kat["lena"]["resize512_blur2_sobel"]
 
 
+@pytest.mark.parametrize("radius", [1, 2, 3, 5])
+def test_blur_sobel_batch(emu, oracle, radius):
+    """gsh_blur_sobel_batch == gs_blur then gs_sobel into a zeroed image (fused for radius 1..3)"""
+    n, h, w = 2, 21, 64
+    src = np.stack([Oracle.synth(w, h, 40 + i) for i in range(n)])
+    dst = np.full_like(src, 9)
+    emu.blur_sobel_batch(dst, src, radius)
+    for i in range(n):
+        assert np.array_equal(dst[i], oracle.sobel(oracle.blur(src[i], radius))), (radius, i)
+
+
 def test_batch_entry_points(emu, oracle):
     """gsh_* batch calls (emulator: 'device' memory is host memory)"""
     n, h, w = 3, 20, 48

@@ -291,6 +291,21 @@ def test_orb_pyramid_device_resident(hip, oracle, shape, levels, nkps):
     pc.orb_pyramid(hip, oracle, Oracle.synth(w, h, 21), pc.Mem("device"), nkps=nkps, levels=levels)
 
 
+def test_blur_sobel_batch(hip, oracle, kat):
+    """gsh_blur_sobel_batch on the 4K KAT frame: the reference-generated blur2->sobel hash"""
+    import torch
+    k = [e for e in kat["synth"] if e["w"] == 3840][0]
+    src = torch.from_numpy(np.stack([Oracle.synth(3840, 2160, k["seed"]), Oracle.synth(3840, 2160, 9)])).cuda()
+    dst = torch.full_like(src, 3)
+    hip.blur_sobel_batch(dst, src, 2)
+    assert fnv(dst[0].cpu().numpy()) == k["blur_sobel"]
+    for r in (1, 3, 4):
+        small = src[:, :300, :640].contiguous()
+        d = torch.full_like(small, 5)
+        hip.blur_sobel_batch(d, small, r)
+        assert_same(d[1].cpu().numpy(), oracle.sobel(oracle.blur(small[1].cpu().numpy(), r)), "blur_sobel r=%d" % r)
+
+
 def test_box_and_filter_kernels_at_frame_sizes(hip, oracle):
     """k_box16 (sliding box sums) and k_filter16 on real frame sizes: 720p against the oracle, and on a
     4K batch the sliding route against the independent integral-image route (gsh_tune key 6 = 3)"""
