@@ -51,6 +51,8 @@ namespace gs { /* gs_fused.cpp */
 void launch_blur_sobel_hist(unsigned radius, dim3 grid, dim3 block, hipStream_t st, uint8_t *dst,
                             const uint8_t *src, unsigned w, unsigned h, unsigned T, size_t frame_bytes,
                             unsigned *partial);
+void launch_blur_sobel(unsigned radius, dim3 grid, dim3 block, hipStream_t st, uint8_t *dst, const uint8_t *src,
+                       unsigned w, unsigned h, unsigned T, size_t frame_bytes);
 }
 using namespace gs;
 
@@ -919,9 +921,8 @@ void gsh_blur_sobel_batch(uint8_t *dst, const uint8_t *src, unsigned w, unsigned
     for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
       const unsigned nn = std::min(kMaxZ, n - f0);
       const StripCfg c = strip_cfg(w, h - 2, nn, 3);
-      unsigned *partial = (unsigned *)ctx().scratch(SL_HISTP, (size_t)nn * c.grid.x * c.grid.y * 256 * 4);
-      launch_blur_sobel_hist(radius, dim3(c.grid.x, c.grid.y, nn), c.block, st, dst + fb * f0, src + fb * f0, w, h,
-                             c.T, fb, partial); /* the per-block histograms are simply not used */
+      launch_blur_sobel(radius, dim3(c.grid.x, c.grid.y, nn), c.block, st, dst + fb * f0, src + fb * f0, w, h,
+                        c.T, fb);
       GS_LAUNCH(k_zero_frame, dim3((2 * w + 2 * h + 255) / 256, nn), dim3(256), 0, st, dst + fb * f0, w, h, fb);
     }
     return;

@@ -18,4 +18,13 @@ void launch_blur_sobel_hist(unsigned radius, dim3 grid, dim3 block, hipStream_t 
   else GS_LAUNCH(k_blur_sobel_hist16<3>, grid, block, 0, st, dst, src, w, h, T, frame_bytes, partial);
 }
 
+/* the same kernel without the histogram half (gsh_blur_sobel_batch) */
+void launch_blur_sobel(unsigned radius, dim3 grid, dim3 block, hipStream_t st, uint8_t *dst, const uint8_t *src,
+                       unsigned w, unsigned h, unsigned T, size_t frame_bytes) {
+  unsigned *none = nullptr;
+  if (radius == 1) GS_LAUNCH((k_blur_sobel_hist16<1, false>), grid, block, 0, st, dst, src, w, h, T, frame_bytes, none);
+  else if (radius == 2) GS_LAUNCH((k_blur_sobel_hist16<2, false>), grid, block, 0, st, dst, src, w, h, T, frame_bytes, none);
+  else GS_LAUNCH((k_blur_sobel_hist16<3, false>), grid, block, 0, st, dst, src, w, h, T, frame_bytes, none);
+}
+
 }  // namespace gs

@@ -53,15 +53,18 @@ GS_DEV void blur_hsum10(const uint32_t (&U)[12], uint32_t (&H)[10]) { /* pairs =
 }
 
 /* grid like the strip kernels; partial: [frame][blockIdx.y * gridDim.x + blockIdx.x][256] */
-template <int R>
+/* HIST = false: gs_blur + gs_sobel only (gsh_blur_sobel_batch): no LDS, no histogram, `partial` unused */
+template <int R, bool HIST = true>
 __global__ __launch_bounds__(256) void k_blur_sobel_hist16(uint8_t *dst, const uint8_t *src,
                                                            unsigned w, unsigned h, unsigned T,
                                                            size_t frame_bytes, unsigned *partial) {
   constexpr int N = 2 * R + 1;
-  __shared__ unsigned lh[256 * 32];
+  __shared__ unsigned lh[HIST ? 256 * 32 : 1];
   const unsigned tid = threadIdx.y * blockDim.x + threadIdx.x, copy = tid & 31u;
-  for (unsigned i = tid; i < 256 * 32; i += 256) lh[i] = 0;
-  __syncthreads();
+  if constexpr (HIST) {
+    for (unsigned i = tid; i < 256 * 32; i += 256) lh[i] = 0;
+    __syncthreads();
+  }
   const Strip<> S(src, dst, w, h, frame_bytes);
   const int y0 = 1 + (int)(S.band * T);
   if (y0 < (int)h - 1) { /* wave-uniform; no early return: every wave reaches the barrier */
@@ -138,22 +141,26 @@ __global__ __launch_bounds__(256) void k_blur_sobel_hist16(uint8_t *dst, const u
       else o = st.step_shift(UB, M);
       /* histogram, branch-free: lanes outside the image, the two frame columns and the dropped
        * rows of the last group add 0. */
-      const unsigned inc = (inimg && i < nrows) ? 1u : 0u;
-      const unsigned inc0 = first ? 0u : inc, inc15 = last ? 0u : inc;
+      if constexpr (HIST) {
+        const unsigned inc = (inimg && i < nrows) ? 1u : 0u;
+        const unsigned inc0 = first ? 0u : inc, inc15 = last ? 0u : inc;
 #pragma unroll
-      for (int k = 0; k < 8; k++) { /* LDS byte offset = bin*128 + copy*4, straight from either half of the pair */
-        atomicAdd((unsigned *)((char *)lh + mad_u32_u16_lo(M[k], 128u, cb)), k == 0 ? inc0 : inc);
-        atomicAdd((unsigned *)((char *)lh + mad_u32_u16_hi(M[k], 128u, cb)), k == 7 ? inc15 : inc);
+        for (int k = 0; k < 8; k++) { /* LDS byte offset = bin*128 + copy*4, straight from either half of the pair */
+          atomicAdd((unsigned *)((char *)lh + mad_u32_u16_lo(M[k], 128u, cb)), k == 0 ? inc0 : inc);
+          atomicAdd((unsigned *)((char *)lh + mad_u32_u16_hi(M[k], 128u, cb)), k == 7 ? inc15 : inc);
+        }
       }
       return o;
     });
   }
-  __syncthreads();
-  unsigned acc = 0;
+  if constexpr (HIST) {
+    __syncthreads();
+    unsigned acc = 0;
 #pragma unroll 8
-  for (unsigned k = 0; k < 32; k++) acc += lh[tid * 32u + ((k + tid) & 31u)];
-  const size_t blk = (size_t)blockIdx.z * gridDim.x * gridDim.y + (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-  partial[blk * 256u + tid] = acc;
+    for (unsigned k = 0; k < 32; k++) acc += lh[tid * 32u + ((k + tid) & 31u)];
+    const size_t blk = (size_t)blockIdx.z * gridDim.x * gridDim.y + (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    partial[blk * 256u + tid] = acc;
+  }
 }
 
 }  // namespace gs
