@@ -68,6 +68,9 @@ def cpu_baseline(w, h, radius, frames_target=48):
             "%d frames %dx%d, same chain, C restatement (oracle/gs_oracle.c)" % (frames, w, h)}
 
 
+BASELINE_METRIC = "Mpix/s (and % HBM roofline) for gs_sobel+gs_blur on 4K uint8, 1/2/4/8 GPU"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -283,7 +286,7 @@ def main():
     thr_all = sh.all_gather_frames(thr, F * sh.world)  # KB-scale result exchange (RCCL when N>1)
 
     out = {
-        "metric": "Mpix/s for gs_blur(r=2)+gs_sobel+gs_threshold(otsu) on 4K uint8",
+        "metric": BASELINE_METRIC,  # BASELINE.json's metric string; the workload is named in config.workload
         "value": round(value, 1), "unit": "Mpix/s", "n_gpus": sh.world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
