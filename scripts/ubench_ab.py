@@ -24,7 +24,7 @@ def call(g, op):
             "sobel": lambda: g.sobel_batch(dst, src), "blur2": lambda: g.blur_batch(dst, src, 2),
             "thr": lambda: g.threshold_batch(dst, 100), "dilate": lambda: g.dilate_batch(dst, src),
             "blur1": lambda: g.blur_batch(dst, src, 1), "blur3": lambda: g.blur_batch(dst, src, 3),
-            "fused": lambda: g.edge_pipeline_batch(dst, None, src, 2, hist, thr), "hist": lambda: g.histogram_batch(src, hist)}[op]
+            "fused": lambda: g.edge_pipeline_batch(dst, None, src, 2, hist, thr), "bs": lambda: g.blur_sobel_batch(dst, src, 2), "hist": lambda: g.histogram_batch(src, hist)}[op]
 hist = torch.zeros((F, 256), dtype=torch.int32, device="cuda")
 thr = torch.zeros((F,), dtype=torch.uint8, device="cuda")
 res = {}
