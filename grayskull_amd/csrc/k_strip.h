@@ -140,19 +140,19 @@ struct SobelKeepCols { /* Fin functor of strip_rows */
   BufRsrc dst;
   unsigned w, x0;
   bool first, last;
-  uint32_t e_next = 0, e_cur = 0; /* dst dword holding the protected byte: rows y+1 and y */
+  uint32_t e = 0; /* dst dword holding the protected byte of the row that is stored next */
   GS_DEV SobelKeepCols(const Strip<> &S) : dst(S.dst), w(S.w), x0(S.x0) {
     first = x0 == 0, last = x0 + 16 == w; /* launcher guarantees w >= 32: never both */
   }
+  /* strip_rows calls prefetch(y) in the iteration that COMPUTES row y and operator() in the next
+   * one, right before row y is stored (and before the next prefetch): one iteration of latency */
   GS_DEV void prefetch(int y) {
-    e_cur = e_next;
     const uint32_t row = (uint32_t)y * w + x0;
-    e_next = buf_load4(dst, first ? row : last ? row + 12 : kOOB);
+    e = buf_load4(dst, first ? row : last ? row + 12 : kOOB);
   }
   GS_DEV U4 operator()(U4 o, int) const {
-    /* operator() for row y runs after prefetch(y+1): row y's dword is e_cur */
-    o.x = first ? perm_b32(o.x, e_cur, 0x07060500u) : o.x; /* byte 0 <- dst */
-    o.w = last ? perm_b32(o.w, e_cur, 0x03060504u) : o.w;  /* byte 3 <- dst */
+    o.x = first ? perm_b32(o.x, e, 0x07060500u) : o.x; /* byte 0 <- dst */
+    o.w = last ? perm_b32(o.w, e, 0x03060504u) : o.w;  /* byte 3 <- dst */
     return o;
   }
 };

@@ -98,6 +98,12 @@ def stencils(g, o, img, mem, radii=(1, 2, 3, 5)):
     g.sobel(d, s)
     assert_same(mem.get(d), o.sobel(img, np.full_like(img, SENTINEL)),
                 "gs_sobel (1-px frame must keep the sentinel) %s" % (img.shape,))
+    # ... and whatever the caller had there: a dst whose border differs from row to row (a constant
+    # sentinel cannot tell rows apart -- a kernel that restored column 0 from the wrong row passed it)
+    d0 = np.random.RandomState(img.shape[0] * 7 + img.shape[1]).randint(0, 256, img.shape).astype(np.uint8)
+    d = mem.put(d0)
+    g.sobel(d, s)
+    assert_same(mem.get(d), o.sobel(img, d0), "gs_sobel (random dst: frame untouched) %s" % (img.shape,))
     for name in ("erode", "dilate"):
         d = mem.zeros(img.shape, fill=SENTINEL)
         getattr(g, name)(d, s)
