@@ -9,6 +9,15 @@ import parity_cases as pc
 from util import assert_same
 
 MEM = pc.Mem("host")
+# Deterministic in CI (the same examples every run); GS_HYPOTHESIS_EXAMPLES=N explores N fresh random
+# examples per test instead (used while developing: it found the gs_sobel dst-border bug).
+import os
+_N = int(os.environ.get("GS_HYPOTHESIS_EXAMPLES", "0"))
+
+
+def _cfg(default):
+    return settings(max_examples=_N or default, deadline=None, derandomize=not _N, database=None,
+                    suppress_health_check=list(HealthCheck))
 widths = st.one_of(st.sampled_from([16, 32, 48, 64, 80, 96, 112, 1024, 1040]), st.integers(1, 70))
 heights = st.one_of(st.integers(1, 12), st.integers(13, 70))
 
@@ -21,7 +30,7 @@ def _img(rs, w, h, kind):
     return (rs.randint(0, 2, (h, w)) * 255).astype(np.uint8)  # binary: saturating sums
 
 
-@settings(max_examples=40, deadline=None, suppress_health_check=list(HealthCheck))
+@_cfg(40)
 @given(w=widths, h=heights, seed=st.integers(0, 2 ** 16), kind=st.integers(0, 2), radius=st.integers(0, 40))
 def test_stencils_any_shape(emu, oracle, w, h, seed, kind, radius):
     if w >= 1024 and h > 8:
@@ -48,7 +57,7 @@ def test_stencils_any_shape(emu, oracle, w, h, seed, kind, radius):
     assert emu.otsu_threshold(s) == oracle.otsu_threshold(img)
 
 
-@settings(max_examples=25, deadline=None, suppress_health_check=list(HealthCheck))
+@_cfg(25)
 @given(w=widths, h=heights, seed=st.integers(0, 2 ** 16), norm=st.sampled_from([1, 2, 9, 16, 255, 256, 300]),
        ks=st.lists(st.integers(-16, 16), min_size=9, max_size=9))
 def test_filter_any_shape(emu, oracle, w, h, seed, norm, ks):
@@ -61,7 +70,7 @@ def test_filter_any_shape(emu, oracle, w, h, seed, norm, ks):
     assert_same(d, oracle.filter(img, k, norm), "gs_filter %dx%d norm=%d k=%s" % (w, h, norm, ks))
 
 
-@settings(max_examples=20, deadline=None, suppress_health_check=list(HealthCheck))
+@_cfg(20)
 @given(n=st.integers(1, 5), w=st.sampled_from([32, 48, 64, 1040]), h=st.integers(3, 40), radius=st.integers(1, 3),
        seed=st.integers(0, 2 ** 16))
 def test_fused_pipeline_any_shape(emu, oracle, n, w, h, radius, seed):
@@ -76,3 +85,68 @@ def test_fused_pipeline_any_shape(emu, oracle, n, w, h, radius, seed):
         t = oracle.otsu_threshold(s)
         assert int(thr[i]) == t, "otsu frame %d" % i
         assert_same(out[i], oracle.threshold(s, t), "pipeline frame %d (%dx%d r=%d)" % (i, w, h, radius))
+
+
+@_cfg(20)
+@given(w=st.integers(7, 90), h=st.integers(7, 60), seed=st.integers(0, 2 ** 16), kind=st.integers(0, 2),
+       threshold=st.sampled_from([0, 1, 5, 20, 60, 200, 255, 300]), nkps=st.integers(1, 80))
+def test_fast_orb_match_any_shape(emu, oracle, w, h, seed, kind, threshold, nkps):
+    rs = np.random.RandomState(seed)
+    img = _img(rs, w, h, kind)
+    sm0 = rs.randint(0, 256, (h, w)).astype(np.uint8)  # the caller's scoremap frame is read by the NMS
+    sm = sm0.copy()
+    k = emu.fast(img.copy(), sm, nkps, threshold)
+    ko, smo = oracle.fast(img, nkps, threshold, sm0)
+    assert_same(k, ko, "gs_fast %dx%d t=%d cap=%d" % (w, h, threshold, nkps))
+    assert_same(sm, smo, "gs_fast scoremap")
+    ka = emu.orb_extract(img.copy(), nkps, threshold, sm0.copy())
+    kao = oracle.orb_extract(img, nkps, threshold, sm0)
+    assert_same(ka, kao, "gs_orb_extract %dx%d t=%d n=%d" % (w, h, threshold, nkps))
+    if len(ka):
+        B = np.roll(img, (1, 2), (0, 1))
+        kb, kbo = emu.orb_extract(B.copy(), nkps, threshold, sm0.copy()), oracle.orb_extract(B, nkps, threshold, sm0)
+        assert_same(kb, kbo, "gs_orb_extract (second frame)")
+        for (mm, md) in ((2 * nkps, 64.0), (3, 256.0)):
+            assert_same(emu.match_orb(ka, kb, mm, md), oracle.match_orb(kao, kbo, mm, md), "gs_match_orb")
+
+
+@_cfg(15)
+@given(w=st.integers(24, 70), h=st.integers(24, 60), seed=st.integers(0, 2 ** 16), cseed=st.integers(0, 50),
+       sf=st.sampled_from([1.1, 1.25, 1.5, 2.0]), mx=st.sampled_from([1.0, 1.6, 2.5]), step=st.integers(1, 3),
+       cap=st.sampled_from([1, 7, 4096]))
+def test_lbp_any_shape(emu, oracle, w, h, seed, cseed, sf, mx, step, cap):
+    from util import random_cascade
+    img = _img(np.random.RandomState(seed), w, h, seed % 3)
+    casc = random_cascade(cseed, nstages=2 + cseed % 3, weaks_per_stage=1 + cseed % 4)
+    ii = oracle.integral(img)
+    r = emu.lbp_detect(casc, ii.copy(), cap, sf, 1.0, mx, step)
+    ro = oracle.lbp_detect(casc, ii, cap, sf, 1.0, mx, step)
+    assert_same(r, ro, "gs_lbp_detect %dx%d sf=%g max=%g step=%d cap=%d" % (w, h, sf, mx, step, cap))
+
+
+@_cfg(20)
+@given(w=st.integers(1, 70), h=st.integers(1, 50), dw=st.integers(1, 90), dh=st.integers(1, 60),
+       seed=st.integers(0, 2 ** 16), nn=st.booleans())
+def test_resize_any_shape(emu, oracle, w, h, dw, dh, seed, nn):
+    img = _img(np.random.RandomState(seed), w, h, seed % 3)
+    d = np.full((dh, dw), 0xAB, np.uint8)
+    emu.resize(d, img.copy(), nn)
+    assert_same(d, oracle.resize(img, dw, dh, nn), "gs_resize%s %dx%d -> %dx%d" % ("_nn" if nn else "", w, h, dw, dh))
+    if w >= 2 and h >= 2:
+        d = np.full((h // 2, w // 2), 0xAB, np.uint8)
+        emu.downsample(d, img.copy())
+        assert_same(d, oracle.downsample(img), "gs_downsample %dx%d" % (w, h))
+
+
+@_cfg(20)
+@given(w=st.integers(1, 60), h=st.integers(1, 40), seed=st.integers(0, 2 ** 16), data=st.data())
+def test_template_any_shape(emu, oracle, w, h, seed, data):
+    rs = np.random.RandomState(seed)
+    img = _img(rs, w, h, seed % 3)
+    tw, th = data.draw(st.integers(1, w)), data.draw(st.integers(1, h))
+    t = rs.randint(0, 256, (th, tw)).astype(np.uint8)
+    r = np.full((h - th + 1, w - tw + 1), 0xAB, np.uint8)
+    emu.match_template(img.copy(), t, r)
+    ro = oracle.match_template(img, t)
+    assert_same(r, ro, "gs_match_template %dx%d in %dx%d" % (tw, th, w, h))
+    assert emu.find_best_match(r) == oracle.find_best_match(ro)
