@@ -136,6 +136,33 @@ _SIGS = {
 EXPORTED_SYMBOLS = tuple(sorted(_SIGS))
 
 
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so / libhsa-runtime64.so and load them by file
+    name; libgrayskull_hip.so needs `libamdhip64.so.7` by SONAME.  If this library comes first, the
+    system runtime is loaded, `import torch` later loads a SECOND runtime and finds no GPU
+    ("No HIP GPUs are available").  So when torch is installed but not imported yet, load its
+    runtime first: ours then binds to it by SONAME and a later `import torch` finds it loaded.
+    Without torch nothing happens and the system ROCm runtime is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if not spec or not spec.origin:
+        return
+    libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        f = os.path.join(libdir, name)
+        if os.path.exists(f):
+            try:
+                C.CDLL(f, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 class Grayskull:
     """Bound libgrayskull_hip.so.  `path` is for the test-suite's emulator build only."""
 
@@ -146,6 +173,8 @@ class Grayskull:
                 "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). grayskull_amd has no CPU fallback." % path)
         self.path = path
+        if os.path.abspath(path) == os.path.abspath(HIP_LIBRARY):
+            _share_torch_hip_runtime()
         self.c = C.CDLL(path)
         for name, (res, args) in _SIGS.items():
             f = getattr(self.c, name)

@@ -30,9 +30,7 @@ def _img(rs, w, h, kind):
     return (rs.randint(0, 2, (h, w)) * 255).astype(np.uint8)  # binary: saturating sums
 
 
-@_cfg(40)
-@given(w=widths, h=heights, seed=st.integers(0, 2 ** 16), kind=st.integers(0, 2), radius=st.integers(0, 40))
-def test_stencils_any_shape(emu, oracle, w, h, seed, kind, radius):
+def _body_stencils_any_shape(emu, oracle, w, h, seed, kind, radius):
     if w >= 1024 and h > 8:
         h = 8  # keep the emulator fast
     img = _img(np.random.RandomState(seed), w, h, kind)
@@ -57,10 +55,7 @@ def test_stencils_any_shape(emu, oracle, w, h, seed, kind, radius):
     assert emu.otsu_threshold(s) == oracle.otsu_threshold(img)
 
 
-@_cfg(25)
-@given(w=widths, h=heights, seed=st.integers(0, 2 ** 16), norm=st.sampled_from([1, 2, 9, 16, 255, 256, 300]),
-       ks=st.lists(st.integers(-16, 16), min_size=9, max_size=9))
-def test_filter_any_shape(emu, oracle, w, h, seed, norm, ks):
+def _body_filter_any_shape(emu, oracle, w, h, seed, norm, ks):
     if w >= 1024 and h > 8:
         h = 8
     img = _img(np.random.RandomState(seed), w, h, seed % 3)
@@ -70,16 +65,17 @@ def test_filter_any_shape(emu, oracle, w, h, seed, norm, ks):
     assert_same(d, oracle.filter(img, k, norm), "gs_filter %dx%d norm=%d k=%s" % (w, h, norm, ks))
 
 
-@_cfg(20)
-@given(n=st.integers(1, 5), w=st.sampled_from([32, 48, 64, 1040]), h=st.integers(3, 40), radius=st.integers(1, 3),
-       seed=st.integers(0, 2 ** 16))
-def test_fused_pipeline_any_shape(emu, oracle, n, w, h, radius, seed):
+def _body_fused_pipeline_any_shape(emu, oracle, n, w, h, radius, seed):
     if w >= 1024 and h > 8:
         h = 8
     rs = np.random.RandomState(seed)
     src = np.stack([_img(rs, w, h, i % 3) for i in range(n)])
-    out, hist, thr = np.full_like(src, 7), np.zeros((n, 256), np.uint32), np.zeros(n, np.uint8)
-    emu.edge_pipeline_batch(out, None, src, radius, hist, thr)
+    mem = pc.Mem("host" if "kernel_emu" in emu.path else "device")  # the batch API takes device memory
+    out_m, hist_m, thr_m = mem.put(np.full_like(src, 7)), mem.put(np.zeros((n, 256), np.uint32)), mem.put(np.zeros(n, np.uint8))
+    emu.edge_pipeline_batch(out_m, None, mem.put(src), radius, hist_m, thr_m)
+    if mem.kind == "device":
+        emu.sync()
+    out, thr = mem.get(out_m), mem.get(thr_m)
     for i in range(n):
         s = oracle.sobel(oracle.blur(src[i], radius))
         t = oracle.otsu_threshold(s)
@@ -87,10 +83,7 @@ def test_fused_pipeline_any_shape(emu, oracle, n, w, h, radius, seed):
         assert_same(out[i], oracle.threshold(s, t), "pipeline frame %d (%dx%d r=%d)" % (i, w, h, radius))
 
 
-@_cfg(20)
-@given(w=st.integers(7, 90), h=st.integers(7, 60), seed=st.integers(0, 2 ** 16), kind=st.integers(0, 2),
-       threshold=st.sampled_from([0, 1, 5, 20, 60, 200, 255, 300]), nkps=st.integers(1, 80))
-def test_fast_orb_match_any_shape(emu, oracle, w, h, seed, kind, threshold, nkps):
+def _body_fast_orb_match_any_shape(emu, oracle, w, h, seed, kind, threshold, nkps):
     rs = np.random.RandomState(seed)
     img = _img(rs, w, h, kind)
     sm0 = rs.randint(0, 256, (h, w)).astype(np.uint8)  # the caller's scoremap frame is read by the NMS
@@ -110,11 +103,7 @@ def test_fast_orb_match_any_shape(emu, oracle, w, h, seed, kind, threshold, nkps
             assert_same(emu.match_orb(ka, kb, mm, md), oracle.match_orb(kao, kbo, mm, md), "gs_match_orb")
 
 
-@_cfg(15)
-@given(w=st.integers(24, 70), h=st.integers(24, 60), seed=st.integers(0, 2 ** 16), cseed=st.integers(0, 50),
-       sf=st.sampled_from([1.1, 1.25, 1.5, 2.0]), mx=st.sampled_from([1.0, 1.6, 2.5]), step=st.integers(1, 3),
-       cap=st.sampled_from([1, 7, 4096]))
-def test_lbp_any_shape(emu, oracle, w, h, seed, cseed, sf, mx, step, cap):
+def _body_lbp_any_shape(emu, oracle, w, h, seed, cseed, sf, mx, step, cap):
     from util import random_cascade
     img = _img(np.random.RandomState(seed), w, h, seed % 3)
     casc = random_cascade(cseed, nstages=2 + cseed % 3, weaks_per_stage=1 + cseed % 4)
@@ -124,10 +113,7 @@ def test_lbp_any_shape(emu, oracle, w, h, seed, cseed, sf, mx, step, cap):
     assert_same(r, ro, "gs_lbp_detect %dx%d sf=%g max=%g step=%d cap=%d" % (w, h, sf, mx, step, cap))
 
 
-@_cfg(20)
-@given(w=st.integers(1, 70), h=st.integers(1, 50), dw=st.integers(1, 90), dh=st.integers(1, 60),
-       seed=st.integers(0, 2 ** 16), nn=st.booleans())
-def test_resize_any_shape(emu, oracle, w, h, dw, dh, seed, nn):
+def _body_resize_any_shape(emu, oracle, w, h, dw, dh, seed, nn):
     img = _img(np.random.RandomState(seed), w, h, seed % 3)
     d = np.full((dh, dw), 0xAB, np.uint8)
     emu.resize(d, img.copy(), nn)
@@ -138,9 +124,7 @@ def test_resize_any_shape(emu, oracle, w, h, dw, dh, seed, nn):
         assert_same(d, oracle.downsample(img), "gs_downsample %dx%d" % (w, h))
 
 
-@_cfg(20)
-@given(w=st.integers(1, 60), h=st.integers(1, 40), seed=st.integers(0, 2 ** 16), data=st.data())
-def test_template_any_shape(emu, oracle, w, h, seed, data):
+def _body_template_any_shape(emu, oracle, w, h, seed, data):
     rs = np.random.RandomState(seed)
     img = _img(rs, w, h, seed % 3)
     tw, th = data.draw(st.integers(1, w)), data.draw(st.integers(1, h))
@@ -150,3 +134,108 @@ def test_template_any_shape(emu, oracle, w, h, seed, data):
     ro = oracle.match_template(img, t)
     assert_same(r, ro, "gs_match_template %dx%d in %dx%d" % (tw, th, w, h))
     assert emu.find_best_match(r) == oracle.find_best_match(ro)
+
+# ---- the same properties through the emulator (CPU suite) and on the real GPU (-m gpu) ----------
+@_cfg(40)
+@given(w=widths, h=heights, seed=st.integers(0, 2 ** 16), kind=st.integers(0, 2), radius=st.integers(0, 40))
+def test_stencils_any_shape(emu, oracle, w, h, seed, kind, radius):
+    _body_stencils_any_shape(emu, oracle, w=w, h=h, seed=seed, kind=kind, radius=radius)
+
+
+@pytest.mark.gpu
+@_cfg(40)
+@given(w=widths, h=heights, seed=st.integers(0, 2 ** 16), kind=st.integers(0, 2), radius=st.integers(0, 40))
+def test_gpu_stencils_any_shape(hip, oracle, w, h, seed, kind, radius):
+    _body_stencils_any_shape(hip, oracle, w=w, h=h, seed=seed, kind=kind, radius=radius)
+
+
+@_cfg(25)
+@given(w=widths, h=heights, seed=st.integers(0, 2 ** 16), norm=st.sampled_from([1, 2, 9, 16, 255, 256, 300]),
+       ks=st.lists(st.integers(-16, 16), min_size=9, max_size=9))
+def test_filter_any_shape(emu, oracle, w, h, seed, norm, ks):
+    _body_filter_any_shape(emu, oracle, w=w, h=h, seed=seed, norm=norm, ks=ks)
+
+
+@pytest.mark.gpu
+@_cfg(25)
+@given(w=widths, h=heights, seed=st.integers(0, 2 ** 16), norm=st.sampled_from([1, 2, 9, 16, 255, 256, 300]),
+       ks=st.lists(st.integers(-16, 16), min_size=9, max_size=9))
+def test_gpu_filter_any_shape(hip, oracle, w, h, seed, norm, ks):
+    _body_filter_any_shape(hip, oracle, w=w, h=h, seed=seed, norm=norm, ks=ks)
+
+
+@_cfg(20)
+@given(n=st.integers(1, 5), w=st.sampled_from([32, 48, 64, 1040]), h=st.integers(3, 40), radius=st.integers(1, 3),
+       seed=st.integers(0, 2 ** 16))
+def test_fused_pipeline_any_shape(emu, oracle, n, w, h, radius, seed):
+    _body_fused_pipeline_any_shape(emu, oracle, n=n, w=w, h=h, radius=radius, seed=seed)
+
+
+@pytest.mark.gpu
+@_cfg(20)
+@given(n=st.integers(1, 5), w=st.sampled_from([32, 48, 64, 1040]), h=st.integers(3, 40), radius=st.integers(1, 3),
+       seed=st.integers(0, 2 ** 16))
+def test_gpu_fused_pipeline_any_shape(hip, oracle, n, w, h, radius, seed):
+    _body_fused_pipeline_any_shape(hip, oracle, n=n, w=w, h=h, radius=radius, seed=seed)
+
+
+@_cfg(20)
+@given(w=st.integers(7, 90), h=st.integers(7, 60), seed=st.integers(0, 2 ** 16), kind=st.integers(0, 2),
+       threshold=st.sampled_from([0, 1, 5, 20, 60, 200, 255, 300]), nkps=st.integers(1, 80))
+def test_fast_orb_match_any_shape(emu, oracle, w, h, seed, kind, threshold, nkps):
+    _body_fast_orb_match_any_shape(emu, oracle, w=w, h=h, seed=seed, kind=kind, threshold=threshold, nkps=nkps)
+
+
+@pytest.mark.gpu
+@_cfg(20)
+@given(w=st.integers(7, 90), h=st.integers(7, 60), seed=st.integers(0, 2 ** 16), kind=st.integers(0, 2),
+       threshold=st.sampled_from([0, 1, 5, 20, 60, 200, 255, 300]), nkps=st.integers(1, 80))
+def test_gpu_fast_orb_match_any_shape(hip, oracle, w, h, seed, kind, threshold, nkps):
+    _body_fast_orb_match_any_shape(hip, oracle, w=w, h=h, seed=seed, kind=kind, threshold=threshold, nkps=nkps)
+
+
+@_cfg(15)
+@given(w=st.integers(24, 70), h=st.integers(24, 60), seed=st.integers(0, 2 ** 16), cseed=st.integers(0, 50),
+       sf=st.sampled_from([1.1, 1.25, 1.5, 2.0]), mx=st.sampled_from([1.0, 1.6, 2.5]), step=st.integers(1, 3),
+       cap=st.sampled_from([1, 7, 4096]))
+def test_lbp_any_shape(emu, oracle, w, h, seed, cseed, sf, mx, step, cap):
+    _body_lbp_any_shape(emu, oracle, w=w, h=h, seed=seed, cseed=cseed, sf=sf, mx=mx, step=step, cap=cap)
+
+
+@pytest.mark.gpu
+@_cfg(15)
+@given(w=st.integers(24, 70), h=st.integers(24, 60), seed=st.integers(0, 2 ** 16), cseed=st.integers(0, 50),
+       sf=st.sampled_from([1.1, 1.25, 1.5, 2.0]), mx=st.sampled_from([1.0, 1.6, 2.5]), step=st.integers(1, 3),
+       cap=st.sampled_from([1, 7, 4096]))
+def test_gpu_lbp_any_shape(hip, oracle, w, h, seed, cseed, sf, mx, step, cap):
+    _body_lbp_any_shape(hip, oracle, w=w, h=h, seed=seed, cseed=cseed, sf=sf, mx=mx, step=step, cap=cap)
+
+
+@_cfg(20)
+@given(w=st.integers(1, 70), h=st.integers(1, 50), dw=st.integers(1, 90), dh=st.integers(1, 60),
+       seed=st.integers(0, 2 ** 16), nn=st.booleans())
+def test_resize_any_shape(emu, oracle, w, h, dw, dh, seed, nn):
+    _body_resize_any_shape(emu, oracle, w=w, h=h, dw=dw, dh=dh, seed=seed, nn=nn)
+
+
+@pytest.mark.gpu
+@_cfg(20)
+@given(w=st.integers(1, 70), h=st.integers(1, 50), dw=st.integers(1, 90), dh=st.integers(1, 60),
+       seed=st.integers(0, 2 ** 16), nn=st.booleans())
+def test_gpu_resize_any_shape(hip, oracle, w, h, dw, dh, seed, nn):
+    _body_resize_any_shape(hip, oracle, w=w, h=h, dw=dw, dh=dh, seed=seed, nn=nn)
+
+
+@_cfg(20)
+@given(w=st.integers(1, 60), h=st.integers(1, 40), seed=st.integers(0, 2 ** 16), data=st.data())
+def test_template_any_shape(emu, oracle, w, h, seed, data):
+    _body_template_any_shape(emu, oracle, w=w, h=h, seed=seed, data=data)
+
+
+@pytest.mark.gpu
+@_cfg(20)
+@given(w=st.integers(1, 60), h=st.integers(1, 40), seed=st.integers(0, 2 ** 16), data=st.data())
+def test_gpu_template_any_shape(hip, oracle, w, h, seed, data):
+    _body_template_any_shape(hip, oracle, w=w, h=h, seed=seed, data=data)
+
+
