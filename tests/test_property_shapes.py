@@ -53,6 +53,14 @@ def _body_stencils_any_shape(emu, oracle, w, h, seed, kind, radius):
     assert_same(emu.integral(s), oracle.integral(img), "gs_integral %dx%d" % (w, h))
     assert_same(emu.histogram(s), oracle.histogram(img), "gs_histogram")
     assert emu.otsu_threshold(s) == oracle.otsu_threshold(img)
+    t = (seed * 7) % 256
+    c = img.copy()
+    emu.threshold(c, t)
+    assert_same(c, oracle.threshold(img, t), "gs_threshold t=%d" % t)
+    cneg = -((seed % 50) + 1)
+    d = np.full_like(img, 0xAB)
+    emu.adaptive_threshold(d, s, radius, cneg)
+    assert_same(d, oracle.adaptive_threshold(img, radius, cneg), "gs_adaptive_threshold c=%d" % cneg)
 
 
 def _body_filter_any_shape(emu, oracle, w, h, seed, norm, ks):
