@@ -86,6 +86,35 @@ static void t_integral(void) {
   assert(gs_integral_sum(ii, 3, 1, 1, 2, 2) == 28);
 }
 
+/* SURVEY 8(f) rank 4 through the same header: crop / resize / template matching */
+static void t_geometry(void) {
+  uint8_t s[16], c[4], n[16], b[4], line[2] = {0, W};
+  for (int i = 0; i < 16; i++) s[i] = (uint8_t)(10 * i);
+  struct gs_image src = {4, 4, s}, crop = {2, 2, c}, nn = {4, 4, n};
+  struct gs_rect roi = {1, 2, 2, 2};
+  gs_crop(crop, src, roi); /* rows 2..3, columns 1..2 */
+  assert(c[0] == 90 && c[1] == 100 && c[2] == 130 && c[3] == 140);
+  uint8_t two[4] = {1, 2, 3, 4};
+  struct gs_image small = {2, 2, two};
+  gs_resize_nn(nn, small); /* every source pixel becomes a 2x2 block */
+  assert(n[0] == 1 && n[1] == 1 && n[2] == 2 && n[5] == 1 && n[10] == 4 && n[15] == 4);
+  /* bilinear 2x1 -> 4x1 with centres at +0.5: sample positions -0.25 (clamped), 0.25, 0.75, 1.25 (clamped) */
+  struct gs_image l2 = {2, 1, line}, l4 = {4, 1, b};
+  gs_resize(l4, l2);
+  assert(b[0] == 0 && b[1] == 63 && b[2] == 191 && b[3] == 255);
+}
+
+static void t_template(void) {
+  uint8_t img[64] = {0}, tm[4] = {W, 40, 40, W}, res[49];
+  img[3 * 8 + 5] = W, img[3 * 8 + 6] = 40, img[4 * 8 + 5] = 40, img[4 * 8 + 6] = W; /* the patch at (5,3) */
+  struct gs_image im = {8, 8, img}, t = {2, 2, tm}, r = {7, 7, res};
+  gs_match_template(im, t, r);
+  assert(res[3 * 7 + 5] == 255);        /* zero squared difference */
+  assert(res[0] < 255);                 /* an all-zero window differs */
+  struct gs_point p = gs_find_best_match(r);
+  assert(p.x == 5 && p.y == 3);
+}
+
 int main(void) {
   t_blur();
   t_morph();
@@ -93,6 +122,8 @@ int main(void) {
   t_hist_thresh_otsu();
   t_adaptive();
   t_integral();
+  t_geometry();
+  t_template();
   printf("dropin C99 tests: all passed\n");
   return 0;
 }
