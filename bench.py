@@ -68,6 +68,55 @@ def cpu_baseline(w, h, radius, frames_target=48):
             "%d frames %dx%d, same chain, C restatement (oracle/gs_oracle.c)" % (frames, w, h)}
 
 
+def run_cfg4(args, sh, g, torch, np, w, h, F, r, lo):
+    """BASELINE configs[4]: every frame goes through gs_blur(r) -> gs_sobel (zeroed dst) -> gs_integral ->
+    gs_lbp_detect(frontalface, sf 1.1, scales 1..4, step 1, max_rects 4096) on the GPU that owns it; frames
+    are sharded by index, nothing but the barrier / max / a count gather crosses GPUs."""
+    from grayskull_amd.cascade import Cascade
+    casc = Cascade.from_blob(os.path.join(ROOT, "tests", "golden", "frontalface_cascade.bin"))
+    G = 16  # frames per inner group (bounds the u32 integral scratch: 16 x 33 MB)
+    src = torch.empty((G, h, w), dtype=torch.uint8, device="cuda")
+    a, b = torch.empty_like(src), torch.empty_like(src)
+    ii = torch.zeros((G, h, w), dtype=torch.int32, device="cuda")
+    rects = torch.zeros((G, 4096, 4), dtype=torch.int32, device="cuda")
+    counts = torch.zeros(F, dtype=torch.int32, device="cuda")
+    dc = g.cascade_create(casc)
+
+    def step():
+        for f0 in range(0, F, G):
+            n = min(G, F - f0)
+            g.synth_batch(src[:n], 1000 + lo + f0)  # frames are generated where they are processed
+            g.blur_batch(a[:n], src[:n], r)
+            b[:n].zero_()
+            g.sobel_batch(b[:n], a[:n])
+            g.integral_batch(b[:n], ii[:n])
+            g.lbp_detect_batch(dc, ii[:n], rects[:n], counts[f0:f0 + n], 4096, 1.1, 1.0, 4.0, 1)
+
+    for _ in range(args.warmup):
+        step()
+    sh.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    sh.barrier()
+    dt = sh.max_over_ranks(time.perf_counter() - t0)
+    all_counts = sh.all_gather_frames(counts, F * sh.world)
+    if sh.rank == 0:
+        print(json.dumps({
+            "metric": "frames/s for gs_blur->gs_sobel->gs_integral->gs_lbp_detect on 4K uint8 (BASELINE configs[4])",
+            "value": round(sh.world * F * args.steps / dt, 2), "unit": "frames/s", "n_gpus": sh.world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "configs[4]: %d frames %dx%d per GPU, %d in total, sharded by frame" % (F, w, h, F * sh.world),
+                       "frames_per_gpu": F, "global_frames": F * sh.world},
+            "Mpix/s": round(sh.world * F * w * h * args.steps / dt / 1e6, 1),
+            "detections_total": int(all_counts.sum()), "detections_first_frames": all_counts[:4].cpu().tolist()}))
+    dc.close()
+    sh.close()
+
+
 BASELINE_METRIC = "Mpix/s (and % HBM roofline) for gs_sobel+gs_blur on 4K uint8, 1/2/4/8 GPU"
 
 
@@ -80,6 +129,9 @@ def main():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--radius", type=int, default=2)
+    ap.add_argument("--workload", default="cfg1", choices=["cfg1", "cfg4"],
+                    help="cfg1 (default): BASELINE configs[1], the metric's workload.  cfg4: configs[4], per frame "
+                         "gs_blur(2) -> gs_sobel -> gs_integral -> gs_lbp_detect, frames sharded over the GPUs")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     args = ap.parse_args()
@@ -101,6 +153,8 @@ def main():
 
     w, h, F, r = args.width, args.height, args.frames, args.radius
     lo = sh.rank * F  # weak scaling: every rank owns F frames, global index lo..lo+F
+    if args.workload == "cfg4":
+        return run_cfg4(args, sh, g, torch, np, w, h, F, r, lo)
     src = torch.empty((F, h, w), dtype=torch.uint8, device="cuda")
     tmp = torch.empty_like(src)
     dst = torch.empty_like(src)
