@@ -58,6 +58,33 @@ def test_strip_kernels_on_unaligned_device_views(hip, oracle):
         assert_same(dv.cpu().numpy(), oracle.threshold(oracle.blur(img, 2), 90), "threshold at offset %d" % off)
         assert int(d[off - 1]) == 0xAB and int(d[off + 64 * 40]) == 0xAB
         assert_same(hip.histogram(s), oracle.histogram(img), "hist at offset %d" % off)
+        # every kernel with an alignment-dependent fast path must take its fallback here
+        hip.sobel(dv, s)
+        assert_same(dv.cpu().numpy()[1:-1, 1:-1], oracle.sobel(img)[1:-1, 1:-1], "sobel at offset %d" % off)
+        for name in ("erode", "dilate"):
+            getattr(hip, name)(dv, s)
+            assert_same(dv.cpu().numpy(), getattr(oracle, name)(img), "%s at offset %d" % (name, off))
+        hip.blur(dv, s, 9)
+        assert_same(dv.cpu().numpy(), oracle.blur(img, 9), "blur r=9 at offset %d" % off)
+        hip.adaptive_threshold(dv, s, 5, 3)
+        assert_same(dv.cpu().numpy(), oracle.adaptive_threshold(img, 5, 3), "adaptive at offset %d" % off)
+        k = np.array([[1, 2, 1], [2, 4, 2], [1, 2, 1]], np.int8)
+        hip.filter(dv, s, k, 16)
+        assert_same(dv.cpu().numpy(), oracle.filter(img, k, 16), "filter at offset %d" % off)
+        assert int(d[off - 1]) == 0xAB and int(d[off + 64 * 40]) == 0xAB
+        half = torch.full((32 * 20 + 64,), 0xAB, dtype=torch.uint8, device="cuda")
+        hv = half[off:off + 32 * 20].view(20, 32)
+        hip.downsample(hv, s)
+        assert_same(hv.cpu().numpy(), oracle.downsample(img), "downsample at offset %d" % off)
+        assert int(half[off - 1]) == 0xAB and int(half[off + 32 * 20]) == 0xAB
+        iib = torch.zeros(64 * 40 * 4 + 64, dtype=torch.uint8, device="cuda")
+        iiv = iib[4 * off:4 * off + 64 * 40 * 4].view(torch.int32).view(40, 64)
+        hip.integral(s, iiv)
+        assert_same(iiv.cpu().numpy().view(np.uint32), oracle.integral(img), "integral at offset %d" % off)
+        t = img[5:13, 7:19].copy()
+        res = torch.zeros((40 - 8 + 1, 64 - 12 + 1), dtype=torch.uint8, device="cuda")
+        hip.match_template(s, torch.from_numpy(t).cuda(), res)
+        assert_same(res.cpu().numpy(), oracle.match_template(img, t), "match_template at offset %d" % off)
 
 
 @pytest.mark.parametrize("mem", [HOST, DEV], ids=["host", "device"])
