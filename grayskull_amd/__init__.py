@@ -120,6 +120,8 @@ _SIGS = {
                               C.c_void_p, C.c_uint, C.c_uint]),
     "gsh_orb_extract": (C.c_uint, [C.c_void_p, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p,
                                    C.c_uint, C.c_uint]),
+    "gsh_orb_extract_batch": (None, [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_uint, C.c_uint]),
     "gsh_orb_pyramid_buffer_bytes": (C.c_size_t, [C.c_uint, C.c_uint, C.c_uint]),
     "gsh_orb_extract_pyramid": (C.c_uint, [C.c_void_p, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p,
                                            C.c_uint, C.c_uint, C.c_uint]),
@@ -392,6 +394,15 @@ class Grayskull:
         kps = np.zeros(max(nkps, 1), KEYPOINT_DTYPE)
         n = self.c.gsh_orb_extract(_ptr(img), w, h, _ptr(scoremap), kps.ctypes.data, nkps, threshold)
         return kps[:n].copy()
+
+    def orb_extract_batch_dev(self, imgs, scoremaps, nkps, threshold):
+        """n same-size device frames -> list of per-frame keypoint arrays (two host round trips in total)"""
+        n, h, w = self._nhw(imgs)
+        kps = np.zeros((n, max(nkps, 1)), KEYPOINT_DTYPE)
+        counts = np.zeros(n, np.uint32)
+        self.c.gsh_orb_extract_batch(_ptr(imgs), w, h, n, _ptr(scoremaps), kps.ctypes.data, counts.ctypes.data, nkps,
+                                     threshold)
+        return [kps[f, :int(counts[f])].copy() for f in range(n)]
 
     def orb_pyramid_buffer_bytes(self, w, h, n_levels):
         return int(self.c.gsh_orb_pyramid_buffer_bytes(w, h, n_levels))

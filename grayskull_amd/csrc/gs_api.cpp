@@ -1120,6 +1120,74 @@ unsigned gsh_orb_extract(const uint8_t *img_dev, unsigned w, unsigned h, uint8_t
   orb_extract_levels(&L, 1, threshold);
   return L.got;
 }
+/* gs_orb_extract (ref :651-669) for n frames of one size with two host round trips in total:
+ * FAST + NMS + emit and the disc moments run as batch launches over all frames. */
+void gsh_orb_extract_batch(const uint8_t *img_dev, unsigned w, unsigned h, unsigned n,
+                           uint8_t *scoremap_dev, struct gs_keypoint *kps_host, unsigned *counts_host,
+                           unsigned nkps, unsigned threshold) {
+  GS_ASSERT(img_dev && scoremap_dev && kps_host && counts_host && nkps > 0 && w > 0 && h > 0);
+  for (unsigned f = 0; f < n; f++) counts_host[f] = 0;
+  if (n == 0 || w < 7 || h < 7) return;
+  hipStream_t st = ctx().s();
+  const size_t fb = (size_t)w * h;
+  const unsigned cap = std::min(nkps * 4u, 5000u), r = 15;
+  unsigned *kps = (unsigned *)ctx().scratch(SL_KPS, (size_t)n * cap * 48 + 16);
+  unsigned *cnt = (unsigned *)ctx().scratch(SL_TOT, (size_t)n * 4 + 16);
+  int *mom = (int *)ctx().scratch(SL_MOM, (size_t)n * cap * 8);
+  launch_fast(img_dev, scoremap_dev, w, h, n, kps, cnt, cap, threshold);
+  GS_LAUNCH(k_orient_moments, dim3(cap, n), dim3(64), 0, st, img_dev, w, h, (const unsigned *)kps, 12u, r, mom,
+            (const unsigned *)cnt, fb);
+  std::vector<unsigned> hk((size_t)n * cap * 12), hn(n);
+  std::vector<int> hm((size_t)n * cap * 2);
+  GS_HIP(hipMemcpyAsync(hn.data(), cnt, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+  GS_HIP(hipMemcpyAsync(hk.data(), kps, hk.size() * 4, hipMemcpyDeviceToHost, st));
+  GS_HIP(hipMemcpyAsync(hm.data(), mom, hm.size() * 4, hipMemcpyDeviceToHost, st));
+  ctx().sync();
+  struct Cand { unsigned x, y, response; int m01, m10; };
+  std::vector<KpIn> kin;
+  std::vector<unsigned> koff(n);
+  std::vector<Cand> cand;
+  for (unsigned f = 0; f < n; f++) { /* host half of ref :657-667, frame by frame */
+    koff[f] = (unsigned)kin.size();
+    const unsigned m = std::min(hn[f], cap);
+    cand.resize(m);
+    for (unsigned i = 0; i < m; i++) {
+      const size_t q = (size_t)f * cap + i;
+      cand[i] = Cand{hk[q * 12], hk[q * 12 + 1], hk[q * 12 + 2], hm[2 * q], hm[2 * q + 1]};
+    }
+    std::stable_sort(cand.begin(), cand.end(),
+                     [](const Cand &a, const Cand &b) { return a.response > b.response; });
+    unsigned kept = 0;
+    gs_keypoint *out = kps_host + (size_t)f * nkps;
+    for (size_t i = 0; i < cand.size() && kept < nkps; i++) {
+      const Cand &c = cand[i];
+      if (c.x >= r && c.y >= r && c.x < w - r && c.y < h - r) {
+        gs_keypoint &k = out[kept];
+        k.pt.x = c.x, k.pt.y = c.y, k.response = c.response;
+        k.angle = atan2f((float)c.m01, (float)c.m10); /* ref :620, :100 */
+        const float angle = k.angle;
+        kin.push_back(KpIn{c.x, c.y, sinf(angle), sinf((float)(angle + 1.57079f))}); /* ref :626 */
+        kept++;
+      }
+    }
+    counts_host[f] = kept;
+  }
+  if (kin.empty()) return;
+  KpIn *dk = (KpIn *)ctx().scratch(SL_KIN, kin.size() * sizeof(KpIn));
+  uint32_t *dd = (uint32_t *)ctx().scratch(SL_DESC, kin.size() * 32);
+  GS_HIP(hipMemcpyAsync(dk, kin.data(), kin.size() * sizeof(KpIn), hipMemcpyHostToDevice, st));
+  for (unsigned f = 0; f < n; f++)
+    if (counts_host[f])
+      GS_LAUNCH(k_brief, dim3(counts_host[f]), dim3(256), 0, st, img_dev + fb * f, w, h,
+                (const KpIn *)(dk + koff[f]), dd + (size_t)koff[f] * 8);
+  std::vector<uint32_t> hd(kin.size() * 8);
+  GS_HIP(hipMemcpyAsync(hd.data(), dd, hd.size() * 4, hipMemcpyDeviceToHost, st));
+  ctx().sync();
+  for (unsigned f = 0; f < n; f++)
+    for (unsigned i = 0; i < counts_host[f]; i++)
+      memcpy(kps_host[(size_t)f * nkps + i].descriptor, &hd[((size_t)koff[f] + i) * 8], 32);
+}
+
 size_t gsh_orb_pyramid_buffer_bytes(unsigned w, unsigned h, unsigned n_levels) {
   if (n_levels > 4) n_levels = 4;
   size_t levels = 0, maps = (size_t)w * h;

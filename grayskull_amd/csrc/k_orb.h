@@ -32,10 +32,16 @@ struct KpIn { unsigned x, y; float sin_a, cos_a; }; /* host -> device per keypoi
 
 /* grid nkp (or an upper bound, with the true count in *count_dev), block 64.
  * pts: (x,y) pairs; out: (m01, m10) int pairs */
+/* blockIdx.y = frame of a batch (frames frame_bytes apart; pts / out / count_dev hold gridDim.x
+ * slots per frame); single images launch with gridDim.y = 1 */
 __global__ __launch_bounds__(64) void k_orient_moments(const uint8_t *img, unsigned w, unsigned h,
                                                        const unsigned *pts, unsigned pt_stride,
-                                                       unsigned r, int *out, const unsigned *count_dev) {
-  if (count_dev && blockIdx.x >= *count_dev) return;
+                                                       unsigned r, int *out, const unsigned *count_dev,
+                                                       size_t frame_bytes = 0) {
+  if (count_dev && blockIdx.x >= count_dev[blockIdx.y]) return;
+  img += (size_t)blockIdx.y * frame_bytes;
+  pts += (size_t)blockIdx.y * gridDim.x * pt_stride;
+  out += (size_t)blockIdx.y * gridDim.x * 2;
   const unsigned x = pts[(size_t)blockIdx.x * pt_stride], y = pts[(size_t)blockIdx.x * pt_stride + 1];
   const int side = 2 * (int)r + 1, total = side * side, rr = (int)(r * r);
   int m01 = 0, m10 = 0;

@@ -116,6 +116,13 @@ void gsh_fast_batch(const uint8_t *img, uint8_t *scoremap, unsigned w, unsigned 
 unsigned gsh_orb_extract(const uint8_t *img_dev, unsigned w, unsigned h, uint8_t *scoremap_dev,
                          struct gs_keypoint *kps_host, unsigned nkps, unsigned threshold);
 
+/* gs_orb_extract for n frames of one size (frames w*h bytes apart): frame f's keypoints go to
+ * kps_host[f*nkps ...], their number to counts_host[f].  scoremap_dev: n frames, same role as in
+ * gsh_fast_batch.  Two host round trips for the whole batch.  Synchronous. */
+void gsh_orb_extract_batch(const uint8_t *img_dev, unsigned w, unsigned h, unsigned n,
+                           uint8_t *scoremap_dev, struct gs_keypoint *kps_host, unsigned *counts_host,
+                           unsigned nkps, unsigned threshold);
+
 /* The reference's ORB caller (examples/nanomagick/nanomagick.c:245-290, extract_pyramid_orb_nm) with
  * every pyramid level resident on the device: up to 4 levels, each gs_downsample (ref :189) of the
  * previous, stopping before a level narrower or lower than 32; nkps / n_levels keypoints per level

@@ -39,6 +39,15 @@ class Mem:
         return self.put(np.full(shape, fill, dtype))
 
 
+def orb_batch(g, o, frames, mem, nkps=40, threshold=20):
+    """gsh_orb_extract_batch (n same-size frames, two round trips) == gs_orb_extract per frame"""
+    sm0 = np.random.RandomState(7).randint(0, 256, frames.shape).astype(np.uint8)
+    got = g.orb_extract_batch_dev(mem.put(frames), mem.put(sm0), nkps, threshold)
+    assert len(got) == len(frames)
+    for f, img in enumerate(frames):
+        assert_same(got[f], o.orb_extract(img, nkps, threshold, sm0[f]), "orb batch frame %d" % f)
+
+
 def orb_pyramid(g, o, img, mem, nkps=90, threshold=20, levels=3, seed=1):
     """gsh_orb_extract_pyramid (nanomagick.c:245-290 with device-resident levels) vs the oracle,
     with a non-zero scratch buffer: pyramid levels, scoremaps and keypoints must all match"""

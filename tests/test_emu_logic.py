@@ -101,6 +101,14 @@ def test_template_wider_than_the_lds_tile(emu, oracle):
         assert_same(r, oracle.match_template(img, t), "gs_match_template %dx%d" % (tw, th))
 
 
+def test_orb_batch(emu, oracle):
+    frames = np.stack([Oracle.synth(96, 80, 31), np.zeros((80, 96), np.uint8), Oracle.synth(96, 80, 32),
+                       np.random.RandomState(3).randint(0, 256, (80, 96)).astype(np.uint8)])
+    pc.orb_batch(emu, oracle, frames, MEM, nkps=40)
+    pc.orb_batch(emu, oracle, frames[:1], MEM, nkps=3)
+    pc.orb_batch(emu, oracle, np.stack([Oracle.synth(40, 6, 1)]), MEM)  # below FAST's minimum size
+
+
 def test_lbp(emu, oracle, cascade):
     img = Oracle.synth(96, 80, 7)
     pc.lbp(emu, oracle, img, MEM, cascade, params=((4096, 1.1, 1.0, 4.0, 1), (10, 1.3, 1.0, 2.0, 3)),

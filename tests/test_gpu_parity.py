@@ -429,6 +429,12 @@ def test_template_matching_large(hip, oracle):
     assert_same(rn[180:180 + rows.shape[0]], rows, "template rows 180..")
 
 
+def test_orb_extract_batch(hip, oracle):
+    frames = np.stack([Oracle.synth(1280, 720, 4 + i) for i in range(5)])
+    frames[2] = 0  # a frame without corners
+    pc.orb_batch(hip, oracle, frames, DEV, nkps=500)
+
+
 def test_pipeline_chunk_overlap(hip, oracle):
     """gsh_edge_pipeline_batch cuts big batches into chunks whose threshold pass runs on a side
     stream under the next chunk's fused kernel: same bytes for every chunking, ragged last chunk,
