@@ -7,7 +7,7 @@ import numpy as np, torch
 import grayskull_amd as gs
 from grayskull_amd.cascade import Cascade
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-g = gs.lib(); g.use_torch_stream()
+g = gs.lib(); g.use_torch_stream(); g.tune(4, int(os.environ.get("C5_PRESET", "0")))
 casc = Cascade.from_blob(os.path.join(ROOT, "tests/golden/frontalface_cascade.bin"))
 n, h, w = int(os.environ.get("C5_FRAMES", 16)), 2160, 3840
 src = torch.empty((n, h, w), dtype=torch.uint8, device="cuda"); g.synth_batch(src, 1000)
