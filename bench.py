@@ -274,7 +274,7 @@ def main():
             "frames": n3, "integral_ms_per_frame": round(ms_ii / n3, 4), "lbp_ms_per_frame": round(ms_lbp / n3, 3),
             "windows_per_frame": nwin, "Gwindows/s": round(nwin * n3 / ms_lbp / 1e6, 2),
             "detections_frame0": int(cn[0]), "expected_frame0 (reference KAT)": 158,
-            "bound": "texture-addresser gather rate (TA busy 94 %), not HBM",
+            "bound": "instruction issue on the gather + compare chain (TA busy 94 %, VALU 60 %), not HBM",
             "reference_1core": "5.98 s/frame, 4.83 Mwin/s (BASELINE.md)"}
         dc.close()
         A = _O.synth(1280, 720, 4)
