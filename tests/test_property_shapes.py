@@ -247,3 +247,35 @@ def test_gpu_template_any_shape(hip, oracle, w, h, seed, data):
     _body_template_any_shape(hip, oracle, w=w, h=h, seed=seed, data=data)
 
 
+
+
+@pytest.mark.gpu
+@_cfg(25)
+@given(n=st.integers(2, 70), per=st.integers(1, 70), w=st.sampled_from([32, 48, 64, 256]), h=st.integers(3, 30),
+       radius=st.integers(1, 3), seed=st.integers(0, 2 ** 16))
+def test_gpu_pipeline_chunking_any(hip, oracle, n, per, w, h, radius, seed):
+    """gsh_edge_pipeline_batch with arbitrary chunk sizes of its side-stream overlap (gsh_tune key 5) gives
+    the bytes of the unsplit call; a few frames are also checked against the oracle"""
+    import torch
+    rs = np.random.RandomState(seed)
+    src = torch.from_numpy(np.stack([_img(rs, w, h, i % 3) for i in range(n)])).cuda()
+    hist = torch.zeros((n, 256), dtype=torch.int32, device="cuda")
+    ref, tref = torch.full_like(src, 1), torch.zeros(n, dtype=torch.uint8, device="cuda")
+    out, thr = torch.full_like(src, 2), torch.zeros(n, dtype=torch.uint8, device="cuda")
+    try:
+        hip.tune(5, -1)
+        hip.edge_pipeline_batch(ref, None, src, radius, hist, tref)
+        href = hist.clone()
+        hip.tune(5, per)
+        for _ in range(2):  # twice: the side stream is rejoined and reused
+            hist.zero_()
+            hip.edge_pipeline_batch(out, None, src, radius, hist, thr)
+        hip.sync()
+        assert bool((out == ref).all()) and bool((thr == tref).all()) and bool((hist == href).all())
+    finally:
+        hip.tune(5, 0)
+    for f in {0, n // 2, n - 1}:
+        s = oracle.sobel(oracle.blur(src[f].cpu().numpy(), radius))
+        t = oracle.otsu_threshold(s)
+        assert int(tref[f]) == t
+        assert_same(ref[f].cpu().numpy(), oracle.threshold(s, t), "frame %d" % f)
