@@ -225,9 +225,10 @@ def main():
     pmc = None
     try:
         pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        kname = "gs::k_blur_sobel_hist16<2>"
-        if (w, h, r) == (3840, 2160, 2) and pt.get("frames_per_launch", {}).get(kname) == fpl:
-            pmc = pt["per_launch"].get(kname, {}).get("total_bytes")
+        # the kernel's printed name carries its template arguments ("<2>" or "<2, true>"): match by prefix
+        names = [k for k in pt["per_launch"] if k.startswith("gs::k_blur_sobel_hist16<2") and "false" not in k]
+        if (w, h, r) == (3840, 2160, 2) and names and pt.get("fused_frames_per_launch") == fpl:
+            pmc = pt["per_launch"][names[0]].get("total_bytes")
     except Exception:
         pass
     roof = {"bound": "hbm", "kernel": "k_blur_sobel_hist16<2> (gs_blur r=2 + gs_sobel + gs_histogram in one launch)",

@@ -37,7 +37,7 @@ for (k, grid), v in vals.items():
             "read_bytes": round(2 * v["FETCH_SIZE"] * 1024), "write_bytes": round(v["WRITE_SIZE"] * 1024),
             "total_bytes": round((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024), "grid_threads": grid}
 out = {"workload": "64 frames 3840x2160 (scripts/pmc_probe.py); the pipeline call launches its fused kernel per 32-frame chunk",
-       "frames_per_launch": {"default": 64, "gs::k_blur_sobel_hist16<2>": 32},
+       "frames_per_launch_default": 64, "fused_frames_per_launch": 32,  # the pipeline launches k_blur_sobel_hist16 per 32-frame chunk
        "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes; read = 2 x FETCH_SIZE KB (gfx950), write = WRITE_SIZE KB",
        "per_launch": traffic}
 json.dump(out, open(os.path.join(root, "pmc_traffic.json"), "w"), indent=1)
