@@ -143,6 +143,31 @@ def _body_template_any_shape(emu, oracle, w, h, seed, data):
     assert_same(r, ro, "gs_match_template %dx%d in %dx%d" % (tw, th, w, h))
     assert emu.find_best_match(r) == oracle.find_best_match(ro)
 
+def _body_crop_copy_any(emu, oracle, w, h, seed, data):
+    img = _img(np.random.RandomState(seed), w, h, seed % 3)
+    rx, ry = data.draw(st.integers(0, w - 1)), data.draw(st.integers(0, h - 1))
+    rw, rh = data.draw(st.integers(1, w - rx)), data.draw(st.integers(1, h - ry))
+    d = np.full((rh, rw), 0xAB, np.uint8)
+    emu.crop(d, img.copy(), rx, ry, rw, rh)
+    assert_same(d, oracle.crop(img, rx, ry, rw, rh), "gs_crop (%d,%d,%d,%d) of %dx%d" % (rx, ry, rw, rh, w, h))
+    d = np.full_like(img, 0xAB)
+    emu.copy(d, img.copy())
+    assert_same(d, img, "gs_copy %dx%d" % (w, h))
+
+
+def _body_orb_drivers_any(emu, oracle, w, h, seed, nkps, threshold, levels, n):
+    """the pyramid driver (nanomagick.c:245-290) and the same-size batch driver vs per-call oracle"""
+    rs = np.random.RandomState(seed)
+    mem = pc.Mem("host" if "kernel_emu" in emu.path else "device")
+    img = _img(rs, w, h, seed % 3)
+    pc.orb_pyramid(emu, oracle, img, mem, nkps=nkps, threshold=threshold, levels=levels, seed=seed)
+    frames = np.stack([_img(rs, w, h, (seed + i) % 3) for i in range(n)])
+    sm0 = rs.randint(0, 256, frames.shape).astype(np.uint8)
+    got = emu.orb_extract_batch_dev(mem.put(frames), mem.put(sm0.copy()), nkps, threshold)
+    for i in range(n):
+        assert_same(got[i], oracle.orb_extract(frames[i], nkps, threshold, sm0[i]), "orb batch frame %d" % i)
+
+
 # ---- the same properties through the emulator (CPU suite) and on the real GPU (-m gpu) ----------
 @_cfg(40)
 @given(w=widths, h=heights, seed=st.integers(0, 2 ** 16), kind=st.integers(0, 2), radius=st.integers(0, 40))
@@ -246,7 +271,34 @@ def test_template_any_shape(emu, oracle, w, h, seed, data):
 def test_gpu_template_any_shape(hip, oracle, w, h, seed, data):
     _body_template_any_shape(hip, oracle, w=w, h=h, seed=seed, data=data)
 
+@_cfg(20)
+@given(w=st.integers(1, 70), h=st.integers(1, 40), seed=st.integers(0, 2 ** 16), data=st.data())
+def test_crop_copy_any(emu, oracle, w, h, seed, data):
+    _body_crop_copy_any(emu, oracle, w, h, seed, data)
 
+
+@pytest.mark.gpu
+@_cfg(20)
+@given(w=st.integers(1, 70), h=st.integers(1, 40), seed=st.integers(0, 2 ** 16), data=st.data())
+def test_gpu_crop_copy_any(hip, oracle, w, h, seed, data):
+    _body_crop_copy_any(hip, oracle, w, h, seed, data)
+
+
+_orb_drv = dict(w=st.integers(16, 90), h=st.integers(16, 70), seed=st.integers(0, 2 ** 16), nkps=st.integers(1, 60),
+                threshold=st.sampled_from([5, 20, 60]), levels=st.integers(1, 4), n=st.integers(1, 3))
+
+
+@_cfg(10)
+@given(**_orb_drv)
+def test_orb_drivers_any(emu, oracle, w, h, seed, nkps, threshold, levels, n):
+    _body_orb_drivers_any(emu, oracle, w, h, seed, nkps, threshold, levels, n)
+
+
+@pytest.mark.gpu
+@_cfg(10)
+@given(**_orb_drv)
+def test_gpu_orb_drivers_any(hip, oracle, w, h, seed, nkps, threshold, levels, n):
+    _body_orb_drivers_any(hip, oracle, w, h, seed, nkps, threshold, levels, n)
 
 
 @pytest.mark.gpu
