@@ -1,0 +1,437 @@
+/*
+ * gsbatch -- multi-stage, multi-file PGM driver over libgrayskull_hip.so (C99 host code).
+ *
+ * SURVEY.md 8(f) rank 3.  The reference's CLI (examples/nanomagick/nanomagick.c:380-446) runs ONE
+ * verb on ONE file per process; chains are shell pipes of PGM streams (reference Makefile:25-30),
+ * i.e. every stage parses a header, allocates, runs and re-serialises the image.  This driver takes
+ * the same verbs with the same arguments and the same validation, but
+ *   - reads all inputs once, groups frames of equal size into batches,
+ *   - uploads a batch once, keeps it in HBM between stages (two ping-pong planes),
+ *   - runs every stage as one gsh_*_batch launch over the whole group (size-changing verbs: one
+ *     stream-ordered gs_* call per frame on device pointers),
+ *   - recognises `blur r : sobel [: threshold otsu]` (r = 1..3) and runs it through the fused
+ *     one-pass kernels (gsh_blur_sobel_batch / gsh_edge_pipeline_batch),
+ *   - downloads once and writes the results.
+ * Per file the output bytes are identical to piping the reference's nanomagick through the same
+ * verbs (tests/test_gsbatch.py).
+ *
+ * Verbs (nanomagick.c:52-141, same argument meaning / error text):
+ *   resize <w> <h> | crop <x> <y> <w> <h> | blur <r> | threshold <t|otsu> | adaptive <r> <c> |
+ *   sobel | morph <erode|dilate> <n>
+ * PGM reading / writing follows the reference's gs_read_pgm / gs_write_pgm (grayskull.h:111-136):
+ * binary P5, maxval 255, header "P5\n%u %u\n255\n".
+ *
+ * usage: gsbatch [-v] -o <outdir> <verb> [args] [: <verb> [args]]... -- in1.pgm [in2.pgm ...]
+ * exit:  0 all files written; 1 usage / stage error / at least one file failed (message on stderr,
+ *        same wording as nanomagick where it has one).
+ */
+#define _POSIX_C_SOURCE 200112L /* clock_gettime under -std=c99 */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "grayskull_hip.h"
+
+enum verb { V_RESIZE, V_CROP, V_BLUR, V_THRESHOLD, V_ADAPTIVE, V_SOBEL, V_MORPH };
+
+struct stage {
+  enum verb v;
+  int a[4];        /* numeric arguments in command-line order */
+  int otsu;        /* threshold otsu */
+  int dilate;      /* morph dilate */
+  const char *raw; /* first argument as typed, for error messages */
+};
+
+static const struct {
+  const char *name;
+  enum verb v;
+  int argc;
+} verbs[] = {{"resize", V_RESIZE, 2},     {"crop", V_CROP, 4},   {"blur", V_BLUR, 1}, {"threshold", V_THRESHOLD, 1},
+             {"adaptive", V_ADAPTIVE, 2}, {"sobel", V_SOBEL, 0}, {"morph", V_MORPH, 2}, {NULL, V_SOBEL, 0}};
+
+struct frame {
+  const char *path;
+  unsigned w, h;   /* input size */
+  uint8_t *data;   /* host pixels (input, later output) */
+  int group;       /* index of the (w,h) group, -1 = unreadable */
+  int failed;
+};
+
+static double now_ms(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
+static void usage(const char *app) {
+  fprintf(stderr,
+          "Usage: %s [-v] -o <outdir> <verb> [params] [: <verb> [params]]... -- in1.pgm [in2.pgm ...]\n"
+          "Verbs: resize <w> <h> | crop <x> <y> <w> <h> | blur <r> | threshold <t|otsu> |\n"
+          "       adaptive <r> <c> | sobel | morph <erode|dilate> <n>\n",
+          app);
+}
+
+/* the reference's reader, grayskull.h:111-127 (same fscanf format, maxval must be 255) */
+static int read_pgm(const char *path, struct frame *f) {
+  FILE *fp = fopen(path, "rb");
+  unsigned w, h, maxval;
+  if (!fp) return -1;
+  if (fscanf(fp, "P5\n%u %u\n%u\n", &w, &h, &maxval) != 3 || maxval != 255 || w == 0 || h == 0) {
+    fclose(fp);
+    return -1;
+  }
+  f->data = (uint8_t *)malloc((size_t)w * h);
+  if (!f->data || fread(f->data, 1, (size_t)w * h, fp) != (size_t)w * h) {
+    free(f->data);
+    f->data = NULL;
+    fclose(fp);
+    return -1;
+  }
+  fclose(fp);
+  f->w = w;
+  f->h = h;
+  return 0;
+}
+
+/* grayskull.h:129-136 */
+static int write_pgm(const char *path, const uint8_t *data, unsigned w, unsigned h) {
+  FILE *fp = fopen(path, "wb");
+  size_t n;
+  if (!fp) return -1;
+  fprintf(fp, "P5\n%u %u\n255\n", w, h);
+  n = fwrite(data, 1, (size_t)w * h, fp);
+  fclose(fp);
+  return n == (size_t)w * h ? 0 : -1;
+}
+
+static int parse_stages(int argc, char **argv, int *pos, struct stage *st, int max_stages) {
+  int n = 0, i = *pos;
+  while (i < argc && strcmp(argv[i], "--") != 0) {
+    int k, j;
+    if (strcmp(argv[i], ":") == 0) {
+      i++;
+      continue;
+    }
+    for (k = 0; verbs[k].name && strcmp(verbs[k].name, argv[i]) != 0; k++) {}
+    if (!verbs[k].name) {
+      fprintf(stderr, "Error: Unknown command '%s'\n", argv[i]);
+      return -1;
+    }
+    if (n == max_stages) {
+      fprintf(stderr, "Error: too many stages\n");
+      return -1;
+    }
+    if (verbs[k].argc > 0 && i + verbs[k].argc >= argc) {
+      fprintf(stderr, "Error: Wrong number of arguments for '%s'\n", argv[i]);
+      return -1;
+    }
+    for (j = 0; j < verbs[k].argc; j++) {
+      const char *s = argv[i + 1 + j];
+      if (strcmp(s, ":") == 0 || strcmp(s, "--") == 0) {
+        fprintf(stderr, "Error: Wrong number of arguments for '%s'\n", argv[i]);
+        return -1;
+      }
+    }
+    memset(&st[n], 0, sizeof st[n]);
+    st[n].v = verbs[k].v;
+    st[n].raw = verbs[k].argc ? argv[i + 1] : "";
+    for (j = 0; j < verbs[k].argc; j++) st[n].a[j] = atoi(argv[i + 1 + j]);
+    if (st[n].v == V_THRESHOLD) st[n].otsu = strcmp(argv[i + 1], "otsu") == 0;
+    if (st[n].v == V_MORPH) {
+      st[n].dilate = strcmp(argv[i + 1], "dilate") == 0;
+      st[n].a[0] = (st[n].dilate || strcmp(argv[i + 1], "erode") == 0) ? 1 : 0; /* valid op */
+    }
+    i += 1 + verbs[k].argc;
+    n++;
+  }
+  *pos = i;
+  return n;
+}
+
+/* nanomagick's per-verb argument checks (nanomagick.c:59-133); the image size is the group's */
+static int check_stage(const struct stage *s, unsigned w, unsigned h) {
+  switch (s->v) {
+    case V_RESIZE:
+      if (s->a[0] <= 0 || s->a[1] <= 0) return fprintf(stderr, "Error: Invalid width or height\n"), -1;
+      break;
+    case V_CROP:
+      if (s->a[0] < 0 || s->a[1] < 0 || s->a[2] <= 0 || s->a[3] <= 0 || s->a[0] + s->a[2] > (int)w ||
+          s->a[1] + s->a[3] > (int)h)
+        return fprintf(stderr, "Error: Invalid crop rectangle\n"), -1;
+      break;
+    case V_BLUR:
+      if (s->a[0] <= 0) return fprintf(stderr, "Error: Invalid radius: %s\n", s->raw), -1;
+      break;
+    case V_THRESHOLD:
+      if (!s->otsu && s->a[0] <= 0) return fprintf(stderr, "Error: Invalid threshold: %s\n", s->raw), -1;
+      break;
+    case V_ADAPTIVE:
+      if (s->a[0] <= 0 || s->a[1] < 0) return fprintf(stderr, "Error: Invalid radius or constant\n"), -1;
+      break;
+    case V_MORPH:
+      if (!s->a[0] || s->a[1] <= 0)
+        return fprintf(stderr, "Error: Invalid morphological operation or iterations\n"), -1;
+      break;
+    case V_SOBEL: break;
+  }
+  return 0;
+}
+
+static void stage_out_size(const struct stage *s, unsigned *w, unsigned *h) {
+  if (s->v == V_RESIZE) *w = (unsigned)s->a[0], *h = (unsigned)s->a[1];
+  if (s->v == V_CROP) *w = (unsigned)s->a[2], *h = (unsigned)s->a[3];
+}
+
+struct planes {
+  uint8_t *cur, *other; /* device, each n * max frame bytes */
+  unsigned *hist;       /* n * 256 u32 */
+  uint8_t *thr_dev;     /* n */
+  uint8_t *thr_host;    /* n */
+};
+
+static void swap_planes(struct planes *p) {
+  uint8_t *t = p->cur;
+  p->cur = p->other;
+  p->other = t;
+}
+
+/* frames whose Otsu threshold is 0 fail exactly like `nanomagick threshold otsu` (nanomagick.c:89-93) */
+static void otsu_failures(struct planes *p, unsigned n, int *failed) {
+  unsigned f;
+  gsh_download(p->thr_host, p->thr_dev, n);
+  for (f = 0; f < n; f++)
+    if (p->thr_host[f] == 0 && !failed[f]) {
+      fprintf(stderr, "Error: Invalid threshold: otsu\n");
+      failed[f] = 1;
+    }
+}
+
+/* run the stage list over n device-resident frames of w x h; returns the output size */
+static void run_stages(const struct stage *st, int ns, struct planes *p, unsigned n, unsigned *pw, unsigned *ph,
+                       int *failed) {
+  unsigned w = *pw, h = *ph, f;
+  int i = 0;
+  while (i < ns) {
+    const struct stage *s = &st[i];
+    const size_t fb = (size_t)w * h;
+    /* blur r (1..3) : sobel [: threshold otsu] -> one pass over the frames */
+    if (s->v == V_BLUR && s->a[0] <= 3 && i + 1 < ns && st[i + 1].v == V_SOBEL) {
+      if (i + 2 < ns && st[i + 2].v == V_THRESHOLD && st[i + 2].otsu) {
+        gsh_edge_pipeline_batch(p->other, NULL, p->cur, w, h, n, (unsigned)s->a[0], p->hist, p->thr_dev);
+        otsu_failures(p, n, failed);
+        i += 3;
+      } else {
+        gsh_blur_sobel_batch(p->other, p->cur, w, h, n, (unsigned)s->a[0]);
+        i += 2;
+      }
+      swap_planes(p);
+      continue;
+    }
+    switch (s->v) {
+      case V_BLUR:
+        gsh_blur_batch(p->other, p->cur, w, h, n, (unsigned)s->a[0]);
+        swap_planes(p);
+        break;
+      case V_SOBEL: /* nanomagick's output image comes from calloc (nanomagick.c:138) */
+        gsh_memset(p->other, 0, fb * n);
+        if (w >= 3 && h >= 3) gsh_sobel_batch(p->other, p->cur, w, h, n);
+        swap_planes(p);
+        break;
+      case V_THRESHOLD: /* copy + in-place threshold (nanomagick.c:94-96): the input is dead, so in place */
+        if (s->otsu) {
+          gsh_otsu_batch(p->cur, w, h, n, p->hist, p->thr_dev);
+          otsu_failures(p, n, failed);
+          gsh_threshold_batch_dev(p->cur, w, h, n, p->thr_dev);
+        } else {
+          gsh_threshold_batch(p->cur, w, h, n, (uint8_t)s->a[0]); /* (uint8_t) like gs_threshold's parameter */
+        }
+        break;
+      case V_ADAPTIVE:
+        gsh_adaptive_threshold_batch(p->other, p->cur, w, h, n, (unsigned)s->a[0], s->a[1]);
+        swap_planes(p);
+        break;
+      case V_MORPH: {
+        int it;
+        for (it = 0; it < s->a[1]; it++) {
+          if (s->dilate)
+            gsh_dilate_batch(p->other, p->cur, w, h, n);
+          else
+            gsh_erode_batch(p->other, p->cur, w, h, n);
+          swap_planes(p);
+        }
+        break;
+      }
+      case V_RESIZE:
+      case V_CROP: {
+        unsigned ow = w, oh = h;
+        stage_out_size(s, &ow, &oh);
+        for (f = 0; f < n; f++) {
+          struct gs_image src = {w, h, p->cur + fb * f};
+          struct gs_image dst = {ow, oh, p->other + (size_t)ow * oh * f};
+          if (s->v == V_RESIZE) {
+            gs_resize(dst, src);
+          } else {
+            struct gs_rect roi = {(unsigned)s->a[0], (unsigned)s->a[1], (unsigned)s->a[2], (unsigned)s->a[3]};
+            gs_crop(dst, src, roi);
+          }
+        }
+        w = ow;
+        h = oh;
+        swap_planes(p);
+        break;
+      }
+    }
+    i++;
+  }
+  *pw = w;
+  *ph = h;
+}
+
+static const char *base_name(const char *path) {
+  const char *s = strrchr(path, '/');
+  return s ? s + 1 : path;
+}
+
+int main(int argc, char **argv) {
+  struct stage st[64];
+  struct frame *fr;
+  const char *outdir = NULL;
+  int verbose = 0, pos = 1, ns, nf, i, g, ngroups = 0, rc = 0;
+  double t_io0, t_up = 0, t_run = 0, t_down = 0, t_read, t_write = 0;
+
+  while (pos < argc && argv[pos][0] == '-' && argv[pos][1] && strcmp(argv[pos], "--") != 0) {
+    if (strcmp(argv[pos], "-v") == 0) {
+      verbose = 1, pos++;
+    } else if (strcmp(argv[pos], "-o") == 0 && pos + 1 < argc) {
+      outdir = argv[pos + 1], pos += 2;
+    } else {
+      usage(argv[0]);
+      return 1;
+    }
+  }
+  ns = parse_stages(argc, argv, &pos, st, 64);
+  if (ns < 0) return 1;
+  if (ns == 0 || !outdir || pos >= argc || strcmp(argv[pos], "--") != 0 || pos + 1 >= argc) {
+    usage(argv[0]);
+    return 1;
+  }
+  pos++;
+  nf = argc - pos;
+  fr = (struct frame *)calloc((size_t)nf, sizeof *fr);
+  if (!fr) return 1;
+
+  t_io0 = now_ms();
+  for (i = 0; i < nf; i++) {
+    int j;
+    fr[i].path = argv[pos + i];
+    fr[i].group = -1;
+    if (read_pgm(fr[i].path, &fr[i]) != 0) {
+      fprintf(stderr, "Error: Could not load %s\n", fr[i].path);
+      fr[i].failed = 1;
+      rc = 1;
+      continue;
+    }
+    for (j = 0; j < i; j++)
+      if (fr[j].group >= 0 && fr[j].w == fr[i].w && fr[j].h == fr[i].h) break;
+    fr[i].group = j < i ? fr[j].group : ngroups++;
+  }
+  t_read = now_ms() - t_io0;
+
+  if (gsh_device_count() < 1) {
+    fprintf(stderr, "Error: no HIP device\n");
+    return 1;
+  }
+  gsh_set_async(1); /* per-frame gs_resize / gs_crop on device pointers stay stream-ordered */
+
+  for (g = 0; g < ngroups; g++) {
+    unsigned w = 0, h = 0, n = 0, f, ow, oh;
+    size_t max_fb, fb;
+    struct planes p;
+    int *failed, bad = 0;
+    double t0;
+    for (i = 0; i < nf; i++)
+      if (fr[i].group == g) w = fr[i].w, h = fr[i].h, n++;
+    /* validate the chain for this size and find the largest plane it needs */
+    ow = w, oh = h, max_fb = (size_t)w * h;
+    for (i = 0; i < ns && !bad; i++) {
+      if (check_stage(&st[i], ow, oh) != 0) bad = 1;
+      stage_out_size(&st[i], &ow, &oh);
+      if ((size_t)ow * oh > max_fb) max_fb = (size_t)ow * oh;
+    }
+    if (bad) { /* nanomagick: the verb prints its message, then "did not produce output image" */
+      for (i = 0; i < nf; i++)
+        if (fr[i].group == g) {
+          fprintf(stderr, "Error: %s: chain did not produce output image\n", fr[i].path);
+          fr[i].failed = 1;
+        }
+      rc = 1;
+      continue;
+    }
+    fb = (size_t)w * h;
+    p.cur = (uint8_t *)gsh_malloc(max_fb * n);
+    p.other = (uint8_t *)gsh_malloc(max_fb * n);
+    p.hist = (unsigned *)gsh_malloc((size_t)n * 256 * sizeof(unsigned));
+    p.thr_dev = (uint8_t *)gsh_malloc(n);
+    p.thr_host = (uint8_t *)malloc(n);
+    failed = (int *)calloc(n, sizeof *failed);
+    if (!p.thr_host || !failed) return 1;
+
+    t0 = now_ms();
+    for (i = 0, f = 0; i < nf; i++)
+      if (fr[i].group == g) gsh_upload(p.cur + fb * f++, fr[i].data, fb);
+    t_up += now_ms() - t0;
+
+    t0 = now_ms();
+    ow = w, oh = h;
+    run_stages(st, ns, &p, n, &ow, &oh, failed);
+    gsh_sync();
+    t_run += now_ms() - t0;
+
+    t0 = now_ms();
+    for (i = 0, f = 0; i < nf; i++)
+      if (fr[i].group == g) {
+        const size_t ofb = (size_t)ow * oh;
+        if (ofb > fb) {
+          free(fr[i].data);
+          fr[i].data = (uint8_t *)malloc(ofb);
+          if (!fr[i].data) return 1;
+        }
+        gsh_download(fr[i].data, p.cur + ofb * f, ofb);
+        fr[i].w = ow, fr[i].h = oh;
+        if (failed[f]) fr[i].failed = 1, rc = 1;
+        f++;
+      }
+    t_down += now_ms() - t0;
+    if (verbose)
+      fprintf(stderr, "group %d: %u frame(s) %ux%u -> %ux%u\n", g, n, w, h, ow, oh);
+    gsh_free(p.cur);
+    gsh_free(p.other);
+    gsh_free(p.hist);
+    gsh_free(p.thr_dev);
+    free(p.thr_host);
+    free(failed);
+  }
+
+  t_io0 = now_ms();
+  for (i = 0; i < nf; i++) {
+    char path[4096];
+    if (fr[i].failed) {
+      if (fr[i].group >= 0) fprintf(stderr, "Error: %s did not produce output image\n", fr[i].path);
+      continue;
+    }
+    snprintf(path, sizeof path, "%s/%s", outdir, base_name(fr[i].path));
+    if (write_pgm(path, fr[i].data, fr[i].w, fr[i].h) != 0) {
+      fprintf(stderr, "Error: Could not save %s\n", path);
+      rc = 1;
+    }
+  }
+  t_write = now_ms() - t_io0;
+  if (verbose)
+    fprintf(stderr, "files %d groups %d | read %.2f ms, upload %.2f ms, stages %.2f ms, download %.2f ms, write %.2f ms\n",
+            nf, ngroups, t_read, t_up, t_run, t_down, t_write);
+  for (i = 0; i < nf; i++) free(fr[i].data);
+  free(fr);
+  gsh_shutdown();
+  return rc;
+}

@@ -1,0 +1,176 @@
+"""gsbatch (grayskull_amd/host/gsbatch.c): the multi-stage, multi-file PGM driver of SURVEY.md 8(f)
+rank 3.  Its outputs must be byte-identical to piping the reference's nanomagick CLI through the same
+verbs, file by file (reference Makefile:10-33, nanomagick.c:380-446).
+
+CPU suite: the C99 program is linked with the kernel-logic emulator and compared with the
+reference's own nanomagick build (compiled where it lies).  GPU suite: linked with
+libgrayskull_hip.so and compared with the oracle's restatement of each verb (no /root/reference on
+the GPU box)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests.util import read_pgm, assert_same
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+NANO = REF + "/examples/nanomagick/nanomagick.c"
+SRC = os.path.join(ROOT, "grayskull_amd", "host", "gsbatch.c")
+CFLAGS = ["gcc", "-std=c99", "-O2", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include")]
+
+
+def write_pgm(path, a):
+    with open(path, "wb") as f:
+        f.write(b"P5\n%d %d\n255\n" % (a.shape[1], a.shape[0]))
+        f.write(np.ascontiguousarray(a).tobytes())
+
+
+def build_emu(tmp_path):
+    emu = os.path.join(ROOT, "tests", "emu")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "grayskull_amd", "csrc"), "emu"])
+    exe = str(tmp_path / "gsbatch_emu")
+    subprocess.check_call(CFLAGS + [SRC, "-o", exe, "-L" + emu, "-lgs_kernel_emu", "-Wl,-rpath," + emu])
+    return exe
+
+
+def build_ref_nano(tmp_path):
+    exe = str(tmp_path / "nano_ref")
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-w", "-I" + REF, "-I" + os.path.dirname(NANO), NANO, "-o", exe, "-lm"])
+    return exe
+
+
+def chain_args(chain):
+    out = []
+    for i, (verb, args) in enumerate(chain):
+        if i:
+            out.append(":")
+        out += [verb, *args]
+    return out
+
+
+def nano_chain(exe, chain, src, tmp_path, tag):
+    """the reference way: one process per verb per file; returns (final path or None, stderr text)"""
+    cur, err = src, b""
+    for i, (verb, args) in enumerate(chain):
+        out = str(tmp_path / ("%s_%d.pgm" % (tag, i)))
+        r = subprocess.run([exe, verb, *args, cur, out], capture_output=True, timeout=900)
+        err += r.stderr
+        if r.returncode != 0:
+            return None, err
+        cur = out
+    return cur, err
+
+
+CHAINS = [
+    [("blur", ["3"]), ("sobel", []), ("threshold", ["otsu"]), ("morph", ["dilate", "2"]), ("morph", ["erode", "3"])],  # fused 3
+    [("blur", ["2"]), ("sobel", [])],                                          # fused 2
+    [("blur", ["9"]), ("sobel", []), ("threshold", ["40"])],                   # unfused (radius > 3)
+    [("resize", ["200", "120"]), ("adaptive", ["7", "3"]), ("crop", ["8", "4", "96", "64"])],
+    [("crop", ["1", "2", "100", "90"]), ("blur", ["1"]), ("threshold", ["otsu"])],
+    [("sobel", []), ("morph", ["dilate", "1"]), ("resize", ["333", "77"])],
+    [("threshold", ["300"])],                                                  # (uint8_t)300 = 44, like nanomagick
+]
+
+
+@pytest.mark.skipif(not os.path.exists(NANO), reason="reference checkout not present")
+def test_gsbatch_equals_piped_nanomagick_emulated(tmp_path):
+    exe, nano = build_emu(tmp_path), build_ref_nano(tmp_path)
+    files = [os.path.join(ROOT, "tests", "golden", "lena.pgm"), REF + "/testdata/aruco.pgm"]
+    from oracle.pyoracle import Oracle
+    for k, (w, h) in enumerate([(160, 96), (160, 96), (131, 101)]):     # two frames share a group
+        p = str(tmp_path / ("synth%d.pgm" % k))
+        write_pgm(p, Oracle.synth(w, h, 20 + k))
+        files.append(p)
+    for c, chain in enumerate(CHAINS):
+        outdir = tmp_path / ("out%d" % c)
+        outdir.mkdir()
+        r = subprocess.run([exe, "-v", "-o", str(outdir), *chain_args(chain), "--", *files], capture_output=True, timeout=1800)
+        assert r.returncode == 0, r.stderr.decode()[-800:]
+        for i, f in enumerate(files):
+            exp, _ = nano_chain(nano, chain, f, tmp_path, "ref%d_%d" % (c, i))
+            got = open(str(outdir / os.path.basename(f)), "rb").read()
+            assert exp is not None and got == open(exp, "rb").read(), "chain %d file %s differs" % (c, f)
+
+
+@pytest.mark.skipif(not os.path.exists(NANO), reason="reference checkout not present")
+def test_gsbatch_errors_like_nanomagick_emulated(tmp_path):
+    """argument validation and per-file failures: same wording, exit 1, nothing written for the file"""
+    exe, nano = build_emu(tmp_path), build_ref_nano(tmp_path)
+    lena = os.path.join(ROOT, "tests", "golden", "lena.pgm")
+    black = str(tmp_path / "black.pgm")
+    write_pgm(black, np.zeros((40, 48), np.uint8))
+    bad = [[("blur", ["0"])], [("threshold", ["0"])], [("adaptive", ["3", "-1"])], [("morph", ["open", "2"])],
+           [("morph", ["erode", "0"])], [("resize", ["0", "10"])], [("crop", ["100", "100", "64", "64"])]]
+    for c, chain in enumerate(bad):
+        outdir = tmp_path / ("bad%d" % c)
+        outdir.mkdir()
+        r = subprocess.run([exe, "-o", str(outdir), *chain_args(chain), "--", lena], capture_output=True, timeout=600)
+        exp, err = nano_chain(nano, chain, lena, tmp_path, "badref%d" % c)
+        assert exp is None and r.returncode == 1
+        first = err.decode().splitlines()[0]
+        assert first in r.stderr.decode(), (first, r.stderr.decode())
+        assert os.listdir(str(outdir)) == []
+    # an all-black frame has Otsu threshold 0: nanomagick refuses it, the other file still goes through
+    outdir = tmp_path / "otsu0"
+    outdir.mkdir()
+    r = subprocess.run([exe, "-o", str(outdir), "threshold", "otsu", "--", black, lena], capture_output=True, timeout=600)
+    exp, err = nano_chain(nano, [("threshold", ["otsu"])], black, tmp_path, "blackref")
+    assert exp is None and r.returncode == 1 and err.decode().splitlines()[0] in r.stderr.decode()
+    assert os.listdir(str(outdir)) == ["lena.pgm"]
+    exp, _ = nano_chain(nano, [("threshold", ["otsu"])], lena, tmp_path, "lenaref")
+    assert open(str(outdir / "lena.pgm"), "rb").read() == open(exp, "rb").read()
+    # unreadable input, unknown verb, missing arguments
+    r = subprocess.run([exe, "-o", str(outdir), "sobel", "--", str(tmp_path / "nope.pgm")], capture_output=True)
+    assert r.returncode == 1 and b"Could not load" in r.stderr
+    r = subprocess.run([exe, "-o", str(outdir), "sharpen", "--", lena], capture_output=True)
+    assert r.returncode == 1 and b"Unknown command 'sharpen'" in r.stderr
+    r = subprocess.run([exe, "-o", str(outdir), "crop", "1", "2", ":", "sobel", "--", lena], capture_output=True)
+    assert r.returncode == 1 and b"Wrong number of arguments for 'crop'" in r.stderr
+
+
+def oracle_chain(o, img, chain):
+    for verb, args in chain:
+        a = [int(x) for x in args if x.lstrip("-").isdigit()]
+        if verb == "blur":
+            img = o.blur(img, a[0])
+        elif verb == "sobel":
+            img = o.sobel(img)
+        elif verb == "threshold":
+            img = o.threshold(img, o.otsu_threshold(img) if args[0] == "otsu" else a[0] & 255)
+        elif verb == "adaptive":
+            img = o.adaptive_threshold(img, a[0], a[1])
+        elif verb == "morph":
+            for _ in range(a[0]):
+                img = o.dilate(img) if args[0] == "dilate" else o.erode(img)
+        elif verb == "resize":
+            img = o.resize(img, a[0], a[1])
+        elif verb == "crop":
+            img = o.crop(img, *a)
+    return img
+
+
+@pytest.mark.gpu
+def test_gsbatch_on_gpu_vs_oracle(tmp_path):
+    """the real binary (make tool) on MI355X: 12 x 1280x720 + 3 ragged frames through every chain"""
+    from oracle.pyoracle import Oracle
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "grayskull_amd", "csrc"), "tool"])
+    exe = os.path.join(ROOT, "grayskull_amd", "gsbatch")
+    o = Oracle("port")
+    files, imgs = [], []
+    for k in range(15):
+        w, h = (1280, 720) if k < 12 else (317 + k, 203)
+        img = Oracle.synth(w, h, 900 + k)
+        p = str(tmp_path / ("f%02d.pgm" % k))
+        write_pgm(p, img)
+        files.append(p)
+        imgs.append(img)
+    for c, chain in enumerate(CHAINS):
+        outdir = tmp_path / ("out%d" % c)
+        outdir.mkdir()
+        r = subprocess.run([exe, "-v", "-o", str(outdir), *chain_args(chain), "--", *files], capture_output=True, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-800:]
+        for f, img in zip(files, imgs):
+            got = read_pgm(str(outdir / os.path.basename(f)))
+            assert_same(got, oracle_chain(o, img, chain), "chain %d %s" % (c, os.path.basename(f)))
