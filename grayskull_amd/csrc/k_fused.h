@@ -136,9 +136,14 @@ __global__ __launch_bounds__(256) void k_blur_sobel_hist16(uint8_t *dst, const u
 #pragma unroll
       for (int k = 0; k < 10; k++) V[k] = pk_sub_u16(pk_add_u16(V[k], Hn[k]), ring[old][k]), ring[fr][k] = Hn[k];
       blurred(y0 + i + 1, UB);
-      U4 o;
-      if constexpr (NS % 2 == 0) o = st.template step<decltype(I)::value & 1>(UB, M);
-      else o = st.step_shift(UB, M);
+      U4 o; /* without the histogram only the bytes are needed (saturating-mad form of the clamp) */
+      if constexpr (NS % 2 == 0) {
+        if constexpr (HIST) o = st.template step<decltype(I)::value & 1>(UB, M);
+        else o = st.template step<decltype(I)::value & 1>(UB);
+      } else {
+        if constexpr (HIST) o = st.step_shift(UB, M);
+        else o = st.step_shift(UB);
+      }
       /* histogram, branch-free: lanes outside the image, the two frame columns and the dropped
        * rows of the last group add 0. */
       if constexpr (HIST) {

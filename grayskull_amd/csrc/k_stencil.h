@@ -42,8 +42,9 @@ __global__ __launch_bounds__(256) void k_sobel16(uint8_t *dst, const uint8_t *sr
     st.init(U0, U1);
   }
   auto body = [&](auto I, int, const uint32_t(&U)[12]) { return st.template step<decltype(I)::value>(U); };
-  if constexpr (KEEP_COLS) strip_rows<2, false>(S, y0, nrows, 1, S.load(y0 + 1), body, SobelKeepCols(S));
-  else strip_rows<2, false>(S, y0, nrows, 1, S.load(y0 + 1), body);
+  constexpr bool EXITS = !GS_SOBEL_NOEXIT;
+  if constexpr (KEEP_COLS) strip_rows<2, false, EXITS>(S, y0, nrows, 1, S.load(y0 + 1), body, SobelKeepCols(S));
+  else strip_rows<2, false, EXITS>(S, y0, nrows, 1, S.load(y0 + 1), body);
 }
 
 /* host-staged gs_sobel: columns 0 and w-1 of rows 1..h-2 of the caller's dst, gathered on the
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256) void k_blur16(uint8_t *dst, const uint8_t *src
 #pragma unroll
     for (int k = 0; k < 8; k++) V[k] = pk_add_u16(V[k], ring[r][k]);
   }
-  strip_rows<N, false>(S, y0, nrows, R, S.load(y0 + R), [&](auto I, int, const uint32_t(&U)[12]) {
+  strip_rows<N, false, !GS_BLUR_NOEXIT>(S, y0, nrows, R, S.load(y0 + R), [&](auto I, int, const uint32_t(&U)[12]) {
     constexpr int slot = (decltype(I)::value + N - 1) % N; /* row i-1 leaves, row i+2R enters */
     uint32_t Hn[8];
     blur_hsum<R>(U, Hn);

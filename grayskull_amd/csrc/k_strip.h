@@ -10,6 +10,16 @@
 
 #include "prims.h"
 
+#ifndef GS_SOBEL_SAT
+#define GS_SOBEL_SAT 1 /* 1: saturating-mad clamp in the per-call sobel kernels (A/B switch) */
+#endif
+#ifndef GS_BLUR_NOEXIT
+#define GS_BLUR_NOEXIT 0
+#endif
+#ifndef GS_SOBEL_NOEXIT
+#define GS_SOBEL_NOEXIT 1 /* 1: k_sobel16 runs whole unroll groups (one basic block, no phi copies) */
+#endif
+
 namespace gs {
 
 template <int N, class F> GS_DEV void static_for(F &&f) {
@@ -171,10 +181,28 @@ struct SobelState {
 #pragma unroll
     for (int k = 0; k < 8; k++) H1[1][k] = h1[k], Pa[k] = pk_mad2_u16(Hp[k], h2[k]);
   }
-  /* PAR = parity of the step: H1[PAR] holds row b-2 and receives row b */
+  /* PAR = parity of the step: H1[PAR] holds row b-2 and receives row b.
+   * Bytes only: (|gx|+|gy|)/2 clamped to 255 is the high byte of min((|gx|+|gy|) * 128, 65535)
+   * (|gx|+|gy| <= 2040), one saturating v_pk_mad_u16 instead of shift + min. */
   template <int PAR> GS_DEV U4 step(const uint32_t (&U)[12]) {
+#if GS_SOBEL_SAT
+    uint32_t H1n[8], H2n[8], M[8];
+    sobel_hpass(U, H1n, H2n);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const uint32_t gx = pk_add_u16(Pa[k], H2n[k]);
+      const uint32_t gy = pk_sub_u16(H1n[k], H1[PAR][k]);
+      Pa[k] = pk_mad2_u16(H2n[k], Hp[k]);
+      Hp[k] = H2n[k];
+      H1[PAR][k] = H1n[k];
+      M[k] = pk_shl7_sat_u16(pk_add_u16(pk_abs_i16(gx), pk_abs_i16(gy)));
+    }
+    return U4{pack_lohi_b1(M[0], M[1]), pack_lohi_b1(M[2], M[3]), pack_lohi_b1(M[4], M[5]),
+              pack_lohi_b1(M[6], M[7])};
+#else
     uint32_t M[8];
     return step<PAR>(U, M);
+#endif
   }
   /* M: the 16 results as u16 pairs (before packing to bytes) */
   template <int PAR> GS_DEV U4 step(const uint32_t (&U)[12], uint32_t (&M)[8]) {
@@ -194,13 +222,21 @@ struct SobelState {
               pack_lohi(M[6], M[7])};
   }
   /* same, H1 history shifted instead of alternated (for callers whose unroll period is odd) */
-  GS_DEV U4 step_shift(const uint32_t (&U)[12], uint32_t (&M)[8]) {
-    const U4 o = step<0>(U, M); /* H1[0] (row b-2) consumed and overwritten with row b */
+  GS_DEV void shift_history() {
 #pragma unroll
     for (int k = 0; k < 8; k++) {
       const uint32_t t = H1[0][k];
       H1[0][k] = H1[1][k], H1[1][k] = t;
     }
+  }
+  GS_DEV U4 step_shift(const uint32_t (&U)[12], uint32_t (&M)[8]) {
+    const U4 o = step<0>(U, M); /* H1[0] (row b-2) consumed and overwritten with row b */
+    shift_history();
+    return o;
+  }
+  GS_DEV U4 step_shift(const uint32_t (&U)[12]) { /* bytes only */
+    const U4 o = step<0>(U);
+    shift_history();
     return o;
   }
 };

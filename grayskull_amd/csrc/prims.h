@@ -21,6 +21,9 @@
 #include <string.h>
 
 #define GS_DEV __device__ __forceinline__
+#ifndef GS_MAD2_OPAQUE
+#define GS_MAD2_OPAQUE 1
+#endif
 
 namespace gs {
 
@@ -128,6 +131,10 @@ GS_DEV uint32_t pk_min_u16(uint32_t a, uint32_t b) {
   uint32_t al = a & 0xffff, bl = b & 0xffff, ah = a >> 16, bh = b >> 16;
   return GS_PK2(al < bl ? al : bl, ah < bh ? ah : bh);
 }
+GS_DEV uint32_t pk_shl7_sat_u16(uint32_t a) { /* min(a * 128, 65535) per half */
+  uint32_t al = (a & 0xffff) * 128u, ah = (a >> 16) * 128u;
+  return GS_PK2(al > 0xffffu ? 0xffffu : al, ah > 0xffffu ? 0xffffu : ah);
+}
 GS_DEV uint32_t pk_max_u16(uint32_t a, uint32_t b) {
   uint32_t al = a & 0xffff, bl = b & 0xffff, ah = a >> 16, bh = b >> 16;
   return GS_PK2(al > bl ? al : bl, ah > bh ? ah : bh);
@@ -211,9 +218,18 @@ GS_DEV uint32_t pk_mad_u16(uint32_t a, uint32_t b, uint32_t c) { return GS_R((gs
 /* 2*a + c per half in ONE v_pk_mad_u16 (hipcc strength-reduces a*2+c into shift+add, so spell it;
  * pure VALU register op: no memory, no hazard beyond what hipcc pads around asm) */
 GS_DEV uint32_t pk_mad2_u16(uint32_t a, uint32_t c) {
+#if GS_MAD2_OPAQUE
+  /* the multiplier pair (2, 2) behind an s_mov the optimiser cannot see through (hoisted out of
+   * loops, one SGPR): the v_pk_mad_u16 itself is then a compiler-visible instruction, so the
+   * scheduler and the hazard recogniser treat it like any other packed op */
+  uint32_t two;
+  asm("s_mov_b32 %0, 0x00020002" : "=s"(two));
+  return pk_mad_u16(a, two, c);
+#else
   uint32_t d;
   asm("v_pk_mad_u16 %0, %1, 2, %2 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(c));
   return d;
+#endif
 }
 /* the instruction scheduler moves nothing across this point (keeps a prefetch where it was put) */
 GS_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
@@ -247,6 +263,13 @@ GS_DEV uint32_t pk_shl_u16(uint32_t a, unsigned s) { return GS_R((gs_u16x2)(GS_U
 GS_DEV uint32_t pk_shr_u16(uint32_t a, unsigned s) { return GS_R((gs_u16x2)(GS_U2(a) >> (unsigned short)s)); } /* v_pk_lshrrev_b16 */
 GS_DEV uint32_t pk_min_u16(uint32_t a, uint32_t b) { return GS_R(__builtin_elementwise_min(GS_U2(a), GS_U2(b))); } /* v_pk_min_u16 */
 GS_DEV uint32_t pk_max_u16(uint32_t a, uint32_t b) { return GS_R(__builtin_elementwise_max(GS_U2(a), GS_U2(b))); } /* v_pk_max_u16 */
+/* min(a * 128, 65535) per half: v_pk_mad_u16 ... clamp (unsigned saturation of the full a*b+c).
+ * For a < 2048 the high byte of each half is min(a >> 1, 255) -- shift, clamp in one lane-op. */
+GS_DEV uint32_t pk_shl7_sat_u16(uint32_t a) {
+  uint32_t d;
+  asm("v_pk_mad_u16 %0, %1, %2, 0 clamp" : "=v"(d) : "v"(a), "s"(0x00800080u));
+  return d;
+}
 GS_DEV uint32_t pk_abs_i16(uint32_t a) { return GS_R(__builtin_elementwise_abs(GS_I2(a))); }           /* v_pk_sub_i16 + v_pk_max_i16 */
 GS_DEV uint32_t pk_max_i16(uint32_t a, uint32_t b) { return GS_R(__builtin_elementwise_max(GS_I2(a), GS_I2(b))); } /* v_pk_max_i16 */
 GS_DEV uint32_t pk_sar_i16(uint32_t a, unsigned s) { return GS_R((gs_i16x2)(GS_I2(a) >> (short)s)); }            /* v_pk_ashrrev_i16 */
@@ -314,6 +337,8 @@ GS_DEV uint32_t unpack_lo(uint32_t d) { return perm_b32(0, d, 0x0c010c00u); }
 GS_DEV uint32_t unpack_hi(uint32_t d) { return perm_b32(0, d, 0x0c030c02u); }
 /* inverse: low bytes of the u16 pairs (lo=(p0,p1), hi=(p2,p3)) -> one dword */
 GS_DEV uint32_t pack_lohi(uint32_t lo, uint32_t hi) { return perm_b32(hi, lo, 0x06040200u); }
+/* same for the HIGH bytes of the u16 pairs */
+GS_DEV uint32_t pack_lohi_b1(uint32_t lo, uint32_t hi) { return perm_b32(hi, lo, 0x07050301u); }
 
 }  // namespace gs
 #endif
