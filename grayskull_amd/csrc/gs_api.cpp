@@ -436,8 +436,28 @@ void launch_fast(const uint8_t *img, uint8_t *score, unsigned w, unsigned h, uns
   const size_t fb = (size_t)w * h;
   const unsigned nitems = (w - 6) * (h - 6);
   const unsigned nchunks = (nitems + kChunkItems - 1) / kChunkItems;
-  GS_LAUNCH(k_fast_score_px, grid2d(w - 6, h - 6, n), dim3(64, 4), 0, st, img, score, w, h, fb,
-            threshold);
+  /* Score pass: per-pixel kernel with the wave-level compass filter by default.  The strip kernel
+   * (gsh_tune key 7 = 1) decides per 256-px row span instead of per 64 px: measured on 32 x 720p
+   * (profiles/r01i_fast_strip_vs_px.log) it is 1.5-2.3x faster on flat / bright frames (23 vs 53 us,
+   * 52 vs 75 us), equal on texture (lena, random) and 1.4x SLOWER on frames with large p < t
+   * regions (135 vs 95 us on the block-noise frames of configs[3]: there every pixel is a
+   * candidate under the reference's unsigned wrap, and a 256-px span almost always touches one). */
+  if (g_tune[7] == 1 && w % 4 == 0 && fb < 0x7fffffffull && ((uintptr_t)img & 3) == 0 && ((uintptr_t)score & 3) == 0 &&
+      threshold <= 0xffffff00u) {
+    /* strip kernel: ~6 waves per SIMD when the batch allows, bands of >= 8 rows */
+    const unsigned cw = (w + 255) / 256, rows = h - 6;
+    unsigned long long T = ((unsigned long long)rows * cw * n + 6143) / 6144;
+    T = T < 8 ? 8 : T > 64 ? 64 : T;
+    const unsigned nb = (rows + (unsigned)T - 1) / (unsigned)T;
+    for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
+      const unsigned nn = std::min(kMaxZ, n - f0);
+      GS_LAUNCH(k_fast_score4, dim3(cw, (nb + 3) / 4, nn), dim3(64, 4), 0, st, img + fb * f0, score + fb * f0, w, h,
+                (unsigned)T, fb, threshold);
+    }
+  } else {
+    GS_LAUNCH(k_fast_score_px, grid2d(w - 6, h - 6, n), dim3(64, 4), 0, st, img, score, w, h, fb,
+              threshold);
+  }
   unsigned long long *mask =
       (unsigned long long *)ctx().scratch(SL_MASK, (size_t)n * nchunks * kChunkWords * 8);
   unsigned *cnt = (unsigned *)ctx().scratch(SL_CNT, (size_t)n * nchunks * 4);

@@ -15,6 +15,7 @@
 #ifndef GS_K_FAST_H
 #define GS_K_FAST_H
 #include "k_compact.h"
+#include "k_strip.h"
 
 namespace gs {
 
@@ -68,20 +69,157 @@ GS_DEV unsigned fast_score(unsigned p, const unsigned (&v)[16], unsigned thresho
   return (ring_has_run9(bright) || ring_has_run9(dark)) ? mind : 0u;
 }
 
-/* pass 1, generic: grid (ceil((w-6)/64), ceil((h-6)/4), n), block (64,4) */
+/* Necessary condition for a circular run of >= 9 of one class: any 9 consecutive ring positions
+ * contain at least two of the compass positions 0, 4, 8, 12, so at least two compass pixels must be
+ * brighter, or at least two darker -- with exactly the class definitions of fast_score (unsigned
+ * wrap of p - t included), so the filter never changes a score. */
+GS_DEV bool fast_compass_candidate(unsigned p, unsigned v0, unsigned v4, unsigned v8, unsigned v12,
+                                   unsigned threshold) {
+  if (threshold > 0xffffff00u) return true; /* u32-wrap regime of fast_score_u32: no filter */
+  const int t = (int)(threshold < 256u ? threshold : 256u), hi = (int)p + t, lo = (int)p - t;
+  const int b = ((int)v0 > hi) + ((int)v4 > hi) + ((int)v8 > hi) + ((int)v12 > hi);
+  const int d = lo < 0 ? 4 - b : ((int)v0 < lo) + ((int)v4 < lo) + ((int)v8 < lo) + ((int)v12 < lo);
+  return b >= 2 || d >= 2;
+}
+
+/* pass 1, generic: grid (ceil((w-6)/64), ceil((h-6)/4), n), block (64,4).
+ * A wave is 64 consecutive pixels of one row; when none of them passes the compass filter the
+ * other 12 ring pixels are never loaded (wave-uniform branch: most waves of a frame with flat or
+ * straight-edged regions). */
 __global__ __launch_bounds__(256) void k_fast_score_px(const uint8_t *img, uint8_t *score,
                                                        unsigned w, unsigned h,
                                                        size_t frame_bytes, unsigned threshold) {
   const unsigned x = 3 + blockIdx.x * 64u + threadIdx.x, y = 3 + blockIdx.y * 4u + threadIdx.y;
-  if (x + 3 >= w || y + 3 >= h) return;
-  const uint8_t *c = img + (size_t)blockIdx.z * frame_bytes + (size_t)y * w + x;
+  const bool in = x + 3 < w && y + 3 < h;
+  const uint8_t *c = img + (size_t)blockIdx.z * frame_bytes + (size_t)(in ? y : 3u) * w + (in ? x : 3u);
   const long W = (long)w;
-  const unsigned v[16] = {c[-3 * W],     c[-3 * W + 1], c[-2 * W + 2], c[-W + 3],
-                          c[3],          c[W + 3],      c[2 * W + 2],  c[3 * W + 1],
-                          c[3 * W],      c[3 * W - 1],  c[2 * W - 2],  c[W - 3],
-                          c[-3],         c[-W - 3],     c[-2 * W - 2], c[-3 * W - 1]};
-  score[(size_t)blockIdx.z * frame_bytes + (size_t)y * w + x] =
-      (uint8_t)fast_score(c[0], v, threshold);
+  const unsigned p = c[0], v0 = c[-3 * W], v4 = c[3], v8 = c[3 * W], v12 = c[-3];
+  const bool cand = in && fast_compass_candidate(p, v0, v4, v8, v12, threshold);
+  unsigned s = 0;
+  if (ballot(cand) != 0) { /* wave-uniform */
+    const unsigned v[16] = {v0,  c[-3 * W + 1], c[-2 * W + 2], c[-W + 3],
+                            v4,  c[W + 3],      c[2 * W + 2],  c[3 * W + 1],
+                            v8,  c[3 * W - 1],  c[2 * W - 2],  c[W - 3],
+                            v12, c[-W - 3],     c[-2 * W - 2], c[-3 * W - 1]};
+    s = fast_score(p, v, threshold);
+  }
+  if (in) score[(size_t)blockIdx.z * frame_bytes + (size_t)y * w + x] = (uint8_t)s;
+}
+
+/* pass 1, strips (w % 4 == 0, 4-byte aligned frames, threshold <= 0xffffff00): a lane owns 4
+ * consecutive pixels (one dword per row), a wave 256 px of a row, and walks DOWN a band of T rows
+ * with the 7 image rows y-3..y+3 in registers as 12-byte windows (L, C, R: the neighbour lanes'
+ * dwords come by v_mov_b32_dpp, only lanes 0 / 63 fetch a halo dword), so every image byte is
+ * loaded once per band and every ring pixel is a static byte of a register.
+ *   Per row the wave first runs the compass filter on packed u16 pairs: with S2 / s2 the second
+ * largest / second smallest of the four compass pixels (8 packed min/max per pair of pixels),
+ * ">= 2 brighter" is S2 > p + t and ">= 2 darker" is s2 < p - t; p < t (the reference's unsigned
+ * wrap, ref :496-498) always passes.  Only pixel slots in which some lane of the wave passes are
+ * scored with fast_score -- the same function as the per-pixel kernel, so scores are identical.
+ * grid (ceil(w/256), ceil(bands/4), n), block (64, 4): the 4 waves of a block are 4 bands. */
+struct FastRow { uint32_t L, C, R; };
+template <int B> GS_DEV unsigned fast_wbyte(const FastRow &r) { /* byte B (0..11) of the window */
+  static_assert(B >= 0 && B < 12, "window byte");
+  const uint32_t d = B < 4 ? r.L : B < 8 ? r.C : r.R;
+  return (d >> (8 * (B & 3))) & 0xffu;
+}
+template <int K> GS_DEV unsigned fast_score_slot(const FastRow (&rw)[7], unsigned threshold) {
+  /* rw[d + 3] = image row y + d; pixel K is window byte 4 + K; ring order of ref :485-486 */
+  const unsigned p = fast_wbyte<4 + K>(rw[3]);
+  const unsigned v[16] = {fast_wbyte<4 + K>(rw[0]),     fast_wbyte<4 + K + 1>(rw[0]), fast_wbyte<4 + K + 2>(rw[1]),
+                          fast_wbyte<4 + K + 3>(rw[2]), fast_wbyte<4 + K + 3>(rw[3]), fast_wbyte<4 + K + 3>(rw[4]),
+                          fast_wbyte<4 + K + 2>(rw[5]), fast_wbyte<4 + K + 1>(rw[6]), fast_wbyte<4 + K>(rw[6]),
+                          fast_wbyte<4 + K - 1>(rw[6]), fast_wbyte<4 + K - 2>(rw[5]), fast_wbyte<4 + K - 3>(rw[4]),
+                          fast_wbyte<4 + K - 3>(rw[3]), fast_wbyte<4 + K - 3>(rw[2]), fast_wbyte<4 + K - 2>(rw[1]),
+                          fast_wbyte<4 + K - 1>(rw[0])};
+  return fast_score(p, v, threshold);
+}
+
+__global__ __launch_bounds__(256) void k_fast_score4(const uint8_t *img, uint8_t *score, unsigned w,
+                                                     unsigned h, unsigned T, size_t frame_bytes,
+                                                     unsigned threshold) {
+  const BufRsrc src = make_buf(img + (size_t)blockIdx.z * frame_bytes, frame_bytes);
+  const unsigned lane = threadIdx.x & 63u, x0 = (blockIdx.x * 64u + threadIdx.x) * 4u;
+  const unsigned band = uniform(blockIdx.y * blockDim.y + threadIdx.y);
+  const int y0 = 3 + (int)(band * T);
+  if (y0 >= (int)h - 3) return; /* whole wave */
+  const int nrows = ((int)h - 3 - y0) < (int)T ? ((int)h - 3 - y0) : (int)T;
+  uint8_t *out = score + (size_t)blockIdx.z * frame_bytes;
+  struct Raw { uint32_t c, hh; };
+  auto load = [&](int y) { /* rows outside the image are never used by an interior pixel */
+    const bool ok = (unsigned)y < h && x0 < w;
+    const uint32_t base = (uint32_t)y * w + x0;
+    uint32_t ho = kOOB;
+    if (lane == 0 && x0 > 0) ho = base - 4;
+    if (lane == 63 && x0 + 4 < w) ho = base + 4;
+    Raw r;
+    r.c = buf_load4(src, ok ? base : kOOB);
+    r.hh = buf_load4(src, ok ? ho : kOOB);
+    return r;
+  };
+  auto widen = [&](const Raw &r) { return FastRow{wave_shr1(r.c, r.hh), r.c, wave_shl1(r.c, r.hh)}; };
+  /* which of this lane's 4 pixels are interior columns (3 <= x < w - 3) */
+  bool col_in[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) col_in[k] = x0 + k >= 3u && x0 + k + 3u < w;
+  const uint32_t in01 = (col_in[0] ? 0xffffu : 0u) | (col_in[1] ? 0xffff0000u : 0u);
+  const uint32_t in23 = (col_in[2] ? 0xffffu : 0u) | (col_in[3] ? 0xffff0000u : 0u);
+  const bool whole = col_in[0] && col_in[3];
+  const uint32_t t16 = threshold < 256u ? threshold : 256u, tt = t16 | (t16 << 16);
+
+  FastRow ring[7]; /* iteration I (mod 7): image row y + d sits in slot (I + d + 3) % 7 */
+  static_for<6>([&](auto K) { ring[decltype(K)::value] = widen(load(y0 - 3 + decltype(K)::value)); });
+  Raw raw = load(y0 + 3);
+  for (int base = 0; base < nrows; base += 7) {
+    static_for<7>([&](auto I) {
+      constexpr int ii = decltype(I)::value;
+      const int i = base + ii;
+      if (i >= nrows) return; /* wave-uniform */
+      const int y = y0 + i;
+      ring[(ii + 6) % 7] = widen(raw);
+      raw = load(y + 4);
+      const FastRow(&r0)[7] = ring;
+      const FastRow rw[7] = {r0[(ii + 0) % 7], r0[(ii + 1) % 7], r0[(ii + 2) % 7], r0[(ii + 3) % 7],
+                             r0[(ii + 4) % 7], r0[(ii + 5) % 7], r0[(ii + 6) % 7]};
+      /* compass filter, pixels (0,1) and (2,3) as u16 pairs */
+      uint32_t cand[2];
+#pragma unroll
+      for (int hp = 0; hp < 2; hp++) {
+        const uint32_t P = hp ? unpack_hi(rw[3].C) : unpack_lo(rw[3].C);
+        const uint32_t a = hp ? unpack_hi(rw[0].C) : unpack_lo(rw[0].C);  /* ( 0, -3) */
+        const uint32_t c = hp ? unpack_hi(rw[6].C) : unpack_lo(rw[6].C);  /* ( 0, +3) */
+        /* (+3, 0): window bytes 7+k;  (-3, 0): window bytes 1+k */
+        const uint32_t b = hp ? perm_b32(rw[3].R, rw[3].C, 0x0c060c05u) : perm_b32(rw[3].R, rw[3].C, 0x0c040c03u);
+        const uint32_t d = hp ? perm_b32(rw[3].C, rw[3].L, 0x0c040c03u) : perm_b32(rw[3].C, rw[3].L, 0x0c020c01u);
+        const uint32_t x = pk_max_u16(a, b), yv = pk_min_u16(a, b), z = pk_max_u16(c, d), u = pk_min_u16(c, d);
+        const uint32_t mid_hi = pk_min_u16(x, z), mid_lo = pk_max_u16(yv, u);
+        const uint32_t S2 = pk_max_u16(mid_hi, mid_lo); /* second largest  */
+        const uint32_t s2 = pk_min_u16(mid_hi, mid_lo); /* second smallest */
+        const uint32_t bright2 = pk_subsat_u16(S2, pk_add_u16(P, tt));   /* != 0 <=> S2 > p + t */
+        const uint32_t dark2 = pk_subsat_u16(pk_subsat_u16(P, tt), s2);  /* != 0 <=> s2 < p - t (p >= t) */
+        const uint32_t wrap = pk_subsat_u16(tt, P);                      /* != 0 <=> p < t */
+        cand[hp] = bright2 | dark2 | wrap;
+      }
+      cand[0] &= in01, cand[1] &= in23;
+      unsigned s[4] = {0, 0, 0, 0};
+      if (ballot((cand[0] | cand[1]) != 0) != 0) { /* wave-uniform; slot by slot */
+        if (ballot((cand[0] & 0xffffu) != 0) != 0) s[0] = fast_score_slot<0>(rw, threshold);
+        if (ballot((cand[0] >> 16) != 0) != 0) s[1] = fast_score_slot<1>(rw, threshold);
+        if (ballot((cand[1] & 0xffffu) != 0) != 0) s[2] = fast_score_slot<2>(rw, threshold);
+        if (ballot((cand[1] >> 16) != 0) != 0) s[3] = fast_score_slot<3>(rw, threshold);
+      }
+      if (x0 < w) {
+        uint8_t *o = out + (size_t)y * w + x0;
+        if (whole) {
+          *(uint32_t *)o = s[0] | (s[1] << 8) | (s[2] << 16) | (s[3] << 24);
+        } else { /* lanes holding border columns: the 3-px frame of the scoremap is never written (ref :489) */
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+            if (col_in[k]) o[k] = (uint8_t)s[k];
+        }
+      }
+    });
+  }
 }
 
 /* idx / d for idx < 2^26 with the host's magic = ceil(2^40 / d) (needs d > 256 to fit 32 bits; the

@@ -131,6 +131,10 @@ GS_DEV uint32_t pk_min_u16(uint32_t a, uint32_t b) {
   uint32_t al = a & 0xffff, bl = b & 0xffff, ah = a >> 16, bh = b >> 16;
   return GS_PK2(al < bl ? al : bl, ah < bh ? ah : bh);
 }
+GS_DEV uint32_t pk_subsat_u16(uint32_t a, uint32_t b) { /* max(a - b, 0) per half */
+  uint32_t al = a & 0xffff, bl = b & 0xffff, ah = a >> 16, bh = b >> 16;
+  return GS_PK2(al > bl ? al - bl : 0u, ah > bh ? ah - bh : 0u);
+}
 GS_DEV uint32_t pk_shl7_sat_u16(uint32_t a) { /* min(a * 128, 65535) per half */
   uint32_t al = (a & 0xffff) * 128u, ah = (a >> 16) * 128u;
   return GS_PK2(al > 0xffffu ? 0xffffu : al, ah > 0xffffu ? 0xffffu : ah);
@@ -263,6 +267,7 @@ GS_DEV uint32_t pk_shl_u16(uint32_t a, unsigned s) { return GS_R((gs_u16x2)(GS_U
 GS_DEV uint32_t pk_shr_u16(uint32_t a, unsigned s) { return GS_R((gs_u16x2)(GS_U2(a) >> (unsigned short)s)); } /* v_pk_lshrrev_b16 */
 GS_DEV uint32_t pk_min_u16(uint32_t a, uint32_t b) { return GS_R(__builtin_elementwise_min(GS_U2(a), GS_U2(b))); } /* v_pk_min_u16 */
 GS_DEV uint32_t pk_max_u16(uint32_t a, uint32_t b) { return GS_R(__builtin_elementwise_max(GS_U2(a), GS_U2(b))); } /* v_pk_max_u16 */
+GS_DEV uint32_t pk_subsat_u16(uint32_t a, uint32_t b) { return GS_R(__builtin_elementwise_sub_sat(GS_U2(a), GS_U2(b))); } /* v_pk_sub_u16 clamp */
 /* min(a * 128, 65535) per half: v_pk_mad_u16 ... clamp (unsigned saturation of the full a*b+c).
  * For a < 2048 the high byte of each half is min(a >> 1, 255) -- shift, clamp in one lane-op. */
 GS_DEV uint32_t pk_shl7_sat_u16(uint32_t a) {

@@ -55,16 +55,37 @@ def test_next_rows(emu, oracle, shape):
     pc.next_rows(emu, oracle, np.random.RandomState(w + h).randint(0, 256, (h, w)).astype(np.uint8), MEM)
 
 
-@pytest.mark.parametrize("shape", [(67, 45), (96, 80), (7, 7), (6, 30), (40, 8), (300, 12)])
+@pytest.mark.parametrize("shape", [(67, 45), (96, 80), (7, 7), (6, 30), (40, 8), (300, 12), (260, 17), (8, 8), (516, 9)])
 def test_fast(emu, oracle, shape):
     w, h = shape
-    pc.fast(emu, oracle, Oracle.synth(w, h, 5), MEM)
-    rs = np.random.RandomState(1)
-    pc.fast(emu, oracle, rs.randint(0, 256, (h, w)).astype(np.uint8), MEM, threshold=5, caps=(5000, 1))
-    pc.fast(emu, oracle, rs.randint(0, 40, (h, w)).astype(np.uint8), MEM, threshold=30)  # p < t everywhere
-    img = rs.randint(0, 256, (h, w)).astype(np.uint8)
-    for t in (0, 1, 255, 256, 300, 0x7fffffff, 0x80000000, 0xffffff00, 0xffffff01, 0xfffffff0, 0xffffffff):
-        pc.fast(emu, oracle, img, MEM, threshold=t, caps=(5000,))  # incl. thresholds where p + t wraps
+    for strip in ((0, 1) if w % 4 == 0 else (0,)):  # gsh_tune key 7 = 1: strip score kernel
+        emu.tune(7, strip)
+        try:
+            pc.fast(emu, oracle, Oracle.synth(w, h, 5), MEM)
+            rs = np.random.RandomState(1)
+            pc.fast(emu, oracle, rs.randint(0, 256, (h, w)).astype(np.uint8), MEM, threshold=5, caps=(5000, 1))
+            pc.fast(emu, oracle, rs.randint(0, 40, (h, w)).astype(np.uint8), MEM, threshold=30)  # p < t everywhere
+            img = rs.randint(0, 256, (h, w)).astype(np.uint8)
+            for t in (0, 1, 255, 256, 300, 0x7fffffff, 0x80000000, 0xffffff00, 0xffffff01, 0xfffffff0, 0xffffffff):
+                pc.fast(emu, oracle, img, MEM, threshold=t, caps=(5000,))  # incl. thresholds where p + t wraps
+        finally:
+            emu.tune(7, 0)
+
+
+def test_fast_strip_kernel_equals_per_pixel_kernel(emu, oracle):
+    """k_fast_score4 (w % 4 == 0: lane = 4 px, rows in registers, compass filter) against k_fast_score_px
+    (the default) and the oracle; gsh_tune key 7 = 1 selects the strip kernel: block corners, noise and a p < t region, two waves wide"""
+    rs = np.random.RandomState(11)
+    img = Oracle.synth(264, 40, 9)
+    img[8:20, 100:140] = rs.randint(0, 12, (12, 40))       # p < threshold: the unsigned-wrap class
+    img[25:33, 250:264] = rs.randint(0, 256, (8, 14))      # texture up to the right border
+    for t in (20, 3, 200):
+        pc.fast(emu, oracle, img, MEM, threshold=t, caps=(5000,))
+        emu.tune(7, 1)
+        try:
+            pc.fast(emu, oracle, img, MEM, threshold=t, caps=(5000,))
+        finally:
+            emu.tune(7, 0)
 
 
 def test_fast_quirk(emu, oracle):
