@@ -93,6 +93,8 @@ _SIGS = {
     "gsh_shutdown": (None, []),
     "gsh_malloc": (C.c_void_p, [C.c_size_t]),
     "gsh_free": (None, [C.c_void_p]),
+    "gsh_host_alloc": (C.c_void_p, [C.c_size_t]),
+    "gsh_host_free": (None, [C.c_void_p]),
     "gsh_memset": (None, [C.c_void_p, C.c_int, C.c_size_t]),
     "gsh_upload": (None, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "gsh_download": (None, [C.c_void_p, C.c_void_p, C.c_size_t]),

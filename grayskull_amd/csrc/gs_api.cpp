@@ -878,6 +878,15 @@ void *gsh_malloc(size_t bytes) {
 void gsh_free(void *p) {
   if (p) GS_HIP(hipFree(p));
 }
+void *gsh_host_alloc(size_t bytes) {
+  ctx().ensure_device();
+  void *p = nullptr;
+  GS_HIP(hipHostMalloc(&p, bytes ? bytes : 1, 0));
+  return p;
+}
+void gsh_host_free(void *p) {
+  if (p) GS_HIP(hipHostFree(p));
+}
 void gsh_memset(void *dev, int byte, size_t bytes) {
   GS_HIP(hipMemsetAsync(dev, byte, bytes, ctx().s()));
 }

@@ -56,6 +56,10 @@ void gsh_shutdown(void);                  /* free this thread's scratch + stream
 
 void *gsh_malloc(size_t bytes);           /* hipMalloc; aborts on failure               */
 void gsh_free(void *dev);
+/* page-locked host memory (hipHostMalloc): gsh_upload / gsh_download and host-pointer gs_* calls
+ * on it move at the full PCIe rate without the driver's pageable staging copy; aborts on failure */
+void *gsh_host_alloc(size_t bytes);
+void gsh_host_free(void *host);
 void gsh_memset(void *dev, int byte, size_t bytes);             /* stream-ordered      */
 void gsh_upload(void *dev, const void *host, size_t bytes);     /* synchronous         */
 void gsh_download(void *host, const void *dev, size_t bytes);   /* synchronous         */

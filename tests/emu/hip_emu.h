@@ -131,6 +131,8 @@ inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((uint64_t)
 #define hipMemcpyDeviceToDevice 3
 inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1); return *p ? 0 : 2; }
 inline hipError_t hipFree(void *p) { free(p); return 0; }
+inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { *p = malloc(n ? n : 1); return *p ? 0 : 2; }
+inline hipError_t hipHostFree(void *p) { free(p); return 0; }
 inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, int) { memcpy(d, s, n); return 0; }
 inline hipError_t hipMemcpy2DAsync(void *d, size_t dp, const void *s, size_t sp, size_t wbytes, size_t rows, int, hipStream_t) {

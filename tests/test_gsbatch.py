@@ -130,6 +130,40 @@ def test_gsbatch_errors_like_nanomagick_emulated(tmp_path):
     assert r.returncode == 1 and b"Wrong number of arguments for 'crop'" in r.stderr
 
 
+def test_gsbatch_pgm_reader_and_slicing_emulated(tmp_path):
+    """(a) a raster whose first bytes are whitespace values: the reference's fscanf swallows them and
+    rejects the file (grayskull.h:116), gsbatch loads it; (b) extra whitespace after maxval: raster
+    starts after it, like the reference; (c) groups larger than the staging slice are cut into slices"""
+    from oracle.pyoracle import Oracle
+    exe = build_emu(tmp_path)
+    o = Oracle("port")
+    rs = np.random.RandomState(3)
+    imgs = [rs.randint(0, 256, (24, 40)).astype(np.uint8) for _ in range(7)]
+    imgs[0][0, :3] = (10, 32, 9)                    # newline, space, tab as the first pixels
+    files = []
+    for k, a in enumerate(imgs):
+        p = str(tmp_path / ("r%d.pgm" % k))
+        with open(p, "wb") as f:
+            f.write(b"P5\n40 24\n255\n" + (b" \n" if k == 1 else b"") + a.tobytes())
+        files.append(p)
+    imgs[1][0, 0] = max(int(imgs[1][0, 0]), 33)    # make sure the raster of file 1 does not start with whitespace
+    with open(files[1], "wb") as f:
+        f.write(b"P5\n40 24\n255\n \n" + imgs[1].tobytes())
+    if os.path.exists(NANO):
+        nano = build_ref_nano(tmp_path)
+        ref0, _ = nano_chain(nano, [("blur", ["1"])], files[0], tmp_path, "ws0")
+        assert ref0 is None                         # the reference cannot read file 0 at all
+        ref1, _ = nano_chain(nano, [("blur", ["1"])], files[1], tmp_path, "ws1")
+        assert_same(read_pgm(ref1), o.blur(imgs[1], 1), "reference reads past the extra whitespace")
+    outdir = tmp_path / "out"
+    outdir.mkdir()
+    env = dict(os.environ, GSBATCH_SLICE_BYTES=str(40 * 24 * 3))  # 3 frames per slice -> 3 slices
+    r = subprocess.run([exe, "-v", "-o", str(outdir), "blur", "1", "--", *files], capture_output=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-800:]
+    for f, a in zip(files, imgs):
+        assert_same(read_pgm(str(outdir / os.path.basename(f))), o.blur(a, 1), os.path.basename(f))
+
+
 def oracle_chain(o, img, chain):
     for verb, args in chain:
         a = [int(x) for x in args if x.lstrip("-").isdigit()]
