@@ -111,6 +111,25 @@ def _body_fast_orb_match_any_shape(emu, oracle, w, h, seed, kind, threshold, nkp
             assert_same(emu.match_orb(ka, kb, mm, md), oracle.match_orb(kao, kbo, mm, md), "gs_match_orb")
 
 
+def _body_fast_strip_kernel(emu, oracle, w4, h, seed, kind, threshold, dark):
+    """gsh_tune key 7 = 1: k_fast_score4 (w % 4 == 0; widths around one and two 256-px waves)"""
+    rs = np.random.RandomState(seed)
+    w = 4 * w4
+    img = _img(rs, w, h, kind)
+    if dark:  # a p < threshold region: the reference's unsigned wrap class
+        img[h // 3: 2 * h // 3, w // 4: w // 2] = rs.randint(0, max(2, min(threshold, 255)), (2 * h // 3 - h // 3, w // 2 - w // 4))
+    sm0 = rs.randint(0, 256, (h, w)).astype(np.uint8)
+    ko, smo = oracle.fast(img, 5000, threshold, sm0)
+    emu.tune(7, 1)
+    try:
+        sm = sm0.copy()
+        k = emu.fast(img.copy(), sm, 5000, threshold)
+    finally:
+        emu.tune(7, 0)
+    assert_same(k, ko, "gs_fast (strip kernel) %dx%d t=%d" % (w, h, threshold))
+    assert_same(sm, smo, "gs_fast scoremap (strip kernel)")
+
+
 def _body_lbp_any_shape(emu, oracle, w, h, seed, cseed, sf, mx, step, cap):
     from util import random_cascade
     img = _img(np.random.RandomState(seed), w, h, seed % 3)
@@ -217,6 +236,21 @@ def test_gpu_fused_pipeline_any_shape(hip, oracle, n, w, h, radius, seed):
        threshold=st.sampled_from([0, 1, 5, 20, 60, 200, 255, 300]), nkps=st.integers(1, 80))
 def test_fast_orb_match_any_shape(emu, oracle, w, h, seed, kind, threshold, nkps):
     _body_fast_orb_match_any_shape(emu, oracle, w=w, h=h, seed=seed, kind=kind, threshold=threshold, nkps=nkps)
+
+
+@_cfg(12)
+@given(w4=st.sampled_from([2, 3, 16, 63, 64, 65, 67, 128, 130]), h=st.integers(7, 30), seed=st.integers(0, 2 ** 16),
+       kind=st.integers(0, 2), threshold=st.sampled_from([0, 1, 5, 20, 60, 200, 255, 256, 300]), dark=st.booleans())
+def test_fast_strip_kernel(emu, oracle, w4, h, seed, kind, threshold, dark):
+    _body_fast_strip_kernel(emu, oracle, w4=w4, h=h, seed=seed, kind=kind, threshold=threshold, dark=dark)
+
+
+@pytest.mark.gpu
+@_cfg(20)
+@given(w4=st.sampled_from([2, 3, 16, 63, 64, 65, 67, 128, 130, 320]), h=st.integers(7, 90), seed=st.integers(0, 2 ** 16),
+       kind=st.integers(0, 2), threshold=st.sampled_from([0, 1, 5, 20, 60, 200, 255, 256, 300]), dark=st.booleans())
+def test_gpu_fast_strip_kernel(hip, oracle, w4, h, seed, kind, threshold, dark):
+    _body_fast_strip_kernel(hip, oracle, w4=w4, h=h, seed=seed, kind=kind, threshold=threshold, dark=dark)
 
 
 @pytest.mark.gpu
