@@ -412,14 +412,14 @@ void launch_otsu(const uint8_t *img, unsigned w, unsigned h, unsigned n, unsigne
 }
 
 /* ------------------------------------------------------------------ ordered compaction driver */
-template <class F>
+template <bool QUAD = false, class F>
 void run_compaction(unsigned long long *mask, unsigned *cnt, unsigned nchunks, unsigned n,
                     unsigned cap, unsigned *totals_dev, F emit) {
   hipStream_t st = ctx().s();
   unsigned *pfx = (unsigned *)ctx().scratch(SL_PFX, (size_t)n * nchunks * 4);
   GS_LAUNCH(k_chunk_scan, dim3(n), dim3(1024), 0, st, (const unsigned *)cnt, nchunks, pfx,
             totals_dev, cap);
-  GS_LAUNCH(k_emit<F>, dim3((nchunks + 3) / 4, n), dim3(256), 0, st,
+  GS_LAUNCH((k_emit<F, QUAD>), dim3((nchunks + 3) / 4, n), dim3(256), 0, st,
             (const unsigned long long *)mask, (const unsigned *)cnt, (const unsigned *)pfx, nchunks,
             cap, emit);
 }
@@ -468,8 +468,8 @@ void launch_fast(const uint8_t *img, uint8_t *score, unsigned w, unsigned h, uns
                              ? (unsigned)(((1ull << 40) + iw - 1) / iw) : 0u;
   GS_LAUNCH(k_fast_nms, dim3(nchunks, n), dim3(256), 0, st, (const uint8_t *)score, w, h, fb, mask,
             cnt, nchunks, magic);
-  run_compaction(mask, cnt, nchunks, n, nkps, counts,
-                 FastEmit{score, w, fb, kps, nkps});
+  run_compaction</*QUAD=*/true>(mask, cnt, nchunks, n, nkps, counts, /* k_fast_nms: 4 items per lane */
+                                FastEmit{score, w, fb, kps, nkps});
 }
 
 /* ------------------------------------------------------------------ LBP cascade */

@@ -62,7 +62,11 @@ __global__ __launch_bounds__(1024) void k_chunk_scan(const unsigned *count, unsi
  * letting lane b take bit b: its rank is the hits before the word + popcount of the lower bits,
  * so the up to 64 hits of a word are written in parallel and in scan order.  (One thread per
  * chunk walked up to 2048 items serially: 100 us for a chunk full of FAST corners.) */
-template <class F>
+/* QUAD: the producer's lanes own 4 consecutive items each (k_fast_nms), so a group of 256 items is
+ * 4 words in SLOT-major form -- word s of the group, bit l = item 256 g + 4 l + s -- i.e. the four
+ * ballots as they come.  Scan order inside a group is then lane-major: lane l's hits rank after
+ * all hits of lanes < l in the four words, slot by slot. */
+template <class F, bool QUAD = false>
 __global__ __launch_bounds__(256) void k_emit(const unsigned long long *mask,
                                               const unsigned *count, const unsigned *prefix,
                                               unsigned nchunks, unsigned cap, F emit) {
@@ -75,6 +79,24 @@ __global__ __launch_bounds__(256) void k_emit(const unsigned long long *mask,
   if (r >= cap) return;
   const unsigned long long mine = lane < kChunkWords ? mask[fc * kChunkWords + lane] : 0ull;
   const uint32_t mlo = (uint32_t)mine, mhi = (uint32_t)(mine >> 32);
+  if constexpr (QUAD) {
+    for (unsigned g = 0; g < kChunkWords / 4 && r < cap; g++) { /* wave-uniform */
+      uint64_t m[4];
+#pragma unroll
+      for (unsigned s = 0; s < 4; s++) m[s] = ((uint64_t)readlane_at(mhi, 4 * g + s) << 32) | readlane_at(mlo, 4 * g + s);
+      if (!(m[0] | m[1] | m[2] | m[3])) continue;
+      const uint64_t lower = (1ull << lane) - 1ull;
+      unsigned rank = r + (unsigned)(__popcll(m[0] & lower) + __popcll(m[1] & lower) + __popcll(m[2] & lower) + __popcll(m[3] & lower));
+#pragma unroll
+      for (unsigned s = 0; s < 4; s++)
+        if ((m[s] >> lane) & 1ull) {
+          if (rank < cap) emit(blockIdx.y, (size_t)c * kChunkItems + g * 256u + lane * 4u + s, rank);
+          rank++;
+        }
+      r += (unsigned)(__popcll(m[0]) + __popcll(m[1]) + __popcll(m[2]) + __popcll(m[3]));
+    }
+    return;
+  }
   for (unsigned k = 0; k < kChunkWords && r < cap; k++) { /* wave-uniform */
     const uint64_t m = ((uint64_t)readlane_at(mhi, k) << 32) | readlane_at(mlo, k);
     if (!m) continue;

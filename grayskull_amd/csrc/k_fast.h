@@ -228,8 +228,22 @@ GS_DEV unsigned div_by(unsigned idx, unsigned d, unsigned magic) {
   return magic ? (unsigned)(((unsigned long long)idx * magic) >> 40) : idx / d;
 }
 
+/* strict 3x3 maximum test of one interior pixel, byte by byte (ref :519-529) */
+GS_DEV bool fast_is_peak(const uint8_t *c, long W) {
+  const unsigned s = c[0];
+  if (!s) return false;
+  unsigned m = c[-W - 1];
+  m = c[-W] > m ? c[-W] : m, m = c[-W + 1] > m ? c[-W + 1] : m;
+  m = c[-1] > m ? c[-1] : m, m = c[1] > m ? c[1] : m;
+  m = c[W - 1] > m ? c[W - 1] : m, m = c[W] > m ? c[W] : m, m = c[W + 1] > m ? c[W + 1] : m;
+  return !(m > s); /* strict: ties survive (ref :524) */
+}
+
 /* pass 2: NMS flags over the interior in raster order, item = (y-3)*(w-6) + (x-3).
- * grid (nchunks, n frames), block 256, 8 items per thread (one chunk per block). */
+ * grid (nchunks, n frames), block 256, one 2048-item chunk per block.  A lane owns 4 consecutive
+ * items: one (unaligned) dword of scores; almost always it is 0 and the lane is done.  Otherwise
+ * the 3x3 neighbourhoods of the 4 pixels are 6 more dwords.  The 4 ballots (one per slot) are
+ * stored as the group's 4 mask words, slot-major; k_emit<F, QUAD> restores scan order. */
 __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t *score, unsigned w, unsigned h,
                                                   size_t frame_bytes, unsigned long long *mask,
                                                   unsigned *chunk_count, unsigned nchunks,
@@ -238,23 +252,51 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t *score, unsigned
   const uint8_t *sf = score + (size_t)blockIdx.y * frame_bytes;
   const unsigned tid = threadIdx.x, wv = tid >> 6;
   const size_t chunk = (size_t)blockIdx.y * nchunks + blockIdx.x;
-  for (unsigned k = 0; k < kChunkItems / 256u; k++) {
-    const unsigned idx = blockIdx.x * kChunkItems + k * 256u + tid;
-    bool kp = false;
+  const long W = (long)w;
+  for (unsigned k = 0; k < kChunkItems / 1024u; k++) {
+    const unsigned idx = blockIdx.x * kChunkItems + k * 1024u + tid * 4u;
+    bool kp[4] = {false, false, false, false};
     if (idx < nitems) {
-      const unsigned yy = div_by(idx, iw, div_magic), x = 3 + (idx - yy * iw), y = 3 + yy;
-      const uint8_t *c = sf + (size_t)y * w + x;
-      const unsigned s = c[0];
-      if (s) {
-        const long W = (long)w;
-        unsigned m = c[-W - 1];
-        m = c[-W] > m ? c[-W] : m, m = c[-W + 1] > m ? c[-W + 1] : m;
-        m = c[-1] > m ? c[-1] : m, m = c[1] > m ? c[1] : m;
-        m = c[W - 1] > m ? c[W - 1] : m, m = c[W] > m ? c[W] : m, m = c[W + 1] > m ? c[W + 1] : m;
-        kp = !(m > s); /* strict: ties survive (ref :524) */
+      const unsigned yy = div_by(idx, iw, div_magic), xo = idx - yy * iw;
+      const uint8_t *c = sf + (size_t)(3 + yy) * w + 3 + xo;
+      if (xo + 3 < iw) { /* the 4 items are 4 consecutive pixels of one row (and all < nitems) */
+        const uint32_t ctr = load_u32_unaligned(c);
+        if (ctr) {
+          /* bytes x-1 .. x+6 of the three rows as two dwords each; pixel j's neighbours are window bytes j, j+1, j+2 */
+          const uint64_t up = load_u32_unaligned(c - W - 1) | ((uint64_t)load_u32_unaligned(c - W + 3) << 32);
+          const uint64_t mid = load_u32_unaligned(c - 1) | ((uint64_t)load_u32_unaligned(c + 3) << 32);
+          const uint64_t dn = load_u32_unaligned(c + W - 1) | ((uint64_t)load_u32_unaligned(c + W + 3) << 32);
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const unsigned s = (ctr >> (8 * j)) & 0xffu;
+            auto byte = [](uint64_t v, int i) { return (unsigned)(v >> (8 * i)) & 0xffu; };
+            unsigned m = byte(up, j);
+            m = byte(up, j + 1) > m ? byte(up, j + 1) : m, m = byte(up, j + 2) > m ? byte(up, j + 2) : m;
+            m = byte(mid, j) > m ? byte(mid, j) : m, m = byte(mid, j + 2) > m ? byte(mid, j + 2) : m;
+            m = byte(dn, j) > m ? byte(dn, j) : m, m = byte(dn, j + 1) > m ? byte(dn, j + 1) : m;
+            m = byte(dn, j + 2) > m ? byte(dn, j + 2) : m;
+            kp[j] = s != 0 && !(m > s);
+          }
+        }
+      } else { /* the group crosses a row end or the end of the frame: item by item */
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const unsigned ij = idx + (unsigned)j;
+          if (ij < nitems) {
+            const unsigned yj = div_by(ij, iw, div_magic), xj = ij - yj * iw; /* iw < 4: several row ends */
+            kp[j] = fast_is_peak(sf + (size_t)(3 + yj) * w + 3 + xj, W);
+          }
+        }
       }
     }
-    publish_flags(kp, mask, chunk_count, chunk * kChunkWords + k * 4u + wv);
+    const uint64_t b0 = ballot(kp[0]), b1 = ballot(kp[1]), b2 = ballot(kp[2]), b3 = ballot(kp[3]);
+    /* the four ballots are the group's four mask words in slot-major form (k_emit<F, QUAD>) */
+    const unsigned total = (unsigned)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
+    if (lane_id() == 0) {
+      const size_t w0 = chunk * kChunkWords + k * 16u + wv * 4u;
+      mask[w0] = b0, mask[w0 + 1] = b1, mask[w0 + 2] = b2, mask[w0 + 3] = b3;
+      if (total) atomicAdd(&chunk_count[chunk], total);
+    }
   }
 }
 
