@@ -56,3 +56,64 @@ def test_gloo_world2_gathers_per_frame_results_in_order():
     for rank, mx, sm, allv in res:
         assert mx == 2.0 and sm == 7.0
         assert allv == [10 * f + 1 for f in range(7)]
+
+
+def _pipeline_worker(rank, world, port, q, emu_so):
+    """one rank of the sharded config-2 / config-5 chains: its frames through the batch entry points (the
+    kernel sources in their emulator build -- no GPU here), per-frame results gathered over gloo"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import numpy as np
+    import grayskull_amd as G
+    from grayskull_amd.shard import Sharder, frame_range
+    from oracle.pyoracle import Oracle
+    g = G.Grayskull(emu_so)
+    sh = Sharder(backend="gloo")
+    total, w, h = 5, 64, 24
+    lo, hi = frame_range(rank, world, total)
+    n = hi - lo
+    src = np.stack([Oracle.synth(w, h, 1000 + f) for f in range(lo, hi)]) if n else np.zeros((0, h, w), np.uint8)
+    dst = np.zeros_like(src)
+    hist = np.zeros((max(n, 1), 256), np.uint32)
+    thr = np.zeros(max(n, 1), np.uint8)
+    if n:
+        g.edge_pipeline_batch(dst, None, src, 2, hist, thr)        # fused blur -> sobel -> otsu -> threshold
+        g.sync()
+    sums = torch.tensor([int(Oracle.fnv1a(dst[i])) for i in range(n)], dtype=torch.int64)
+    sh.barrier()
+    all_thr = sh.all_gather_frames(torch.from_numpy(thr[:n].astype(np.int32)), total)
+    all_sum = sh.all_gather_frames(sums, total)
+    q.put((rank, all_thr.tolist(), all_sum.tolist()))
+    sh.close()
+
+
+def test_gloo_world2_sharded_pipeline_equals_oracle_on_every_frame():
+    """BASELINE configs[1]/[4] sharding, world_size 2 on CPU: frames split by frame_range, each rank
+    runs its share through gsh_edge_pipeline_batch, rank-ordered all-gather of the per-frame Otsu
+    thresholds and output hashes; every rank sees all 5 frames' results == the oracle's"""
+    import subprocess
+    import numpy as np
+    from oracle.pyoracle import Oracle
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "grayskull_amd", "csrc"), "emu"])
+    emu_so = os.path.join(ROOT, "tests", "emu", "libgs_kernel_emu.so")
+    o = Oracle("port")
+    exp_thr, exp_sum = [], []
+    for f in range(5):
+        e = o.sobel(o.blur(Oracle.synth(64, 24, 1000 + f), 2))
+        t = o.otsu_threshold(e)
+        exp_thr.append(int(t))
+        exp_sum.append(int(Oracle.fnv1a(o.threshold(e, t))))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    ps = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, q, emu_so)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=300) for _ in ps]
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, thr, sums in res:
+        assert thr == exp_thr, "rank %d thresholds" % rank
+        assert sums == exp_sum, "rank %d output hashes" % rank
