@@ -208,3 +208,54 @@ def test_gsbatch_on_gpu_vs_oracle(tmp_path):
         for f, img in zip(files, imgs):
             got = read_pgm(str(outdir / os.path.basename(f)))
             assert_same(got, oracle_chain(o, img, chain), "chain %d %s" % (c, os.path.basename(f)))
+
+
+def _random_chain(rs, w, h):
+    """a valid random verb chain for a w x h image (tracks the size through resize / crop)"""
+    chain = []
+    for _ in range(rs.randint(1, 6)):
+        v = rs.choice(["blur", "sobel", "threshold", "adaptive", "morph", "resize", "crop"])
+        if v == "blur":
+            chain.append(("blur", [str(rs.choice([1, 2, 3, 4, 7]))]))
+        elif v == "sobel":
+            if w >= 3 and h >= 3:
+                chain.append(("sobel", []))
+        elif v == "threshold":
+            chain.append(("threshold", [str(rs.randint(1, 300))]))      # otsu can legitimately fail (t == 0)
+        elif v == "adaptive":
+            chain.append(("adaptive", [str(rs.randint(1, 9)), str(rs.randint(0, 12))]))
+        elif v == "morph":
+            chain.append(("morph", [str(rs.choice(["erode", "dilate"])), str(rs.randint(1, 4))]))
+        elif v == "resize":
+            w, h = int(rs.randint(8, 80)), int(rs.randint(8, 60))
+            chain.append(("resize", [str(w), str(h)]))
+        elif v == "crop" and w > 8 and h > 8:
+            cw, ch = int(rs.randint(4, w)), int(rs.randint(4, h))
+            x, y = int(rs.randint(0, w - cw + 1)), int(rs.randint(0, h - ch + 1))
+            chain.append(("crop", [str(x), str(y), str(cw), str(ch)]))
+            w, h = cw, ch
+    return chain or [("blur", ["1"])]
+
+
+@pytest.mark.skipif(not os.path.exists(NANO), reason="reference checkout not present")
+def test_gsbatch_random_chains_equal_piped_nanomagick_emulated(tmp_path):
+    """16 random verb chains over three files of two sizes, against the reference CLI run verb by verb"""
+    exe, nano = build_emu(tmp_path), build_ref_nano(tmp_path)
+    rs = np.random.RandomState(2024)
+    files = []
+    for k, (w, h) in enumerate([(64, 48), (64, 48), (37, 29)]):
+        p = str(tmp_path / ("rnd%d.pgm" % k))
+        a = rs.randint(0, 256, (h, w)).astype(np.uint8)
+        a[0, 0] = max(int(a[0, 0]), 33)          # keep the reference's reader happy (see the reader test)
+        write_pgm(p, a)
+        files.append(p)
+    for c in range(16):
+        chain = _random_chain(rs, 37, 29)        # valid for the smaller size, hence for both
+        outdir = tmp_path / ("rc%d" % c)
+        outdir.mkdir()
+        r = subprocess.run([exe, "-o", str(outdir), *chain_args(chain), "--", *files], capture_output=True, timeout=900)
+        assert r.returncode == 0, (chain, r.stderr.decode()[-500:])
+        for i, f in enumerate(files):
+            exp, err = nano_chain(nano, chain, f, tmp_path, "rcref%d_%d" % (c, i))
+            assert exp is not None, (chain, err)
+            assert open(str(outdir / os.path.basename(f)), "rb").read() == open(exp, "rb").read(), (chain, f)
