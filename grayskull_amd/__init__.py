@@ -116,6 +116,7 @@ _SIGS = {
     "gsh_lbp_detect_batch": (None, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint,
                                     C.c_void_p, C.c_void_p, C.c_uint, C.c_float, C.c_float,
                                     C.c_float, C.c_int]),
+    "gsh_lbp_count_evaluated": (None, [C.c_void_p]),
     "gsh_lbp_window_count": (C.c_uint64, [C.c_void_p, C.c_uint, C.c_uint, C.c_float, C.c_float,
                                           C.c_float, C.c_int]),
     "gsh_fast_batch": (None, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_void_p,
@@ -381,6 +382,10 @@ class Grayskull:
         n, h, w = self._nhw(ii)
         self.c.gsh_lbp_detect_batch(dcascade.handle, _ptr(ii), w, h, n, _ptr(rects), _ptr(counts),
                                     max_rects, scale_factor, min_scale, max_scale, step)
+
+    def lbp_count_evaluated(self, counter):
+        """counter: one-element int64 device tensor (zeroed by the caller) or None to switch off"""
+        self.c.gsh_lbp_count_evaluated(_ptr(counter) if counter is not None else None)
 
     def lbp_window_count(self, cascade, iw, ih, scale_factor, min_scale, max_scale, step):
         return int(self.c.gsh_lbp_window_count(C.addressof(cascade.as_struct()), iw, ih,

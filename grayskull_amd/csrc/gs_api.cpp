@@ -204,6 +204,8 @@ inline bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 /* ---- launch tuning (gsh_tune): 0 rows per band (0 = auto), 1 block shape, 2 prefetch depth */
 int g_tune[8] = {0, 1, 1, 0, 0, 0, 0, 0};
+/* gsh_lbp_count_evaluated: device counter that receives the windows the cascade really evaluated */
+thread_local unsigned long long *g_lbp_evaluated = nullptr;
 
 struct StripCfg { dim3 grid, block; unsigned T; };
 /* rows: output rows per frame.  One wave per (1024-px column block, band, frame).  Measured on
@@ -580,11 +582,17 @@ void launch_lbp_padded(gsh_cascade *dc, const unsigned *padded, unsigned iw, uns
   unsigned long long *mask =
       (unsigned long long *)ctx().scratch(SL_MASK, (size_t)n * nch * kChunkWords * 8);
   const unsigned nsc0 = (unsigned)dc->scales.size();
-  unsigned *cnt = (unsigned *)ctx().scratch(SL_CNT, ((size_t)n * nch + (size_t)n * nsc0) * 4);
-  GS_HIP(hipMemsetAsync(cnt, 0, ((size_t)n * nch + (size_t)n * nsc0) * 4, st));
+  /* chunk counters, then the early-exit counters: one per group of 32 chunks, one per 1024 */
+  const unsigned ngroups = (nch >> kLbpGroupShift) + 1, nsupers = (nch >> kLbpSuperShift) + 1;
+  const size_t ncnt = (size_t)n * nch + (size_t)n * ngroups + (size_t)n * nsupers;
+  unsigned *cnt = (unsigned *)ctx().scratch(SL_CNT, ncnt * 4);
+  GS_HIP(hipMemsetAsync(cnt, 0, ncnt * 4, st));
   GS_HIP(hipMemsetAsync(mask, 0, (size_t)n * nch * kChunkWords * 8, st));
   LbpArgs a;
-  a.scale_hits = cnt + (size_t)n * nch;
+  a.hits_group = cnt + (size_t)n * nch;
+  a.hits_super = a.hits_group + (size_t)n * ngroups;
+  a.ngroups = ngroups, a.nsupers = nsupers;
+  a.evaluated = g_lbp_evaluated;
   a.nscales = nsc0, a.cap = max_rects;
   a.padded = padded;
   a.frame_stride = (size_t)(iw + 1) * (ih + 1);
@@ -1124,6 +1132,7 @@ void gsh_lbp_detect_batch(const gsh_cascade *dc, const unsigned *ii, unsigned iw
   launch_lbp_unpadded(const_cast<gsh_cascade *>(dc), ii, iw, ih, n, (unsigned *)rects, counts,
                       max_rects, scale_factor, min_scale, max_scale, step);
 }
+void gsh_lbp_count_evaluated(unsigned long long *counter_dev) { g_lbp_evaluated = counter_dev; }
 uint64_t gsh_lbp_window_count(const struct gs_lbp_cascade *c, unsigned iw, unsigned ih,
                               float scale_factor, float min_scale, float max_scale, int step) {
   gsh_cascade tmp;

@@ -45,9 +45,18 @@ struct LbpArgs {
   unsigned long long *mask;     /* n frames x total_chunks*kChunkWords (pre-zeroed) */
   unsigned *chunk_count;        /* n frames x total_chunks (pre-zeroed) */
   unsigned total_chunks;
-  unsigned *scale_hits;         /* n frames x nscales: detections counted so far in EARLIER scales */
+  /* Early exit at max_rects (ref :819-823).  Chunks are numbered in scan order (scale, then window
+   * rows); 32 consecutive chunks form a group, 32 groups a super-group.  A finished chunk adds its
+   * detections to its group's and its super-group's counter; a starting chunk sums the counters
+   * of everything that lies wholly BEFORE its own group -- a lower bound of the detections that
+   * precede it in the reference's scan order -- and skips when that reaches the cap. */
+  unsigned *hits_group;         /* n frames x ngroups   (pre-zeroed) */
+  unsigned *hits_super;         /* n frames x nsupers   (pre-zeroed) */
+  unsigned ngroups, nsupers;
   unsigned nscales, cap;        /* cap = max_rects */
+  unsigned long long *evaluated; /* optional: += windows of every chunk that was not skipped */
 };
+constexpr unsigned kLbpGroupShift = 5, kLbpSuperShift = 10; /* chunks per group / super-group (log2) */
 
 /* cascade tables of one scale, staged in LDS by the block: every lane of every wave evaluates
  * the same weak classifier of the same scale, so these reads are same-address broadcasts
@@ -191,11 +200,28 @@ __global__ __launch_bounds__(256) void k_lbp_cascade(LbpArgs a, LbpPhases ph) {
   if (blockIdx.x >= sc.nchunks) return; /* whole block */
   const unsigned tid = threadIdx.x;
   /* The reference stops scanning once max_rects detections exist (ref :819-823), and the output is
-   * the FIRST max_rects hits in (scale, y, x) order.  Hits already counted in earlier scales can
-   * only grow, so if they reach the cap no window of this scale can be among the first max_rects:
-   * skip the block (its mask words and counter stay zero).  A stale (smaller) read only skips
-   * less. */
-  if (atomicAdd(&a.scale_hits[(size_t)blockIdx.z * a.nscales + blockIdx.y], 0u) >= a.cap) return;
+   * the FIRST max_rects hits in (scale, y, x) order.  Detections published by chunks that precede
+   * this one in that order can only grow, so once they reach the cap no window of this chunk can
+   * be among the first max_rects: skip the block (its mask words and counter stay zero).  The
+   * counters are read with returning atomics (served where the adds are performed); a stale or
+   * partial sum only skips less, so the result is exact for any dispatch order -- and blocks are
+   * dispatched in (scale, chunk) order, so on frames that reach the cap nearly everything after
+   * that point is skipped. */
+  const unsigned lin = sc.chunk_base + blockIdx.x;
+  __shared__ unsigned before_s;
+  if (tid < 64u) { /* one wave sums; the decision must be the same for the whole block */
+    const unsigned g1 = lin >> kLbpGroupShift, g2 = lin >> kLbpSuperShift;
+    unsigned *hs = a.hits_super + (size_t)blockIdx.z * a.nsupers;
+    unsigned *hg = a.hits_group + (size_t)blockIdx.z * a.ngroups;
+    unsigned before = 0;
+    for (unsigned q = tid; q < g2; q += 64u) before += atomicAdd(&hs[q], 0u);
+    const unsigned gq = (g2 << (kLbpSuperShift - kLbpGroupShift)) + tid; /* the <= 31 earlier groups of the own super-group */
+    if (gq < g1) before += atomicAdd(&hg[gq], 0u);
+    before = wave_sum(before);
+    if (tid == 0) before_s = before;
+  }
+  __syncthreads();
+  if (before_s >= a.cap) return;
   const LbpLds t = lbp_stage_tables(smem, a, a.geom + (size_t)blockIdx.y * a.nweaks, tid, 256u);
   char *extra = smem + ((lbp_lds_bytes(a.nstages, a.nweaks, a.nsub) + 15) & ~(size_t)15);
   uint16_t *queue = (uint16_t *)extra;                       /* [2][kChunkItems] */
@@ -254,12 +280,12 @@ __global__ __launch_bounds__(256) void k_lbp_cascade(LbpArgs a, LbpPhases ph) {
       c = (unsigned)__popcll(wv);
     }
     c = wave_sum(c);
-    if (tid == 0 && c) {
+    if (tid == 0 && c) { /* hits are rare: few atomics */
       a.chunk_count[chunk] = c;
-      /* scale_hits[s] = hits counted so far in scales < s (hits are rare: few atomics) */
-      for (unsigned q = blockIdx.y + 1; q < a.nscales; q++)
-        atomicAdd(&a.scale_hits[(size_t)blockIdx.z * a.nscales + q], c);
+      atomicAdd(&a.hits_group[(size_t)blockIdx.z * a.ngroups + (lin >> kLbpGroupShift)], c);
+      atomicAdd(&a.hits_super[(size_t)blockIdx.z * a.nsupers + (lin >> kLbpSuperShift)], c);
     }
+    if (tid == 0 && a.evaluated) atomicAdd(a.evaluated, (unsigned long long)(nwin - first < kChunkItems ? nwin - first : kChunkItems));
   }
 }
 

@@ -257,3 +257,32 @@ def test_lbp_cap_reached_in_early_scales(emu, oracle, cascade):
     edges = oracle.sobel(oracle.blur(Oracle.synth(160, 120, 1000), 2))
     pc.lbp(emu, oracle, edges, MEM, cascade, params=((4096, 1.1, 1.0, 4.0, 1), (5, 1.1, 1.0, 4.0, 1), (60, 1.2, 1.0, 3.0, 2)))
     pc.lbp(emu, oracle, Oracle.synth(64, 48, 9), MEM, random_cascade(1), params=((3, 1.25, 1.0, 2.0, 1), (200, 1.1, 1.0, 2.0, 1)))
+
+
+def test_lbp_chunk_granular_early_exit(emu, oracle, cascade):
+    """max_rects early exit at chunk-group granularity (ref :819-831): a chunk is skipped once the
+    detections published by the groups that wholly precede it reach the cap.  The result must be the
+    reference's first max_rects hits for every cap; on frames with enough chunks (> 32 per scale)
+    small caps must really skip work (counter of evaluated windows)."""
+    edges = oracle.sobel(oracle.blur(Oracle.synth(352, 288, 1000), 2))
+    ii = oracle.integral(edges)
+    total = emu.lbp_window_count(cascade, 352, 288, 1.1, 1.0, 4.0, 1)
+    evaluated = {}
+    for cap in (1, 20, 60, 4096):
+        cnt = np.zeros(1, np.uint64)
+        emu.lbp_count_evaluated(cnt)
+        try:
+            r = emu.lbp_detect(cascade, ii.copy(), cap, 1.1, 1.0, 4.0, 1)
+        finally:
+            emu.lbp_count_evaluated(None)
+        assert_same(r, oracle.lbp_detect(cascade, ii, cap, 1.1, 1.0, 4.0, 1), "cap %d" % cap)
+        evaluated[cap] = int(cnt[0])
+    assert evaluated[4096] == total, "nothing to skip when the cap is never reached"
+    assert evaluated[1] < evaluated[20] < total and evaluated[20] <= evaluated[60] <= total, evaluated
+    # a permissive random cascade: thousands of hits per scale, caps inside the first scale / across scales
+    rc = random_cascade(2)
+    img = Oracle.synth(300, 260, 5)
+    ii = oracle.integral(img)
+    for cap in (1, 100, 3000, 40000):
+        assert_same(emu.lbp_detect(rc, ii.copy(), cap, 1.3, 1.0, 3.0, 1), oracle.lbp_detect(rc, ii, cap, 1.3, 1.0, 3.0, 1),
+                    "random cascade cap %d" % cap)

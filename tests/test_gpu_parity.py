@@ -628,3 +628,62 @@ def test_user_stream_and_async_mode(hip, oracle):
     finally:
         hip.set_async(False)
         hip.set_stream(None)
+
+
+def test_config4_chain_on_one_4k_frame(hip, oracle, cascade):
+    """BASELINE configs[4] for ONE frame of its batch: synth(3840x2160, seed 1000) -> gs_blur(2) ->
+    gs_sobel (zeroed dst) -> gs_integral -> gs_lbp_detect(frontalface, 4096, 1.1, 1, 4, 1), device
+    resident, bit-exact against the oracle (which, like the reference, stops at 4096 detections)."""
+    import torch
+    w, h = 3840, 2160
+    img = Oracle.synth(w, h, 1000)
+    src = torch.empty((1, h, w), dtype=torch.uint8, device="cuda")
+    hip.synth_batch(src, 1000)
+    assert_same(src[0].cpu().numpy(), img, "device-side generator")
+    a, b = torch.empty_like(src), torch.zeros_like(src)
+    ii = torch.zeros((1, h, w), dtype=torch.int32, device="cuda")
+    rects = torch.zeros((1, 4096, 4), dtype=torch.int32, device="cuda")
+    counts = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ev = torch.zeros(1, dtype=torch.int64, device="cuda")
+    dc = hip.cascade_create(cascade)
+    hip.blur_batch(a, src, 2)
+    hip.sobel_batch(b, a)
+    hip.integral_batch(b, ii)
+    hip.lbp_count_evaluated(ev)
+    try:
+        hip.lbp_detect_batch(dc, ii, rects, counts, 4096, 1.1, 1.0, 4.0, 1)
+        hip.sync()
+    finally:
+        hip.lbp_count_evaluated(None)
+    dc.close()
+    es = oracle.sobel(oracle.blur(img, 2))
+    assert_same(b[0].cpu().numpy(), es, "blur -> sobel")
+    eii = oracle.integral(es)
+    assert_same(ii[0].cpu().numpy().view(np.uint32), eii, "integral of the edge map")
+    ro = oracle.lbp_detect(cascade, eii, 4096, 1.1, 1.0, 4.0, 1)
+    n = int(counts[0])
+    assert n == len(ro) == 4096, (n, len(ro))  # the edge maps of this batch always reach the cap
+    got = rects[0, :n].cpu().numpy().view(np.uint32)
+    assert_same(got, np.stack([ro["x"], ro["y"], ro["w"], ro["h"]], 1), "first 4096 detections in scan order")
+    total = hip.lbp_window_count(cascade, w, h, 1.1, 1.0, 4.0, 1)
+    assert total == 120012941  # SURVEY 8(d)
+    # on this frame the 4096th detection lies a third of the way into the LAST scale (91x91 windows, y = 658):
+    # the chunks behind it are skipped, everything before it has to be evaluated
+    assert 0.90 * total < int(ev[0]) < total, "%d of %d windows evaluated" % (int(ev[0]), total)
+
+
+def test_lbp_caps_on_edge_maps(hip, oracle, cascade):
+    """max_rects = 1, 100, 4096 (and more than there are) on sobel edge maps, host and device tables"""
+    import torch
+    edges = oracle.sobel(oracle.blur(Oracle.synth(1920, 1080, 1001), 2))
+    ii = oracle.integral(edges)
+    dii = torch.from_numpy(ii.view(np.int32)).cuda()
+    for cap in (1, 100, 4096, 20000):
+        ro = oracle.lbp_detect(cascade, ii, cap, 1.1, 1.0, 4.0, 1)
+        assert_same(hip.lbp_detect(cascade, ii.copy(), cap, 1.1, 1.0, 4.0, 1), ro, "host table, cap %d" % cap)
+        assert_same(hip.lbp_detect(cascade, dii, cap, 1.1, 1.0, 4.0, 1), ro, "device table, cap %d" % cap)
+    rc = random_cascade(2)
+    ii = oracle.integral(Oracle.synth(1280, 720, 6))
+    for cap in (1, 100, 5000, 200000):
+        assert_same(hip.lbp_detect(rc, ii.copy(), cap, 1.3, 1.0, 3.0, 1), oracle.lbp_detect(rc, ii, cap, 1.3, 1.0, 3.0, 1),
+                    "random cascade, cap %d" % cap)
