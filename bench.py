@@ -7,21 +7,40 @@ synthetic block-noise frames (SURVEY.md 8c generator, run on the GPU, bit-identi
 one).  A step = one pass of that chain over the whole batch; value = input Mpix/s, whole job.
 Frames shard by frame across ranks (weak scaling: --frames per GPU); no data-path collective.
 
-roofline: the slowest kernel of the chain, timed live with events on the launch stream;
-algorithmic bytes = SURVEY.md 8(d) per-pixel traffic x pixels per launch.
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment launches the N ranks
+itself (torch.distributed.run, one process per GPU, RCCL); under the driver's own torchrun launch it
+is simply one of the ranks.
+
+roofline: the dominant kernel of the timed step (the fused blur+sobel+histogram kernel), timed live
+with HIP events on the stream it is launched on.  `frac` is PHYSICAL: the bytes the launch moves
+(1 read + 1 write per pixel; PMC traffic beside it) / time / 8 TB/s.  The kernel is VALU-bound, so
+the `valu` block prices its instruction mix against the issue rates measured by
+scripts/ubench_valu.cpp (profiles/r02a_ubench_valu.log).  SURVEY 8(d)'s per-call-equivalent figure
+(5 B/px for the three calls it replaces) is reported as `percall_equivalent`, never as `frac`.
 cpu_baseline: the unmodified reference (oracle/_ref, kind "reference") or the C restatement
 (kind "port") on the host cores, same chain, bounded frame sample, rank 0 at N=1 only.
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0   # same table: measured float4 copy ceiling
+BASELINE_METRIC = "Mpix/s (and % HBM roofline) for gs_sobel+gs_blur on 4K uint8, 1/2/4/8 GPU"
+
+# Fused kernel k_blur_sobel_hist16<2>: VALU wave-instructions per wave per source row (16 px per lane),
+# by issue class, counted in the source (DESIGN.md 3.1) and confirmed against the ISA by
+# scripts/isa_count.py; rates = chip-wide wave-instructions/s measured by scripts/ubench_valu.cpp at
+# 8 waves per SIMD (profiles/r02a_ubench_valu.log).  "full" = v_add_u32 / v_sub_u32 / v_and_b32 ...,
+# "half" = packed-16, v_perm_b32, v_alignbit_b32, multiplies, every VOP3 form.
+VALU_RATE_GINST = {"full": 1000.0, "half": 578.0}
+FUSED_OPS_PER_ROW_FILE = os.path.join(ROOT, "profiles", "fused_isa_mix.json")
 
 
 def time_stream(torch, fn, reps):
@@ -37,9 +56,17 @@ def time_stream(torch, fn, reps):
     return e0.elapsed_time(e1) / reps
 
 
+def hbm_block(nbytes, ms, **extra):
+    """physical HBM roofline block of one launch (or launch group): bytes really moved / time / peak"""
+    gbs = nbytes / ms / 1e6
+    d = {"ms": round(ms, 4), "bytes": float(nbytes), "GB/s": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
+         "frac_of_copy_ceiling": round(gbs / HBM_COPY_GBS, 4)}
+    d.update(extra)
+    return d
+
+
 def cpu_baseline(w, h, radius, frames_target=48):
     import threading
-    import numpy as np
     from oracle import pyoracle
     kind = "reference" if pyoracle.have_reference() else "port"
     cores = max(1, min(os.cpu_count() or 1, 32))
@@ -68,6 +95,30 @@ def cpu_baseline(w, h, radius, frames_target=48):
             "%d frames %dx%d, same chain, C restatement (oracle/gs_oracle.c)" % (frames, w, h)}
 
 
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks_if_needed(args):
+    """`python bench.py --gpus N` on its own: become `torch.distributed.run` with N ranks."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    if os.environ.get("GS_BENCH_BACKEND") != "gloo":  # the gloo rehearsal shares one GPU on purpose
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.exit("bench.py: --gpus %d requested but only %d GPU(s) visible -- refusing to run a smaller job "
+                     "under that label" % (args.gpus, have))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.execv(sys.executable, cmd)
+
+
 def run_cfg4(args, sh, g, torch, np, w, h, F, r, lo):
     """BASELINE configs[4]: every frame goes through gs_blur(r) -> gs_sobel (zeroed dst) -> gs_integral ->
     gs_lbp_detect(frontalface, sf 1.1, scales 1..4, step 1, max_rects 4096) on the GPU that owns it; frames
@@ -80,6 +131,7 @@ def run_cfg4(args, sh, g, torch, np, w, h, F, r, lo):
     ii = torch.zeros((G, h, w), dtype=torch.int32, device="cuda")
     rects = torch.zeros((G, 4096, 4), dtype=torch.int32, device="cuda")
     counts = torch.zeros(F, dtype=torch.int32, device="cuda")
+    evaluated = torch.zeros(2, dtype=torch.int64, device="cuda")
     dc = g.cascade_create(casc)
 
     def step():
@@ -102,7 +154,13 @@ def run_cfg4(args, sh, g, torch, np, w, h, F, r, lo):
     torch.cuda.synchronize()
     sh.barrier()
     dt = sh.max_over_ranks(time.perf_counter() - t0)
+    g.lbp_count_evaluated(evaluated)  # one more, untimed step with the counting build of the cascade kernel
+    step()
+    torch.cuda.synchronize()
+    g.lbp_count_evaluated(None)
     all_counts = sh.all_gather_frames(counts, F * sh.world)
+    ev_total = sh.sum_over_ranks(float(evaluated[0].item())) * args.steps
+    nwin = g.lbp_window_count(casc, w, h, 1.1, 1.0, 4.0, 1)
     if sh.rank == 0:
         print(json.dumps({
             "metric": "frames/s for gs_blur->gs_sobel->gs_integral->gs_lbp_detect on 4K uint8 (BASELINE configs[4])",
@@ -112,12 +170,31 @@ def run_cfg4(args, sh, g, torch, np, w, h, F, r, lo):
             "config": {"workload": "configs[4]: %d frames %dx%d per GPU, %d in total, sharded by frame" % (F, w, h, F * sh.world),
                        "frames_per_gpu": F, "global_frames": F * sh.world},
             "Mpix/s": round(sh.world * F * w * h * args.steps / dt / 1e6, 1),
+            "windows_per_frame_full_scan": nwin,
+            "windows_evaluated_per_frame": round(ev_total / (sh.world * F * args.steps), 1),
+            "Gwindows/s_evaluated": round(ev_total / dt / 1e9, 2),
+            "rccl_ranks_seen": sh.ranks_seen(),
             "detections_total": int(all_counts.sum()), "detections_first_frames": all_counts[:4].cpu().tolist()}))
     dc.close()
     sh.close()
 
 
-BASELINE_METRIC = "Mpix/s (and % HBM roofline) for gs_sobel+gs_blur on 4K uint8, 1/2/4/8 GPU"
+def fused_valu_block(lpx, w, fms):
+    """VALU pricing of one fused-kernel launch: wave-instructions by issue class / measured issue rate.
+    lpx pixels per launch -> wave-rows = lpx / 1024 * (columns of waves cover ceil(w/1024)*1024 px per row)."""
+    try:
+        mix = json.load(open(FUSED_OPS_PER_ROW_FILE))
+    except Exception:
+        return None
+    wave_rows = lpx / w * ((w + 1023) // 1024)
+    sec = {k: wave_rows * mix["per_wave_row"][k] / (VALU_RATE_GINST[k] * 1e9) for k in ("full", "half")}
+    t = sec["full"] + sec["half"]
+    return {"wave_instructions_per_wave_row": mix["per_wave_row"], "source": mix.get("source"),
+            "issue_rate_Gwaveinst_s": VALU_RATE_GINST, "valu_ms_at_measured_issue_rate": round(t * 1e3, 4),
+            "valu_frac": round(t * 1e3 / fms, 4),
+            "lds_atomics_per_wave_row": mix["per_wave_row"].get("ds_add"),
+            "note": "valu_frac = time the kernel's VALU instructions need at the chip's measured issue rates / measured "
+                    "launch time; rates from profiles/r02a_ubench_valu.log"}
 
 
 def main():
@@ -134,7 +211,9 @@ def main():
                          "gs_blur(2) -> gs_sobel -> gs_integral -> gs_lbp_detect, frames sharded over the GPUs")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-other", action="store_true", help="skip the other_configs / per-kernel extras (profiling runs)")
     args = ap.parse_args()
+    spawn_ranks_if_needed(args)
 
     import numpy as np
     import torch
@@ -144,8 +223,11 @@ def main():
     # GS_BENCH_BACKEND=gloo GS_BENCH_DEVICE=0: rehearse the N>1 code path on a 1-GPU box (ranks
     # share the GPU, so the number means nothing); the driver's runs use neither.
     sh = Sharder(backend=os.environ.get("GS_BENCH_BACKEND") or None)
-    assert sh.world == args.gpus or sh.world == 1, "WORLD_SIZE must match --gpus"
+    if sh.world != args.gpus:
+        sys.exit("bench.py: WORLD_SIZE=%d does not match --gpus %d" % (sh.world, args.gpus))
     device = int(os.environ.get("GS_BENCH_DEVICE", sh.local_rank))
+    if device >= torch.cuda.device_count():
+        sys.exit("bench.py: rank %d wants cuda:%d but only %d GPU(s) are visible" % (sh.rank, device, torch.cuda.device_count()))
     torch.cuda.set_device(device)
     g = gs.lib()
     g.set_device(device)
@@ -188,24 +270,29 @@ def main():
     g.profile(False)
     npx = F * w * h
     value = sh.world * npx * args.steps / dt / 1e6
+    ms_step = dt / args.steps * 1e3
 
     # ---- per-kernel timing on the launch stream (after the timed region) -------------------
     reps = max(5, min(args.steps, 20))
     ms_unfused = time_stream(torch, step_unfused, reps)
     ms_fused = time_stream(torch, step, reps)
+    bs = "gs_blur(r=%d)+gs_sobel, one pass (gsh_blur_sobel_batch)" % r
+    # (call, bytes the launch really moves, SURVEY 8d per-call bytes)
     kernels = {
-        "gs_blur(r=%d)+gs_sobel, one pass (gsh_blur_sobel_batch)" % r: (lambda: g.blur_sobel_batch(dst, src, r), 4.0 * npx),
-        "gs_blur(r=%d) k_blur16" % r: (lambda: g.blur_batch(tmp, src, r), 2.0 * npx),
-        "gs_sobel k_sobel16": (lambda: g.sobel_batch(dst, tmp), float(F * (w * h + (w - 2) * (h - 2)))),
-        "gs_histogram+otsu": (lambda: g.otsu_batch(dst, hist, thr), 1.0 * npx),
-        "gs_threshold k_threshold": (lambda: g.threshold_batch(dst, thr), 2.0 * npx),
-        "gs_erode k_morph16": (lambda: g.erode_batch(dst, src), 2.0 * npx),
+        bs: (lambda: g.blur_sobel_batch(dst, src, r), 2.0 * npx, 4.0 * npx),
+        "gs_blur(r=%d) k_blur16" % r: (lambda: g.blur_batch(tmp, src, r), 2.0 * npx, 2.0 * npx),
+        "gs_sobel k_sobel16": (lambda: g.sobel_batch(dst, tmp), float(F * (w * h + (w - 2) * (h - 2))),
+                               float(F * (w * h + (w - 2) * (h - 2)))),
+        "gs_histogram+otsu": (lambda: g.otsu_batch(dst, hist, thr), 1.0 * npx, 1.0 * npx),
+        "gs_threshold k_threshold": (lambda: g.threshold_batch(dst, thr), 2.0 * npx, 2.0 * npx),
+        "gs_erode k_morph16": (lambda: g.erode_batch(dst, src), 2.0 * npx, 2.0 * npx),
     }
     ktab = {}
-    for name, (fn, nbytes) in kernels.items():
+    for name, (fn, moved, percall) in kernels.items():
         ms = time_stream(torch, fn, reps)
-        ktab[name] = {"ms": round(ms, 4), "GB/s": round(nbytes / ms / 1e6, 1),
-                      "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4), "bytes": nbytes}
+        ktab[name] = hbm_block(moved, ms)
+        if percall != moved:
+            ktab[name]["percall_equivalent_GB/s"] = round(percall / ms / 1e6, 1)
     # The fused kernel itself: average over ALL its launches inside the timed region above (HIP events
     # recorded by the library on the launch stream, gsh_profile).  A step launches it once per
     # 32-frame chunk; chunk i's threshold pass runs on a side stream under chunk i+1's fused
@@ -214,14 +301,8 @@ def main():
     fms = tot_ms / max(nl, 1)
     fpl = F / launches_per_step           # frames per launch (nl may be capped at 4096 bracketed launches)
     lpx = fpl * w * h                     # pixels per launch
-    ktab[fk] = {"ms": round(fms, 4), "GB/s": round(2.0 * lpx / fms / 1e6, 1),
-                "frac": round(2.0 * lpx / fms / 1e6 / HBM_PEAK_GBS, 4), "bytes": 2.0 * lpx,
-                "frames_per_launch": fpl, "launches_timed": nl,
-                "note": "per launch, HIP events on the launch stream over the timed region; replaces blur+sobel+histogram (5 B/px unfused)"}
-    # dominant kernel of the timed step = the fused kernel.  SURVEY.md 8(d): a fused kernel is
-    # reported against the UNFUSED per-call sum of the calls it performs (gs_blur 2 + gs_sobel 2 +
-    # gs_histogram 1 = 5 B/px), with the bytes it really moves (1 R + 1 W) stated beside it.
-    percall = 5.0 * lpx
+    ktab[fk] = hbm_block(2.0 * lpx, fms, frames_per_launch=fpl, launches_timed=nl,
+                         note="per launch, HIP events on the launch stream over the timed region; 1 R + 1 W per pixel")
     pmc = None
     try:
         pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
@@ -231,97 +312,28 @@ def main():
             pmc = pt["per_launch"][names[0]].get("total_bytes")
     except Exception:
         pass
+    moved = 2.0 * lpx
     roof = {"bound": "hbm", "kernel": "k_blur_sobel_hist16<2> (gs_blur r=2 + gs_sobel + gs_histogram in one launch)",
-            "achieved": round(percall / fms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(percall / fms / 1e6 / HBM_PEAK_GBS, 4), "traffic": pmc,
-            "accounting": "unfused per-call sum, 5 B/px (SURVEY 8d); the launch itself reads 1 and writes 1 B/px",
-            "algorithmic_bytes_per_launch": percall, "avg_launch_ms": round(fms, 4), "frames_per_launch": fpl,
-            "actual_io": {"bytes_per_px": 2, "GB/s": ktab[fk]["GB/s"], "frac": ktab[fk]["frac"],
-                          "note": "VALU-bound (257 lane-ops per 16 px + 16 LDS atomics; VALU busy 86 %, profiles/r01e_fused_sq_counters.txt)"},
+            "achieved": round(moved / fms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(moved / fms / 1e6 / HBM_PEAK_GBS, 4), "traffic": pmc,
+            "accounting": "physical: bytes the launch moves (1 read + 1 write per pixel) / HIP-event launch time / 8 TB/s",
+            "algorithmic_bytes_per_launch": moved, "avg_launch_ms": round(fms, 4), "frames_per_launch": fpl,
+            "frac_from_pmc_traffic": round(pmc / fms / 1e6 / HBM_PEAK_GBS, 4) if pmc else None,
+            "limited_by": "valu", "valu": fused_valu_block(lpx, w, fms),
+            "percall_equivalent": {"bytes_per_px": 5, "GB/s": round(5.0 * lpx / fms / 1e6, 1),
+                                   "note": "SURVEY 8(d): the three calls this launch replaces (gs_blur 2 + gs_sobel 2 + "
+                                           "gs_histogram 1 B/px) would move 5 B/px; a fusion-equivalent throughput, "
+                                           "not a roofline fraction (it can exceed the peak)"},
+            "chain_physical": {"bytes_per_px": 4, "GB/s": round(4.0 * npx / ms_step / 1e6, 1),
+                               "frac": round(4.0 * npx / ms_step / 1e6 / HBM_PEAK_GBS, 4),
+                               "frac_of_copy_ceiling": round(4.0 * npx / ms_step / 1e6 / HBM_COPY_GBS, 4),
+                               "note": "whole timed step: fused pass 1 R + 1 W, threshold pass 1 R + 1 W per pixel"},
             "per_call_kernels": {k: ktab[k]["frac"] for k in ktab if k != fk},
             "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc, corrected per MI355X_MICROARCH.md)" if pmc else None}
 
-    # north-star shape: gs_sobel alone on 4096x4096, rotating over 64 distinct frames (1 GiB/plane)
-    ns = None
-    if sh.world == 1:
-        n4 = 64
-        a4 = torch.empty((n4, 4096, 4096), dtype=torch.uint8, device="cuda")
-        b4 = torch.zeros_like(a4)
-        g.synth_batch(a4, 2)
-        ms = time_stream(torch, lambda: g.sobel_batch(b4, a4), reps)
-        by = float(n4 * (4096 * 4096 + 4094 * 4094))
-        ns = {"Mpix/s": round(n4 * 4096 * 4096 / ms / 1e3, 1), "GB/s": round(by / ms / 1e6, 1),
-              "frac_hbm_peak": round(by / ms / 1e6 / HBM_PEAK_GBS, 4), "frames": n4}
-        del a4, b4
-
-    # ---- the other single-GPU configs of BASELINE.json, for the record (not the headline metric) --
-    other = None
-    if sh.world == 1:
-        from grayskull_amd.cascade import Cascade
-        from oracle.pyoracle import Oracle as _O
-        other = {}
-        casc = Cascade.from_blob(os.path.join(ROOT, "tests", "golden", "frontalface_cascade.bin"))
-        n3, h3, w3 = 8, 1080, 1920
-        s3 = torch.empty((n3, h3, w3), dtype=torch.uint8, device="cuda")
-        g.synth_batch(s3, 3)
-        ii3 = torch.zeros((n3, h3, w3), dtype=torch.int32, device="cuda")
-        rc = torch.zeros((n3, 4096, 4), dtype=torch.int32, device="cuda")
-        cn = torch.zeros(n3, dtype=torch.int32, device="cuda")
-        dc = g.cascade_create(casc)
-        ms_ii = time_stream(torch, lambda: g.integral_batch(s3, ii3), 5)
-        ms_lbp = time_stream(torch, lambda: g.lbp_detect_batch(dc, ii3, rc, cn, 4096, 1.1, 1.0, 4.0, 1), 3)
-        nwin = g.lbp_window_count(casc, w3, h3, 1.1, 1.0, 4.0, 1)
-        other["configs[2] gs_integral + gs_lbp_detect(frontalface) 1920x1080 sf=1.1 scales 1..4 step 1"] = {
-            "frames": n3, "integral_ms_per_frame": round(ms_ii / n3, 4), "lbp_ms_per_frame": round(ms_lbp / n3, 3),
-            "windows_per_frame": nwin, "Gwindows/s": round(nwin * n3 / ms_lbp / 1e6, 2),
-            "detections_frame0": int(cn[0]), "expected_frame0 (reference KAT)": 158,
-            "bound": "instruction issue on the gather + compare chain (TA busy 94 %, VALU 60 %), not HBM",
-            "reference_1core": "5.98 s/frame, 4.83 Mwin/s (BASELINE.md)"}
-        dc.close()
-        A = _O.synth(1280, 720, 4)
-        B = np.zeros_like(A)
-        B[:717, :1275] = A[3:, 5:]
-        dA, dB = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
-        sm = torch.zeros_like(dA)
-        ka = g.orb_extract_dev(dA, sm, 500, 20)
-        t1 = time.perf_counter()
-        for _ in range(10):
-            ka = g.orb_extract_dev(dA, sm, 500, 20)
-        t_orb = (time.perf_counter() - t1) / 10
-        kb = g.orb_extract_dev(dB, sm, 500, 20)
-        t1 = time.perf_counter()
-        for _ in range(10):
-            mm = g.match_orb(ka, kb, 2500, 60.0)
-        t_match = (time.perf_counter() - t1) / 10
-        other["configs[3] gs_orb_extract x2 + gs_match_orb 1280x720 threshold=20 nkps=500"] = {
-            "orb_extract_ms": round(t_orb * 1e3, 3), "keypoints": int(len(ka)), "match_ms": round(t_match * 1e3, 3),
-            "matches": int(len(mm)), "expected_matches (reference KAT)": 337,
-            "note": "wall time incl. the host round trips (host libm atan2f/sinf, stable sort)",
-            "reference_1core": "70 ms extract, 48.6 ms match (BASELINE.md)"}
-        del s3, ii3, rc, cn
-        # configs[4], one GPU's share: per frame gs_blur(2) -> gs_sobel -> gs_integral -> gs_lbp_detect on 4K
-        n5 = 8
-        a5, b5 = tmp[:n5], dst[:n5]
-        ii5 = torch.zeros((n5, h, w), dtype=torch.int32, device="cuda")
-        rc5 = torch.zeros((n5, 4096, 4), dtype=torch.int32, device="cuda")
-        cn5 = torch.zeros(n5, dtype=torch.int32, device="cuda")
-        dc5 = g.cascade_create(casc)
-
-        def chain5():
-            g.blur_batch(a5, src[:n5], 2)
-            b5.zero_()
-            g.sobel_batch(b5, a5)
-            g.integral_batch(b5, ii5)
-            g.lbp_detect_batch(dc5, ii5, rc5, cn5, 4096, 1.1, 1.0, 4.0, 1)
-        ms5 = time_stream(torch, chain5, 2)
-        nwin5 = g.lbp_window_count(casc, w, h, 1.1, 1.0, 4.0, 1)
-        other["configs[4] per-GPU share: gs_blur(2) -> gs_sobel -> gs_integral -> gs_lbp_detect per 3840x2160 frame"] = {
-            "frames": n5, "ms_per_frame": round(ms5 / n5, 3), "frames_per_s_per_gpu": round(n5 / ms5 * 1e3, 1),
-            "Gwindows/s": round(nwin5 * n5 / ms5 / 1e6, 2), "detections": cn5.cpu().tolist()[:4],
-            "note": "frames shard across GPUs with no exchange: 4096 frames on 8 GPUs = 512 per GPU; "
-                    "the cascade dominates (120 M windows per frame)"}
-        dc5.close()
-        del ii5, rc5, cn5
+    ns = other = None
+    if sh.world == 1 and not args.no_other:
+        ns, other = extras(g, torch, np, src, tmp, dst, w, h, reps)
 
     # ---- verification against the oracle (outside the timed region) -------------------------
     parity = "skipped"
@@ -331,7 +343,7 @@ def main():
         step()
         torch.cuda.synchronize()
         ok = True
-        vf = sorted({0, min(31, F - 1), min(32, F - 1), F - 1})  # both sides of a chunk boundary
+        vf = sorted({0, min(31, F - 1), min(32, F - 1), F // 2, F - 1})  # both sides of a chunk boundary
         for f in vf:
             img = Oracle.synth(w, h, 1000 + lo + f)
             s = o.sobel(o.blur(img, r))
@@ -339,28 +351,30 @@ def main():
             ok &= int(thr[f]) == t and np.array_equal(dst[f].cpu().numpy(), o.threshold(s, t))
         parity = "bit-exact vs oracle on frames %s" % vf if ok else "MISMATCH"
     thr_all = sh.all_gather_frames(thr, F * sh.world)  # KB-scale result exchange (RCCL when N>1)
+    ranks_seen = sh.ranks_seen()
 
     out = {
         "metric": BASELINE_METRIC,  # BASELINE.json's metric string; the workload is named in config.workload
         "value": round(value, 1), "unit": "Mpix/s", "n_gpus": sh.world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
         "data": "synthetic",
         "config": {"workload": "configs[1]: gs_blur(r=%d) -> gs_sobel -> gs_otsu_threshold -> gs_threshold, "
                                "%dx%d uint8, %d frames per GPU resident in HBM" % (r, w, h, F),
                    "frames_per_gpu": F, "global_frames": F * sh.world, "sharding": "by frame, no data-path collective",
                    "chain_algorithmic_bytes_per_px_unfused": 7, "hbm_peak_GBs": HBM_PEAK_GBS},
+        "rccl_ranks_seen": ranks_seen, "backend": sh.backend,
         "fused": {"ms_per_step": round(ms_fused, 4), "Mpix/s": round(npx / ms_fused / 1e3, 1),
                   "hbm_bytes_per_px": 4, "hbm_GB/s": round(4.0 * npx / ms_fused / 1e6, 1),
                   "hbm_frac_of_peak": round(4.0 * npx / ms_fused / 1e6 / HBM_PEAK_GBS, 4), "note": "blur+sobel+histogram in one kernel per 32-frame chunk; each chunk's threshold pass runs under the next chunk's fused kernel"},
         "unfused": {"ms_per_step": round(ms_unfused, 4), "Mpix/s": round(npx / ms_unfused / 1e3, 1),
-                    "hbm_bytes_per_px": 7, "note": "separate gs_blur, gs_sobel, histogram, threshold kernels"},
+                    "hbm_bytes_per_px": 7, "hbm_GB/s": round(7.0 * npx / ms_unfused / 1e6, 1),
+                    "hbm_frac_of_peak": round(7.0 * npx / ms_unfused / 1e6 / HBM_PEAK_GBS, 4),
+                    "note": "separate gs_blur, gs_sobel, histogram, threshold kernels"},
         "blur_sobel_only": {  # BASELINE.json's metric names gs_sobel+gs_blur: that chain alone, one pass
-            "ms_per_step": ktab["gs_blur(r=%d)+gs_sobel, one pass (gsh_blur_sobel_batch)" % r]["ms"],
-            "Mpix/s": round(npx / ktab["gs_blur(r=%d)+gs_sobel, one pass (gsh_blur_sobel_batch)" % r]["ms"] / 1e3, 1),
-            "percall_accounting_GB/s (4 B/px)": ktab["gs_blur(r=%d)+gs_sobel, one pass (gsh_blur_sobel_batch)" % r]["GB/s"],
-            "frac_of_hbm_peak_percall_accounting": ktab["gs_blur(r=%d)+gs_sobel, one pass (gsh_blur_sobel_batch)" % r]["frac"],
-            "bytes_actually_moved_per_px": 2, "bound": "VALU"},
+            "ms_per_step": ktab[bs]["ms"], "Mpix/s": round(npx / ktab[bs]["ms"] / 1e3, 1),
+            "hbm_GB/s (2 B/px moved)": ktab[bs]["GB/s"], "frac": ktab[bs]["frac"],
+            "percall_equivalent_GB/s (4 B/px)": ktab[bs].get("percall_equivalent_GB/s"), "limited_by": "valu"},
         "roofline": roof, "kernels": ktab, "sobel_4096x4096": ns, "other_configs": other, "parity": parity,
         "otsu_thresholds_gathered": int(thr_all.numel()),
     }
@@ -369,6 +383,124 @@ def main():
     if sh.rank == 0:
         print(json.dumps(out))
     sh.close()
+
+
+def extras(g, torch, np, src, tmp, dst, w, h, reps):
+    """north-star shape and the other single-GPU configs of BASELINE.json, each with its own physical
+    roofline block (not the headline metric)"""
+    from grayskull_amd.cascade import Cascade
+    from oracle.pyoracle import Oracle as _O
+    # north-star shape: gs_sobel alone on 4096x4096, rotating over 64 distinct frames (1 GiB/plane)
+    n4 = 64
+    a4 = torch.empty((n4, 4096, 4096), dtype=torch.uint8, device="cuda")
+    b4 = torch.zeros_like(a4)
+    g.synth_batch(a4, 2)
+    ms = time_stream(torch, lambda: g.sobel_batch(b4, a4), reps)
+    by = float(n4 * (4096 * 4096 + 4094 * 4094))
+    ns = {"Mpix/s": round(n4 * 4096 * 4096 / ms / 1e3, 1), "GB/s": round(by / ms / 1e6, 1),
+          "frac_hbm_peak": round(by / ms / 1e6 / HBM_PEAK_GBS, 4), "frames": n4}
+    del a4, b4
+
+    other = {}
+    casc = Cascade.from_blob(os.path.join(ROOT, "tests", "golden", "frontalface_cascade.bin"))
+    n3, h3, w3 = 8, 1080, 1920
+    s3 = torch.empty((n3, h3, w3), dtype=torch.uint8, device="cuda")
+    g.synth_batch(s3, 3)
+    ii3 = torch.zeros((n3, h3, w3), dtype=torch.int32, device="cuda")
+    rc = torch.zeros((n3, 4096, 4), dtype=torch.int32, device="cuda")
+    cn = torch.zeros(n3, dtype=torch.int32, device="cuda")
+    ev = torch.zeros(2, dtype=torch.int64, device="cuda")
+    dc = g.cascade_create(casc)
+    ms_ii = time_stream(torch, lambda: g.integral_batch(s3, ii3), 5)
+    ms_lbp = time_stream(torch, lambda: g.lbp_detect_batch(dc, ii3, rc, cn, 4096, 1.1, 1.0, 4.0, 1), 3)
+    g.lbp_count_evaluated(ev)
+    g.lbp_detect_batch(dc, ii3, rc, cn, 4096, 1.1, 1.0, 4.0, 1)
+    torch.cuda.synchronize()
+    g.lbp_count_evaluated(None)
+    nwin = g.lbp_window_count(casc, w3, h3, 1.1, 1.0, 4.0, 1)
+    nev, nweak = int(ev[0]), int(ev[1])
+    other["configs[2] gs_integral + gs_lbp_detect(frontalface) 1920x1080 sf=1.1 scales 1..4 step 1"] = {
+        "frames": n3, "integral_ms_per_frame": round(ms_ii / n3, 4), "lbp_ms_per_frame": round(ms_lbp / n3, 3),
+        "windows_per_frame": nwin, "windows_evaluated_per_frame": nev // n3,
+        "Gwindows/s": round(nev / ms_lbp / 1e6, 2),
+        "detections_frame0": int(cn[0]), "expected_frame0 (reference KAT)": 158,
+        "integral_roofline": hbm_block(5.0 * n3 * h3 * w3, ms_ii, bytes_per_px=5,
+                                       note="algorithmic 1 R + 4 W per px; the three-launch form moves ~6.1 (PMC)"),
+        "lbp_roofline": lbp_gather_block(nweak, ms_lbp),
+        "reference_1core": "5.98 s/frame, 4.83 Mwin/s (BASELINE.md)"}
+    dc.close()
+    A = _O.synth(1280, 720, 4)
+    B = np.zeros_like(A)
+    B[:717, :1275] = A[3:, 5:]
+    dA, dB = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
+    sm = torch.zeros_like(dA)
+    ka = g.orb_extract_dev(dA, sm, 500, 20)
+    t1 = time.perf_counter()
+    for _ in range(10):
+        ka = g.orb_extract_dev(dA, sm, 500, 20)
+    t_orb = (time.perf_counter() - t1) / 10
+    kb = g.orb_extract_dev(dB, sm, 500, 20)
+    t1 = time.perf_counter()
+    for _ in range(10):
+        mm = g.match_orb(ka, kb, 2500, 60.0)
+    t_match = (time.perf_counter() - t1) / 10
+    # gs_fast alone, batched (score pass 1 R + 1 W, NMS 1 R: 3 B/px)
+    nf = 32
+    f7 = torch.empty((nf, 720, 1280), dtype=torch.uint8, device="cuda")
+    g.synth_batch(f7, 4)
+    sm7 = torch.zeros_like(f7)
+    kp7 = torch.zeros((nf, 2000, 12), dtype=torch.int32, device="cuda")
+    cn7 = torch.zeros(nf, dtype=torch.int32, device="cuda")
+    ms_fast = time_stream(torch, lambda: g.fast_batch(f7, sm7, kp7, cn7, 2000, 20), 5)
+    other["configs[3] gs_orb_extract x2 + gs_match_orb 1280x720 threshold=20 nkps=500"] = {
+        "orb_extract_ms": round(t_orb * 1e3, 3), "keypoints": int(len(ka)), "match_ms": round(t_match * 1e3, 3),
+        "matches": int(len(mm)), "expected_matches (reference KAT)": 337,
+        "note": "wall time incl. the host round trips (host libm atan2f/sinf, stable sort)",
+        "gs_fast_roofline": hbm_block(3.0 * nf * 720 * 1280, ms_fast, bytes_per_px=3, frames=nf, limited_by="valu",
+                                      note="score pass 1 R + 1 W, NMS 1 R; the score pass is ~140 lane-ops per candidate pixel"),
+        "reference_1core": "70 ms extract, 48.6 ms match (BASELINE.md)"}
+    del s3, ii3, rc, cn, f7, sm7, kp7
+    # configs[4], one GPU's share: per frame gs_blur(2) -> gs_sobel -> gs_integral -> gs_lbp_detect on 4K
+    n5 = 8
+    a5, b5 = tmp[:n5], dst[:n5]
+    ii5 = torch.zeros((n5, h, w), dtype=torch.int32, device="cuda")
+    rc5 = torch.zeros((n5, 4096, 4), dtype=torch.int32, device="cuda")
+    cn5 = torch.zeros(n5, dtype=torch.int32, device="cuda")
+    dc5 = g.cascade_create(casc)
+
+    def chain5():
+        g.blur_batch(a5, src[:n5], 2)
+        b5.zero_()
+        g.sobel_batch(b5, a5)
+        g.integral_batch(b5, ii5)
+        g.lbp_detect_batch(dc5, ii5, rc5, cn5, 4096, 1.1, 1.0, 4.0, 1)
+    ms5 = time_stream(torch, chain5, 2)
+    ev.zero_()
+    g.lbp_count_evaluated(ev)
+    ms5_lbp = time_stream(torch, lambda: g.lbp_detect_batch(dc5, ii5, rc5, cn5, 4096, 1.1, 1.0, 4.0, 1), 1)
+    g.lbp_count_evaluated(None)
+    nev5, nweak5 = int(ev[0]) // 2, int(ev[1]) // 2  # time_stream runs fn twice (warm-up + 1 rep)
+    nwin5 = g.lbp_window_count(casc, w, h, 1.1, 1.0, 4.0, 1)
+    other["configs[4] per-GPU share: gs_blur(2) -> gs_sobel -> gs_integral -> gs_lbp_detect per 3840x2160 frame"] = {
+        "frames": n5, "ms_per_frame": round(ms5 / n5, 3), "frames_per_s_per_gpu": round(n5 / ms5 * 1e3, 1),
+        "windows_per_frame_full_scan": nwin5, "windows_evaluated_per_frame": nev5 // n5,
+        "Gwindows/s_evaluated": round(nev5 / ms5_lbp / 1e6, 2), "detections": cn5.cpu().tolist()[:4],
+        "lbp_roofline": lbp_gather_block(nweak5, ms5_lbp),
+        "note": "frames shard across GPUs with no exchange: 4096 frames on 8 GPUs = 512 per GPU; the cascade dominates "
+                "(120 M windows per frame; chunks behind the 4096th detection are skipped like the reference stops there)"}
+    dc5.close()
+    return ns, other
+
+
+def lbp_gather_block(weak_evals, ms):
+    """gather-bytes model of the cascade: every weak classifier a window evaluates reads
+    16 integral-image corners = 64 B through the texture path; ceiling = the 37 B/clk/CU measured in
+    profiles/r01h_gather_cost_microbench.txt x 256 CUs x 2.4 GHz."""
+    peak = 37.0 * 256 * 2.4  # GB/s
+    gbs = weak_evals * 64.0 / ms / 1e6
+    return {"bound": "L1/TA gather bytes", "weak_classifier_evaluations": weak_evals, "bytes": weak_evals * 64.0,
+            "ms": round(ms, 4), "GB/s": round(gbs, 1), "peak_GB/s": round(peak, 1), "frac": round(gbs / peak, 4),
+            "note": "16 dword corners per evaluated weak classifier (lane-level count, gsh_lbp_count_evaluated[1])"}
 
 
 if __name__ == "__main__":

@@ -632,7 +632,10 @@ void launch_lbp_padded(gsh_cascade *dc, const unsigned *padded, unsigned iw, uns
     ph.end[ph.n - 1] = dc->nstages;
   }
   const size_t lds_all = ((lds + 15) & ~(size_t)15) + 2 * kChunkItems * 2 + 64 * 4 + 16;
-  if (dc->guard) GS_LAUNCH(k_lbp_cascade<true>, g, dim3(256), lds_all, st, a, ph);
+  if (a.evaluated) { /* counting build: the same kernel + one register that counts classifier evaluations */
+    if (dc->guard) GS_LAUNCH((k_lbp_cascade<true, true>), g, dim3(256), lds_all, st, a, ph);
+    else GS_LAUNCH((k_lbp_cascade<false, true>), g, dim3(256), lds_all, st, a, ph);
+  } else if (dc->guard) GS_LAUNCH(k_lbp_cascade<true>, g, dim3(256), lds_all, st, a, ph);
   else GS_LAUNCH(k_lbp_cascade<false>, g, dim3(256), lds_all, st, a, ph);
   run_compaction(mask, cnt, nch, n, max_rects, counts,
                  LbpEmit{dc->d_scales, (unsigned)dc->scales.size(), step, rects, max_rects});

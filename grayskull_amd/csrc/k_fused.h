@@ -37,16 +37,16 @@ GS_DEV void blur_hsum10(const uint32_t (&U)[12], uint32_t (&H)[10]) { /* pairs =
   for (int j = 0; j <= 10; j++) A[j + 1] = alignbit(U[j + 1], U[j], 16);
   if constexpr (R == 1) {
 #pragma unroll
-    for (int k = 0; k < 10; k++) H[k] = pk_add_u16(pk_add_u16(A[k + 1], U[k + 1]), A[k + 2]);
+    for (int k = 0; k < 10; k++) H[k] = add2(A[k + 1], U[k + 1], A[k + 2]);
   } else {
     uint32_t Q[11]; /* Q[j] = U[j] + A[j+1]: the 2-px sums starting at both pixels of pair j */
 #pragma unroll
-    for (int j = 0; j <= 10; j++) Q[j] = pk_add_u16(U[j], A[j + 1]);
+    for (int j = 0; j <= 10; j++) Q[j] = add2(U[j], A[j + 1]);
 #pragma unroll
     for (int k = 0; k < 10; k++) {
       const int j = k + 1; /* U[j] = pair k */
-      uint32_t t = pk_add_u16(pk_add_u16(Q[j - 1], Q[j]), U[j + 1]);        /* -2 .. +2 */
-      if constexpr (R >= 3) t = pk_add_u16(pk_add_u16(t, A[j - 1]), A[j + 2]); /* -3, +3 */
+      uint32_t t = add2(Q[j - 1], Q[j], U[j + 1]);              /* -2 .. +2: one v_add3_u32 */
+      if constexpr (R >= 3) t = add2(t, A[j - 1], A[j + 2]);     /* -3, +3 */
       H[k] = t;
     }
   }
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void k_blur_sobel_hist16(uint8_t *dst, const u
       strip_unpack(S.load(y0 - 1 - R + kk), U);
       blur_hsum10<R>(U, ring[kk + P0]);
 #pragma unroll
-      for (int k = 0; k < 10; k++) V[k] = pk_add_u16(V[k], ring[kk + P0][k]);
+      for (int k = 0; k < 10; k++) V[k] = add2(V[k], ring[kk + P0][k]);
     });
     blurred(y0 - 1, UB0);
     {
@@ -121,11 +121,31 @@ __global__ __launch_bounds__(256) void k_blur_sobel_hist16(uint8_t *dst, const u
       strip_unpack(S.load(y0 + R), U);
       blur_hsum10<R>(U, Hn); /* enters slot 0 (SPARE: the free slot); the oldest row (slot P0) leaves */
 #pragma unroll
-      for (int k = 0; k < 10; k++) V[k] = pk_sub_u16(pk_add_u16(V[k], Hn[k]), ring[P0][k]), ring[0][k] = Hn[k];
+      for (int k = 0; k < 10; k++) V[k] = sub2(add2(V[k], Hn[k]), ring[P0][k]), ring[0][k] = Hn[k];
     }
     blurred(y0, UB1);
     st.init(UB0, UB1);
     const uint32_t cb = copy << 2; /* byte offset of this lane's histogram copy inside a bin */
+    /* per-lane increments, fixed for the kernel: lanes outside the image and the two frame columns count 0 */
+    const unsigned inc_in = inimg ? 1u : 0u, inc_first = (inimg && !first) ? 1u : 0u, inc_last = (inimg && !last) ? 1u : 0u;
+
+    /* The histogram of row i is added during row i+1 (software pipelining): an LDS atomic costs the
+     * CU's LDS pipe ~8-13 cycles per wave-instruction (scripts/ubench_valu.cpp), 16 of them per row and
+     * wave -- about as much LDS time per CU as the row's VALU time per SIMD.  Issued in a burst after
+     * the row's last results (hipcc sinks instructions nobody waits for to the end of the block),
+     * they fill the LDS queue and stall the wave.  So the previous row's 16 atomics are threaded
+     * through values of THIS row's arithmetic (lds_add_through): the even pixels' through the new
+     * vertical sums V[k], the odd pixels' through the sobel column sums C[k+1]. */
+    uint32_t Mp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned livep = 0; /* wave-uniform: the previous row counts */
+    auto hist_lo = [&](int k, uint32_t &through) {
+      const unsigned inc = (k == 0 ? inc_first : inc_in) & livep;
+      lds_add_through(lh, mad_u32_u16_lo(Mp[k], 128u, cb), inc, through); /* LDS byte offset = bin*128 + copy*4 */
+    };
+    auto hist_hi = [&](int k, uint32_t &through) {
+      const unsigned inc = (k == 7 ? inc_last : inc_in) & livep;
+      lds_add_through(lh, mad_u32_u16_hi(Mp[k], 128u, cb), inc, through);
+    };
 
     strip_rows<NS, false, /*EXITS=*/false>(S, y0, nrows, R + 1, S.load(y0 + R + 1), [&](auto I, int i, const uint32_t(&U)[12]) {
       /* iteration I, SPARE: slot I+1 is free (its row left last iteration), slot I+2 holds the
@@ -134,31 +154,41 @@ __global__ __launch_bounds__(256) void k_blur_sobel_hist16(uint8_t *dst, const u
       uint32_t UB[12], M[8], Hn[10];
       blur_hsum10<R>(U, Hn);
 #pragma unroll
-      for (int k = 0; k < 10; k++) V[k] = pk_sub_u16(pk_add_u16(V[k], Hn[k]), ring[old][k]), ring[fr][k] = Hn[k];
+      for (int k = 0; k < 10; k++) {
+        V[k] = sub2(add2(V[k], Hn[k]), ring[old][k]), ring[fr][k] = Hn[k];
+        if constexpr (HIST) {
+          if (k >= 1 && k <= 8) hist_lo(k - 1, V[k]);
+        }
+      }
       blurred(y0 + i + 1, UB);
+      auto hook = [&](int j, uint32_t &c) { /* C[1..9]: the odd pixels of pairs 0..7 ride on C[1..8] */
+        if (j <= 8) hist_hi(j - 1, c);
+      };
       U4 o; /* without the histogram only the bytes are needed (saturating-mad form of the clamp) */
       if constexpr (NS % 2 == 0) {
-        if constexpr (HIST) o = st.template step<decltype(I)::value & 1>(UB, M);
+        if constexpr (HIST) o = st.template step<decltype(I)::value & 1>(UB, M, hook);
         else o = st.template step<decltype(I)::value & 1>(UB);
       } else {
-        if constexpr (HIST) o = st.step_shift(UB, M);
+        if constexpr (HIST) o = st.step_shift(UB, M, hook);
         else o = st.step_shift(UB);
       }
       /* histogram, branch-free: lanes outside the image, the two frame columns and the dropped
        * rows of the last group add 0. */
       if constexpr (HIST) {
-        const unsigned inc = (inimg && i < nrows) ? 1u : 0u;
-        const unsigned inc0 = first ? 0u : inc, inc15 = last ? 0u : inc;
 #pragma unroll
-        for (int k = 0; k < 8; k++) { /* LDS byte offset = bin*128 + copy*4, straight from either half of the pair */
-          atomicAdd((unsigned *)((char *)lh + mad_u32_u16_lo(M[k], 128u, cb)), k == 0 ? inc0 : inc);
-          atomicAdd((unsigned *)((char *)lh + mad_u32_u16_hi(M[k], 128u, cb)), k == 7 ? inc15 : inc);
-        }
+        for (int k = 0; k < 8; k++) Mp[k] = M[k];
+        livep = i < nrows ? 1u : 0u; /* wave-uniform: rows past the band end are dropped */
       }
       return o;
     });
+    if constexpr (HIST) { /* the last row */
+      uint32_t t = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) hist_lo(k, t), hist_hi(k, t);
+    }
   }
   if constexpr (HIST) {
+    lds_drain(); /* the threaded atomics are not in hipcc's lgkmcnt bookkeeping */
     __syncthreads();
     unsigned acc = 0;
 #pragma unroll 8

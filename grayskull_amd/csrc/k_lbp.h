@@ -54,7 +54,8 @@ struct LbpArgs {
   unsigned *hits_super;         /* n frames x nsupers   (pre-zeroed) */
   unsigned ngroups, nsupers;
   unsigned nscales, cap;        /* cap = max_rects */
-  unsigned long long *evaluated; /* optional: += windows of every chunk that was not skipped */
+  unsigned long long *evaluated; /* optional (COUNT kernels): [0] += windows of every chunk that was not
+                                    skipped, [1] += weak classifiers evaluated, summed over windows */
 };
 constexpr unsigned kLbpGroupShift = 5, kLbpSuperShift = 10; /* chunks per group / super-group (log2) */
 
@@ -122,9 +123,9 @@ GS_DEV LbpCorners lbp_gather(const LbpLds &t, const unsigned *Pg, unsigned origi
 #ifndef GS_LBP_PREFETCH
 #define GS_LBP_PREFETCH 1 /* classifiers whose corners are in flight ahead of the arithmetic (MI355X: 1 -> 30.6, 2 -> 28.1, 3 -> 24.9 Gwin/s) */
 #endif
-template <bool GUARD>
+template <bool GUARD, bool COUNT = false>
 GS_DEV bool lbp_window_stages(const LbpLds &t, const unsigned *Pg, unsigned origin,
-                              unsigned limit, unsigned s0, unsigned s1) {
+                              unsigned limit, unsigned s0, unsigned s1, unsigned *evals = nullptr) {
   constexpr int PD = GS_LBP_PREFETCH;
   const unsigned wend = uniform(t.stage[s1 - 1].first) + uniform(t.stage[s1 - 1].count);
   unsigned wi = uniform(t.stage[s0].first);
@@ -138,6 +139,7 @@ GS_DEV bool lbp_window_stages(const LbpLds &t, const unsigned *Pg, unsigned orig
     float sum = 0.0f;
     for (unsigned k = 0; k < count; k++, wi++) {
       const LbpCorners cur = q[0];
+      if constexpr (COUNT) ++*evals;
 #pragma unroll
       for (int d = 0; d + 1 < PD; d++) q[d] = q[d + 1];
       const LbpWeak wk = t.weak[wi];
@@ -190,7 +192,7 @@ GS_DEV size_t lbp_block_lds_bytes(unsigned nstages, unsigned nweaks, unsigned ns
   return lbp_lds_bytes(nstages, nweaks, nsub) + 2 * kChunkItems * 2 + 64 * 4 + 16;
 }
 
-template <bool GUARD>
+template <bool GUARD, bool COUNT = false>
 __global__ __launch_bounds__(256) void k_lbp_cascade(LbpArgs a, LbpPhases ph) {
 #ifndef GS_EMU
 #pragma clang fp contract(off)
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(256) void k_lbp_cascade(LbpArgs a, LbpPhases ph) {
   const unsigned nwin = sc.nx * sc.ny, first = blockIdx.x * kChunkItems;
   const unsigned *Pg = a.padded + (size_t)blockIdx.z * a.frame_stride;
   unsigned n_in = nwin - first < kChunkItems ? nwin - first : kChunkItems;
-  unsigned cur = 0;
+  unsigned cur = 0, evals = 0;
   for (unsigned p = 0; p < ph.n; p++) {
     const unsigned s0 = p ? ph.end[p - 1] : 0u, s1 = ph.end[p];
     const bool lastp = p + 1 == ph.n;
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(256) void k_lbp_cascade(LbpArgs a, LbpPhases ph) {
       unsigned local = 0;
       if (i < n_in) {
         local = p ? qin[i] : i;
-        pass = lbp_window_stages<GUARD>(t, Pg, lbp_origin(a, sc, first + local), a.limit_bytes, s0, s1);
+        pass = lbp_window_stages<GUARD, COUNT>(t, Pg, lbp_origin(a, sc, first + local), a.limit_bytes, s0, s1, &evals);
       }
       if (lastp) {
         if (pass) atomicOr(&bits[local >> 5], 1u << (local & 31u));
@@ -285,7 +287,11 @@ __global__ __launch_bounds__(256) void k_lbp_cascade(LbpArgs a, LbpPhases ph) {
       atomicAdd(&a.hits_group[(size_t)blockIdx.z * a.ngroups + (lin >> kLbpGroupShift)], c);
       atomicAdd(&a.hits_super[(size_t)blockIdx.z * a.nsupers + (lin >> kLbpSuperShift)], c);
     }
-    if (tid == 0 && a.evaluated) atomicAdd(a.evaluated, (unsigned long long)(nwin - first < kChunkItems ? nwin - first : kChunkItems));
+  }
+  if constexpr (COUNT) { /* measurement build of the kernel (gsh_lbp_count_evaluated) */
+    const unsigned ev = wave_sum(evals);
+    if ((tid & 63u) == 0) atomicAdd(a.evaluated + 1, (unsigned long long)ev);
+    if (tid == 0) atomicAdd(a.evaluated, (unsigned long long)(nwin - first < kChunkItems ? nwin - first : kChunkItems));
   }
 }
 

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void k_blur16(uint8_t *dst, const uint8_t *src
     strip_unpack(S.load(y0 - R + r), U);
     blur_hsum<R>(U, ring[r]);
 #pragma unroll
-    for (int k = 0; k < 8; k++) V[k] = pk_add_u16(V[k], ring[r][k]);
+    for (int k = 0; k < 8; k++) V[k] = add2(V[k], ring[r][k]);
   }
   strip_rows<N, false, !GS_BLUR_NOEXIT>(S, y0, nrows, R, S.load(y0 + R), [&](auto I, int, const uint32_t(&U)[12]) {
     constexpr int slot = (decltype(I)::value + N - 1) % N; /* row i-1 leaves, row i+2R enters */
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void k_blur16(uint8_t *dst, const uint8_t *src
 #pragma unroll
       for (int t = 0; t < 2; t++) {
         const int k = 2 * g + t;
-        V[k] = pk_sub_u16(pk_add_u16(V[k], Hn[k]), ring[slot][k]);
+        V[k] = sub2(add2(V[k], Hn[k]), ring[slot][k]); /* unsigned fields, no carry / borrow: plain 32-bit ops */
         ring[slot][k] = Hn[k];
 #pragma unroll
         for (int hlf = 0; hlf < 2; hlf++) { /* quotient = byte 3 of the product */
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void k_downsample8(uint8_t *dst, const uint8_t
     for (int t = 0; t < 2; t++) {
       const uint32_t da = ra[2 * q + t], db = rb[2 * q + t]; /* 4 src px of each row -> 2 outputs */
       /* vertical sums as u16 pairs: (p0+q0, p1+q1) and (p2+q2, p3+q3) */
-      const uint32_t v01 = pk_add_u16(unpack_lo(da), unpack_lo(db)), v23 = pk_add_u16(unpack_hi(da), unpack_hi(db));
+      const uint32_t v01 = add2(unpack_lo(da), unpack_lo(db)), v23 = add2(unpack_hi(da), unpack_hi(db));
       const uint32_t s0 = (v01 & 0xffffu) + (v01 >> 16), s1 = (v23 & 0xffffu) + (v23 >> 16);
       out |= ((s0 >> 2) | ((s1 >> 2) << 8)) << (16 * t);
     }

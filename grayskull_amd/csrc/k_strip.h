@@ -36,29 +36,39 @@ struct RawRow { U4 v; uint32_t hh; };
  * wave's lanes are 64 consecutive strips of one band), blockDim.y stacks further bands.
  * INVERT complements in-image bytes on the way in and all bytes on the way out
  * (erode == ~dilate(~x)): the hardware's zero fill then acts as the 255 fill erosion needs. */
+/* Addressing: a row's byte offset is wave-uniform (SALU), the lane's column offset is fixed for the
+ * whole kernel, so every buffer offset is ONE full-rate v_add_u32 of the two.  Out-of-image rows
+ * and lanes are encoded in the summands themselves: kRowOOB + any valid column and any valid row +
+ * kOOB both land beyond the frame (< 2^31 - 1 bytes, see strip_ok), and kRowOOB + kOOB = 2^32 - 1. */
+constexpr uint32_t kRowOOB = 0x7fffffffu;
 template <bool INVERT = false> struct Strip {
   BufRsrc src, dst;
   unsigned w, h, x0, lane, band;
+  uint32_t col_off, halo_off; /* this lane's 16 B / its halo dword inside a row (kOOB: none) */
   GS_DEV Strip(const uint8_t *s, uint8_t *d, unsigned w_, unsigned h_, size_t frame_bytes)
       : src(make_buf(s + (size_t)blockIdx.z * frame_bytes, frame_bytes)),
         dst(make_buf(d + (size_t)blockIdx.z * frame_bytes, frame_bytes)), w(w_), h(h_) {
     lane = threadIdx.x & 63u;
     x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 16u;
     band = uniform(blockIdx.y * blockDim.y + threadIdx.y); /* same for the wave's 64 lanes: SGPR */
+    col_off = x0 < w ? x0 : kOOB;
+    halo_off = kOOB;
+    if (lane == 0 && x0 > 0 && x0 < w) halo_off = x0 - 4;
+    if (lane == 63 && x0 + 16 < w) halo_off = x0 + 16;
+  }
+  GS_DEV uint32_t row_off(int y, bool ok = true) const { /* y, ok wave-uniform */
+    return (ok && (unsigned)y < h) ? (uint32_t)y * w : kRowOOB;
   }
   /* row y: this lane's 16 B; lane 0 also fetches the 4 B left of the wave's 1 KiB, lane 63 the
    * 4 B right of it (one shared instruction).  Everything outside the image reads 0. */
   GS_DEV RawRow load(int y) const {
-    const bool ok = (unsigned)y < h && x0 < w;
-    const uint32_t base = (uint32_t)y * w + x0;
+    const uint32_t row = row_off(y);
     RawRow r;
-    r.v = buf_load16(src, ok ? base : kOOB);
-    uint32_t ho = kOOB;
-    if (lane == 0 && x0 > 0) ho = base - 4;
-    if (lane == 63 && x0 + 16 < w) ho = base + 16;
-    r.hh = buf_load4(src, ok ? ho : kOOB);
+    r.v = buf_load16(src, row + col_off);
+    r.hh = buf_load4(src, row + halo_off);
     if (INVERT) { /* complement in-image bytes only: out-of-range stays 0 in the inverted domain */
-      const uint32_t m = ok ? 0xffffffffu : 0u, hm = (ok && ho != kOOB) ? 0xffffffffu : 0u;
+      const bool ok = (unsigned)y < h && x0 < w;
+      const uint32_t m = ok ? 0xffffffffu : 0u, hm = (ok && halo_off != kOOB) ? 0xffffffffu : 0u;
       r.v = U4{r.v.x ^ m, r.v.y ^ m, r.v.z ^ m, r.v.w ^ m};
       r.hh ^= hm;
     }
@@ -67,7 +77,7 @@ template <bool INVERT = false> struct Strip {
   /* whole 16 B of row y (dropped when !ok or the lane is outside the image) */
   GS_DEV void store(int y, bool ok, U4 o) const {
     if (INVERT) o = U4{~o.x, ~o.y, ~o.z, ~o.w};
-    buf_store16(dst, (ok && x0 < w) ? (uint32_t)y * w + x0 : kOOB, o);
+    buf_store16(dst, row_off(y, ok) + col_off, o);
   }
 };
 
@@ -135,30 +145,31 @@ GS_DEV void strip_rows(const Strip<INVERT> &S, int y0, int nrows, int lead, RawR
  * groups, so with KEEP_COLS the lane holding column 0 (w-1) fetches dst's own first (last) dword
  * of the row one iteration ahead and writes that byte back unchanged.  KEEP_COLS=false is for
  * callers that do not care (interior-only copy back, or frame zeroed afterwards). */
-GS_DEV void sobel_hpass(const uint32_t (&U)[12], uint32_t (&H1)[8], uint32_t (&H2)[8]) {
-  uint32_t A[11];
+/* odd-aligned pairs of a row: A[j] = (px 2j-3, px 2j-2), j = 1..9 */
+GS_DEV void sobel_apairs(const uint32_t (&U)[12], uint32_t (&A)[10]) {
 #pragma unroll
-  for (int j = 1; j <= 9; j++) A[j] = alignbit(U[j + 1], U[j], 16); /* (px 2j-3, 2j-2) */
+  for (int j = 1; j <= 9; j++) A[j] = alignbit(U[j + 1], U[j], 16);
+}
+/* H1[k] = r[x-1] + 2 r[x] + r[x+1] for the own pairs k = 0..7 (<= 1020 per field) */
+GS_DEV void sobel_h1(const uint32_t (&U)[12], const uint32_t (&A)[10], uint32_t (&H1)[8]) {
 #pragma unroll
-  for (int k = 0; k < 8; k++) {
-    H2[k] = pk_sub_u16(A[k + 2], A[k + 1]);
-    H1[k] = pk_mad2_u16(U[k + 2], pk_add_u16(A[k + 1], A[k + 2]));
-  }
+  for (int k = 0; k < 8; k++) H1[k] = pk_mad2_u16(U[k + 2], add2(A[k + 1], A[k + 2]));
 }
 
 struct SobelKeepCols { /* Fin functor of strip_rows */
   BufRsrc dst;
   unsigned w, x0;
   bool first, last;
+  uint32_t keep_off;
   uint32_t e = 0; /* dst dword holding the protected byte of the row that is stored next */
   GS_DEV SobelKeepCols(const Strip<> &S) : dst(S.dst), w(S.w), x0(S.x0) {
     first = x0 == 0, last = x0 + 16 == w; /* launcher guarantees w >= 32: never both */
+    keep_off = first ? x0 : last ? x0 + 12 : kOOB;
   }
   /* strip_rows calls prefetch(y) in the iteration that COMPUTES row y and operator() in the next
    * one, right before row y is stored (and before the next prefetch): one iteration of latency */
   GS_DEV void prefetch(int y) {
-    const uint32_t row = (uint32_t)y * w + x0;
-    e = buf_load4(dst, first ? row : last ? row + 12 : kOOB);
+    e = buf_load4(dst, (uint32_t)y * w + keep_off); /* rows handed in are inside the frame */
   }
   GS_DEV U4 operator()(U4 o, int) const {
     o.x = first ? perm_b32(o.x, e, 0x07060500u) : o.x; /* byte 0 <- dst */
@@ -167,36 +178,57 @@ struct SobelKeepCols { /* Fin functor of strip_rows */
   }
 };
 
-/* vertical state of the sobel recurrence, one new input row b per step (output row y = b-1):
- *   gx(y) = H2(b-2) + 2 H2(b-1) + H2(b) = Pa + H2(b),   Pa' = H2(b-1) + 2 H2(b),
- *   gy(y) = H1(b) - H1(b-2).
- * 32 registers instead of a 3-row ring of (H1,H2) = 48, and only a 2-step static rotation. */
+/* Vertical state of the sobel recurrence, one new input row b per step (output row y = b-1).
+ * Everything is kept UNSIGNED so that sums are plain 32-bit adds on field pairs (full issue rate on
+ * gfx950, prims.h add2) and only the two absolute differences need packed max / min:
+ *   C(y)[x]  = r(b-2)[x] + 2 r(b-1)[x] + r(b)[x]   on the odd-aligned pairs A -- as T(b-1) + T(b)
+ *              with T(b) = A(b-1) + A(b);            |gx| = |C[x+1] - C[x-1]| = absdiff(C_A[k+2], C_A[k+1])
+ *   |gy|     = |H1(b) - H1(b-2)|,                     H1 = r[x-1] + 2 r[x] + r[x+1].
+ * 34 registers of state (Ap, Tp: 9 + 9, H1 history 2 x 8), 2-step static rotation for H1 only.
+ * (The signed form gx = Pa + H2(b), Pa' = H2(b-1) + 2 H2(b) needed 5 packed-16 ops per pair for
+ * |gx|; this one needs 2 plus ~2 plain adds.) */
 struct SobelState {
-  uint32_t Pa[8], Hp[8], H1[2][8];
+  uint32_t Ap[10], Tp[10], H1[2][8];
   /* prime with input rows y0-1 (r0) and y0 (r1) */
   GS_DEV void init(const uint32_t (&U0)[12], const uint32_t (&U1)[12]) {
-    uint32_t h1[8], h2[8];
-    sobel_hpass(U0, H1[0], h2);
-    sobel_hpass(U1, h1, Hp);
+    uint32_t A0[10];
+    sobel_apairs(U0, A0);
+    sobel_apairs(U1, Ap);
+    sobel_h1(U0, A0, H1[0]);
+    sobel_h1(U1, Ap, H1[1]);
 #pragma unroll
-    for (int k = 0; k < 8; k++) H1[1][k] = h1[k], Pa[k] = pk_mad2_u16(Hp[k], h2[k]);
+    for (int j = 1; j <= 9; j++) Tp[j] = add2(A0[j], Ap[j]);
   }
-  /* PAR = parity of the step: H1[PAR] holds row b-2 and receives row b.
-   * Bytes only: (|gx|+|gy|)/2 clamped to 255 is the high byte of min((|gx|+|gy|) * 128, 65535)
-   * (|gx|+|gy| <= 2040), one saturating v_pk_mad_u16 instead of shift + min. */
-  template <int PAR> GS_DEV U4 step(const uint32_t (&U)[12]) {
-#if GS_SOBEL_SAT
-    uint32_t H1n[8], H2n[8], M[8];
-    sobel_hpass(U, H1n, H2n);
+  /* |gx| + |gy| (<= 2040 per field) for the 8 own pairs; PAR = parity of the step: H1[PAR] holds
+   * row b-2 and receives row b */
+  struct NoHook { GS_DEV void operator()(int, uint32_t &) const {} };
+  /* hook(j, C[j]) is called as soon as C[j] exists (the fused kernel threads an LDS atomic of the
+   * previous row through it, see k_fused.h) */
+  template <int PAR, class Hook = NoHook> GS_DEV void magnitude(const uint32_t (&U)[12], uint32_t (&m)[8], Hook hook = Hook()) {
+    uint32_t A[10], C[10], H1n[8];
+    sobel_apairs(U, A);
+#pragma unroll
+    for (int j = 1; j <= 9; j++) {
+      const uint32_t Tn = add2(Ap[j], A[j]);
+      C[j] = add2(Tp[j], Tn);
+      Tp[j] = Tn, Ap[j] = A[j];
+      hook(j, C[j]);
+    }
+    sobel_h1(U, A, H1n);
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-      const uint32_t gx = pk_add_u16(Pa[k], H2n[k]);
-      const uint32_t gy = pk_sub_u16(H1n[k], H1[PAR][k]);
-      Pa[k] = pk_mad2_u16(H2n[k], Hp[k]);
-      Hp[k] = H2n[k];
+      m[k] = add2(absdiff2(C[k + 2], C[k + 1]), absdiff2(H1n[k], H1[PAR][k]));
       H1[PAR][k] = H1n[k];
-      M[k] = pk_shl7_sat_u16(pk_add_u16(pk_abs_i16(gx), pk_abs_i16(gy)));
     }
+  }
+  /* Bytes only: (|gx|+|gy|)/2 clamped to 255 is the high byte of min((|gx|+|gy|) * 128, 65535),
+   * one saturating v_pk_mad_u16 instead of shift + min. */
+  template <int PAR> GS_DEV U4 step(const uint32_t (&U)[12]) {
+#if GS_SOBEL_SAT
+    uint32_t M[8];
+    magnitude<PAR>(U, M);
+#pragma unroll
+    for (int k = 0; k < 8; k++) M[k] = pk_shl7_sat_u16(M[k]);
     return U4{pack_lohi_b1(M[0], M[1]), pack_lohi_b1(M[2], M[3]), pack_lohi_b1(M[4], M[5]),
               pack_lohi_b1(M[6], M[7])};
 #else
@@ -205,19 +237,10 @@ struct SobelState {
 #endif
   }
   /* M: the 16 results as u16 pairs (before packing to bytes) */
-  template <int PAR> GS_DEV U4 step(const uint32_t (&U)[12], uint32_t (&M)[8]) {
-    uint32_t H1n[8], H2n[8];
-    sobel_hpass(U, H1n, H2n);
+  template <int PAR, class Hook = NoHook> GS_DEV U4 step(const uint32_t (&U)[12], uint32_t (&M)[8], Hook hook = Hook()) {
+    magnitude<PAR>(U, M, hook);
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const uint32_t gx = pk_add_u16(Pa[k], H2n[k]);
-      const uint32_t gy = pk_sub_u16(H1n[k], H1[PAR][k]);
-      Pa[k] = pk_mad2_u16(H2n[k], Hp[k]);
-      Hp[k] = H2n[k];
-      H1[PAR][k] = H1n[k];
-      const uint32_t m = pk_shr_u16(pk_add_u16(pk_abs_i16(gx), pk_abs_i16(gy)), 1);
-      M[k] = pk_min_u16(m, 0x00ff00ffu);
-    }
+    for (int k = 0; k < 8; k++) M[k] = pk_min_u16(pk_shr_u16(M[k], 1), 0x00ff00ffu);
     return U4{pack_lohi(M[0], M[1]), pack_lohi(M[2], M[3]), pack_lohi(M[4], M[5]),
               pack_lohi(M[6], M[7])};
   }
@@ -229,8 +252,8 @@ struct SobelState {
       H1[0][k] = H1[1][k], H1[1][k] = t;
     }
   }
-  GS_DEV U4 step_shift(const uint32_t (&U)[12], uint32_t (&M)[8]) {
-    const U4 o = step<0>(U, M); /* H1[0] (row b-2) consumed and overwritten with row b */
+  template <class Hook = NoHook> GS_DEV U4 step_shift(const uint32_t (&U)[12], uint32_t (&M)[8], Hook hook = Hook()) {
+    const U4 o = step<0>(U, M, hook); /* H1[0] (row b-2) consumed and overwritten with row b */
     shift_history();
     return o;
   }
@@ -262,14 +285,14 @@ GS_DEV void blur_hsum(const uint32_t (&U)[12], uint32_t (&H)[8]) {
 #pragma unroll
   for (int j = jlo; j <= jhi; j++) {
     A[j] = alignbit(U[j + 1], U[j], 16); /* pair starting one px after U[j] */
-    P[j] = pk_add_u16(U[j], A[j]);       /* 2-px sums (x, x+1) for both halves */
+    P[j] = add2(U[j], A[j]);             /* 2-px sums (x, x+1) for both halves */
   }
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     const int j = k + 2; /* U[j] = own pair k */
-    if constexpr (R == 1) H[k] = pk_add_u16(A[j - 1], P[j]);
-    else if constexpr (R == 2) H[k] = pk_add_u16(pk_add_u16(P[j - 1], P[j]), U[j + 1]);
-    else H[k] = pk_add_u16(pk_add_u16(pk_add_u16(A[j - 2], P[j - 1]), P[j]), P[j + 1]);
+    if constexpr (R == 1) H[k] = add2(A[j - 1], P[j]);
+    else if constexpr (R == 2) H[k] = add2(P[j - 1], P[j], U[j + 1]);
+    else H[k] = add2(add2(A[j - 2], P[j - 1], P[j]), P[j + 1]);
   }
 }
 

@@ -125,6 +125,11 @@ GS_DEV uint32_t load_u32_unaligned(const uint8_t *p) {
 GS_DEV uint32_t mad_u32_u16_lo(uint32_t a, uint32_t b, uint32_t c) { return (a & 0xffffu) * (b & 0xffffu) + c; }
 GS_DEV uint32_t mad_u32_u16_hi(uint32_t a, uint32_t b, uint32_t c) { return (a >> 16) * (b & 0xffffu) + c; }
 GS_DEV void sched_fence() {}
+GS_DEV void lds_add_through(unsigned *lds_base, uint32_t byte_off, uint32_t value, uint32_t &through) {
+  (void)through;
+  atomicAdd((unsigned *)((char *)lds_base + byte_off), value);
+}
+GS_DEV void lds_drain() {}
 GS_DEV uint32_t pk_shl_u16(uint32_t a, unsigned s) { return GS_PK2((a & 0xffff) << s, (a >> 16) << s); }
 GS_DEV uint32_t pk_shr_u16(uint32_t a, unsigned s) { return GS_PK2((a & 0xffff) >> s, (a >> 16) >> s); }
 GS_DEV uint32_t pk_min_u16(uint32_t a, uint32_t b) {
@@ -237,6 +242,20 @@ GS_DEV uint32_t pk_mad2_u16(uint32_t a, uint32_t c) {
 }
 /* the instruction scheduler moves nothing across this point (keeps a prefetch where it was put) */
 GS_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+/* LDS atomic add (no return value) at byte address `lds_byte` of the block's LDS, tied into the
+ * dependency chain of `through`: the instruction is issued after `through` has been produced and
+ * before anything consumes it.  hipcc gives an atomic nobody waits for the lowest priority and sinks
+ * all of a row's atomics to the end of the scheduling region, where the burst fills the LDS queue
+ * and stalls the wave; threading them through values of the surrounding arithmetic spreads them
+ * at no instruction cost.  The statement is invisible to hipcc's lgkmcnt bookkeeping: the caller
+ * drains with lds_drain() before the block's barrier. */
+template <class T> GS_DEV uint32_t lds_address(T *p) { /* byte address inside the block's LDS */
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)p;
+}
+GS_DEV void lds_add_through(unsigned *lds_base, uint32_t byte_off, uint32_t value, uint32_t &through) {
+  asm volatile("ds_add_u32 %1, %2" : "+v"(through) : "v"(lds_address(lds_base) + byte_off), "v"(value) : "memory");
+}
+GS_DEV void lds_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 /* a*b + c per half with a wave-uniform multiplier pair b (SGPR): kept as one v_pk_mad_u16 even
  * when b is a power of two */
 GS_DEV uint32_t pk_mad_u16_s(uint32_t a, uint32_t b, uint32_t c) {
@@ -281,6 +300,25 @@ GS_DEV uint32_t pk_sar_i16(uint32_t a, unsigned s) { return GS_R((gs_i16x2)(GS_I
 #endif
 
 /* ------------------------------------------------------------------ common */
+/* Two u16 fields per dword whose sums cannot carry out of a field (unsigned pixel sums) are added
+ * with PLAIN 32-bit adds: on gfx950 v_add_u32 / v_sub_u32 issue at the full rate (~900 G
+ * wave-instructions/s chip-wide) and a three-input sum is one v_add3_u32, while every packed-16
+ * instruction (v_pk_add_u16 ...) issues at ~577 G -- measured by scripts/ubench_valu.cpp,
+ * profiles/r02a_ubench_valu.log.  sub2 needs every field of a >= the same field of b. */
+#ifndef GS_PLAIN_ADDS
+#define GS_PLAIN_ADDS 1 /* 0: the packed-16 spelling, kept for A/B builds (make variant EXTRA=-DGS_PLAIN_ADDS=0) */
+#endif
+#if GS_PLAIN_ADDS
+GS_DEV uint32_t add2(uint32_t a, uint32_t b) { return a + b; }
+GS_DEV uint32_t add2(uint32_t a, uint32_t b, uint32_t c) { return a + b + c; }
+GS_DEV uint32_t sub2(uint32_t a, uint32_t b) { return a - b; }
+#else
+GS_DEV uint32_t add2(uint32_t a, uint32_t b) { return pk_add_u16(a, b); }
+GS_DEV uint32_t add2(uint32_t a, uint32_t b, uint32_t c) { return pk_add_u16(pk_add_u16(a, b), c); }
+GS_DEV uint32_t sub2(uint32_t a, uint32_t b) { return pk_sub_u16(a, b); }
+#endif
+/* |a - b| per field for unsigned fields: max - min (the difference cannot borrow) */
+GS_DEV uint32_t absdiff2(uint32_t a, uint32_t b) { return sub2(pk_max_u16(a, b), pk_min_u16(a, b)); }
 GS_DEV unsigned umin(unsigned a, unsigned b) { return a < b ? a : b; }
 /* |a - b| for a, b < 65536 (v_sad_u16 with zero high halves on the GPU) */
 GS_DEV unsigned absdiff_u16(unsigned a, unsigned b) {

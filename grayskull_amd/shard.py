@@ -63,6 +63,10 @@ class Sharder:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return float(t.item())
 
+    def ranks_seen(self):
+        """all-reduce of 1 over the job's backend (RCCL on the GPUs): the number of ranks that take part"""
+        return int(round(self.sum_over_ranks(1.0)))
+
     def all_gather_frames(self, local, total):
         """local: 1-D tensor with this rank's per-frame results (frame_range order, equal-length
         shards padded); returns the `total` per-frame values in global frame order"""

@@ -107,9 +107,10 @@ void gsh_cascade_destroy(gsh_cascade *dc);
 void gsh_lbp_detect_batch(const gsh_cascade *dc, const unsigned *ii, unsigned iw, unsigned ih,
                           unsigned n, struct gs_rect *rects, unsigned *counts, unsigned max_rects,
                           float scale_factor, float min_scale, float max_scale, int step);
-/* Measurement aid: while `counter_dev` (one device u64, caller-zeroed) is set, every cascade
- * launch of this thread adds the number of windows it really evaluated -- chunks skipped because
- * max_rects detections precede them in scan order (ref :819-823) are not counted.  NULL = off. */
+/* Measurement aid: while `counter_dev` (TWO device u64, caller-zeroed) is set, every cascade launch
+ * of this thread adds [0] the number of windows it really evaluated -- chunks skipped because
+ * max_rects detections precede them in scan order (ref :819-823) are not counted -- and [1] the
+ * number of weak classifiers evaluated, summed over windows.  NULL = off (the default kernels). */
 void gsh_lbp_count_evaluated(unsigned long long *counter_dev);
 /* number of windows gs_lbp_detect visits for this geometry (for Mwin/s reporting) */
 uint64_t gsh_lbp_window_count(const struct gs_lbp_cascade *c, unsigned iw, unsigned ih,

@@ -129,6 +129,41 @@
 ALL(X)
 #undef X
 
+// v_cndmask_b32 with the mask in VCC written by a VALU compare before the loop / in an SGPR pair
+// written by SALU / freshly written by a v_cmp each time (the cmp_cnd row above)
+__global__ __launch_bounds__(256) void k_cnd_vcc_once(uint32_t *out, int iters, unsigned long long *cyc) {
+  uint32_t a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+  uint32_t b = threadIdx.x * 3u + 1u, c = blockIdx.x + 5u;
+  asm volatile("v_cmp_lt_u32 vcc, %0, %1\ns_nop 4\n" ::"v"(b), "v"(c) : "vcc");
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int i = 0; i < iters; i++) {
+    asm volatile(R8(cndmask_b32_LINE) R8(cndmask_b32_LINE) R8(cndmask_b32_LINE) R8(cndmask_b32_LINE)
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                 : "v"(b), "v"(c));
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  if (blockIdx.x == 0 && threadIdx.x == 0) cyc[0] = t1 - t0;
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+}
+#define cnd_sgpr_LINE(i) "v_cndmask_b32_e64 %" #i ", %" #i ", %8, %10\n"
+__global__ __launch_bounds__(256) void k_cnd_sgpr(uint32_t *out, int iters, unsigned long long *cyc) {
+  uint32_t a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+  uint32_t b = threadIdx.x * 3u + 1u, c = blockIdx.x + 5u;
+  unsigned long long m = 0x5555aaaa3333ccccull ^ (unsigned long long)blockIdx.x;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int i = 0; i < iters; i++) {
+    asm volatile(R8(cnd_sgpr_LINE) R8(cnd_sgpr_LINE) R8(cnd_sgpr_LINE) R8(cnd_sgpr_LINE)
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                 : "v"(b), "v"(c), "s"(m));
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  if (blockIdx.x == 0 && threadIdx.x == 0) cyc[0] = t1 - t0;
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+}
+// the same select spelled with bit operations on a per-lane all-ones / all-zeros mask register
+#define bfi_sel_LINE(i) "v_bfi_b32 %" #i ", %9, %8, %" #i "\n"
+DEFK(k_bfi_select, bfi_sel_LINE)
+
 // LDS atomic rate (histogram): ds_add_u32 without return, address pattern = lane-private copies
 __global__ __launch_bounds__(256) void k_ds_add(uint32_t *out, int iters, unsigned long long *cyc, int mode) {
   __shared__ unsigned lh[256 * 32];
@@ -171,7 +206,7 @@ int main(int argc, char **argv) {
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
 #define X(n) {#n, k_##n},
-  const Entry tab[] = {ALL(X)};
+  const Entry tab[] = {ALL(X){"cndmask_vcc_set_once", k_cnd_vcc_once}, {"cndmask_e64_sgprmask", k_cnd_sgpr}, {"bfi_select", k_bfi_select}};
 #undef X
   printf("%-18s %6s %14s %14s %12s\n", "instruction", "w/SIMD", "Gwave-inst/s", "cyc/inst/SIMD", "ns/launch");
   for (const Entry &e : tab) {

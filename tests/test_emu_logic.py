@@ -269,7 +269,7 @@ def test_lbp_chunk_granular_early_exit(emu, oracle, cascade):
     total = emu.lbp_window_count(cascade, 352, 288, 1.1, 1.0, 4.0, 1)
     evaluated = {}
     for cap in (1, 20, 60, 4096):
-        cnt = np.zeros(1, np.uint64)
+        cnt = np.zeros(2, np.uint64)
         emu.lbp_count_evaluated(cnt)
         try:
             r = emu.lbp_detect(cascade, ii.copy(), cap, 1.1, 1.0, 4.0, 1)

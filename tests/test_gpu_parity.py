@@ -644,7 +644,7 @@ def test_config4_chain_on_one_4k_frame(hip, oracle, cascade):
     ii = torch.zeros((1, h, w), dtype=torch.int32, device="cuda")
     rects = torch.zeros((1, 4096, 4), dtype=torch.int32, device="cuda")
     counts = torch.zeros(1, dtype=torch.int32, device="cuda")
-    ev = torch.zeros(1, dtype=torch.int64, device="cuda")
+    ev = torch.zeros(2, dtype=torch.int64, device="cuda")
     dc = hip.cascade_create(cascade)
     hip.blur_batch(a, src, 2)
     hip.sobel_batch(b, a)

@@ -6,8 +6,9 @@ resolves to OUR implementation; everything out of scope (gs_crop, gs_resize, gs_
 the reference's static inline code, as SURVEY.md 8(b) prescribes.
 
 On this CPU-only box "our implementation" is the kernel-logic emulator build of the same sources
-(tests/emu/libgs_kernel_emu.so); on a GPU box the same wrapper links libgrayskull_hip.so (the
-`gpu`-marked variant, which needs /root/reference too and therefore skips on the driver's GPU box).
+(tests/emu/libgs_kernel_emu.so).  The same programs linked against libgrayskull_hip.so are prebuilt
+by `make -C oracle ref` (oracle/_ref/ref_test_hip, nano_hip) and run on the GPU box by
+tests/test_gpu_vs_reference.py, which has no /root/reference.
 Nothing from the reference is copied: the wrapper #includes the files in place."""
 import os
 import re
@@ -24,24 +25,13 @@ def _ensure_emu():
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "grayskull_amd", "csrc"), "emu"])
 
 
-def _prototypes():
-    text = open(os.path.join(ROOT, "include", "grayskull.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    protos = [" ".join(p.split()) for p in re.findall(r"^GS_API\s+([^;]+);", text, flags=re.M)]
-    names = [re.search(r"(gs_\w+)\s*\(", p).group(1) for p in protos]
-    return protos, names
-
-
 def _wrapper(tmp_path, unit):
-    protos, names = _prototypes()
-    lines = ["/* generated by tests/test_reference_suite.py */"]
-    lines += ["#define %s refonly_%s" % (n, n) for n in names]  # the reference's own copies: renamed, unused
-    lines += ['#include "%s/grayskull.h"' % REF]
-    lines += ["#undef %s" % n for n in names]
-    lines += ["extern %s;" % p for p in protos]  # ours
-    lines += ['#include "%s"' % unit, ""]
+    """oracle/gen_ref_wrapper.py: the reference program, unmodified, with the hot-path symbols extern"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from gen_ref_wrapper import wrapper_text
+    text, names = wrapper_text(REF, unit)
     src = tmp_path / "wrapper.c"
-    src.write_text("\n".join(lines))
+    src.write_text(text)
     return str(src), names
 
 
@@ -63,14 +53,6 @@ def test_reference_unit_tests_pass_against_our_kernels_emulated(tmp_path):
     emu = os.path.join(ROOT, "tests", "emu")
     _ensure_emu()
     r = _build_and_run(tmp_path, emu, "gs_kernel_emu", REF + "/test.c")
-    assert r.returncode == 0, (r.stdout + r.stderr).decode()[-2000:]
-
-
-@pytest.mark.gpu
-@pytest.mark.skipif(not os.path.exists(REF + "/test.c"), reason="reference checkout not present on this box")
-def test_reference_unit_tests_pass_against_hip_library(tmp_path):
-    lib = os.path.join(ROOT, "grayskull_amd")
-    r = _build_and_run(tmp_path, lib, "grayskull_hip", REF + "/test.c")
     assert r.returncode == 0, (r.stdout + r.stderr).decode()[-2000:]
 
 
