@@ -206,6 +206,10 @@ class Grayskull:
     def set_async(self, on):
         self.c.gsh_set_async(1 if on else 0)
 
+    def shutdown(self):
+        """gsh_shutdown: release the calling thread's device scratch, streams and events"""
+        self.c.gsh_shutdown()
+
     def sync(self):
         self.c.gsh_sync()
 

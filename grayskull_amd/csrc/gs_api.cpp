@@ -15,6 +15,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <map>
 #include <vector>
 
 #include "k_box.h"
@@ -66,12 +68,39 @@ enum Slot { SL_IN = 0, SL_OUT, SL_AUX, SL_AUX2, SL_II, SL_PAD, SL_MASK, SL_CNT, 
 /* gsh_edge_pipeline_batch: frames per chunk (measured best for 64..512-frame batches of 4K frames:
  * profiles/r01g_chunk_overlap.log) and the most chunks per call */
 constexpr unsigned kChunkFrames = 32, kMaxChunks = 64;
+/* per-(thread, cascade) scan geometry of the last gs_lbp_detect call: the scale list and the
+ * per-(scale, classifier) corner offsets on the device.  Lives in the calling thread's context, not
+ * in the cascade handle, so threads sharing one handle never touch each other's tables. */
+struct LbpGeomCache {
+  unsigned iw = 0, ih = 0;
+  float sf = 0, mn = 0, mx = 0;
+  int step = 0;
+  std::vector<LbpScale> scales;
+  LbpScale *d_scales = nullptr;
+  LbpGeom *d_geom = nullptr;
+  size_t d_scales_cap = 0, d_geom_cap = 0;
+  unsigned total_chunks = 0, max_chunks = 0;
+  bool guard = false;
+  unsigned long long nwindows = 0;
+};
 struct Ctx {
   int device = 0;
   bool device_set = false;
   hipStream_t stream = nullptr;
   bool own_stream = false, user_stream = false, async = false;
   struct Buf { void *p = nullptr; size_t cap = 0; } slot[SL_COUNT];
+  bool jump_ready = false; /* SL_JUMP holds the xorshift jump table of gsh_synth_batch */
+  std::map<unsigned long long, LbpGeomCache> geom_cache; /* keyed by gsh_cascade::id */
+  void drop_geom() {
+    for (auto &kv : geom_cache) {
+      if (kv.second.d_scales) (void)hipFree(kv.second.d_scales);
+      if (kv.second.d_geom) (void)hipFree(kv.second.d_geom);
+    }
+    geom_cache.clear();
+  }
+  /* a host thread that drives one GPU and exits (gsbatch --gpus N) gives its scratch, streams and
+   * events back without having to remember gsh_shutdown() */
+  ~Ctx() { release(); }
 #ifndef GS_EMU
   /* gsh_profile: events bracketing the pipeline's fused-kernel launches on their stream */
   static constexpr int kProfPairs = 4096;
@@ -150,6 +179,8 @@ struct Ctx {
       if (b.p) (void)hipFree(b.p);
       b.p = nullptr, b.cap = 0;
     }
+    jump_ready = false;
+    drop_geom();
 #ifndef GS_EMU
     for (auto &e : prof_ev) {
       if (e) (void)hipEventDestroy(e);
@@ -203,7 +234,7 @@ dim3 grid2d(unsigned w, unsigned h, unsigned n) { return dim3((w + 63) / 64, (h 
 inline bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 /* ---- launch tuning (gsh_tune): 0 rows per band (0 = auto), 1 block shape, 2 prefetch depth */
-int g_tune[8] = {0, 1, 1, 0, 0, 0, 0, 0};
+int g_tune[10] = {0, 1, 1, 0, 0, 0, 0, 0, 0, 0};
 /* gsh_lbp_count_evaluated: device counter that receives the windows the cascade really evaluated */
 thread_local unsigned long long *g_lbp_evaluated = nullptr;
 
@@ -238,7 +269,10 @@ StripCfg strip_cfg(unsigned w, unsigned rows, unsigned n, unsigned waves_per_sim
 inline bool strip_ok(unsigned w, unsigned h, const void *a, const void *b) {
   return w % 16 == 0 && (unsigned long long)w * h < 0x7fffffffull && al16(a) && al16(b);
 }
-constexpr unsigned kMaxZ = 32768; /* frames per launch (grid.z limit 65535) */
+/* frames per launch (grid.y / grid.z limit 65535); gsh_tune key 8 lowers it so that the splitting
+ * logic of every launcher can be exercised with a handful of frames */
+inline unsigned max_frames_per_launch() { return g_tune[8] > 0 ? (unsigned)g_tune[8] : 32768u; }
+#define kMaxZ (max_frames_per_launch())
 
 /* ------------------------------------------------------------------ stencil launchers */
 /* keep_cols: true = columns 0 / w-1 keep dst's bytes like the reference (the kernel re-writes
@@ -431,6 +465,12 @@ void launch_fast(const uint8_t *img, uint8_t *score, unsigned w, unsigned h, uns
                  unsigned *kps, unsigned *counts, unsigned nkps, unsigned threshold) {
   hipStream_t st = ctx().s();
   if (n == 0) return;
+  if (n > kMaxZ) { /* grid.y / grid.z carry the frame index: split like every other launcher */
+    for (unsigned f0 = 0; f0 < n; f0 += kMaxZ)
+      launch_fast(img + (size_t)w * h * f0, score + (size_t)w * h * f0, w, h, std::min(kMaxZ, n - f0),
+                  kps + (size_t)f0 * nkps * 12, counts + f0, nkps, threshold);
+    return;
+  }
   if (w < 7 || h < 7) { /* reference loops are empty for 3 <= dim < 7 */
     GS_HIP(hipMemsetAsync(counts, 0, (size_t)n * 4, st));
     return;
@@ -484,17 +524,7 @@ struct gsh_cascade {
   LbpWeak *d_weak = nullptr;
   LbpStage *d_stage = nullptr;
   int32_t *d_subsets = nullptr;
-  /* geometry cache (last call) */
-  unsigned g_iw = 0, g_ih = 0;
-  float g_sf = 0, g_min = 0, g_max = 0;
-  int g_step = 0;
-  std::vector<LbpScale> scales;
-  LbpScale *d_scales = nullptr;
-  LbpGeom *d_geom = nullptr;
-  size_t d_scales_cap = 0, d_geom_cap = 0;
-  unsigned total_chunks = 0, max_chunks = 0;
-  bool guard = false;
-  unsigned long long nwindows = 0;
+  unsigned long long id = 0; /* unique per handle: key of the calling threads' geometry caches */
 };
 
 namespace {
@@ -536,52 +566,57 @@ void build_scales(const gsh_cascade &c, unsigned iw, unsigned ih, float scale_fa
   }
 }
 
-void cascade_prepare(gsh_cascade *dc, unsigned iw, unsigned ih, float sf, float mn, float mx,
-                     int step) {
-  if (dc->g_iw == iw && dc->g_ih == ih && dc->g_sf == sf && dc->g_min == mn && dc->g_max == mx &&
-      dc->g_step == step && dc->d_scales)
-    return;
+LbpGeomCache &cascade_prepare(const gsh_cascade *dc, unsigned iw, unsigned ih, float sf, float mn, float mx,
+                              int step) {
+  Ctx &cx = ctx();
+  if (cx.geom_cache.size() > 16 && !cx.geom_cache.count(dc->id)) { /* handles come and go: bound the cache */
+    cx.sync();
+    cx.drop_geom();
+  }
+  LbpGeomCache &gc = cx.geom_cache[dc->id];
+  if (gc.iw == iw && gc.ih == ih && gc.sf == sf && gc.mn == mn && gc.mx == mx && gc.step == step && gc.d_scales)
+    return gc;
   std::vector<LbpGeom> geom;
-  build_scales(*dc, iw, ih, sf, mn, mx, step, dc->scales, geom, dc->guard, dc->nwindows);
-  ctx().sync(); /* tables may be in use by an earlier launch */
-  const size_t sb = std::max<size_t>(1, dc->scales.size()) * sizeof(LbpScale);
+  build_scales(*dc, iw, ih, sf, mn, mx, step, gc.scales, geom, gc.guard, gc.nwindows);
+  cx.sync(); /* tables may be in use by an earlier launch of this thread */
+  const size_t sb = std::max<size_t>(1, gc.scales.size()) * sizeof(LbpScale);
   const size_t gb = std::max<size_t>(1, geom.size()) * sizeof(LbpGeom);
-  if (dc->d_scales_cap < sb) {
-    if (dc->d_scales) GS_HIP(hipFree(dc->d_scales));
-    GS_HIP(hipMalloc((void **)&dc->d_scales, sb));
-    dc->d_scales_cap = sb;
+  if (gc.d_scales_cap < sb) {
+    if (gc.d_scales) GS_HIP(hipFree(gc.d_scales));
+    GS_HIP(hipMalloc((void **)&gc.d_scales, sb));
+    gc.d_scales_cap = sb;
   }
-  if (dc->d_geom_cap < gb) {
-    if (dc->d_geom) GS_HIP(hipFree(dc->d_geom));
-    GS_HIP(hipMalloc((void **)&dc->d_geom, gb));
-    dc->d_geom_cap = gb;
+  if (gc.d_geom_cap < gb) {
+    if (gc.d_geom) GS_HIP(hipFree(gc.d_geom));
+    GS_HIP(hipMalloc((void **)&gc.d_geom, gb));
+    gc.d_geom_cap = gb;
   }
-  if (!dc->scales.empty()) {
-    GS_HIP(hipMemcpy(dc->d_scales, dc->scales.data(), dc->scales.size() * sizeof(LbpScale),
-                     hipMemcpyHostToDevice));
-    GS_HIP(hipMemcpy(dc->d_geom, geom.data(), geom.size() * sizeof(LbpGeom), hipMemcpyHostToDevice));
+  if (!gc.scales.empty()) {
+    GS_HIP(hipMemcpy(gc.d_scales, gc.scales.data(), gc.scales.size() * sizeof(LbpScale), hipMemcpyHostToDevice));
+    GS_HIP(hipMemcpy(gc.d_geom, geom.data(), geom.size() * sizeof(LbpGeom), hipMemcpyHostToDevice));
   }
-  dc->total_chunks = 0, dc->max_chunks = 0;
-  for (auto &s : dc->scales) {
-    dc->total_chunks += s.nchunks;
-    dc->max_chunks = std::max(dc->max_chunks, s.nchunks);
+  gc.total_chunks = 0, gc.max_chunks = 0;
+  for (auto &sc : gc.scales) {
+    gc.total_chunks += sc.nchunks;
+    gc.max_chunks = std::max(gc.max_chunks, sc.nchunks);
   }
-  dc->g_iw = iw, dc->g_ih = ih, dc->g_sf = sf, dc->g_min = mn, dc->g_max = mx, dc->g_step = step;
+  gc.iw = iw, gc.ih = ih, gc.sf = sf, gc.mn = mn, gc.mx = mx, gc.step = step;
+  return gc;
 }
 
 /* padded: n frames of (iw+1)*(ih+1) u32 on device */
-void launch_lbp_padded(gsh_cascade *dc, const unsigned *padded, unsigned iw, unsigned ih,
-                       unsigned n, unsigned *rects, unsigned *counts, unsigned max_rects,
+void launch_lbp_padded(const gsh_cascade *dc, const LbpGeomCache &gc, const unsigned *padded, unsigned iw,
+                       unsigned ih, unsigned n, unsigned *rects, unsigned *counts, unsigned max_rects,
                        int step) {
   hipStream_t st = ctx().s();
-  if (dc->scales.empty() || max_rects == 0) {
+  if (gc.scales.empty() || max_rects == 0) {
     GS_HIP(hipMemsetAsync(counts, 0, (size_t)n * 4, st));
     return;
   }
-  const unsigned nch = dc->total_chunks;
+  const unsigned nch = gc.total_chunks;
   unsigned long long *mask =
       (unsigned long long *)ctx().scratch(SL_MASK, (size_t)n * nch * kChunkWords * 8);
-  const unsigned nsc0 = (unsigned)dc->scales.size();
+  const unsigned nsc0 = (unsigned)gc.scales.size();
   /* chunk counters, then the early-exit counters: one per group of 32 chunks, one per 1024 */
   const unsigned ngroups = (nch >> kLbpGroupShift) + 1, nsupers = (nch >> kLbpSuperShift) + 1;
   const size_t ncnt = (size_t)n * nch + (size_t)n * ngroups + (size_t)n * nsupers;
@@ -600,11 +635,11 @@ void launch_lbp_padded(gsh_cascade *dc, const unsigned *padded, unsigned iw, uns
   a.limit_bytes = (unsigned)((a.frame_stride - 1) * 4);
   a.step = step;
   a.nweaks = dc->nweaks, a.nstages = dc->nstages, a.nsub = dc->nsub;
-  a.scales = dc->d_scales, a.geom = dc->d_geom, a.weak = dc->d_weak, a.stage = dc->d_stage;
+  a.scales = gc.d_scales, a.geom = gc.d_geom, a.weak = dc->d_weak, a.stage = dc->d_stage;
   a.subsets = dc->d_subsets;
   a.mask = mask, a.chunk_count = cnt, a.total_chunks = nch;
-  const unsigned nsc = (unsigned)dc->scales.size();
-  const dim3 g(dc->max_chunks, nsc, n);
+  const unsigned nsc = (unsigned)gc.scales.size();
+  const dim3 g(gc.max_chunks, nsc, n);
   const size_t lds = (size_t)dc->nstages * sizeof(LbpStage) +
                      (size_t)dc->nweaks * (sizeof(LbpWeak) + sizeof(LbpGeom)) + (size_t)dc->nsub * 4;
   GS_ASSERT(lds <= 60 * 1024 && "cascade tables must fit the block's LDS");
@@ -633,21 +668,21 @@ void launch_lbp_padded(gsh_cascade *dc, const unsigned *padded, unsigned iw, uns
   }
   const size_t lds_all = ((lds + 15) & ~(size_t)15) + 2 * kChunkItems * 2 + 64 * 4 + 16;
   if (a.evaluated) { /* counting build: the same kernel + one register that counts classifier evaluations */
-    if (dc->guard) GS_LAUNCH((k_lbp_cascade<true, true>), g, dim3(256), lds_all, st, a, ph);
+    if (gc.guard) GS_LAUNCH((k_lbp_cascade<true, true>), g, dim3(256), lds_all, st, a, ph);
     else GS_LAUNCH((k_lbp_cascade<false, true>), g, dim3(256), lds_all, st, a, ph);
-  } else if (dc->guard) GS_LAUNCH(k_lbp_cascade<true>, g, dim3(256), lds_all, st, a, ph);
+  } else if (gc.guard) GS_LAUNCH(k_lbp_cascade<true>, g, dim3(256), lds_all, st, a, ph);
   else GS_LAUNCH(k_lbp_cascade<false>, g, dim3(256), lds_all, st, a, ph);
   run_compaction(mask, cnt, nch, n, max_rects, counts,
-                 LbpEmit{dc->d_scales, (unsigned)dc->scales.size(), step, rects, max_rects});
+                 LbpEmit{gc.d_scales, (unsigned)gc.scales.size(), step, rects, max_rects});
 }
 
 constexpr unsigned kLbpGroup = 8; /* frames per cascade launch (bounds mask/padded scratch) */
 
-void launch_lbp_unpadded(gsh_cascade *dc, const unsigned *ii, unsigned iw, unsigned ih, unsigned n,
+void launch_lbp_unpadded(const gsh_cascade *dc, const unsigned *ii, unsigned iw, unsigned ih, unsigned n,
                          unsigned *rects, unsigned *counts, unsigned max_rects, float sf, float mn,
                          float mx, int step) {
   GS_ASSERT(step > 0);
-  cascade_prepare(dc, iw, ih, sf, mn, mx, step);
+  const LbpGeomCache &gc = cascade_prepare(dc, iw, ih, sf, mn, mx, step);
   hipStream_t st = ctx().s();
   const size_t fp = (size_t)iw * ih, pp = (size_t)(iw + 1) * (ih + 1);
   for (unsigned f0 = 0; f0 < n; f0 += kLbpGroup) {
@@ -655,7 +690,7 @@ void launch_lbp_unpadded(gsh_cascade *dc, const unsigned *ii, unsigned iw, unsig
     unsigned *padded = (unsigned *)ctx().scratch(SL_PAD, pp * 4 * nn);
     GS_LAUNCH(k_integral_pad, dim3((iw + 64) / 64, (ih + 4) / 4, nn), dim3(64, 4), 0, st,
               ii + fp * f0, iw, ih, padded);
-    launch_lbp_padded(dc, padded, iw, ih, nn, rects + (size_t)f0 * max_rects * 4, counts + f0,
+    launch_lbp_padded(dc, gc, padded, iw, ih, nn, rects + (size_t)f0 * max_rects * 4, counts + f0,
                       max_rects, step);
   }
 }
@@ -871,7 +906,7 @@ unsigned gsh_profile_read(double *total_ms) {
   return n;
 }
 void gsh_tune(int key, int value) {
-  if (key >= 0 && key < 8) g_tune[key] = value;
+  if (key >= 0 && key < 10) g_tune[key] = value;
 }
 void gsh_probe_strip_copy(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned n) {
   GS_ASSERT(dst && src && w % 16 == 0 && al16(dst) && al16(src));
@@ -1090,6 +1125,8 @@ gsh_cascade *gsh_cascade_create(const struct gs_lbp_cascade *c) {
   GS_ASSERT(c && c->features && c->weak_feature_idx && c->subsets);
   ctx().ensure_device();
   gsh_cascade *dc = new gsh_cascade();
+  static std::atomic<unsigned long long> next_id{1};
+  dc->id = next_id.fetch_add(1);
   dc->window_w = c->window_w, dc->window_h = c->window_h;
   dc->nfeatures = c->nfeatures, dc->nweaks = c->nweaks, dc->nstages = c->nstages;
   dc->features.assign(c->features, c->features + (size_t)c->nfeatures * 4);
@@ -1124,15 +1161,21 @@ void gsh_cascade_destroy(gsh_cascade *dc) {
   if (!dc) return;
   ctx().sync();
   (void)hipFree(dc->d_weak), (void)hipFree(dc->d_stage), (void)hipFree(dc->d_subsets);
-  if (dc->d_scales) (void)hipFree(dc->d_scales);
-  if (dc->d_geom) (void)hipFree(dc->d_geom);
+  /* geometry tables of this handle in the calling thread's cache go with it; other threads' entries
+   * are keyed by the (never reused) id and are dropped when their context is released */
+  auto it = ctx().geom_cache.find(dc->id);
+  if (it != ctx().geom_cache.end()) {
+    if (it->second.d_scales) (void)hipFree(it->second.d_scales);
+    if (it->second.d_geom) (void)hipFree(it->second.d_geom);
+    ctx().geom_cache.erase(it);
+  }
   delete dc;
 }
 void gsh_lbp_detect_batch(const gsh_cascade *dc, const unsigned *ii, unsigned iw, unsigned ih,
                           unsigned n, struct gs_rect *rects, unsigned *counts, unsigned max_rects,
                           float scale_factor, float min_scale, float max_scale, int step) {
   GS_ASSERT(dc && ii && rects && counts && iw > 0 && ih > 0);
-  launch_lbp_unpadded(const_cast<gsh_cascade *>(dc), ii, iw, ih, n, (unsigned *)rects, counts,
+  launch_lbp_unpadded(dc, ii, iw, ih, n, (unsigned *)rects, counts,
                       max_rects, scale_factor, min_scale, max_scale, step);
 }
 void gsh_lbp_count_evaluated(unsigned long long *counter_dev) { g_lbp_evaluated = counter_dev; }
@@ -1167,6 +1210,14 @@ void gsh_orb_extract_batch(const uint8_t *img_dev, unsigned w, unsigned h, unsig
                            uint8_t *scoremap_dev, struct gs_keypoint *kps_host, unsigned *counts_host,
                            unsigned nkps, unsigned threshold) {
   GS_ASSERT(img_dev && scoremap_dev && kps_host && counts_host && nkps > 0 && w > 0 && h > 0);
+  constexpr unsigned kOrbGroup = 4096; /* frames per pass: bounds the host-side candidate buffers and grid.y */
+  if (n > kOrbGroup) {
+    for (unsigned f0 = 0; f0 < n; f0 += kOrbGroup)
+      gsh_orb_extract_batch(img_dev + (size_t)w * h * f0, w, h, std::min(kOrbGroup, n - f0),
+                            scoremap_dev + (size_t)w * h * f0, kps_host + (size_t)f0 * nkps, counts_host + f0, nkps,
+                            threshold);
+    return;
+  }
   for (unsigned f = 0; f < n; f++) counts_host[f] = 0;
   if (n == 0 || w < 7 || h < 7) return;
   hipStream_t st = ctx().s();
@@ -1245,6 +1296,7 @@ unsigned gsh_orb_extract_pyramid(const uint8_t *img_dev, unsigned w, unsigned h,
                                  unsigned n_levels) {
   GS_ASSERT(img_dev && buffer_dev && kps_host && w > 0 && h > 0);
   if (n_levels > 4) n_levels = 4;
+  if (n_levels == 0 || nkps == 0) return 0; /* the reference driver's level loop is empty (nanomagick.c:262) */
   const uint8_t *lev[4];
   unsigned lw[4], lh[4], total = 0;
   size_t off = 0;
@@ -1354,7 +1406,7 @@ void gsh_synth_batch(uint8_t *dst, unsigned w, unsigned h, unsigned n, uint32_t 
   GS_ASSERT(dst && w > 0 && h > 0);
   if (!n) return;
   hipStream_t st = ctx().s();
-  static thread_local bool jump_ready = false;
+  bool &jump_ready = ctx().jump_ready; /* cleared when the scratch is released (shutdown / device switch) */
   SynthJump *dj = (SynthJump *)ctx().scratch(SL_JUMP, sizeof(SynthJump));
   if (!jump_ready) {
     SynthJump J;
@@ -1617,15 +1669,48 @@ void gs_integral(struct gs_image src, unsigned *ii) { /* ref :744 */
   finish(host);
 }
 
-/* cascade flattening is cached per calling thread, keyed by the struct's contents */
+/* The reference re-reads the caller's tables on every call (ref :790-835), so a cascade edited in
+ * place, or freed and rebuilt at the same addresses, must take effect.  The flattened device copy
+ * is therefore cached per calling thread keyed by a hash of the table CONTENTS (FNV-1a 64 over
+ * ~7 KB: microseconds next to the launch), never by the struct's pointer values. */
+static uint64_t cascade_content_hash(const struct gs_lbp_cascade *c) {
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&](const void *p, size_t n) {
+    const uint8_t *b = (const uint8_t *)p;
+    for (size_t i = 0; i < n; i++) h = (h ^ b[i]) * 1099511628211ull;
+  };
+  const uint16_t dims[5] = {c->window_w, c->window_h, c->nfeatures, c->nweaks, c->nstages};
+  mix(dims, sizeof dims);
+  mix(c->features, (size_t)c->nfeatures * 4);
+  mix(c->weak_feature_idx, (size_t)c->nweaks * 2);
+  mix(c->weak_left_val, (size_t)c->nweaks * 4);
+  mix(c->weak_right_val, (size_t)c->nweaks * 4);
+  mix(c->weak_subset_offset, (size_t)c->nweaks * 2);
+  mix(c->weak_num_subsets, (size_t)c->nweaks * 2);
+  unsigned nsub = 0;
+  for (unsigned i = 0; i < c->nweaks; i++)
+    nsub = std::max(nsub, (unsigned)c->weak_subset_offset[i] + c->weak_num_subsets[i]);
+  mix(c->subsets, (size_t)nsub * 4);
+  mix(c->stage_weak_start, (size_t)c->nstages * 2);
+  mix(c->stage_nweaks, (size_t)c->nstages * 2);
+  mix(c->stage_threshold, (size_t)c->nstages * 4);
+  return h;
+}
 static gsh_cascade *cached_cascade(const struct gs_lbp_cascade *c) {
-  static thread_local gsh_cascade *dc = nullptr;
-  static thread_local struct gs_lbp_cascade key;
-  if (dc && memcmp(&key, c, sizeof key) == 0) return dc;
-  if (dc) gsh_cascade_destroy(dc);
-  dc = gsh_cascade_create(c);
-  key = *c;
-  return dc;
+  struct Slot {
+    gsh_cascade *dc = nullptr;
+    uint64_t hash = 0;
+    ~Slot() {
+      if (dc) gsh_cascade_destroy(dc);
+    }
+  };
+  static thread_local Slot slot;
+  const uint64_t h = cascade_content_hash(c);
+  if (slot.dc && slot.hash == h) return slot.dc;
+  if (slot.dc) gsh_cascade_destroy(slot.dc);
+  slot.dc = gsh_cascade_create(c);
+  slot.hash = h;
+  return slot.dc;
 }
 
 unsigned gs_lbp_detect(const struct gs_lbp_cascade *c, const unsigned *ii, unsigned iw,
@@ -1738,6 +1823,14 @@ float gs_compute_orientation(struct gs_image img, unsigned x, unsigned y, unsign
   GS_ASSERT(GS_VALID(img) && x >= r && y >= r && x < img.w - r && y < img.h - r);
   hipStream_t st = ctx().s();
   const uint8_t *patch = stage_patch(img, (int)x, (int)y, (int)r, SL_AUX2);
+  if (r > kOrientExactR) { /* partial sums can pass 2^24: the reference's float32 order, one thread */
+    float *df = (float *)ctx().scratch(SL_MOM, 16);
+    GS_LAUNCH(k_orient_moments_seq, dim3(1), dim3(1), 0, st, patch, 2 * r + 1, 2 * r + 1, r, r, r, df);
+    float mf[2];
+    GS_HIP(hipMemcpyAsync(mf, df, 8, hipMemcpyDeviceToHost, st));
+    ctx().sync();
+    return atan2f(mf[0], mf[1]);
+  }
   unsigned pt[2] = {r, r};
   unsigned *dp = (unsigned *)ctx().scratch(SL_KIN, 16);
   int *dm = (int *)ctx().scratch(SL_MOM, 16);

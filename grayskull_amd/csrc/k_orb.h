@@ -57,6 +57,30 @@ __global__ __launch_bounds__(64) void k_orient_moments(const uint8_t *img, unsig
   if (threadIdx.x == 0) out[2 * blockIdx.x] = m01, out[2 * blockIdx.x + 1] = m10;
 }
 
+/* The integer sums above equal the reference's float32 accumulation (ref :610-618) only while every
+ * partial sum stays below 2^24: 255 * sum |dy| over the disc ~ 255 * (4/3) r^3, i.e. r <= kOrientExactR
+ * (gs_orb_extract always uses r = 15).  For larger radii the drop-in gs_compute_orientation runs the
+ * reference's loop as it stands: ONE thread, dy outer / dx inner, float32 adds in that order. */
+constexpr unsigned kOrientExactR = 36;
+__global__ void k_orient_moments_seq(const uint8_t *img, unsigned w, unsigned h, unsigned x, unsigned y,
+                                     unsigned r, float *out) {
+#ifndef GS_EMU
+#pragma clang fp contract(off)
+#endif
+  if (threadIdx.x || blockIdx.x) return;
+  float m01 = 0, m10 = 0;
+  const int R = (int)r, rr = (int)(r * r);
+  for (int dy = -R; dy <= R; dy++)
+    for (int dx = -R; dx <= R; dx++)
+      if (dx * dx + dy * dy <= rr) {
+        const unsigned sx = x + (unsigned)dx, sy = y + (unsigned)dy;
+        const int I = (sx < w && sy < h) ? img[(size_t)sy * w + sx] : 0;
+        m01 += (float)(dy * I);
+        m10 += (float)(dx * I);
+      }
+  out[0] = m01, out[1] = m10;
+}
+
 /* grid nkp, block 256 (thread = one of the 256 point pairs); desc: nkp x 8 u32 */
 __global__ __launch_bounds__(256) void k_brief(const uint8_t *img, unsigned w, unsigned h,
                                                const KpIn *kin, uint32_t *desc) {

@@ -19,15 +19,17 @@
  *     calling thread's stream (see grayskull_hip.h), synchronised before return
  *     unless gsh_set_async(1).
  *
- * Out of scope here (not on the hot path): gs_crop, gs_copy,
- * gs_resize*, gs_blobs, contours, perspective, template matching, PGM I/O.
- * Callers that need them include the reference header for those functions.
+ * Out of scope here (not on the hot path): gs_blobs, contours,
+ * perspective correction, PGM I/O, gs_alloc / gs_free.  Callers that need them
+ * include the reference header for those functions.
  */
 #ifndef GRAYSKULL_H
 #define GRAYSKULL_H
 
 #include <limits.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -79,6 +81,10 @@ static inline void gs_set(struct gs_image img, unsigned x, unsigned y, uint8_t v
 }
 static inline uint32_t gs_integral_sum(const unsigned *ii, unsigned iw, unsigned x, unsigned y,
                                        unsigned w, unsigned h) {
+  if (!(ii && iw > 0 && x + w <= iw)) { /* gs_assert of ref :756, same message and abort() */
+    fprintf(stderr, "Assertion failed: %s\n", "ii && iw > 0 && x + w <= iw");
+    abort();
+  }
   unsigned x2 = x + w - 1, y2 = y + h - 1;
   unsigned A = (x > 0 && y > 0) ? ii[(y - 1) * iw + (x - 1)] : 0;
   unsigned B = (y > 0) ? ii[(y - 1) * iw + x2] : 0;

@@ -687,3 +687,64 @@ def test_lbp_caps_on_edge_maps(hip, oracle, cascade):
     for cap in (1, 100, 5000, 200000):
         assert_same(hip.lbp_detect(rc, ii.copy(), cap, 1.3, 1.0, 3.0, 1), oracle.lbp_detect(rc, ii, cap, 1.3, 1.0, 3.0, 1),
                     "random cascade, cap %d" % cap)
+
+
+def test_70000_frame_fast_batch(hip, oracle):
+    """more frames than a grid dimension holds (65535) in ONE gsh_fast_batch call"""
+    import torch
+    from test_emu_logic import fast_many_frames
+    n = 70000
+    one, ko, smo = fast_many_frames(hip, oracle, n)
+    frames = torch.from_numpy(np.repeat(one[None], n, 0)).cuda()
+    frames[n - 1] = 5
+    sm = torch.zeros_like(frames)
+    kps = torch.zeros((n, 4, 12), dtype=torch.int32, device="cuda")
+    counts = torch.zeros(n, dtype=torch.int32, device="cuda")
+    hip.fast_batch(frames, sm, kps, counts, 4, 20)
+    hip.sync()
+    c = counts.cpu().numpy()
+    assert (c[:n - 1] == 1).all() and c[n - 1] == 0
+    k = kps.cpu().numpy().view(np.uint32)
+    assert (k[:n - 1, 0] == ko.view(np.uint32).reshape(-1)[None]).all()
+    assert bool((sm[:n - 1] == torch.from_numpy(smo).cuda()[None]).all())
+
+
+def test_two_threads_share_one_cascade_handle(hip, oracle, cascade):
+    """gsh_lbp_detect_batch keeps its scan geometry per calling thread, not in the (shared, const)
+    handle: two threads scanning different frame sizes through one handle must not disturb each other"""
+    import threading
+    import torch
+    dc = hip.cascade_create(cascade)
+    jobs = []
+    for (w, h, seed) in ((320, 240, 3), (256, 200, 4)):
+        img = Oracle.synth(w, h, seed)
+        ii = oracle.integral(img)
+        jobs.append((w, h, torch.from_numpy(ii.view(np.int32)).cuda()[None].contiguous(), oracle.lbp_detect(cascade, ii, 500, 1.2, 1.0, 3.0, 1)))
+    errors = []
+
+    def work(job):
+        try:
+            w, h, dii, ro = job
+            hip.set_device(0)
+            rects = torch.zeros((1, 500, 4), dtype=torch.int32, device="cuda")
+            counts = torch.zeros(1, dtype=torch.int32, device="cuda")
+            for _ in range(25):
+                hip.lbp_detect_batch(dc, dii, rects, counts, 500, 1.2, 1.0, 3.0, 1)
+                hip.sync()
+                n = int(counts[0])
+                got = rects[0, :n].cpu().numpy().view(np.uint32)
+                exp = np.stack([ro["x"], ro["y"], ro["w"], ro["h"]], 1) if len(ro) else got
+                if n != len(ro) or not np.array_equal(got, exp):
+                    errors.append((w, h, n, len(ro)))
+                    return
+            hip.shutdown()
+        except Exception as e:  # noqa
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(j,)) for j in jobs]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    dc.close()
+    assert not errors, errors
