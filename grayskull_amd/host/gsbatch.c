@@ -18,14 +18,26 @@
  * Verbs (nanomagick.c:52-141, same argument meaning / error text):
  *   resize <w> <h> | crop <x> <y> <w> <h> | blur <r> | threshold <t|otsu> | adaptive <r> <c> |
  *   sobel | morph <erode|dilate> <n>
+ * and, as the LAST stage of a chain, the two feature verbs (nanomagick.c:217-243, :347-376):
+ *   keypoints <n> <t>   gs_fast (cap 5000, threshold t) on the GPU; the n strongest are drawn as
+ *                       crosses like nanomagick does and listed in <out>.keypoints.txt ("x y response")
+ *   faces <n>           gs_integral + gs_lbp_detect (cap 100, scale 1.2, 1..4, step n) on the GPU with
+ *                       the cascade blob given by --cascade; boxes drawn like nanomagick, listed in
+ *                       <out>.faces.txt ("x y w h").  (nanomagick's 640x480 limit is its static buffer
+ *                       and is not imposed here.)
+ * --gpus N shards the files of every size group over N GPUs (contiguous, balanced blocks of the
+ * group's files: the frame_range rule of grayskull_amd/shard.py), one host thread per device
+ * (gsh_set_device); frames never leave their GPU and no collective is needed -- the per-file results
+ * land in the process's own memory.
  * PGM reading / writing follows the reference's gs_read_pgm / gs_write_pgm (grayskull.h:111-136):
  * binary P5, maxval 255, header "P5\n%u %u\n255\n".
  *
- * usage: gsbatch [-v] -o <outdir> <verb> [args] [: <verb> [args]]... -- in1.pgm [in2.pgm ...]
+ * usage: gsbatch [-v] [--gpus N] [--cascade blob] -o <outdir> <verb> [args] [: <verb> [args]]... -- in1.pgm [in2.pgm ...]
  * exit:  0 all files written; 1 usage / stage error / at least one file failed (message on stderr,
  *        same wording as nanomagick where it has one).
  */
-#define _POSIX_C_SOURCE 200112L /* clock_gettime under -std=c99 */
+#define _POSIX_C_SOURCE 200112L /* clock_gettime, pthreads under -std=c99 */
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -37,7 +49,9 @@ static size_t kSliceBytes = (size_t)64 << 20; /* per plane and slice (8 4K frame
    Measured on 64 4K files (profiles/r01i_gsbatch_64x4k.log): page-locking the staging buffer costs ~85 ms
    per GiB, so small slices win: 0.44 s wall at 64 MiB vs 0.64 s at 1 GiB */
 
-enum verb { V_RESIZE, V_CROP, V_BLUR, V_THRESHOLD, V_ADAPTIVE, V_SOBEL, V_MORPH };
+enum verb { V_RESIZE, V_CROP, V_BLUR, V_THRESHOLD, V_ADAPTIVE, V_SOBEL, V_MORPH, V_KEYPOINTS, V_FACES };
+#define IS_TERMINAL(v) ((v) == V_KEYPOINTS || (v) == V_FACES)
+enum { kFastCap = 5000, kFaceCap = 100 }; /* nanomagick.c:224, :349 */
 
 struct stage {
   enum verb v;
@@ -52,7 +66,8 @@ static const struct {
   enum verb v;
   int argc;
 } verbs[] = {{"resize", V_RESIZE, 2},     {"crop", V_CROP, 4},   {"blur", V_BLUR, 1}, {"threshold", V_THRESHOLD, 1},
-             {"adaptive", V_ADAPTIVE, 2}, {"sobel", V_SOBEL, 0}, {"morph", V_MORPH, 2}, {NULL, V_SOBEL, 0}};
+             {"adaptive", V_ADAPTIVE, 2}, {"sobel", V_SOBEL, 0}, {"morph", V_MORPH, 2},
+             {"keypoints", V_KEYPOINTS, 2}, {"faces", V_FACES, 1}, {NULL, V_SOBEL, 0}};
 
 struct frame {
   const char *path;
@@ -70,9 +85,10 @@ static double now_ms(void) {
 
 static void usage(const char *app) {
   fprintf(stderr,
-          "Usage: %s [-v] -o <outdir> <verb> [params] [: <verb> [params]]... -- in1.pgm [in2.pgm ...]\n"
+          "Usage: %s [-v] [--gpus N] [--cascade blob] -o <outdir> <verb> [params] [: <verb> [params]]... -- in1.pgm [in2.pgm ...]\n"
           "Verbs: resize <w> <h> | crop <x> <y> <w> <h> | blur <r> | threshold <t|otsu> |\n"
-          "       adaptive <r> <c> | sobel | morph <erode|dilate> <n>\n",
+          "       adaptive <r> <c> | sobel | morph <erode|dilate> <n>\n"
+          "       last stage only: keypoints <n> <t> | faces <n>  (faces needs --cascade)\n",
           app);
 }
 
@@ -173,6 +189,12 @@ static int parse_stages(int argc, char **argv, int *pos, struct stage *st, int m
     n++;
   }
   *pos = i;
+  for (i = 0; i + 1 < n; i++)
+    if (IS_TERMINAL(st[i].v)) {
+      fprintf(stderr, "Error: '%s' writes detections, not an image to filter on: it must be the last stage\n",
+              st[i].v == V_FACES ? "faces" : "keypoints");
+      return -1;
+    }
   return n;
 }
 
@@ -199,6 +221,13 @@ static int check_stage(const struct stage *s, unsigned w, unsigned h) {
     case V_MORPH:
       if (!s->a[0] || s->a[1] <= 0)
         return fprintf(stderr, "Error: Invalid morphological operation or iterations\n"), -1;
+      break;
+    case V_KEYPOINTS: /* nanomagick.c:219-222 */
+      if (s->a[0] <= 0 || s->a[1] < 0)
+        return fprintf(stderr, "Error: Invalid number of keypoints or threshold\n"), -1;
+      break;
+    case V_FACES: /* nanomagick.c:351-355 */
+      if (s->a[0] <= 0) return fprintf(stderr, "Error: minimum neighbors must be positive\n"), -1;
       break;
     case V_SOBEL: break;
   }
@@ -308,6 +337,8 @@ static void run_stages(const struct stage *st, int ns, struct planes *p, unsigne
         swap_planes(p);
         break;
       }
+      case V_KEYPOINTS:
+      case V_FACES: break; /* terminal verbs: detect_* below, after the image chain */
     }
     i++;
   }
@@ -320,18 +351,305 @@ static const char *base_name(const char *path) {
   return s ? s + 1 : path;
 }
 
+/* ---- LBP cascade blob (layout: grayskull_amd/cascade.py; tests/golden/frontalface_cascade.bin) ---- */
+struct cascade_file {
+  struct gs_lbp_cascade c;
+  uint8_t *raw;
+};
+static int load_cascade(const char *path, struct cascade_file *cf) {
+  FILE *fp = fopen(path, "rb");
+  long sz;
+  uint16_t hdr[6];
+  uint32_t nsub;
+  size_t off = 20, cnt[10], esz[10] = {1, 2, 4, 4, 2, 2, 4, 2, 2, 4};
+  const void *arr[10];
+  int i;
+  if (!fp) return -1;
+  if (fseek(fp, 0, SEEK_END) != 0 || (sz = ftell(fp)) < 20 || fseek(fp, 0, SEEK_SET) != 0) return fclose(fp), -1;
+  cf->raw = (uint8_t *)malloc((size_t)sz);
+  if (!cf->raw || fread(cf->raw, 1, (size_t)sz, fp) != (size_t)sz) return fclose(fp), -1;
+  fclose(fp);
+  if (memcmp(cf->raw, "LBPC", 4) != 0) return -1;
+  memcpy(hdr, cf->raw + 4, sizeof hdr); /* window_w, window_h, nfeatures, nweaks, nstages, pad */
+  memcpy(&nsub, cf->raw + 16, 4);
+  cnt[0] = (size_t)hdr[2] * 4, cnt[1] = cnt[2] = cnt[3] = cnt[4] = cnt[5] = hdr[3], cnt[6] = nsub;
+  cnt[7] = cnt[8] = cnt[9] = hdr[4];
+  for (i = 0; i < 10; i++) {
+    arr[i] = cf->raw + off;
+    off += (cnt[i] * esz[i] + 3) & ~(size_t)3;
+  }
+  if (off > (size_t)sz) return -1;
+  cf->c.window_w = hdr[0], cf->c.window_h = hdr[1], cf->c.nfeatures = hdr[2], cf->c.nweaks = hdr[3], cf->c.nstages = hdr[4];
+  cf->c.features = (const int8_t *)arr[0], cf->c.weak_feature_idx = (const uint16_t *)arr[1];
+  cf->c.weak_left_val = (const float *)arr[2], cf->c.weak_right_val = (const float *)arr[3];
+  cf->c.weak_subset_offset = (const uint16_t *)arr[4], cf->c.weak_num_subsets = (const uint16_t *)arr[5];
+  cf->c.subsets = (const int32_t *)arr[6], cf->c.stage_weak_start = (const uint16_t *)arr[7];
+  cf->c.stage_nweaks = (const uint16_t *)arr[8], cf->c.stage_threshold = (const float *)arr[9];
+  return 0;
+}
+
+/* nanomagick.c:172-184, restated: Bresenham with clipping */
+static void draw_line(uint8_t *img, unsigned w, unsigned h, unsigned x1, unsigned y1, unsigned x2, unsigned y2,
+                      uint8_t color) {
+  int dx = abs((int)x2 - (int)x1), dy = abs((int)y2 - (int)y1);
+  int sx = x1 < x2 ? 1 : -1, sy = y1 < y2 ? 1 : -1, err = dx - dy;
+  int x = (int)x1, y = (int)y1;
+  for (;;) {
+    int e2;
+    if (x >= 0 && x < (int)w && y >= 0 && y < (int)h) img[(size_t)y * w + (unsigned)x] = color;
+    if (x == (int)x2 && y == (int)y2) break;
+    e2 = 2 * err;
+    if (e2 > -dy) err -= dy, x += sx;
+    if (e2 < dx) err += dx, y += sy;
+  }
+}
+static void set_px(uint8_t *img, unsigned w, unsigned h, unsigned x, unsigned y) { /* gs_set: out of range = no-op */
+  if (x < w && y < h) img[(size_t)y * w + x] = 255;
+}
+static int by_response_desc(const void *a, const void *b) { /* nanomagick.c:211-215, same comparator, same libc qsort */
+  const struct gs_keypoint *k1 = (const struct gs_keypoint *)a, *k2 = (const struct gs_keypoint *)b;
+  return (int)(k2->response - k1->response);
+}
+
+/* everything one worker (= one GPU) needs */
+struct job {
+  int device, ndev, verbose;
+  const struct stage *st;
+  int ns;
+  struct frame *fr;
+  int nf, ngroups;
+  const char *outdir;
+  const struct gs_lbp_cascade *cascade;
+  int rc;
+  double t_alloc, t_read, t_up, t_run, t_down, t_write;
+};
+
+/* contiguous, balanced share of `total` items for worker `rank` of `world` (grayskull_amd/shard.py frame_range) */
+static void frame_range(unsigned rank, unsigned world, unsigned total, unsigned *lo, unsigned *hi) {
+  const unsigned base = total / world, rem = total % world;
+  *lo = rank * base + (rank < rem ? rank : rem);
+  *hi = *lo + base + (rank < rem ? 1 : 0);
+}
+
+static void *worker(void *arg) {
+  struct job *jb = (struct job *)arg;
+  const struct stage *st = jb->st;
+  const int ns = jb->ns, nf = jb->nf;
+  struct frame *fr = jb->fr;
+  const struct stage *term = (ns > 0 && IS_TERMINAL(st[ns - 1].v)) ? &st[ns - 1] : NULL;
+  gsh_cascade *dc = NULL;
+  int g, i;
+  gsh_set_device(jb->device);
+  gsh_set_async(1); /* per-frame gs_resize / gs_crop on device pointers stay stream-ordered */
+  if (term && term->v == V_FACES) dc = gsh_cascade_create(jb->cascade);
+
+  for (g = 0; g < jb->ngroups; g++) {
+    unsigned w = 0, h = 0, ngroup = 0, n, lo, hi, f, ow, oh;
+    size_t max_fb, fb;
+    struct planes p;
+    int *failed, bad = 0;
+    uint8_t *stage;
+    unsigned cap, b0;
+    int *idx;
+    double t0;
+    /* terminal-verb buffers */
+    uint8_t *score = NULL;
+    struct gs_keypoint *kps_dev = NULL, *kps_host = NULL;
+    unsigned *ii = NULL, *cnt_dev = NULL, *cnt_host = NULL;
+    struct gs_rect *rects_dev = NULL, *rects_host = NULL;
+    for (i = 0; i < nf; i++)
+      if (fr[i].group == g) w = fr[i].w, h = fr[i].h, ngroup++;
+    /* the share index rotates with the group so that many small groups (one odd-sized file each)
+     * spread over the GPUs instead of all landing on GPU 0 */
+    frame_range((unsigned)(jb->device + g) % (unsigned)jb->ndev, (unsigned)jb->ndev, ngroup, &lo, &hi);
+    n = hi - lo;
+    if (n == 0) continue;
+    /* validate the chain for this size and find the largest plane it needs */
+    ow = w, oh = h, max_fb = (size_t)w * h;
+    for (i = 0; i < ns && !bad; i++) {
+      if (check_stage(&st[i], ow, oh) != 0) bad = 1;
+      stage_out_size(&st[i], &ow, &oh);
+      if ((size_t)ow * oh > max_fb) max_fb = (size_t)ow * oh;
+    }
+    idx = (int *)malloc(ngroup * sizeof *idx);
+    if (!idx) return jb->rc = 1, (void *)0;
+    for (i = 0, f = 0; i < nf; i++)
+      if (fr[i].group == g) idx[f++] = i;
+    if (bad) { /* nanomagick: the verb prints its message, then "did not produce output image" */
+      for (f = lo; f < hi; f++) {
+        fprintf(stderr, "Error: %s: chain did not produce output image\n", fr[idx[f]].path);
+        fr[idx[f]].failed = 1;
+      }
+      jb->rc = 1;
+      free(idx);
+      continue;
+    }
+    fb = (size_t)w * h;
+    /* a group is processed in slices of at most kSliceBytes per plane, so that the page-locked
+     * staging buffer and the two device planes stay bounded whatever the number of files */
+    cap = (unsigned)(kSliceBytes / max_fb);
+    if (term && cap > 256) cap = 256; /* 240 KB of keypoint records / 4 bytes of integral per pixel per frame */
+    cap = cap < 1 ? 1 : cap > n ? n : cap;
+    t0 = now_ms();
+    p.cur = (uint8_t *)gsh_malloc(max_fb * cap);
+    p.other = (uint8_t *)gsh_malloc(max_fb * cap);
+    p.hist = (unsigned *)gsh_malloc((size_t)cap * 256 * sizeof(unsigned));
+    p.thr_dev = (uint8_t *)gsh_malloc(cap);
+    p.thr_host = (uint8_t *)malloc(cap);
+    failed = (int *)malloc(cap * sizeof *failed);
+    stage = (uint8_t *)gsh_host_alloc(max_fb * cap); /* page-locked: one DMA each way per slice */
+    if (term) {
+      const size_t ofb = (size_t)ow * oh;
+      cnt_dev = (unsigned *)gsh_malloc((size_t)cap * sizeof(unsigned));
+      cnt_host = (unsigned *)malloc((size_t)cap * sizeof(unsigned));
+      if (term->v == V_KEYPOINTS) {
+        score = (uint8_t *)gsh_malloc(ofb * cap);
+        kps_dev = (struct gs_keypoint *)gsh_malloc((size_t)cap * kFastCap * sizeof *kps_dev);
+        kps_host = (struct gs_keypoint *)malloc((size_t)cap * kFastCap * sizeof *kps_host);
+      } else {
+        ii = (unsigned *)gsh_malloc(ofb * cap * sizeof(unsigned));
+        rects_dev = (struct gs_rect *)gsh_malloc((size_t)cap * kFaceCap * sizeof *rects_dev);
+        rects_host = (struct gs_rect *)malloc((size_t)cap * kFaceCap * sizeof *rects_host);
+      }
+      if (!cnt_host || (term->v == V_KEYPOINTS ? !kps_host : !rects_host)) return jb->rc = 1, (void *)0;
+    }
+    jb->t_alloc += now_ms() - t0;
+    if (!p.thr_host || !failed) return jb->rc = 1, (void *)0;
+
+    for (b0 = 0; b0 < n; b0 += cap) {
+      const unsigned nb = n - b0 < cap ? n - b0 : cap;
+      memset(failed, 0, nb * sizeof *failed);
+      t0 = now_ms();
+      for (f = 0; f < nb; f++) {
+        const struct frame *fi = &fr[idx[lo + b0 + f]];
+        if (read_pgm_pixels(fi, stage + fb * f) != 0) {
+          fprintf(stderr, "Error: Could not load %s\n", fi->path);
+          memset(stage + fb * f, 0, fb);
+          failed[f] = 2; /* unreadable: no second message later */
+        }
+      }
+      jb->t_read += now_ms() - t0;
+
+      t0 = now_ms();
+      gsh_upload(p.cur, stage, fb * nb);
+      jb->t_up += now_ms() - t0;
+
+      t0 = now_ms();
+      ow = w, oh = h;
+      run_stages(st, ns, &p, nb, &ow, &oh, failed);
+      if (term && term->v == V_KEYPOINTS) { /* nanomagick.c:229-230: gs_fast into a zeroed score map, cap 5000 */
+        gsh_memset(score, 0, (size_t)ow * oh * nb);
+        gsh_fast_batch(p.cur, score, ow, oh, nb, kps_dev, cnt_dev, kFastCap, (unsigned)term->a[1]);
+      } else if (term) { /* nanomagick.c:362-364 */
+        gsh_integral_batch(p.cur, ow, oh, nb, ii);
+        gsh_lbp_detect_batch(dc, ii, ow, oh, nb, rects_dev, cnt_dev, kFaceCap, 1.2f, 1.0f, 4.0f, term->a[0]);
+      }
+      gsh_sync();
+      jb->t_run += now_ms() - t0;
+
+      t0 = now_ms();
+      gsh_download(stage, p.cur, (size_t)ow * oh * nb);
+      if (term) {
+        gsh_download(cnt_host, cnt_dev, (size_t)nb * sizeof(unsigned));
+        if (term->v == V_KEYPOINTS) gsh_download(kps_host, kps_dev, (size_t)nb * kFastCap * sizeof *kps_host);
+        else gsh_download(rects_host, rects_dev, (size_t)nb * kFaceCap * sizeof *rects_host);
+      }
+      jb->t_down += now_ms() - t0;
+
+      t0 = now_ms();
+      for (f = 0; f < nb; f++) {
+        struct frame *fi = &fr[idx[lo + b0 + f]];
+        uint8_t *img = stage + (size_t)ow * oh * f;
+        char path[4096];
+        if (failed[f]) {
+          if (failed[f] == 1) fprintf(stderr, "Error: %s did not produce output image\n", fi->path);
+          fi->failed = 1, jb->rc = 1;
+          continue;
+        }
+        if (term) { /* records first (the numbers before any drawing), then nanomagick's drawing */
+          FILE *rec;
+          unsigned k, cnt = cnt_host[f];
+          snprintf(path, sizeof path, "%s/%s.%s.txt", jb->outdir, base_name(fi->path),
+                   term->v == V_KEYPOINTS ? "keypoints" : "faces");
+          rec = fopen(path, "w");
+          if (!rec) {
+            fprintf(stderr, "Error: Could not save %s\n", path);
+            jb->rc = 1;
+          }
+          if (term->v == V_KEYPOINTS) {
+            struct gs_keypoint *kp = kps_host + (size_t)f * kFastCap;
+            const unsigned show = (unsigned)term->a[0] < cnt ? (unsigned)term->a[0] : cnt;
+            qsort(kp, cnt, sizeof *kp, by_response_desc);
+            for (k = 0; k < show; k++) {
+              const unsigned x = kp[k].pt.x, y = kp[k].pt.y;
+              int d;
+              if (rec) fprintf(rec, "%u %u %u\n", x, y, kp[k].response);
+              for (d = -2; d <= 2; d++) set_px(img, ow, oh, x, y + (unsigned)d), set_px(img, ow, oh, x + (unsigned)d, y);
+            }
+          } else {
+            const struct gs_rect *r = rects_host + (size_t)f * kFaceCap;
+            for (k = 0; k < cnt; k++) {
+              if (rec) fprintf(rec, "%u %u %u %u\n", r[k].x, r[k].y, r[k].w, r[k].h);
+              draw_line(img, ow, oh, r[k].x, r[k].y, r[k].x + r[k].w, r[k].y, 255);
+              draw_line(img, ow, oh, r[k].x, r[k].y + r[k].h, r[k].x + r[k].w, r[k].y + r[k].h, 255);
+              draw_line(img, ow, oh, r[k].x, r[k].y, r[k].x, r[k].y + r[k].h, 255);
+              draw_line(img, ow, oh, r[k].x + r[k].w, r[k].y, r[k].x + r[k].w, r[k].y + r[k].h, 255);
+            }
+          }
+          if (rec) fclose(rec);
+        }
+        snprintf(path, sizeof path, "%s/%s", jb->outdir, base_name(fi->path));
+        if (write_pgm(path, img, ow, oh) != 0) {
+          fprintf(stderr, "Error: Could not save %s\n", path);
+          jb->rc = 1;
+        }
+      }
+      jb->t_write += now_ms() - t0;
+    }
+    if (jb->verbose)
+      fprintf(stderr, "gpu %d group %d: %u of %u frame(s) %ux%u -> %ux%u\n", jb->device, g, n, ngroup, w, h, ow, oh);
+    gsh_free(p.cur);
+    gsh_free(p.other);
+    gsh_free(p.hist);
+    gsh_free(p.thr_dev);
+    gsh_host_free(stage);
+    gsh_free(score);
+    gsh_free(kps_dev);
+    gsh_free(ii);
+    gsh_free(rects_dev);
+    gsh_free(cnt_dev);
+    free(kps_host);
+    free(rects_host);
+    free(cnt_host);
+    free(p.thr_host);
+    free(failed);
+    free(idx);
+  }
+  if (dc) gsh_cascade_destroy(dc);
+  gsh_shutdown();
+  return (void *)0;
+}
+
 int main(int argc, char **argv) {
   struct stage st[64];
   struct frame *fr;
-  const char *outdir = NULL;
-  int verbose = 0, pos = 1, ns, nf, i, g, ngroups = 0, rc = 0;
-  double t_io0, t_up = 0, t_run = 0, t_down = 0, t_read, t_write = 0, t_alloc = 0;
+  const char *outdir = NULL, *cascade_path = getenv("GSBATCH_CASCADE");
+  struct cascade_file cf;
+  struct job *jobs;
+  pthread_t *th;
+  int verbose = 0, pos = 1, ns, nf, i, ngroups = 0, rc = 0, ngpus = 1, d;
+  double t_io0, t_read, t0;
 
+  memset(&cf, 0, sizeof cf);
   while (pos < argc && argv[pos][0] == '-' && argv[pos][1] && strcmp(argv[pos], "--") != 0) {
     if (strcmp(argv[pos], "-v") == 0) {
       verbose = 1, pos++;
     } else if (strcmp(argv[pos], "-o") == 0 && pos + 1 < argc) {
       outdir = argv[pos + 1], pos += 2;
+    } else if (strcmp(argv[pos], "--gpus") == 0 && pos + 1 < argc) {
+      ngpus = atoi(argv[pos + 1]), pos += 2;
+    } else if (strcmp(argv[pos], "--cascade") == 0 && pos + 1 < argc) {
+      cascade_path = argv[pos + 1], pos += 2;
     } else {
       usage(argv[0]);
       return 1;
@@ -339,12 +657,19 @@ int main(int argc, char **argv) {
   }
   ns = parse_stages(argc, argv, &pos, st, 64);
   if (ns < 0) return 1;
-  if (ns == 0 || !outdir || pos >= argc || strcmp(argv[pos], "--") != 0 || pos + 1 >= argc) {
+  if (ns == 0 || !outdir || ngpus < 1 || pos >= argc || strcmp(argv[pos], "--") != 0 || pos + 1 >= argc) {
     usage(argv[0]);
     return 1;
   }
   pos++;
   nf = argc - pos;
+  if (st[ns - 1].v == V_FACES) {
+    if (!cascade_path || load_cascade(cascade_path, &cf) != 0) {
+      fprintf(stderr, "Error: faces needs a cascade blob (--cascade <file> or GSBATCH_CASCADE)%s%s\n",
+              cascade_path ? ": cannot read " : "", cascade_path ? cascade_path : "");
+      return 1;
+    }
+  }
   if (getenv("GSBATCH_SLICE_BYTES")) kSliceBytes = (size_t)strtoull(getenv("GSBATCH_SLICE_BYTES"), NULL, 10);
   fr = (struct frame *)calloc((size_t)nf, sizeof *fr);
   if (!fr) return 1;
@@ -366,119 +691,45 @@ int main(int argc, char **argv) {
   }
   t_read = now_ms() - t_io0;
 
-  if (gsh_device_count() < 1) {
+  d = gsh_device_count();
+  if (d < 1) {
     fprintf(stderr, "Error: no HIP device\n");
     return 1;
   }
-  gsh_set_async(1); /* per-frame gs_resize / gs_crop on device pointers stay stream-ordered */
-
-  for (g = 0; g < ngroups; g++) {
-    unsigned w = 0, h = 0, n = 0, f, ow, oh;
-    size_t max_fb, fb;
-    struct planes p;
-    int *failed, bad = 0;
-    uint8_t *stage;
-    unsigned cap, b0;
-    int *idx;
-    double t0;
-    for (i = 0; i < nf; i++)
-      if (fr[i].group == g) w = fr[i].w, h = fr[i].h, n++;
-    /* validate the chain for this size and find the largest plane it needs */
-    ow = w, oh = h, max_fb = (size_t)w * h;
-    for (i = 0; i < ns && !bad; i++) {
-      if (check_stage(&st[i], ow, oh) != 0) bad = 1;
-      stage_out_size(&st[i], &ow, &oh);
-      if ((size_t)ow * oh > max_fb) max_fb = (size_t)ow * oh;
-    }
-    if (bad) { /* nanomagick: the verb prints its message, then "did not produce output image" */
-      for (i = 0; i < nf; i++)
-        if (fr[i].group == g) {
-          fprintf(stderr, "Error: %s: chain did not produce output image\n", fr[i].path);
-          fr[i].failed = 1;
-        }
-      rc = 1;
-      continue;
-    }
-    fb = (size_t)w * h;
-    /* a group is processed in slices of at most kSliceBytes per plane, so that the page-locked
-     * staging buffer and the two device planes stay bounded whatever the number of files */
-    cap = (unsigned)(kSliceBytes / max_fb);
-    cap = cap < 1 ? 1 : cap > n ? n : cap;
-    idx = (int *)malloc(n * sizeof *idx);
-    t0 = now_ms();
-    p.cur = (uint8_t *)gsh_malloc(max_fb * cap);
-    p.other = (uint8_t *)gsh_malloc(max_fb * cap);
-    p.hist = (unsigned *)gsh_malloc((size_t)cap * 256 * sizeof(unsigned));
-    p.thr_dev = (uint8_t *)gsh_malloc(cap);
-    p.thr_host = (uint8_t *)malloc(cap);
-    failed = (int *)malloc(cap * sizeof *failed);
-    stage = (uint8_t *)gsh_host_alloc(max_fb * cap); /* page-locked: one DMA each way per slice */
-    t_alloc += now_ms() - t0;
-    if (!p.thr_host || !failed || !idx) return 1;
-    for (i = 0, f = 0; i < nf; i++)
-      if (fr[i].group == g) idx[f++] = i;
-
-    for (b0 = 0; b0 < n; b0 += cap) {
-      const unsigned nb = n - b0 < cap ? n - b0 : cap;
-      memset(failed, 0, nb * sizeof *failed);
-      t0 = now_ms();
-      for (f = 0; f < nb; f++) {
-        const struct frame *fi = &fr[idx[b0 + f]];
-        if (read_pgm_pixels(fi, stage + fb * f) != 0) {
-          fprintf(stderr, "Error: Could not load %s\n", fi->path);
-          memset(stage + fb * f, 0, fb);
-          failed[f] = 2; /* unreadable: no second message later */
-        }
-      }
-      t_read += now_ms() - t0;
-
-      t0 = now_ms();
-      gsh_upload(p.cur, stage, fb * nb);
-      t_up += now_ms() - t0;
-
-      t0 = now_ms();
-      ow = w, oh = h;
-      run_stages(st, ns, &p, nb, &ow, &oh, failed);
-      gsh_sync();
-      t_run += now_ms() - t0;
-
-      t0 = now_ms();
-      gsh_download(stage, p.cur, (size_t)ow * oh * nb);
-      t_down += now_ms() - t0;
-
-      t0 = now_ms();
-      for (f = 0; f < nb; f++) {
-        struct frame *fi = &fr[idx[b0 + f]];
-        char path[4096];
-        if (failed[f]) {
-          if (failed[f] == 1) fprintf(stderr, "Error: %s did not produce output image\n", fi->path);
-          fi->failed = 1, rc = 1;
-        } else {
-          snprintf(path, sizeof path, "%s/%s", outdir, base_name(fi->path));
-          if (write_pgm(path, stage + (size_t)ow * oh * f, ow, oh) != 0) {
-            fprintf(stderr, "Error: Could not save %s\n", path);
-            rc = 1;
-          }
-        }
-      }
-      t_write += now_ms() - t0;
-    }
-    if (verbose)
-      fprintf(stderr, "group %d: %u frame(s) %ux%u -> %ux%u\n", g, n, w, h, ow, oh);
-    gsh_free(p.cur);
-    gsh_free(p.other);
-    gsh_free(p.hist);
-    gsh_free(p.thr_dev);
-    gsh_host_free(stage);
-    free(p.thr_host);
-    free(failed);
-    free(idx);
+  if (ngpus > d) {
+    fprintf(stderr, "Error: --gpus %d but only %d HIP device(s) visible\n", ngpus, d);
+    return 1;
   }
 
-  if (verbose)
-    fprintf(stderr, "files %d groups %d | alloc %.2f ms, read %.2f ms, upload %.2f ms, stages %.2f ms, download %.2f ms, write %.2f ms\n",
-            nf, ngroups, t_alloc, t_read, t_up, t_run, t_down, t_write);
+  jobs = (struct job *)calloc((size_t)ngpus, sizeof *jobs);
+  th = (pthread_t *)calloc((size_t)ngpus, sizeof *th);
+  if (!jobs || !th) return 1;
+  t0 = now_ms();
+  for (d = 0; d < ngpus; d++) {
+    struct job *jb = &jobs[d];
+    jb->device = d, jb->ndev = ngpus, jb->verbose = verbose, jb->st = st, jb->ns = ns, jb->fr = fr, jb->nf = nf;
+    jb->ngroups = ngroups, jb->outdir = outdir, jb->cascade = &cf.c;
+    if (ngpus == 1) {
+      worker(jb); /* the calling thread is the one worker */
+    } else if (pthread_create(&th[d], NULL, worker, jb) != 0) {
+      fprintf(stderr, "Error: cannot start the worker for GPU %d\n", d);
+      return 1;
+    }
+  }
+  for (d = 0; d < ngpus; d++) {
+    if (ngpus > 1) pthread_join(th[d], NULL);
+    rc |= jobs[d].rc;
+  }
+  if (verbose) {
+    fprintf(stderr, "files %d groups %d gpus %d | headers %.2f ms, workers %.2f ms wall\n", nf, ngroups, ngpus, t_read,
+            now_ms() - t0);
+    for (d = 0; d < ngpus; d++)
+      fprintf(stderr, "gpu %d: alloc %.2f ms, read %.2f ms, upload %.2f ms, stages %.2f ms, download %.2f ms, write %.2f ms\n", d,
+              jobs[d].t_alloc, jobs[d].t_read, jobs[d].t_up, jobs[d].t_run, jobs[d].t_down, jobs[d].t_write);
+  }
+  free(cf.raw);
+  free(jobs);
+  free(th);
   free(fr);
-  gsh_shutdown();
   return rc;
 }

@@ -8,7 +8,7 @@
 namespace emu {
 
 State &S() {
-  static State s;
+  static thread_local State s; /* one emulated device per host thread */
   return s;
 }
 

@@ -32,7 +32,7 @@
 #define __device__
 #define __host__
 #define __forceinline__ inline
-#define __shared__ static
+#define __shared__ static thread_local /* one emulated device per host thread (gsbatch --gpus N) */
 #define __launch_bounds__(...)
 #define __restrict__ __restrict
 
@@ -145,6 +145,10 @@ inline hipError_t hipStreamCreate(hipStream_t *s) { *s = nullptr; return 0; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
 inline hipError_t hipGetLastError() { return 0; }
 inline hipError_t hipSetDevice(int) { return 0; }
-inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return 0; }
+inline hipError_t hipGetDeviceCount(int *n) { /* GS_EMU_DEVICES: pretend to have that many GPUs (multi-GPU host logic) */
+  const char *e = getenv("GS_EMU_DEVICES");
+  *n = e && atoi(e) > 0 ? atoi(e) : 1;
+  return 0;
+}
 inline const char *hipGetErrorString(hipError_t) { return "emu"; }
 #endif

@@ -31,7 +31,7 @@ def build_emu(tmp_path):
     emu = os.path.join(ROOT, "tests", "emu")
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "grayskull_amd", "csrc"), "emu"])
     exe = str(tmp_path / "gsbatch_emu")
-    subprocess.check_call(CFLAGS + [SRC, "-o", exe, "-L" + emu, "-lgs_kernel_emu", "-Wl,-rpath," + emu])
+    subprocess.check_call(CFLAGS + [SRC, "-o", exe, "-L" + emu, "-lgs_kernel_emu", "-pthread", "-Wl,-rpath," + emu])
     return exe
 
 
@@ -92,6 +92,97 @@ def test_gsbatch_equals_piped_nanomagick_emulated(tmp_path):
             exp, _ = nano_chain(nano, chain, f, tmp_path, "ref%d_%d" % (c, i))
             got = open(str(outdir / os.path.basename(f)), "rb").read()
             assert exp is not None and got == open(exp, "rb").read(), "chain %d file %s differs" % (c, f)
+
+
+CASCADE = os.path.join(ROOT, "tests", "golden", "frontalface_cascade.bin")
+FEATURE_CHAINS = [
+    [("keypoints", ["100", "20"])],
+    [("blur", ["1"]), ("keypoints", ["30", "10"])],
+    [("faces", ["1"])],
+    [("blur", ["2"]), ("sobel", []), ("faces", ["1"])],   # the chain of BASELINE configs[4], through the CLI
+    [("resize", ["200", "150"]), ("faces", ["2"])],
+]
+
+
+def read_records(path):
+    return [tuple(int(x) for x in line.split()) for line in open(path).read().splitlines()]
+
+
+def check_feature_outputs(outdir, f, chain, o, casc):
+    """the sidecar records = what the reference computes before drawing (nanomagick.c:229-233, :362-364)"""
+    img = oracle_chain(o, read_pgm(f), chain[:-1])
+    verb, args = chain[-1]
+    if verb == "keypoints":
+        n, t = int(args[0]), int(args[1])
+        kps, _ = o.fast(img, 5000, t)
+        rec = read_records(str(outdir / (os.path.basename(f) + ".keypoints.txt")))
+        assert len(rec) == min(n, len(kps))
+        # qsort by response: the multiset of the strongest responses is fixed, their coordinates are among the detections
+        assert sorted(r[2] for r in rec) == sorted(sorted((int(k) for k in kps["response"]), reverse=True)[:len(rec)])
+        have = {(int(k["x"]), int(k["y"]), int(k["response"])) for k in kps}
+        assert all(r in have for r in rec)
+    else:
+        ro = o.lbp_detect(casc, o.integral(img), 100, 1.2, 1.0, 4.0, int(args[0]))
+        rec = read_records(str(outdir / (os.path.basename(f) + ".faces.txt")))
+        assert rec == [(int(r["x"]), int(r["y"]), int(r["w"]), int(r["h"])) for r in ro]
+
+
+@pytest.mark.skipif(not os.path.exists(NANO), reason="reference checkout not present")
+@pytest.mark.parametrize("gpus", [1, 2])
+def test_gsbatch_feature_verbs_equal_piped_nanomagick_emulated(tmp_path, gpus):
+    """keypoints / faces as the last stage: the drawn PGM is byte-identical to the piped reference CLI, the
+    sidecar lists the detections; with --gpus 2 (two emulated devices, one host thread each) the files of a
+    group are split over the workers and every output is still the same"""
+    from oracle.pyoracle import Oracle
+    from grayskull_amd.cascade import Cascade
+    exe, nano = build_emu(tmp_path), build_ref_nano(tmp_path)
+    o, casc = Oracle("port"), Cascade.from_blob(CASCADE)
+    files = [os.path.join(ROOT, "tests", "golden", "lena.pgm")]
+    for k, (w, h) in enumerate([(160, 120), (160, 120), (160, 120), (131, 101)]):   # three frames share a group
+        p = str(tmp_path / ("synth%d.pgm" % k))
+        a = Oracle.synth(w, h, 40 + k)
+        a[0, 0] = max(int(a[0, 0]), 33)  # a raster that starts with a whitespace byte is unreadable for the reference (grayskull.h:116)
+        write_pgm(p, a)
+        files.append(p)
+    env = dict(os.environ, GS_EMU_DEVICES="2")
+    for c, chain in enumerate(FEATURE_CHAINS):
+        outdir = tmp_path / ("fout%d" % c)
+        outdir.mkdir()
+        r = subprocess.run([exe, "-v", "--gpus", str(gpus), "--cascade", CASCADE, "-o", str(outdir), *chain_args(chain), "--", *files],
+                           capture_output=True, timeout=1800, env=env)
+        assert r.returncode == 0, r.stderr.decode()[-800:]
+        if gpus == 2:
+            assert b"gpu 1 group 1: " in r.stderr and b"gpu 0 group 1: " in r.stderr  # both workers took a share of the 3-frame group
+        compared = 0
+        for i, f in enumerate(files):
+            exp, err = nano_chain(nano, chain, f, tmp_path, "fref%d_%d" % (c, i))
+            got = open(str(outdir / os.path.basename(f)), "rb").read()
+            if exp is None:  # an intermediate PGM of the pipe started with a whitespace-valued pixel: the
+                assert b"Could not load" in err, err  # reference cannot read its own output back (grayskull.h:116)
+            else:
+                assert got == open(exp, "rb").read(), "chain %d file %s: drawn image differs" % (c, f)
+                compared += 1
+            check_feature_outputs(outdir, f, chain, o, casc)
+        assert compared >= len(files) - 1
+
+
+def test_gsbatch_feature_verb_errors_emulated(tmp_path):
+    exe = build_emu(tmp_path)
+    lena = os.path.join(ROOT, "tests", "golden", "lena.pgm")
+    out = tmp_path / "o"
+    out.mkdir()
+    r = subprocess.run([exe, "-o", str(out), "keypoints", "10", "20", ":", "sobel", "--", lena], capture_output=True)
+    assert r.returncode == 1 and b"must be the last stage" in r.stderr
+    r = subprocess.run([exe, "-o", str(out), "faces", "1", "--", lena], capture_output=True,
+                       env={k: v for k, v in os.environ.items() if k != "GSBATCH_CASCADE"})
+    assert r.returncode == 1 and b"faces needs a cascade blob" in r.stderr
+    r = subprocess.run([exe, "--cascade", CASCADE, "-o", str(out), "faces", "0", "--", lena], capture_output=True)
+    assert r.returncode == 1 and b"minimum neighbors must be positive" in r.stderr
+    r = subprocess.run([exe, "-o", str(out), "keypoints", "0", "20", "--", lena], capture_output=True)
+    assert r.returncode == 1 and b"Invalid number of keypoints or threshold" in r.stderr
+    r = subprocess.run([exe, "--gpus", "3", "-o", str(out), "sobel", "--", lena], capture_output=True)
+    assert r.returncode == 1 and b"--gpus 3 but only 1 HIP device(s) visible" in r.stderr
+    assert os.listdir(str(out)) == []
 
 
 @pytest.mark.skipif(not os.path.exists(NANO), reason="reference checkout not present")
@@ -259,3 +350,34 @@ def test_gsbatch_random_chains_equal_piped_nanomagick_emulated(tmp_path):
             exp, err = nano_chain(nano, chain, f, tmp_path, "rcref%d_%d" % (c, i))
             assert exp is not None, (chain, err)
             assert open(str(outdir / os.path.basename(f)), "rb").read() == open(exp, "rb").read(), (chain, f)
+
+
+@pytest.mark.gpu
+def test_gsbatch_feature_verbs_on_gpu(tmp_path):
+    """keypoints / faces chains through the real binary on MI355X: records vs the oracle, drawn PGMs vs the
+    reference CLI's own build (oracle/_ref/nano_ref, prebuilt in the build container) where it is shipped"""
+    from oracle.pyoracle import Oracle
+    from grayskull_amd.cascade import Cascade
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "grayskull_amd", "csrc"), "tool"])
+    exe = os.path.join(ROOT, "grayskull_amd", "gsbatch")
+    nano = os.path.join(ROOT, "oracle", "_ref", "nano_ref")
+    o, casc = Oracle("port"), Cascade.from_blob(CASCADE)
+    files = [os.path.join(ROOT, "tests", "golden", "lena.pgm")]
+    for k, (w, h) in enumerate([(640, 480), (640, 480), (640, 480), (333, 207)]):
+        p = str(tmp_path / ("synth%d.pgm" % k))
+        a = Oracle.synth(w, h, 60 + k)
+        a[0, 0] = max(int(a[0, 0]), 33)
+        write_pgm(p, a)
+        files.append(p)
+    for c, chain in enumerate(FEATURE_CHAINS):
+        outdir = tmp_path / ("fout%d" % c)
+        outdir.mkdir()
+        r = subprocess.run([exe, "-v", "--cascade", CASCADE, "-o", str(outdir), *chain_args(chain), "--", *files],
+                           capture_output=True, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-800:]
+        for i, f in enumerate(files):
+            check_feature_outputs(outdir, f, chain, o, casc)
+            if os.path.exists(nano):
+                exp, err = nano_chain(nano, chain, f, tmp_path, "gref%d_%d" % (c, i))
+                if exp is not None:
+                    assert open(str(outdir / os.path.basename(f)), "rb").read() == open(exp, "rb").read(), (c, f)
