@@ -125,6 +125,8 @@ _SIGS = {
                                    C.c_uint, C.c_uint]),
     "gsh_orb_extract_batch": (None, [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_uint, C.c_uint]),
+    "gsh_orb_extract_batch_nostdlib": (None, [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_uint, C.c_uint]),
     "gsh_orb_pyramid_buffer_bytes": (C.c_size_t, [C.c_uint, C.c_uint, C.c_uint]),
     "gsh_orb_extract_pyramid": (C.c_uint, [C.c_void_p, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p,
                                            C.c_uint, C.c_uint, C.c_uint]),
@@ -418,6 +420,12 @@ class Grayskull:
 
     def orb_pyramid_buffer_bytes(self, w, h, n_levels):
         return int(self.c.gsh_orb_pyramid_buffer_bytes(w, h, n_levels))
+
+    def orb_extract_batch_nostdlib(self, imgs, scoremaps, kps, counts, nkps, threshold):
+        """device-resident gs_orb_extract (GS_NO_STDLIB trig): kps (n, nkps, 12) int32 and counts (n) device tensors"""
+        n, h, w = self._nhw(imgs)
+        self.c.gsh_orb_extract_batch_nostdlib(_ptr(imgs), w, h, n, _ptr(scoremaps), _ptr(kps), _ptr(counts), nkps,
+                                              threshold)
 
     def orb_extract_pyramid_dev(self, img, buffer, nkps, threshold, n_levels):
         """nanomagick.c:245-290 on a device image; buffer: device bytes (levels + scoremaps)"""

@@ -1280,6 +1280,36 @@ void gsh_orb_extract_batch(const uint8_t *img_dev, unsigned w, unsigned h, unsig
       memcpy(kps_host[(size_t)f * nkps + i].descriptor, &hd[((size_t)koff[f] + i) * 8], 32);
 }
 
+/* gs_orb_extract (ref :651-669) for n frames, everything on the device, no host round trip: FAST ->
+ * selection (stable descending sort + 15-px border filter + cap, k_orb_select) -> orientation + BRIEF
+ * (k_orb_describe) with the reference's GS_NO_STDLIB trig (ref :70-88).  Results are those of the
+ * reference header compiled with -DGS_NO_STDLIB; the libm flavour (glibc atan2f / sinf bits) stays
+ * with gsh_orb_extract_batch, whose trig runs on the host. */
+void gsh_orb_extract_batch_nostdlib(const uint8_t *img_dev, unsigned w, unsigned h, unsigned n,
+                                    uint8_t *scoremap_dev, struct gs_keypoint *kps_dev, unsigned *counts_dev,
+                                    unsigned nkps, unsigned threshold) {
+  GS_ASSERT(img_dev && scoremap_dev && kps_dev && counts_dev && nkps > 0 && w > 0 && h > 0);
+  if (n == 0) return;
+  hipStream_t st = ctx().s();
+  if (w < 7 || h < 7) {
+    GS_HIP(hipMemsetAsync(counts_dev, 0, (size_t)n * 4, st));
+    return;
+  }
+  const size_t fb = (size_t)w * h;
+  const unsigned cap = std::min(nkps * 4u, 5000u);
+  for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
+    const unsigned nn = std::min(kMaxZ, n - f0);
+    unsigned *cand = (unsigned *)ctx().scratch(SL_KPS, (size_t)nn * cap * 48 + 16);
+    unsigned *cnt = (unsigned *)ctx().scratch(SL_TOT, (size_t)nn * 4 + 16);
+    launch_fast(img_dev + fb * f0, scoremap_dev + fb * f0, w, h, nn, cand, cnt, cap, threshold);
+    unsigned *out = (unsigned *)kps_dev + (size_t)f0 * nkps * 12;
+    GS_LAUNCH(k_orb_select, dim3(nn), dim3(64), 0, st, (const unsigned *)cand, (const unsigned *)cnt, cap, w, h, nkps,
+              out, counts_dev + f0);
+    GS_LAUNCH(k_orb_describe, dim3(nkps, nn), dim3(256), 0, st, img_dev + fb * f0, w, h, fb, out,
+              (const unsigned *)(counts_dev + f0), nkps);
+  }
+}
+
 size_t gsh_orb_pyramid_buffer_bytes(unsigned w, unsigned h, unsigned n_levels) {
   if (n_levels > 4) n_levels = 4;
   size_t levels = 0, maps = (size_t)w * h;

@@ -108,6 +108,154 @@ __global__ __launch_bounds__(256) void k_brief(const uint8_t *img, unsigned w, u
   }
 }
 
+/* ------------------------------------------------------------------ device-resident ORB (GS_NO_STDLIB trig) */
+/* The reference's own trig for builds without libm (ref :70-88, used by examples/wasm/grayskull.c:32):
+ * two float32 polynomials made of + - x / and compares only, so the GPU reproduces them bit for bit
+ * (fp contract off; hipcc's float division is correctly rounded by default).  With them the whole of
+ * gs_orb_extract (ref :651-669) runs on the device with no host round trip. */
+GS_DEV float gs_atan2_poly(float y, float x) { /* ref :70-78 */
+  if (x == 0.0f) return y > 0.0f ? 1.570796f : (y < 0.0f ? -1.570796f : 0.0f);
+  float r, angle;
+  const float abs_y = y >= 0.0f ? y : -y;
+  if (x >= 0.0f) {
+    r = (x - abs_y) / (x + abs_y);
+    angle = 0.785398f - 0.785398f * r;
+  } else {
+    r = (x + abs_y) / (abs_y - x);
+    angle = 3.0f * 0.785398f - 0.785398f * r;
+  }
+  return y < 0.0f ? -angle : angle;
+}
+GS_DEV float gs_sin_poly(float x) { /* ref :80-88 */
+  while (x > 3.141592f) x -= 6.283185f;
+  while (x < -3.141592f) x += 6.283185f;
+  int sign = 1;
+  if (x < 0) x = -x, sign = -1;
+  if (x > 1.570796f) x = 3.141592f - x;
+  const float x2 = x * x, res = x * (1.0f - x2 * (0.16666667f - 0.0083333310f * x2));
+  return (float)sign * res;
+}
+
+/* Selection step of gs_orb_extract (ref :657-667) for one frame per WAVE: the FAST candidates arrive in
+ * scan order; the reference bubble-sorts them by response, descending and stable, then keeps the first
+ * nkps that lie >= 15 px inside the image.  Filtering commutes with a stable sort, and a response is
+ * a scoremap byte, so: count the in-border candidates per response (256 LDS counters), rank of a
+ * candidate = (in-border candidates with a larger response) + (earlier in-border candidates with the
+ * same response), keep rank < nkps.  The "earlier, same response" part is resolved 64 candidates at a
+ * time: the wave peels off one distinct response per iteration (readfirstlane + ballot).
+ * grid n frames, block 64.  cand: n x cap records (12 u32), out: n x nkps records. */
+__global__ __launch_bounds__(64) void k_orb_select(const unsigned *cand, const unsigned *cand_count, unsigned cap,
+                                                  unsigned w, unsigned h, unsigned nkps, unsigned *out,
+                                                  unsigned *out_count) {
+  __shared__ unsigned cnt[256], base[256];
+  const unsigned lane = threadIdx.x, f = blockIdx.x, r = 15u;
+  const unsigned n = cand_count[f] < cap ? cand_count[f] : cap;
+  const unsigned *c = cand + (size_t)f * cap * 12u;
+  unsigned *o = out + (size_t)f * nkps * 12u;
+  for (unsigned i = lane; i < 256u; i += 64u) cnt[i] = 0;
+  __syncthreads();
+  for (unsigned i = lane; i < n; i += 64u) {
+    const unsigned x = c[(size_t)i * 12u], y = c[(size_t)i * 12u + 1], resp = c[(size_t)i * 12u + 2] & 255u;
+    if (x >= r && y >= r && x < w - r && y < h - r) atomicAdd(&cnt[resp], 1u);
+  }
+  __syncthreads();
+  /* base[v] = in-border candidates with a response > v: suffix sums, 4 bins per lane (lane 0 = bins 252..255) */
+  {
+    unsigned own[4], tot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) own[k] = cnt[255u - (lane * 4u + (unsigned)k)], tot += own[k];
+    unsigned run = wave_incl_scan(tot) - tot; /* candidates in the lanes before this one = larger responses */
+    const unsigned total = readlane_last(wave_incl_scan(tot));
+#pragma unroll
+    for (int k = 0; k < 4; k++) base[255u - (lane * 4u + (unsigned)k)] = run, run += own[k];
+    if (lane == 0) out_count[f] = total < nkps ? total : nkps;
+  }
+  __syncthreads();
+  for (unsigned i0 = 0; i0 < n; i0 += 64u) { /* wave-uniform trip count */
+    const unsigned i = i0 + lane;
+    unsigned x = 0, y = 0, resp = 0;
+    bool ok = false;
+    if (i < n) {
+      x = c[(size_t)i * 12u], y = c[(size_t)i * 12u + 1], resp = c[(size_t)i * 12u + 2];
+      ok = x >= r && y >= r && x < w - r && y < h - r;
+    }
+    uint64_t todo = ballot(ok);
+    unsigned rank = 0xffffffffu;
+    while (todo) { /* one distinct response per iteration */
+      const unsigned first = (unsigned)__builtin_ctzll(todo);
+      const unsigned v = readlane_at(resp, first) & 255u;
+      const uint64_t same = ballot(ok && (resp & 255u) == v) & todo;
+      const unsigned start = base[v];
+      if ((same >> lane) & 1ull) rank = start + (unsigned)__popcll(same & ((1ull << lane) - 1ull));
+      __syncthreads(); /* every lane has read base[v] */
+      if (lane == first) base[v] = start + (unsigned)__popcll(same);
+      __syncthreads();
+      todo &= ~same;
+    }
+    if (ok && rank < nkps) {
+      unsigned *q = o + (size_t)rank * 12u;
+      q[0] = x, q[1] = y, q[2] = resp;
+#pragma unroll
+      for (int k = 3; k < 12; k++) q[k] = 0;
+    }
+  }
+}
+
+/* Orientation (ref :608-621) and rotated BRIEF (ref :623-637) of the selected keypoints with the
+ * GS_NO_STDLIB trig, one 256-thread block per keypoint: the disc moments are integer sums (exact,
+ * r = 15), thread 0 evaluates the two polynomials, then thread i tests point pair i.
+ * grid (nkps, n frames); kps: n x nkps records (12 u32), count: n. */
+__global__ __launch_bounds__(256) void k_orb_describe(const uint8_t *img, unsigned w, unsigned h, size_t frame_bytes,
+                                                     unsigned *kps, const unsigned *count, unsigned nkps) {
+#ifndef GS_EMU
+#pragma clang fp contract(off)
+#endif
+  __shared__ int part[2][4];
+  __shared__ float trig[2];
+  const unsigned f = blockIdx.y, k = blockIdx.x, i = threadIdx.x;
+  if (k >= count[f]) return; /* whole block */
+  img += (size_t)f * frame_bytes;
+  unsigned *kp = kps + ((size_t)f * nkps + k) * 12u;
+  const unsigned x = kp[0], y = kp[1];
+  const int r = 15, side = 2 * r + 1, total = side * side;
+  int m01 = 0, m10 = 0;
+  for (int t = (int)i; t < total; t += 256) {
+    const int dy = t / side - r, dx = t % side - r;
+    if (dx * dx + dy * dy <= r * r) {
+      const unsigned sx = x + (unsigned)dx, sy = y + (unsigned)dy;
+      const int I = (sx < w && sy < h) ? img[(size_t)sy * w + sx] : 0;
+      m01 += dy * I, m10 += dx * I;
+    }
+  }
+  m01 = wave_sum_i(m01), m10 = wave_sum_i(m10);
+  if ((i & 63u) == 0) part[0][i >> 6] = m01, part[1][i >> 6] = m10;
+  __syncthreads();
+  if (i == 0) {
+    const int a = part[0][0] + part[0][1] + part[0][2] + part[0][3], b = part[1][0] + part[1][1] + part[1][2] + part[1][3];
+    const float angle = gs_atan2_poly((float)a, (float)b);                  /* ref :620 */
+    kp[3] = __builtin_bit_cast(uint32_t, angle);
+    trig[0] = gs_sin_poly(angle), trig[1] = gs_sin_poly((float)(angle + 1.57079f)); /* ref :626 */
+  }
+  __syncthreads();
+  const float sin_a = trig[0], cos_a = trig[1];
+  const int p0 = k_brief_pattern[4 * i], p1 = k_brief_pattern[4 * i + 1];
+  const int p2 = k_brief_pattern[4 * i + 2], p3 = k_brief_pattern[4 * i + 3];
+  const float m00 = (float)p0 * cos_a, m01f = (float)p1 * sin_a;
+  const float m10f = (float)p0 * sin_a, m11 = (float)p1 * cos_a;
+  const float n00 = (float)p2 * cos_a, n01 = (float)p3 * sin_a;
+  const float n10 = (float)p2 * sin_a, n11 = (float)p3 * cos_a;
+  const float dx1 = m00 - m01f, dy1 = m10f + m11, dx2 = n00 - n01, dy2 = n10 + n11;
+  const unsigned x1 = (unsigned)((int)x + (int)dx1), y1 = (unsigned)((int)y + (int)dy1);
+  const unsigned x2 = (unsigned)((int)x + (int)dx2), y2 = (unsigned)((int)y + (int)dy2);
+  const unsigned I1 = (x1 < w && y1 < h) ? img[(size_t)y1 * w + x1] : 0u;
+  const unsigned I2 = (x2 < w && y2 < h) ? img[(size_t)y2 * w + x2] : 0u;
+  const uint64_t m = ballot(I1 > I2);
+  if (lane_id() == 0) {
+    const unsigned wv = i >> 6;
+    kp[4 + 2 * wv] = (uint32_t)m, kp[4 + 2 * wv + 1] = (uint32_t)(m >> 32);
+  }
+}
+
 /* keypoint record = 12 dwords, descriptor at dword 4 (grayskull.h:42-47).
  * One WAVE per query: the 64 lanes stride over the train descriptors, each keeping the
  * reference's (best, second, first-argmin) state; states merge with

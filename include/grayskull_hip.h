@@ -133,6 +133,14 @@ unsigned gsh_orb_extract(const uint8_t *img_dev, unsigned w, unsigned h, uint8_t
 void gsh_orb_extract_batch(const uint8_t *img_dev, unsigned w, unsigned h, unsigned n,
                            uint8_t *scoremap_dev, struct gs_keypoint *kps_host, unsigned *counts_host,
                            unsigned nkps, unsigned threshold);
+/* gs_orb_extract for n device frames with NO host round trip: the selection (stable sort by response,
+ * border filter, cap) and the trig run on the device.  The trig is the reference's GS_NO_STDLIB pair
+ * (ref :70-88, the polynomials its wasm build uses), so results equal the reference header compiled
+ * with -DGS_NO_STDLIB bit for bit -- angles and descriptors differ from the libm build's, like the
+ * reference's own two builds differ.  kps_dev: n x nkps records, counts_dev: n; stream-ordered. */
+void gsh_orb_extract_batch_nostdlib(const uint8_t *img_dev, unsigned w, unsigned h, unsigned n,
+                                    uint8_t *scoremap_dev, struct gs_keypoint *kps_dev, unsigned *counts_dev,
+                                    unsigned nkps, unsigned threshold);
 
 /* The reference's ORB caller (examples/nanomagick/nanomagick.c:245-290, extract_pyramid_orb_nm) with
  * every pyramid level resident on the device: up to 4 levels, each gs_downsample (ref :189) of the

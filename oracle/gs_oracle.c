@@ -393,6 +393,36 @@ unsigned orc_fast(const uint8_t *img, unsigned w, unsigned h, uint8_t *scoremap,
 }
 
 /* ---------------------------------------------------------------- ORB */
+/* The reference has two trig back-ends: libm (ref :100-101, what `make test` and nanomagick use) and,
+ * under -DGS_NO_STDLIB, the two polynomials of ref :70-88 (what the wasm build uses,
+ * examples/wasm/grayskull.c:32).  The polynomials are pure + - x / float32 and therefore reproducible
+ * on the GPU; orc_set_nostdlib(1) switches this restatement to them. */
+static int g_nostdlib = 0;
+void orc_set_nostdlib(int on) { g_nostdlib = on != 0; }
+float orc_atan2_poly(float y, float x) { /* ref :70-78 */
+  if (x == 0.0f) return y > 0.0f ? 1.570796f : (y < 0.0f ? -1.570796f : 0.0f);
+  float r, angle, abs_y = y >= 0.0f ? y : -y;
+  if (x >= 0.0f) {
+    r = (x - abs_y) / (x + abs_y);
+    angle = 0.785398f - 0.785398f * r;
+  } else {
+    r = (x + abs_y) / (abs_y - x);
+    angle = 3.0f * 0.785398f - 0.785398f * r;
+  }
+  return y < 0.0f ? -angle : angle;
+}
+float orc_sin_poly(float x) { /* ref :80-88 */
+  while (x > 3.141592f) x -= 6.283185f;
+  while (x < -3.141592f) x += 6.283185f;
+  int sign = 1;
+  if (x < 0) x = -x, sign = -1;
+  if (x > 1.570796f) x = 3.141592f - x;
+  float x2 = x * x, res = x * (1.0f - x2 * (0.16666667f - 0.0083333310f * x2));
+  return sign * res;
+}
+static float trig_atan2(float y, float x) { return g_nostdlib ? orc_atan2_poly(y, x) : atan2f(y, x); }
+static float trig_sin(float x) { return g_nostdlib ? orc_sin_poly(x) : sinf(x); }
+
 /* ref :608-621 -- intensity-centroid moments over the disc dx^2+dy^2 <= r^2, float accum */
 void orc_orientation_moments(const uint8_t *img, unsigned w, unsigned h, unsigned x, unsigned y,
                              unsigned r, float *m01, float *m10) {
@@ -411,14 +441,14 @@ float orc_orientation(const uint8_t *img, unsigned w, unsigned h, unsigned x, un
                       unsigned r) {
   float m01, m10;
   orc_orientation_moments(img, w, h, x, y, r, &m01, &m10);
-  return atan2f(m01, m10); /* ref :100, :620 */
+  return trig_atan2(m01, m10); /* ref :100 / :70, :620 */
 }
 
 /* ref :623-637 -- rotated BRIEF-256; cos = sin(angle + 1.57079f); float32, no FMA;
  * (int) truncation; out-of-image taps read 0; bit i set iff I1 > I2 */
 void orc_brief(const uint8_t *img, unsigned w, unsigned h, orc_keypoint *kp) {
   int x = (int)kp->x, y = (int)kp->y;
-  float ang = kp->angle, sn = sinf(ang), cs = sinf((float)(ang + 1.57079f));
+  float ang = kp->angle, sn = trig_sin(ang), cs = trig_sin((float)(ang + 1.57079f));
   memset(kp->desc, 0, sizeof kp->desc);
   for (int i = 0; i < 256; i++) {
     const int8_t *q = &k_brief[i * 4];

@@ -75,6 +75,10 @@ unsigned orc_lbp_detect(const orc_cascade *c, const unsigned *ii, unsigned iw, u
 /* FAST / ORB / matching */
 unsigned orc_fast(const uint8_t *img, unsigned w, unsigned h, uint8_t *scoremap, orc_keypoint *kps,
                   unsigned nkps, unsigned threshold);
+/* 1: the GS_NO_STDLIB polynomials of ref :70-88 for gs_atan2 / gs_sin; 0 (default): libm, ref :100-101 */
+void orc_set_nostdlib(int on);
+float orc_atan2_poly(float y, float x);
+float orc_sin_poly(float x);
 float orc_orientation(const uint8_t *img, unsigned w, unsigned h, unsigned x, unsigned y,
                       unsigned r);
 void orc_orientation_moments(const uint8_t *img, unsigned w, unsigned h, unsigned x, unsigned y,

@@ -20,6 +20,7 @@ from grayskull_amd._abi import (GsImage, GsLbpCascade, KEYPOINT_DTYPE, MATCH_DTY
 HERE = os.path.dirname(os.path.abspath(__file__))
 PORT_SO = os.path.join(HERE, "libgs_oracle.so")
 REF_SO = os.path.join(HERE, "_ref", "libgs_ref.so")
+REF_NOSTDLIB_SO = os.path.join(HERE, "_ref", "libgs_ref_nostdlib.so")  # same header, -DGS_NO_STDLIB (ref :68-88)
 
 u8p = C.POINTER(C.c_uint8)
 
@@ -31,6 +32,10 @@ def build():
 
 def have_reference():
     return os.path.exists(REF_SO)
+
+
+def have_reference_nostdlib():
+    return os.path.exists(REF_NOSTDLIB_SO)
 
 
 def _p(a):
@@ -59,9 +64,24 @@ class Oracle:
             self.lib = C.CDLL(PORT_SO)
         elif kind == "reference":
             self.lib = C.CDLL(REF_SO)
+        elif kind == "reference_nostdlib":  # polynomial gs_atan2 / gs_sin (ref :70-88), everything else identical
+            self.lib = C.CDLL(REF_NOSTDLIB_SO)
+        elif kind == "port_nostdlib":       # the restatement with its trig switched to the same polynomials
+            if not os.path.exists(PORT_SO):
+                build()
+            # a private copy of the library: orc_set_nostdlib is process-global state of one loaded image
+            import shutil
+            import tempfile
+            tmp = tempfile.NamedTemporaryFile(suffix=".so", delete=False)
+            tmp.close()
+            shutil.copyfile(PORT_SO, tmp.name)
+            self.lib = C.CDLL(tmp.name)
+            self.lib.orc_set_nostdlib(1)
+            self.lib.orc_atan2_poly.restype = C.c_float
+            self.lib.orc_sin_poly.restype = C.c_float
         else:
             raise ValueError(kind)
-        self.port = kind == "port"
+        self.port = kind.startswith("port")
         L = self.lib
         if self.port:
             L.orc_fnv1a.restype = C.c_uint32

@@ -240,3 +240,26 @@ def lbp(g, o, img, mem, casc, params=((4096, 1.1, 1.0, 4.0, 1),), windows=((0, 0
     for (x, y, sc) in windows:
         assert g.lbp_window(casc, ii_m, x, y, sc) == o.lbp_window(casc, ii, x, y, sc), \
             "gs_lbp_window (%d,%d,%g)" % (x, y, sc)
+
+
+def orb_nostdlib(g, o_nostdlib, frames, nkps=60, threshold=20):
+    """gsh_orb_extract_batch_nostdlib (device-resident, GS_NO_STDLIB trig of ref :70-88) vs the reference header
+    compiled with -DGS_NO_STDLIB (or the restatement switched to the same polynomials), frame by frame"""
+    frames = np.ascontiguousarray(frames)
+    n = frames.shape[0]
+    mem = Mem("device") if _is_gpu(g) else Mem("host")
+    d = mem.put(frames)
+    sm = mem.zeros(frames.shape)
+    kps = mem.put(np.zeros((n, nkps, 12), np.uint32))
+    counts = mem.put(np.zeros(n, np.uint32))
+    g.orb_extract_batch_nostdlib(d, sm, kps, counts, nkps, threshold)
+    g.sync()
+    k, c = mem.get(kps, np.uint32), mem.get(counts, np.uint32)
+    for f in range(n):
+        ko = o_nostdlib.orb_extract(frames[f], nkps, threshold)
+        assert int(c[f]) == len(ko), "frame %d: %d vs %d keypoints" % (f, int(c[f]), len(ko))
+        assert_same(k[f, :len(ko)].reshape(-1).view(ko.dtype), ko, "device-resident ORB (NO_STDLIB trig) frame %d" % f)
+
+
+def _is_gpu(g):
+    return "emulator" not in g.version()

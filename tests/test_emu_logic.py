@@ -2,6 +2,8 @@
 compiled for the host-fiber SIMT emulator (tests/emu) and compared with the oracle on tiny
 inputs.  This is a development/CI aid for a container without a GPU -- the real parity tests are
 the `-m gpu` ones in test_gpu_parity.py, which run the HIP build on the MI355X."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -365,3 +367,25 @@ def test_fast_batch_split_over_several_launches(emu, oracle):
         assert_same(kps[f, :1].reshape(-1).view(ko.dtype), ko, "frame %d" % f)
         assert_same(sm[f], smo, "scoremap %d" % f)
     assert counts[n - 1] == 0
+
+
+def test_device_resident_orb_with_the_reference_nostdlib_trig(emu, reference):
+    """gsh_orb_extract_batch_nostdlib: selection (stable sort by response + border filter + cap), orientation and
+    BRIEF on the device with the GS_NO_STDLIB polynomials (ref :70-88) == the reference header built with
+    -DGS_NO_STDLIB; the restatement switched to the polynomials agrees with that build too"""
+    from oracle import pyoracle
+    if not pyoracle.have_reference_nostdlib():
+        pytest.skip("oracle/_ref/libgs_ref_nostdlib.so not present")
+    ref_ns, port_ns = Oracle("reference_nostdlib"), Oracle("port_nostdlib")
+    frames = np.stack([Oracle.synth(128, 96, 70 + i) for i in range(3)])
+    frames[2] = np.random.RandomState(2).randint(0, 256, (96, 128)).astype(np.uint8)
+    for nkps in (60, 7, 2000):  # cap = min(4 nkps, 5000): 240 / 28 / 5000 candidates
+        pc.orb_nostdlib(emu, ref_ns, frames, nkps=nkps)
+    for f in range(3):
+        assert_same(port_ns.orb_extract(frames[f], 60, 20), ref_ns.orb_extract(frames[f], 60, 20), "restatement, polynomial trig")
+    flat = np.full((1, 40, 40), 9, np.uint8)  # no candidates at all; and a frame smaller than 7 px
+    pc.orb_nostdlib(emu, ref_ns, flat, nkps=10)
+    for y in (-3.5, -1.0, 0.0, 2.0):  # the polynomials themselves, including the x == 0 branch
+        for x in (-2.0, 0.0, 1.0, 7.25):
+            assert np.float32(port_ns.lib.orc_atan2_poly(C.c_float(y), C.c_float(x))).tobytes() == \
+                np.float32(ref_ns.atan2(y, x)).tobytes()

@@ -119,3 +119,17 @@ def test_nanomagick_cli_same_outputs_on_hip_library(tmp_path):
             outs.append((open(out, "rb").read() if os.path.exists(out) else b"", r.stdout))
         assert outs[0][0] == outs[1][0], "nanomagick %s %s: output image differs" % (verb, args)
         assert outs[0][1] == outs[1][1], "nanomagick %s %s: printed text differs" % (verb, args)
+
+
+def test_device_resident_orb_nostdlib_at_the_kat_sizes(hip):
+    """gsh_orb_extract_batch_nostdlib (no host round trip) == the reference header compiled with -DGS_NO_STDLIB
+    (oracle/_ref/libgs_ref_nostdlib.so) at the three KAT sizes of SURVEY 8(c), nkps = 500, threshold 20"""
+    from oracle import pyoracle
+    if not pyoracle.have_reference_nostdlib():
+        pytest.skip("oracle/_ref/libgs_ref_nostdlib.so was not prebuilt")
+    ref_ns = Oracle("reference_nostdlib")
+    for (w, h, seed, nf) in ((1920, 1080, 3, 2), (1280, 720, 4, 3), (67, 45, 5, 2), (640, 480, 11, 4)):
+        frames = np.stack([Oracle.synth(w, h, seed + 100 * i) for i in range(nf)])
+        pc.orb_nostdlib(hip, ref_ns, frames, nkps=500)
+    pc.orb_nostdlib(hip, ref_ns, np.stack([Oracle.synth(320, 240, 5)]), nkps=2000)  # cap 5000
+    pc.orb_nostdlib(hip, ref_ns, np.full((2, 64, 64), 77, np.uint8), nkps=50)       # nothing to find
