@@ -452,14 +452,20 @@ def extras(g, torch, np, src, tmp, dst, w, h, reps):
     kp7 = torch.zeros((nf, 2000, 12), dtype=torch.int32, device="cuda")
     cn7 = torch.zeros(nf, dtype=torch.int32, device="cuda")
     ms_fast = time_stream(torch, lambda: g.fast_batch(f7, sm7, kp7, cn7, 2000, 20), 5)
+    # device-resident gs_orb_extract (GS_NO_STDLIB trig, no host round trip), same 32 frames, 500 keypoints each
+    ko7 = torch.zeros((nf, 500, 12), dtype=torch.int32, device="cuda")
+    ms_orb_dev = time_stream(torch, lambda: g.orb_extract_batch_nostdlib(f7, sm7, ko7, cn7, 500, 20), 5)
     other["configs[3] gs_orb_extract x2 + gs_match_orb 1280x720 threshold=20 nkps=500"] = {
         "orb_extract_ms": round(t_orb * 1e3, 3), "keypoints": int(len(ka)), "match_ms": round(t_match * 1e3, 3),
         "matches": int(len(mm)), "expected_matches (reference KAT)": 337,
         "note": "wall time incl. the host round trips (host libm atan2f/sinf, stable sort)",
+        "device_resident_orb_extract_ms_per_frame": round(ms_orb_dev / nf, 4),
+        "device_resident_note": "gsh_orb_extract_batch_nostdlib, %d frames per call, the reference's GS_NO_STDLIB trig "
+                                "(ref :70-88), no host round trip; bit-exact vs the -DGS_NO_STDLIB reference build" % nf,
         "gs_fast_roofline": hbm_block(3.0 * nf * 720 * 1280, ms_fast, bytes_per_px=3, frames=nf, limited_by="valu",
                                       note="score pass 1 R + 1 W, NMS 1 R; the score pass is ~140 lane-ops per candidate pixel"),
         "reference_1core": "70 ms extract, 48.6 ms match (BASELINE.md)"}
-    del s3, ii3, rc, cn, f7, sm7, kp7
+    del s3, ii3, rc, cn, f7, sm7, kp7, ko7
     # configs[4], one GPU's share: per frame gs_blur(2) -> gs_sobel -> gs_integral -> gs_lbp_detect on 4K
     n5 = 8
     a5, b5 = tmp[:n5], dst[:n5]
