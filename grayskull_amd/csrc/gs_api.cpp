@@ -461,8 +461,11 @@ void run_compaction(unsigned long long *mask, unsigned *cnt, unsigned nchunks, u
 }
 
 /* ------------------------------------------------------------------ FAST */
+/* clip_w / clip_h (single frame only): the caller's score map is smaller than the image; positions
+ * outside it read 0 in the NMS pass like gs_get does (ref :524) */
 void launch_fast(const uint8_t *img, uint8_t *score, unsigned w, unsigned h, unsigned n,
-                 unsigned *kps, unsigned *counts, unsigned nkps, unsigned threshold) {
+                 unsigned *kps, unsigned *counts, unsigned nkps, unsigned threshold, unsigned clip_w = 0,
+                 unsigned clip_h = 0) {
   hipStream_t st = ctx().s();
   if (n == 0) return;
   if (n > kMaxZ) { /* grid.y / grid.z carry the frame index: split like every other launcher */
@@ -500,6 +503,8 @@ void launch_fast(const uint8_t *img, uint8_t *score, unsigned w, unsigned h, uns
     GS_LAUNCH(k_fast_score_px, grid2d(w - 6, h - 6, n), dim3(64, 4), 0, st, img, score, w, h, fb,
               threshold);
   }
+  if (clip_w && n == 1 && (clip_w < w || clip_h < h))
+    GS_LAUNCH(k_fast_clip, grid2d(w, h, 1), dim3(64, 4), 0, st, score, w, h, clip_w, clip_h);
   unsigned long long *mask =
       (unsigned long long *)ctx().scratch(SL_MASK, (size_t)n * nchunks * kChunkWords * 8);
   unsigned *cnt = (unsigned *)ctx().scratch(SL_CNT, (size_t)n * nchunks * 4);
@@ -1812,22 +1817,38 @@ unsigned gs_fast(struct gs_image img, struct gs_image scoremap, struct gs_keypoi
   GS_ASSERT(GS_VALID(img) && kps && nkps > 0);
   const unsigned w = img.w, h = img.h;
   if (w < 7 || h < 7) return 0;
-  /* the reference goes through gs_set/gs_get, which tolerate an invalid or differently sized
-   * scoremap; the device path needs the usual same-size map (what every caller passes) */
-  GS_ASSERT(GS_VALID(scoremap) && scoremap.w == w && scoremap.h == h);
+  /* The reference writes the map through gs_set and reads it through gs_get (ref :512, :518-524), so a
+   * map of another size -- or no map at all -- is legal: positions outside it are never written and
+   * read 0.  Same here: the kernels run on an image-sized device map M that starts as the caller's
+   * map where the two overlap (0 elsewhere); positions outside the caller's map are zeroed again
+   * between the two passes; the overlap is copied back. */
+  if (!GS_VALID(scoremap)) return 0; /* every gs_get(scoremap) is 0: the NMS pass skips every pixel */
   const size_t nb = (size_t)w * h;
   const uint8_t *s = (const uint8_t *)stage_in(img.data, nb, SL_IN);
+  const bool same = scoremap.w == w && scoremap.h == h;
   const bool mhost = !is_dev(scoremap.data);
-  uint8_t *dm = mhost ? (uint8_t *)ctx().scratch(SL_AUX, nb) : scoremap.data;
+  const unsigned ow = std::min(w, scoremap.w), oh = std::min(h, scoremap.h); /* overlap */
+  uint8_t *dm = (mhost || !same) ? (uint8_t *)ctx().scratch(SL_AUX, nb) : scoremap.data;
   /* NMS reads the caller's 3-px frame (ref :524): ship the whole map in */
-  if (mhost) GS_HIP(hipMemcpyAsync(dm, scoremap.data, nb, hipMemcpyHostToDevice, ctx().s()));
+  if (same) {
+    if (mhost) GS_HIP(hipMemcpyAsync(dm, scoremap.data, nb, hipMemcpyHostToDevice, ctx().s()));
+  } else {
+    GS_HIP(hipMemsetAsync(dm, 0, nb, ctx().s()));
+    GS_HIP(hipMemcpy2DAsync(dm, w, scoremap.data, scoremap.w, ow, oh,
+                            mhost ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, ctx().s()));
+  }
   const bool khost = !is_dev(kps);
   unsigned *dk = khost ? (unsigned *)ctx().scratch(SL_KPS, (size_t)nkps * 48) : (unsigned *)kps;
   unsigned *dcnt = (unsigned *)ctx().scratch(SL_TOT, 16);
-  launch_fast(s, dm, w, h, 1, dk, dcnt, nkps, threshold);
+  launch_fast(s, dm, w, h, 1, dk, dcnt, nkps, threshold, same ? 0u : scoremap.w, same ? 0u : scoremap.h);
   unsigned n = 0;
   GS_HIP(hipMemcpyAsync(&n, dcnt, 4, hipMemcpyDeviceToHost, ctx().s()));
-  if (mhost) GS_HIP(hipMemcpyAsync(scoremap.data, dm, nb, hipMemcpyDeviceToHost, ctx().s()));
+  if (same) {
+    if (mhost) GS_HIP(hipMemcpyAsync(scoremap.data, dm, nb, hipMemcpyDeviceToHost, ctx().s()));
+  } else {
+    GS_HIP(hipMemcpy2DAsync(scoremap.data, scoremap.w, dm, w, ow, oh,
+                            mhost ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, ctx().s()));
+  }
   ctx().sync();
   if (khost && n) GS_HIP(hipMemcpy(kps, dk, (size_t)n * 48, hipMemcpyDeviceToHost));
   return n;

@@ -301,6 +301,15 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t *score, unsigned
 }
 
 /* compaction functor: item -> gs_keypoint {{x,y}, score, 0, {0}} (ref :530), 48 B = 12 dwords */
+/* gs_fast with a score map smaller than the image (ref :512, :518-524: the map is written through gs_set
+ * and read through gs_get, i.e. positions outside it read 0): zero them between the two passes.
+ * grid (ceil(w/64), ceil(h/4)), block (64, 4) */
+__global__ __launch_bounds__(256) void k_fast_clip(uint8_t *score, unsigned w, unsigned h, unsigned clip_w,
+                                                  unsigned clip_h) {
+  const unsigned x = blockIdx.x * 64u + threadIdx.x, y = blockIdx.y * 4u + threadIdx.y;
+  if (x < w && y < h && (x >= clip_w || y >= clip_h)) score[(size_t)y * w + x] = 0;
+}
+
 struct FastEmit {
   const uint8_t *score;
   unsigned w;

@@ -389,3 +389,17 @@ def test_device_resident_orb_with_the_reference_nostdlib_trig(emu, reference):
         for x in (-2.0, 0.0, 1.0, 7.25):
             assert np.float32(port_ns.lib.orc_atan2_poly(C.c_float(y), C.c_float(x))).tobytes() == \
                 np.float32(ref_ns.atan2(y, x)).tobytes()
+
+
+def test_fast_with_a_score_map_of_another_size(emu, reference):
+    """the reference writes the score map through gs_set and reads it through gs_get (ref :512, :518-524): a map
+    smaller or larger than the image is legal, positions outside it read 0 and are never written"""
+    img = Oracle.synth(96, 72, 31)
+    rs = np.random.RandomState(5)
+    for (sw, sh) in ((96, 72), (91, 70), (50, 72), (96, 30), (101, 80), (40, 33), (4, 4)):
+        sm0 = rs.randint(0, 3, (sh, sw)).astype(np.uint8)  # a caller's map is not necessarily zeroed
+        sm = sm0.copy()
+        got = emu.fast(img, sm, 500, 20)
+        exp, sm_exp = reference.fast(img, 500, 20, scoremap=sm0)
+        assert_same(got, exp, "keypoints with a %dx%d map" % (sw, sh))
+        assert_same(sm, sm_exp, "score map %dx%d after the call" % (sw, sh))

@@ -133,3 +133,8 @@ def test_device_resident_orb_nostdlib_at_the_kat_sizes(hip):
         pc.orb_nostdlib(hip, ref_ns, frames, nkps=500)
     pc.orb_nostdlib(hip, ref_ns, np.stack([Oracle.synth(320, 240, 5)]), nkps=2000)  # cap 5000
     pc.orb_nostdlib(hip, ref_ns, np.full((2, 64, 64), 77, np.uint8), nkps=50)       # nothing to find
+
+
+def test_fast_score_map_of_another_size_vs_reference(hip, reference):
+    from test_emu_logic import test_fast_with_a_score_map_of_another_size as body
+    body(hip, reference)
