@@ -365,3 +365,53 @@ def test_gpu_pipeline_chunking_any(hip, oracle, n, per, w, h, radius, seed):
         t = oracle.otsu_threshold(s)
         assert int(tref[f]) == t
         assert_same(ref[f].cpu().numpy(), oracle.threshold(s, t), "frame %d" % f)
+
+
+# ---- round 2: device-resident ORB (GS_NO_STDLIB trig) and score maps of another size --------------------
+_CACHE = {}
+
+
+def _body_orb_nostdlib_any_shape(g, w, h, seed, kind, threshold, nkps, nframes):
+    from oracle import pyoracle
+    from oracle.pyoracle import Oracle
+    if not pyoracle.have_reference_nostdlib():
+        pytest.skip("oracle/_ref/libgs_ref_nostdlib.so not present")
+    rs = np.random.RandomState(seed)
+    frames = np.stack([_img(rs, w, h, kind) for _ in range(nframes)])
+    if "ref_ns" not in _CACHE:
+        _CACHE["ref_ns"] = Oracle("reference_nostdlib")
+    # gs_orb_extract needs w, h >= 31 for any keypoint to survive the 15-px border; smaller frames must give 0
+    pc.orb_nostdlib(g, _CACHE["ref_ns"], frames, nkps=nkps, threshold=threshold)
+
+
+@_cfg(12)
+@given(w=st.integers(7, 96), h=st.integers(7, 72), seed=st.integers(0, 2 ** 16), kind=st.integers(0, 2),
+       threshold=st.sampled_from([1, 5, 20, 60, 200]), nkps=st.sampled_from([1, 3, 40, 1300]), nframes=st.integers(1, 3))
+def test_orb_nostdlib_any_shape(emu, w, h, seed, kind, threshold, nkps, nframes):
+    _body_orb_nostdlib_any_shape(emu, w=w, h=h, seed=seed, kind=kind, threshold=threshold, nkps=nkps, nframes=nframes)
+
+
+@pytest.mark.gpu
+@_cfg(12)
+@given(w=st.integers(7, 96), h=st.integers(7, 72), seed=st.integers(0, 2 ** 16), kind=st.integers(0, 2),
+       threshold=st.sampled_from([1, 5, 20, 60, 200]), nkps=st.sampled_from([1, 3, 40, 1300]), nframes=st.integers(1, 3))
+def test_gpu_orb_nostdlib_any_shape(hip, w, h, seed, kind, threshold, nkps, nframes):
+    _body_orb_nostdlib_any_shape(hip, w=w, h=h, seed=seed, kind=kind, threshold=threshold, nkps=nkps, nframes=nframes)
+
+
+def _body_fast_any_scoremap(g, reference, w, h, sw, sh, seed, threshold):
+    rs = np.random.RandomState(seed)
+    img = _img(rs, w, h, seed % 3)
+    sm0 = rs.randint(0, 4, (sh, sw)).astype(np.uint8)
+    sm = sm0.copy()
+    got = g.fast(img, sm, 300, threshold)
+    exp, sm_exp = reference.fast(img, 300, threshold, scoremap=sm0)
+    assert_same(got, exp, "gs_fast %dx%d with a %dx%d score map" % (w, h, sw, sh))
+    assert_same(sm, sm_exp, "score map after the call")
+
+
+@_cfg(15)
+@given(w=st.integers(7, 70), h=st.integers(7, 50), sw=st.integers(1, 80), sh=st.integers(1, 60), seed=st.integers(0, 2 ** 16),
+       threshold=st.sampled_from([0, 5, 20, 100]))
+def test_fast_any_scoremap_size(emu, reference, w, h, sw, sh, seed, threshold):
+    _body_fast_any_scoremap(emu, reference, w=w, h=h, sw=sw, sh=sh, seed=seed, threshold=threshold)
