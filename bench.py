@@ -287,12 +287,25 @@ def main():
         "gs_threshold k_threshold": (lambda: g.threshold_batch(dst, thr), 2.0 * npx, 2.0 * npx),
         "gs_erode k_morph16": (lambda: g.erode_batch(dst, src), 2.0 * npx, 2.0 * npx),
     }
+    # gs_integral on 64 frames (u32 table: 2.1 GB): bytes moved from the PMC passes when they cover this shape
+    n_ii = min(64, F)
+    ii_buf = torch.empty((n_ii, h, w), dtype=torch.int32, device="cuda")
+    moved_ii = 5.0 * n_ii * w * h
+    try:
+        pt_ii = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["per_launch"]
+        if (w, h, n_ii) == (3840, 2160, 64):
+            moved_ii = float(sum(v["total_bytes"] for k, v in pt_ii.items() if k.startswith("gs::k_integral_")))
+    except Exception:
+        pass
+    kernels["gs_integral (3 launches: colsum, colbase, wave), %d frames" % n_ii] = (
+        lambda: g.integral_batch(src[:n_ii], ii_buf), moved_ii, 5.0 * n_ii * w * h)
     ktab = {}
     for name, (fn, moved, percall) in kernels.items():
         ms = time_stream(torch, fn, reps)
         ktab[name] = hbm_block(moved, ms)
         if percall != moved:
             ktab[name]["percall_equivalent_GB/s"] = round(percall / ms / 1e6, 1)
+    del ii_buf
     # The fused kernel itself: average over ALL its launches inside the timed region above (HIP events
     # recorded by the library on the launch stream, gsh_profile).  A step launches it once per
     # 32-frame chunk; chunk i's threshold pass runs on a side stream under chunk i+1's fused

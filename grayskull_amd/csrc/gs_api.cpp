@@ -83,6 +83,7 @@ struct LbpGeomCache {
   bool guard = false;
   unsigned long long nwindows = 0;
 };
+struct gsh_cascade_tables_deleter { void operator()(struct ::gsh_cascade *dc) const; };
 struct Ctx {
   int device = 0;
   bool device_set = false;
@@ -91,6 +92,10 @@ struct Ctx {
   struct Buf { void *p = nullptr; size_t cap = 0; } slot[SL_COUNT];
   bool jump_ready = false; /* SL_JUMP holds the xorshift jump table of gsh_synth_batch */
   std::map<unsigned long long, LbpGeomCache> geom_cache; /* keyed by gsh_cascade::id */
+  /* flattened copy of the caller's struct gs_lbp_cascade for the drop-in gs_lbp_* calls, keyed by a hash
+   * of the table contents (cached_cascade); owned here so that it goes away with the context, in order */
+  struct ::gsh_cascade *dropin_cascade = nullptr;
+  uint64_t dropin_cascade_hash = 0;
   void drop_geom() {
     for (auto &kv : geom_cache) {
       if (kv.second.d_scales) (void)hipFree(kv.second.d_scales);
@@ -181,6 +186,8 @@ struct Ctx {
     }
     jump_ready = false;
     drop_geom();
+    if (dropin_cascade) gsh_cascade_tables_deleter()(dropin_cascade);
+    dropin_cascade = nullptr;
 #ifndef GS_EMU
     for (auto &e : prof_ev) {
       if (e) (void)hipEventDestroy(e);
@@ -531,6 +538,14 @@ struct gsh_cascade {
   int32_t *d_subsets = nullptr;
   unsigned long long id = 0; /* unique per handle: key of the calling threads' geometry caches */
 };
+
+namespace {
+/* the device tables of a handle, without touching any context (used while a context is being released) */
+void gsh_cascade_tables_deleter::operator()(gsh_cascade *dc) const {
+  (void)hipFree(dc->d_weak), (void)hipFree(dc->d_stage), (void)hipFree(dc->d_subsets);
+  delete dc;
+}
+}  // namespace
 
 namespace {
 
@@ -1165,7 +1180,6 @@ gsh_cascade *gsh_cascade_create(const struct gs_lbp_cascade *c) {
 void gsh_cascade_destroy(gsh_cascade *dc) {
   if (!dc) return;
   ctx().sync();
-  (void)hipFree(dc->d_weak), (void)hipFree(dc->d_stage), (void)hipFree(dc->d_subsets);
   /* geometry tables of this handle in the calling thread's cache go with it; other threads' entries
    * are keyed by the (never reused) id and are dropped when their context is released */
   auto it = ctx().geom_cache.find(dc->id);
@@ -1174,7 +1188,7 @@ void gsh_cascade_destroy(gsh_cascade *dc) {
     if (it->second.d_geom) (void)hipFree(it->second.d_geom);
     ctx().geom_cache.erase(it);
   }
-  delete dc;
+  gsh_cascade_tables_deleter()(dc);
 }
 void gsh_lbp_detect_batch(const gsh_cascade *dc, const unsigned *ii, unsigned iw, unsigned ih,
                           unsigned n, struct gs_rect *rects, unsigned *counts, unsigned max_rects,
@@ -1732,20 +1746,13 @@ static uint64_t cascade_content_hash(const struct gs_lbp_cascade *c) {
   return h;
 }
 static gsh_cascade *cached_cascade(const struct gs_lbp_cascade *c) {
-  struct Slot {
-    gsh_cascade *dc = nullptr;
-    uint64_t hash = 0;
-    ~Slot() {
-      if (dc) gsh_cascade_destroy(dc);
-    }
-  };
-  static thread_local Slot slot;
+  Ctx &cx = ctx();
   const uint64_t h = cascade_content_hash(c);
-  if (slot.dc && slot.hash == h) return slot.dc;
-  if (slot.dc) gsh_cascade_destroy(slot.dc);
-  slot.dc = gsh_cascade_create(c);
-  slot.hash = h;
-  return slot.dc;
+  if (cx.dropin_cascade && cx.dropin_cascade_hash == h) return cx.dropin_cascade;
+  if (cx.dropin_cascade) gsh_cascade_destroy(cx.dropin_cascade);
+  cx.dropin_cascade = gsh_cascade_create(c);
+  cx.dropin_cascade_hash = h;
+  return cx.dropin_cascade;
 }
 
 unsigned gs_lbp_detect(const struct gs_lbp_cascade *c, const unsigned *ii, unsigned iw,
