@@ -21,6 +21,9 @@
  * and, as the LAST stage of a chain, the two feature verbs (nanomagick.c:217-243, :347-376):
  *   keypoints <n> <t>   gs_fast (cap 5000, threshold t) on the GPU; the n strongest are drawn as
  *                       crosses like nanomagick does and listed in <out>.keypoints.txt ("x y response")
+ *   orb <template.pgm>  nanomagick's pyramid ORB matcher (nanomagick.c:245-345): 3-level gs_orb_extract of the
+ *                       template and of the frame (2500 keypoints, threshold 20), gs_match_orb (300, 60.0),
+ *                       the stitched picture with the 15 best matches drawn, and <out>.orb.txt
  *   faces <n>           gs_integral + gs_lbp_detect (cap 100, scale 1.2, 1..4, step n) on the GPU with
  *                       the cascade blob given by --cascade; boxes drawn like nanomagick, listed in
  *                       <out>.faces.txt ("x y w h").  (nanomagick's 640x480 limit is its static buffer
@@ -49,9 +52,9 @@ static size_t kSliceBytes = (size_t)64 << 20; /* per plane and slice (8 4K frame
    Measured on 64 4K files (profiles/r01i_gsbatch_64x4k.log): page-locking the staging buffer costs ~85 ms
    per GiB, so small slices win: 0.44 s wall at 64 MiB vs 0.64 s at 1 GiB */
 
-enum verb { V_RESIZE, V_CROP, V_BLUR, V_THRESHOLD, V_ADAPTIVE, V_SOBEL, V_MORPH, V_KEYPOINTS, V_FACES };
-#define IS_TERMINAL(v) ((v) == V_KEYPOINTS || (v) == V_FACES)
-enum { kFastCap = 5000, kFaceCap = 100 }; /* nanomagick.c:224, :349 */
+enum verb { V_RESIZE, V_CROP, V_BLUR, V_THRESHOLD, V_ADAPTIVE, V_SOBEL, V_MORPH, V_KEYPOINTS, V_FACES, V_ORB };
+#define IS_TERMINAL(v) ((v) == V_KEYPOINTS || (v) == V_FACES || (v) == V_ORB)
+enum { kFastCap = 5000, kFaceCap = 100, kOrbKps = 2500, kOrbMatches = 300 }; /* nanomagick.c:224, :349, :301-306 */
 
 struct stage {
   enum verb v;
@@ -67,7 +70,7 @@ static const struct {
   int argc;
 } verbs[] = {{"resize", V_RESIZE, 2},     {"crop", V_CROP, 4},   {"blur", V_BLUR, 1}, {"threshold", V_THRESHOLD, 1},
              {"adaptive", V_ADAPTIVE, 2}, {"sobel", V_SOBEL, 0}, {"morph", V_MORPH, 2},
-             {"keypoints", V_KEYPOINTS, 2}, {"faces", V_FACES, 1}, {NULL, V_SOBEL, 0}};
+             {"keypoints", V_KEYPOINTS, 2}, {"faces", V_FACES, 1}, {"orb", V_ORB, 1}, {NULL, V_SOBEL, 0}};
 
 struct frame {
   const char *path;
@@ -88,7 +91,7 @@ static void usage(const char *app) {
           "Usage: %s [-v] [--gpus N] [--cascade blob] -o <outdir> <verb> [params] [: <verb> [params]]... -- in1.pgm [in2.pgm ...]\n"
           "Verbs: resize <w> <h> | crop <x> <y> <w> <h> | blur <r> | threshold <t|otsu> |\n"
           "       adaptive <r> <c> | sobel | morph <erode|dilate> <n>\n"
-          "       last stage only: keypoints <n> <t> | faces <n>  (faces needs --cascade)\n",
+          "       last stage only: keypoints <n> <t> | faces <n> (needs --cascade) | orb <template.pgm>\n",
           app);
 }
 
@@ -192,7 +195,7 @@ static int parse_stages(int argc, char **argv, int *pos, struct stage *st, int m
   for (i = 0; i + 1 < n; i++)
     if (IS_TERMINAL(st[i].v)) {
       fprintf(stderr, "Error: '%s' writes detections, not an image to filter on: it must be the last stage\n",
-              st[i].v == V_FACES ? "faces" : "keypoints");
+              st[i].v == V_FACES ? "faces" : st[i].v == V_ORB ? "orb" : "keypoints");
       return -1;
     }
   return n;
@@ -229,6 +232,7 @@ static int check_stage(const struct stage *s, unsigned w, unsigned h) {
     case V_FACES: /* nanomagick.c:351-355 */
       if (s->a[0] <= 0) return fprintf(stderr, "Error: minimum neighbors must be positive\n"), -1;
       break;
+    case V_ORB:
     case V_SOBEL: break;
   }
   return 0;
@@ -338,7 +342,8 @@ static void run_stages(const struct stage *st, int ns, struct planes *p, unsigne
         break;
       }
       case V_KEYPOINTS:
-      case V_FACES: break; /* terminal verbs: detect_* below, after the image chain */
+      case V_FACES:
+      case V_ORB: break; /* terminal verbs: handled by the worker after the image chain */
     }
     i++;
   }
@@ -442,6 +447,27 @@ static void *worker(void *arg) {
   gsh_set_device(jb->device);
   gsh_set_async(1); /* per-frame gs_resize / gs_crop on device pointers stay stream-ordered */
   if (term && term->v == V_FACES) dc = gsh_cascade_create(jb->cascade);
+  /* orb <template.pgm>: the template is read once and lives on the device */
+  struct frame tmpl;
+  uint8_t *tmpl_host = NULL, *tmpl_dev = NULL;
+  struct gs_keypoint *tkps = NULL, *skps = NULL;
+  struct gs_match *matches = NULL;
+  memset(&tmpl, 0, sizeof tmpl);
+  if (term && term->v == V_ORB) {
+    tmpl.path = term->raw;
+    if (read_pgm_header(tmpl.path, &tmpl) != 0 || !(tmpl_host = (uint8_t *)malloc((size_t)tmpl.w * tmpl.h)) ||
+        read_pgm_pixels(&tmpl, tmpl_host) != 0) {
+      if (jb->device == 0) printf("Error: Cannot load template image %s\n", tmpl.path); /* nanomagick.c:294, on stdout */
+      tmpl.w = 0;
+    } else {
+      tmpl_dev = (uint8_t *)gsh_malloc((size_t)tmpl.w * tmpl.h);
+      gsh_upload(tmpl_dev, tmpl_host, (size_t)tmpl.w * tmpl.h);
+    }
+    tkps = (struct gs_keypoint *)malloc(5000 * sizeof *tkps); /* nanomagick.c:301 */
+    skps = (struct gs_keypoint *)malloc(5000 * sizeof *skps);
+    matches = (struct gs_match *)malloc(kOrbMatches * sizeof *matches);
+    if (!tkps || !skps || !matches) return jb->rc = 1, (void *)0;
+  }
 
   for (g = 0; g < jb->ngroups; g++) {
     unsigned w = 0, h = 0, ngroup = 0, n, lo, hi, f, ow, oh;
@@ -453,6 +479,8 @@ static void *worker(void *arg) {
     int *idx;
     double t0;
     /* terminal-verb buffers */
+    uint8_t *orb_buf = NULL;
+    size_t orb_buf_bytes = 0;
     uint8_t *score = NULL;
     struct gs_keypoint *kps_dev = NULL, *kps_host = NULL;
     unsigned *ii = NULL, *cnt_dev = NULL, *cnt_host = NULL;
@@ -498,7 +526,13 @@ static void *worker(void *arg) {
     p.thr_host = (uint8_t *)malloc(cap);
     failed = (int *)malloc(cap * sizeof *failed);
     stage = (uint8_t *)gsh_host_alloc(max_fb * cap); /* page-locked: one DMA each way per slice */
-    if (term) {
+    if (term && term->v == V_ORB) {
+      /* one scratch buffer for both pyramids, like nanomagick's (there: a static 1 MiB array, which a
+       * frame beyond ~700x500 overruns; here: as large as the bigger pyramid needs) */
+      const size_t a = tmpl.w ? gsh_orb_pyramid_buffer_bytes(tmpl.w, tmpl.h, 3) : 0, b = gsh_orb_pyramid_buffer_bytes(ow, oh, 3);
+      orb_buf_bytes = a > b ? a : b;
+      orb_buf = (uint8_t *)gsh_malloc(orb_buf_bytes);
+    } else if (term) {
       const size_t ofb = (size_t)ow * oh;
       cnt_dev = (unsigned *)gsh_malloc((size_t)cap * sizeof(unsigned));
       cnt_host = (unsigned *)malloc((size_t)cap * sizeof(unsigned));
@@ -540,7 +574,7 @@ static void *worker(void *arg) {
       if (term && term->v == V_KEYPOINTS) { /* nanomagick.c:229-230: gs_fast into a zeroed score map, cap 5000 */
         gsh_memset(score, 0, (size_t)ow * oh * nb);
         gsh_fast_batch(p.cur, score, ow, oh, nb, kps_dev, cnt_dev, kFastCap, (unsigned)term->a[1]);
-      } else if (term) { /* nanomagick.c:362-364 */
+      } else if (term && term->v == V_FACES) { /* nanomagick.c:362-364 */
         gsh_integral_batch(p.cur, ow, oh, nb, ii);
         gsh_lbp_detect_batch(dc, ii, ow, oh, nb, rects_dev, cnt_dev, kFaceCap, 1.2f, 1.0f, 4.0f, term->a[0]);
       }
@@ -549,7 +583,7 @@ static void *worker(void *arg) {
 
       t0 = now_ms();
       gsh_download(stage, p.cur, (size_t)ow * oh * nb);
-      if (term) {
+      if (term && term->v != V_ORB) {
         gsh_download(cnt_host, cnt_dev, (size_t)nb * sizeof(unsigned));
         if (term->v == V_KEYPOINTS) gsh_download(kps_host, kps_dev, (size_t)nb * kFastCap * sizeof *kps_host);
         else gsh_download(rects_host, rects_dev, (size_t)nb * kFaceCap * sizeof *rects_host);
@@ -564,6 +598,63 @@ static void *worker(void *arg) {
         if (failed[f]) {
           if (failed[f] == 1) fprintf(stderr, "Error: %s did not produce output image\n", fi->path);
           fi->failed = 1, jb->rc = 1;
+          continue;
+        }
+        if (term && term->v == V_ORB) { /* nanomagick.c:292-345, frame by frame like one process per file */
+          unsigned nt, nsc, nm, k, x, y;
+          FILE *rec;
+          uint8_t *out;
+          if (!tmpl.w) { /* the verb returned without an image (nanomagick.c:294-297) */
+            fprintf(stderr, "Error: Command 'orb' did not produce output image\n");
+            fi->failed = 1, jb->rc = 1;
+            continue;
+          }
+          /* the scratch buffer starts zeroed in every nanomagick process and the scene's pyramid is built
+           * over what the template's left behind (its never-written score-map frames are read by the NMS) */
+          gsh_memset(orb_buf, 0, orb_buf_bytes);
+          nt = gsh_orb_extract_pyramid(tmpl_dev, tmpl.w, tmpl.h, orb_buf, tkps, kOrbKps, 20, 3);
+          nsc = gsh_orb_extract_pyramid(p.cur + (size_t)ow * oh * f, ow, oh, orb_buf, skps, kOrbKps, 20, 3);
+          nm = gs_match_orb(tkps, nt, skps, nsc, matches, kOrbMatches, 60.0f);
+          snprintf(path, sizeof path, "%s/%s.orb.txt", jb->outdir, base_name(fi->path));
+          rec = fopen(path, "w");
+          if (rec) fprintf(rec, "Template: %u keypoints, Scene: %u keypoints, Matches: %u\n", nt, nsc, nm);
+          if (nm == 0) {
+            if (rec) fclose(rec);
+            fprintf(stderr, "Error: Command 'orb' did not produce output image\n"); /* nanomagick.c:431 */
+            fi->failed = 1, jb->rc = 1;
+            continue;
+          }
+          for (k = 0; k + 1 < nm; k++) { /* nanomagick.c:312-318: the same exchange sort, same order of ties */
+            unsigned j;
+            for (j = k + 1; j < nm; j++)
+              if (matches[j].distance < matches[k].distance) {
+                const struct gs_match t = matches[k];
+                matches[k] = matches[j], matches[j] = t;
+              }
+          }
+          for (k = 0; rec && k < nm; k++)
+            fprintf(rec, "%u %u %u  %u %u  %u %u\n", matches[k].idx1, matches[k].idx2, matches[k].distance,
+                    tkps[matches[k].idx1].pt.x, tkps[matches[k].idx1].pt.y, skps[matches[k].idx2].pt.x,
+                    skps[matches[k].idx2].pt.y);
+          if (rec) fclose(rec);
+          { /* stitched picture: template left, frame right, the 15 best matches as lines (nanomagick.c:321-342) */
+            const unsigned sw = tmpl.w + ow, sh = tmpl.h > oh ? tmpl.h : oh;
+            out = (uint8_t *)calloc((size_t)sw * sh, 1);
+            if (!out) return jb->rc = 1, (void *)0;
+            for (y = 0; y < tmpl.h; y++) memcpy(out + (size_t)y * sw, tmpl_host + (size_t)y * tmpl.w, tmpl.w);
+            for (y = 0; y < oh; y++) memcpy(out + (size_t)y * sw + tmpl.w, img + (size_t)y * ow, ow);
+            for (k = 0; k < (nm < 15 ? nm : 15); k++) {
+              const unsigned x1 = tkps[matches[k].idx1].pt.x, y1 = tkps[matches[k].idx1].pt.y;
+              x = skps[matches[k].idx2].pt.x + tmpl.w, y = skps[matches[k].idx2].pt.y;
+              draw_line(out, sw, sh, x1, y1, x, y, 255);
+            }
+            snprintf(path, sizeof path, "%s/%s", jb->outdir, base_name(fi->path));
+            if (write_pgm(path, out, sw, sh) != 0) {
+              fprintf(stderr, "Error: Could not save %s\n", path);
+              jb->rc = 1;
+            }
+            free(out);
+          }
           continue;
         }
         if (term) { /* records first (the numbers before any drawing), then nanomagick's drawing */
@@ -613,6 +704,7 @@ static void *worker(void *arg) {
     gsh_free(p.hist);
     gsh_free(p.thr_dev);
     gsh_host_free(stage);
+    gsh_free(orb_buf);
     gsh_free(score);
     gsh_free(kps_dev);
     gsh_free(ii);
@@ -626,6 +718,11 @@ static void *worker(void *arg) {
     free(idx);
   }
   if (dc) gsh_cascade_destroy(dc);
+  gsh_free(tmpl_dev);
+  free(tmpl_host);
+  free(tkps);
+  free(skps);
+  free(matches);
   gsh_shutdown();
   return (void *)0;
 }

@@ -166,6 +166,54 @@ def test_gsbatch_feature_verbs_equal_piped_nanomagick_emulated(tmp_path, gpus):
         assert compared >= len(files) - 1
 
 
+@pytest.mark.skipif(not os.path.exists(NANO), reason="reference checkout not present")
+def test_gsbatch_orb_verb_equals_nanomagick_emulated(tmp_path):
+    """`orb <template.pgm>` as the last stage: the stitched picture with the 15 best matches is byte-identical to the
+    reference CLI's, the sidecar's first line is the line nanomagick prints (nanomagick.c:308)"""
+    from oracle.pyoracle import Oracle
+    exe, nano = build_emu(tmp_path), build_ref_nano(tmp_path)
+    lena = os.path.join(ROOT, "tests", "golden", "lena.pgm")
+    shifted = str(tmp_path / "shifted.pgm")
+    a = read_pgm(lena)
+    b = np.zeros_like(a)
+    b[:-3, :-5] = a[3:, 5:]
+    b[0, 0] = 40
+    write_pgm(shifted, b)
+    other = str(tmp_path / "synth.pgm")
+    c = Oracle.synth(160, 120, 77)
+    c[0, 0] = max(int(c[0, 0]), 33)
+    write_pgm(other, c)
+    files = [lena, shifted, other]
+    for ci, chain in enumerate([[("orb", [lena])], [("blur", ["1"]), ("orb", [lena])]]):
+        outdir = tmp_path / ("orb%d" % ci)
+        outdir.mkdir()
+        r = subprocess.run([exe, "-o", str(outdir), *chain_args(chain), "--", *files], capture_output=True, timeout=1800)
+        for i, f in enumerate(files):
+            cur, line = f, b""
+            for k, (verb, args) in enumerate(chain):  # the reference way, keeping the last stage's stdout
+                out = str(tmp_path / ("oref%d_%d_%d.pgm" % (ci, i, k)))
+                rr = subprocess.run([nano, verb, *args, cur, out], capture_output=True, timeout=900)
+                cur, line = (out if rr.returncode == 0 else None), rr.stdout
+                if cur is None:
+                    break
+            rec = open(str(outdir / (os.path.basename(f) + ".orb.txt"))).read().splitlines()
+            assert rec[0] + "\n" == line.decode(), (f, rec[0], line)
+            mine = str(outdir / os.path.basename(f))
+            if cur is None:  # no matches: nanomagick writes nothing, neither do we
+                assert not os.path.exists(mine) and r.returncode == 1
+            else:
+                assert open(mine, "rb").read() == open(cur, "rb").read(), "orb picture differs for %s" % f
+                nmatch = int(rec[0].rsplit(" ", 1)[1])
+                assert len(rec) == 1 + nmatch
+                d = [int(x.split()[2]) for x in rec[1:]]
+                assert d == sorted(d)
+    # an unreadable template: nanomagick's message, no output
+    outdir = tmp_path / "orbbad"
+    outdir.mkdir()
+    r = subprocess.run([exe, "-o", str(outdir), "orb", str(tmp_path / "nope.pgm"), "--", lena], capture_output=True, timeout=600)
+    assert r.returncode == 1 and b"Cannot load template image" in r.stdout and os.listdir(str(outdir)) == []
+
+
 def test_gsbatch_feature_verb_errors_emulated(tmp_path):
     exe = build_emu(tmp_path)
     lena = os.path.join(ROOT, "tests", "golden", "lena.pgm")
@@ -381,3 +429,33 @@ def test_gsbatch_feature_verbs_on_gpu(tmp_path):
                 exp, err = nano_chain(nano, chain, f, tmp_path, "gref%d_%d" % (c, i))
                 if exp is not None:
                     assert open(str(outdir / os.path.basename(f)), "rb").read() == open(exp, "rb").read(), (c, f)
+
+
+@pytest.mark.gpu
+def test_gsbatch_orb_verb_on_gpu(tmp_path):
+    """`orb <template>` through the real binary on MI355X against the reference CLI's own build (prebuilt)"""
+    nano = os.path.join(ROOT, "oracle", "_ref", "nano_ref")
+    if not os.path.exists(nano):
+        pytest.skip("oracle/_ref/nano_ref was not prebuilt")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "grayskull_amd", "csrc"), "tool"])
+    exe = os.path.join(ROOT, "grayskull_amd", "gsbatch")
+    lena = os.path.join(ROOT, "tests", "golden", "lena.pgm")
+    a = read_pgm(lena)
+    files = [lena]
+    for k, (dx, dy) in enumerate([(5, 3), (1, 9)]):
+        b = np.zeros_like(a)
+        b[:-dy, :-dx] = a[dy:, dx:]
+        b[0, 0] = 40
+        p = str(tmp_path / ("shift%d.pgm" % k))
+        write_pgm(p, b)
+        files.append(p)
+    outdir = tmp_path / "orb"
+    outdir.mkdir()
+    r = subprocess.run([exe, "-o", str(outdir), "orb", lena, "--", *files], capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-500:]
+    for i, f in enumerate(files):
+        out = str(tmp_path / ("ref%d.pgm" % i))
+        rr = subprocess.run([nano, "orb", lena, f, out], capture_output=True, timeout=600)
+        assert rr.returncode == 0
+        assert open(str(outdir / (os.path.basename(f) + ".orb.txt"))).read().splitlines()[0] + "\n" == rr.stdout.decode()
+        assert open(str(outdir / os.path.basename(f)), "rb").read() == open(out, "rb").read(), f
