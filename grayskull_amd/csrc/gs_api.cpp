@@ -84,6 +84,17 @@ struct LbpGeomCache {
   unsigned long long nwindows = 0;
 };
 struct gsh_cascade_tables_deleter { void operator()(struct ::gsh_cascade *dc) const; };
+/* Events that order the library's own streams on ONE device need no system-scope fence: a plain
+ * hipEventRecord releases to the system (L2 write-back of everything the previous kernel left dirty),
+ * measured at ~37 us per record between back-to-back launches that each write 265 MB (scripts/ubench_gaps.py,
+ * profiles/r02f_launch_gaps.log; inside the pipeline the side stream's threshold pass fills that gap, so
+ * the step time moves by < 0.5 %, profiles/r02f_event_flags.log).  GS_EVENT_FLAGS (experiment hook): 0 = HIP's default. */
+#ifndef GS_EMU
+#ifndef GS_EVENT_FLAGS
+#define GS_EVENT_FLAGS hipEventDisableSystemFence
+#endif
+inline unsigned sync_event_flags() { return GS_EVENT_FLAGS; }
+#endif
 struct Ctx {
   int device = 0;
   bool device_set = false;
@@ -115,7 +126,7 @@ struct Ctx {
   void prof_mark(int which, hipStream_t on) { /* which: 0 before, 1 after the launch */
     if (!prof_on || prof_n >= (unsigned)kProfPairs) return;
     hipEvent_t &e = prof_ev[2 * prof_n + which];
-    if (!e) GS_HIP(hipEventCreate(&e)); /* normally pre-created by gsh_profile */
+    if (!e) GS_HIP(hipEventCreateWithFlags(&e, sync_event_flags())); /* normally pre-created by gsh_profile */
     GS_HIP(hipEventRecord(e, on));
     if (which) prof_n++;
   }
@@ -135,8 +146,8 @@ struct Ctx {
       if (hipStreamGetPriority(s(), &mine) != hipSuccess) mine = 0;
       GS_HIP(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, mine == lo && lo != hi ? hi : lo));
     }
-    GS_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
-    for (auto &e : ev_chunk) GS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    GS_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming | sync_event_flags()));
+    for (auto &e : ev_chunk) GS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming | sync_event_flags()));
   }
 #endif
 
@@ -902,7 +913,7 @@ void gsh_profile(int on) {
   c.prof_n = 0;
   /* on > 1: create that many event pairs now, so that none is created inside a timed region */
   for (int i = 0; on > 1 && i < 2 * std::min(on, (int)Ctx::kProfPairs); i++)
-    if (!c.prof_ev[i]) GS_HIP(hipEventCreate(&c.prof_ev[i]));
+    if (!c.prof_ev[i]) GS_HIP(hipEventCreateWithFlags(&c.prof_ev[i], sync_event_flags())); /* timing on, no system fence */
 #else
   (void)on;
 #endif

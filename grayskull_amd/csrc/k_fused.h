@@ -54,8 +54,11 @@ GS_DEV void blur_hsum10(const uint32_t (&U)[12], uint32_t (&H)[10]) { /* pairs =
 
 /* grid like the strip kernels; partial: [frame][blockIdx.y * gridDim.x + blockIdx.x][256] */
 /* HIST = false: gs_blur + gs_sobel only (gsh_blur_sobel_batch): no LDS, no histogram, `partial` unused */
+#ifndef GS_FUSED_VGPR_ATTR
+#define GS_FUSED_VGPR_ATTR /* experiment hook: -DGS_FUSED_VGPR_ATTR='__attribute__((amdgpu_num_vgpr(144)))' */
+#endif
 template <int R, bool HIST = true>
-__global__ __launch_bounds__(256) void k_blur_sobel_hist16(uint8_t *dst, const uint8_t *src,
+__global__ __launch_bounds__(256) GS_FUSED_VGPR_ATTR void k_blur_sobel_hist16(uint8_t *dst, const uint8_t *src,
                                                            unsigned w, unsigned h, unsigned T,
                                                            size_t frame_bytes, unsigned *partial) {
   constexpr int N = 2 * R + 1;
