@@ -269,10 +269,26 @@ StripCfg strip_cfg(unsigned w, unsigned rows, unsigned n, unsigned waves_per_sim
   if (g_tune[0] > 0) {
     t = (unsigned long long)g_tune[0];
   } else {
-    unsigned long long nb = 1024ull * waves_per_simd / (waves_x * n); /* bands per frame */
+    /* bands per frame: the launch should fill the chip's resident-wave capacity a whole number of
+     * times.  One round when the batch is small enough; for big batches (512 4K frames: 2048 wave
+     * columns against 3072 slots at 3 waves per SIMD) one band per frame would leave a third of the
+     * chip idle for the whole launch and two bands would run a 1.33rd round at a third occupancy, so
+     * take the band count whose last round is fullest (here 3: exactly two rounds; gsh_blur_sobel_batch
+     * 512 frames 1.96 -> 1.89 ms, 200 frames 0.90 -> 0.74 ms, profiles/r02f_band_count_512.log). */
+    const unsigned long long cap = 1024ull * waves_per_simd, wn = waves_x * n;
     const unsigned long long nb_max = rows / 8 ? rows / 8 : 1; /* bands of >= 8 rows */
+    unsigned long long nb = cap / wn;
     if (nb < 1) nb = 1;
     if (nb > nb_max) nb = nb_max;
+    /* (only for the VALU-heavy fused kernels, which run 3 waves per SIMD: the HBM-bound per-call
+     * kernels lose 3-6 % to the extra halo rows of shorter bands, profiles/r02f_band_count_512.log) */
+    if (waves_per_simd <= 3 && nb < 4 && wn * nb * 8 < cap * 7) { /* a lone round under 7/8 full: try 2..6 rounds */
+      double best = (double)((wn * nb + cap - 1) / cap) * cap / (double)(wn * nb);
+      for (unsigned long long c = nb + 1; c <= nb_max && c <= nb + 6; c++) {
+        const double waste = (double)((wn * c + cap - 1) / cap) * cap / (double)(wn * c);
+        if (waste < best - 0.02) best = waste, nb = c;
+      }
+    }
     t = (rows + nb - 1) / nb;
   }
   c.T = (unsigned)t;
