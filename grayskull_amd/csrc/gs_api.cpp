@@ -257,17 +257,27 @@ int g_tune[10] = {0, 1, 1, 0, 0, 0, 0, 0, 0, 0};
 thread_local unsigned long long *g_lbp_evaluated = nullptr;
 
 struct StripCfg { dim3 grid, block; unsigned T; };
-/* rows: output rows per frame.  One wave per (1024-px column block, band, frame).  Measured on
- * MI355X (profiles/r01d_ubench_T_fine.log): fastest when every wave of the launch is resident
- * at once and bands divide the rows evenly -- ~5 waves per SIMD x 1024 SIMDs = 5120 waves
- * (64 x 4K frames: 20 bands of 108 rows; 128-row bands leave a ragged 17th band: +10 % time). */
-StripCfg strip_cfg(unsigned w, unsigned rows, unsigned n, unsigned waves_per_simd = 5) {
+/* rows: output rows per frame.  One wave per (1024-px column block, band, frame).
+ * HBM-bound per-call kernels (waves_per_simd >= 5) take SHORT bands of 8 rows (more for wide halos):
+ * blocks are dispatched in band order, so the few thousand waves that are resident at any time work
+ * on neighbouring rows of a few frames -- the DRAM pages they stream through are shared and the
+ * halo rows of the next band are still in the Infinity Cache -- instead of each wave streaming its
+ * own distant band.  Measured (profiles/r02g_small_bands_*.log, 64 frames): gs_sobel 4096x4096
+ * 4.87 -> 5.62 TB/s (0.61 -> 0.70 of 8 TB/s) although it re-reads 2 halo rows per 8, 3840x2160
+ * 4.76 -> 5.23; gs_blur(2) 4.88 -> 5.34 / 4.65 -> 4.90; erode 5.05 -> 5.57; plain strip copy 5.08 ->
+ * 5.59.  Round 1 sized bands so that every wave of the launch was resident at once (20 bands of
+ * 108 rows for 64 4K frames) and never tried bands below 16 rows.
+ * The VALU-heavy fused kernels (waves_per_simd 3) keep long bands: each band first recomputes
+ * 2R+2 rows of horizontal sums (8-row bands: 0.25 -> 0.38 ms per 64 frames). */
+StripCfg strip_cfg(unsigned w, unsigned rows, unsigned n, unsigned waves_per_simd = 5, unsigned halo_rows = 2) {
   StripCfg c;
   const unsigned strips = (w + 15) / 16;
   const unsigned long long waves_x = (strips + 63) / 64;
   unsigned long long t;
   if (g_tune[0] > 0) {
     t = (unsigned long long)g_tune[0];
+  } else if (waves_per_simd >= 5) {
+    t = std::max(8u, 2u * halo_rows);
   } else {
     /* bands per frame: the launch should fill the chip's resident-wave capacity a whole number of
      * times.  One round when the batch is small enough; for big batches (512 4K frames: 2048 wave
@@ -422,7 +432,7 @@ void launch_blur(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsig
   if (radius >= 1 && radius <= 3 && strip_ok(w, h, dst, src) && h > 2 * radius && w > 2 * radius) {
     for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
       const unsigned nn = std::min(kMaxZ, n - f0);
-      const StripCfg c = strip_cfg(w, h, nn);
+      const StripCfg c = strip_cfg(w, h, nn, 5, 2 * radius);
       uint8_t *d = dst + fb * f0;
       const uint8_t *s = src + fb * f0;
       if (radius == 1) GS_LAUNCH(k_blur16<1>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb);
