@@ -76,6 +76,9 @@ struct State {
   std::vector<WaveX> waves;
   const std::function<void()> *body = nullptr;
   char *dyn_lds = nullptr;
+  ~State() { /* one State per host thread: give the fiber stacks back when the thread ends */
+    for (auto &f : fibers) free(f.stack);
+  }
 };
 State &S();
 

@@ -459,3 +459,29 @@ def test_gsbatch_orb_verb_on_gpu(tmp_path):
         assert rr.returncode == 0
         assert open(str(outdir / (os.path.basename(f) + ".orb.txt"))).read().splitlines()[0] + "\n" == rr.stdout.decode()
         assert open(str(outdir / os.path.basename(f)), "rb").read() == open(out, "rb").read(), f
+
+
+def test_gsbatch_two_workers_asan_clean(tmp_path):
+    """the C driver with two worker threads (two emulated devices), every kind of chain, under AddressSanitizer
+    with leak detection: no invalid access, nothing left behind when the workers exit (per-thread library
+    context with a destructor) -- the host logic of `--gpus N`, which no 1-GPU box can run for real"""
+    emu_dir = os.path.join(ROOT, "tests", "emu")
+    csrc = os.path.join(ROOT, "grayskull_amd", "csrc")
+    lib = str(tmp_path / "libgs_kernel_emu.so")
+    san = ["-fsanitize=address", "-fno-omit-frame-pointer", "-g", "-O1"]
+    subprocess.check_call(["g++", "-DGS_EMU", *san, "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-w",
+                           "-I" + emu_dir, "-I" + csrc, os.path.join(csrc, "gs_api.cpp"), os.path.join(csrc, "gs_fused.cpp"),
+                           os.path.join(emu_dir, "hip_emu.cpp"), "-o", lib])
+    exe = str(tmp_path / "gsbatch_asan")
+    subprocess.check_call(["gcc", "-std=c99", *san, "-I" + os.path.join(ROOT, "include"), SRC, "-o", exe,
+                           "-L" + str(tmp_path), "-lgs_kernel_emu", "-pthread", "-Wl,-rpath," + str(tmp_path)])
+    lena = os.path.join(ROOT, "tests", "golden", "lena.pgm")
+    env = dict(os.environ, GS_EMU_DEVICES="2", ASAN_OPTIONS="detect_stack_use_after_return=0:detect_leaks=1:exitcode=66")
+    for c, chain in enumerate([["blur", "2", ":", "sobel", ":", "faces", "1"], ["blur", "1", ":", "threshold", "otsu", ":", "morph", "dilate", "2"],
+                               ["keypoints", "50", "20"], ["orb", lena]]):
+        out = tmp_path / ("asan%d" % c)
+        out.mkdir()
+        r = subprocess.run([exe, "--gpus", "2", "--cascade", CASCADE, "-o", str(out), *chain, "--", lena, lena, lena],
+                           capture_output=True, timeout=900, env=env)
+        err = r.stderr.decode()
+        assert r.returncode == 0 and "ERROR: AddressSanitizer" not in err and "LeakSanitizer" not in err, err[-1500:]
