@@ -364,6 +364,17 @@ def main():
             ok &= int(thr[f]) == t and np.array_equal(dst[f].cpu().numpy(), o.threshold(s, t))
         parity = "bit-exact vs oracle on frames %s" % vf if ok else "MISMATCH"
     thr_all = sh.all_gather_frames(thr, F * sh.world)  # KB-scale result exchange (RCCL when N>1)
+    # per-frame output checksums (sum of the bytes of each thresholded frame, computed on the owning GPU), gathered
+    # in global frame order: SURVEY 8(e)'s "checksum of checksums" -- the same number whatever N is for the same
+    # global frames; pixel planes never cross GPUs
+    step()
+    sums = torch.zeros(F, dtype=torch.int64, device="cuda")
+    g.checksum_batch(dst, sums)
+    torch.cuda.synchronize()
+    sums_all = sh.all_gather_frames(sums, F * sh.world)
+    digest = 1469598103934665603
+    for v in sums_all.cpu().tolist():
+        digest = ((digest ^ (v & 0xffffffffffffffff)) * 1099511628211) & 0xffffffffffffffff
     ranks_seen = sh.ranks_seen()
 
     out = {
@@ -390,6 +401,7 @@ def main():
             "percall_equivalent_GB/s (4 B/px)": ktab[bs].get("percall_equivalent_GB/s"), "limited_by": "valu"},
         "roofline": roof, "kernels": ktab, "sobel_4096x4096": ns, "other_configs": other, "parity": parity,
         "otsu_thresholds_gathered": int(thr_all.numel()),
+        "output_checksum_of_checksums": "%016x" % digest, "output_checksums_gathered": int(sums_all.numel()),
     }
     if sh.rank == 0 and sh.world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(w, h, r)
