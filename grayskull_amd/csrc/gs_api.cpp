@@ -712,7 +712,13 @@ void launch_lbp_padded(const gsh_cascade *dc, const LbpGeomCache &gc, const unsi
         {2, 5, 99, 99, 99, 99, 99, 99},
         {2, 6, 99, 99, 99, 99, 99, 99},
         {3, 7, 99, 99, 99, 99, 99, 99}};
+    unsigned custom[kLbpMaxPhases];
     const unsigned *pr = presets[(g_tune[4] >= 0 && g_tune[4] < 8) ? g_tune[4] : 0];
+    if (g_tune[4] >= 1000) { /* experiments: 1000 + e0 + 32 e1 + 1024 e2 + 32768 e3 (0 = no further split) */
+      unsigned v = (unsigned)g_tune[4] - 1000u;
+      for (unsigned i = 0; i < kLbpMaxPhases; i++, v >>= 5) custom[i] = (v & 31u) ? (v & 31u) : 99u;
+      pr = custom;
+    }
     ph.n = 0;
     unsigned prev = 0;
     for (unsigned i = 0; i < kLbpMaxPhases && prev < dc->nstages; i++) {
@@ -722,6 +728,11 @@ void launch_lbp_padded(const gsh_cascade *dc, const LbpGeomCache &gc, const unsi
     }
     if (ph.n == 0) ph.n = 1, ph.end[0] = dc->nstages;
     ph.end[ph.n - 1] = dc->nstages;
+    /* preset 0 (default): first re-packing point chosen per block between stages 2 and 6 (k_lbp.h) */
+    ph.adaptive_max = (g_tune[4] == 0 && dc->nstages > 2) ? 6u : 0u;
+    ph.adaptive_tenths = 2u;
+    if (ph.adaptive_max && g_tune[9] > 0) /* experiments: key 9 = max + 16 * tenths */
+      ph.adaptive_max = (unsigned)g_tune[9] & 15u, ph.adaptive_tenths = (unsigned)g_tune[9] >> 4;
   }
   const size_t lds_all = ((lds + 15) & ~(size_t)15) + 2 * kChunkItems * 2 + 64 * 4 + 16;
   if (a.evaluated) { /* counting build: the same kernel + one register that counts classifier evaluations */

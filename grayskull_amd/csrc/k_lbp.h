@@ -184,7 +184,21 @@ GS_DEV unsigned lbp_origin(const LbpArgs &a, const LbpScale &sc, unsigned idx) {
  * measured 3-4x SLOWER).  The finished mask words and their popcount go to the ordered
  * compaction (k_compact.h) -- same bits as publishing ballots, no atomics on global memory. */
 constexpr unsigned kLbpMaxPhases = 8;
-struct LbpPhases { unsigned n; unsigned end[kLbpMaxPhases]; }; /* phase p = stages [end[p-1], end[p]) */
+struct LbpPhases { /* phase p = stages [end[p-1], end[p]) */
+  unsigned n;
+  unsigned end[kLbpMaxPhases];
+  /* adaptive_max > 0: the FIRST re-packing point is chosen per block.  The dense phase (one window per lane,
+   * consecutive windows: the cheapest gathers) runs stages [0, end[0]) and then goes on stage by stage, dead
+   * windows masked, while more than adaptive_tenths/10 of the chunk's windows are alive and fewer than
+   * adaptive_max stages are done: re-packing a set that has barely shrunk trades cheap consecutive gathers for
+   * scattered ones and saves few lanes.  Block-noise frames (63 % die in stage 0) re-pack after stage 2 as the
+   * fixed split (2,4,7) does (3.92 vs 3.90 ms per 4K frame); on edge maps, where far more windows of a chunk
+   * survive the first stages, blocks stay dense for up to 6 stages: 6.33 -> 5.76 ms per 4K frame
+   * (profiles/r02h_lbp_adaptive.log; fixed splits tuned for one input lose 3-10 % on the other,
+   * profiles/r02h_lbp_splits.log).  The later re-packing points follow at +2 and +5 stages. */
+  unsigned adaptive_max;
+  unsigned adaptive_tenths; /* re-pack once alive <= tenths/10 of the chunk */
+};
 
 /* grid (max chunks per scale, nscales, n frames), block 256;
  * dynamic LDS = lbp_lds_bytes(...) + 2 queues x 2048 u16 + 64 mask words + 2 counters */
@@ -236,9 +250,71 @@ __global__ __launch_bounds__(256) void k_lbp_cascade(LbpArgs a, LbpPhases ph) {
   const unsigned *Pg = a.padded + (size_t)blockIdx.z * a.frame_stride;
   unsigned n_in = nwin - first < kChunkItems ? nwin - first : kChunkItems;
   unsigned cur = 0, evals = 0;
-  for (unsigned p = 0; p < ph.n; p++) {
-    const unsigned s0 = p ? ph.end[p - 1] : 0u, s1 = ph.end[p];
-    const bool lastp = p + 1 == ph.n;
+  unsigned ends[kLbpMaxPhases], np = ph.n, pstart = 0;
+#pragma unroll
+  for (unsigned i = 0; i < kLbpMaxPhases; i++) ends[i] = ph.end[i];
+  if (ph.adaptive_max) { /* dense pre-phase with a block-local choice of the first re-packing point */
+    __shared__ unsigned alive_count;
+    if (tid == 0) alive_count = 0;
+    __syncthreads();
+    unsigned alive = 0; /* bit k: window k * 256 + tid of the chunk is still alive */
+#pragma unroll
+    for (unsigned k = 0; k < kChunkItems / 256u; k++) alive |= (k * 256u + tid < n_in ? 1u : 0u) << k;
+    unsigned s_prev = 0, e = ph.end[0] < a.nstages ? ph.end[0] : a.nstages;
+    for (;;) { /* block-uniform */
+      for (unsigned k = 0; k < kChunkItems / 256u; k++) { /* uniform trip count; dead lanes idle */
+        if (k * 256u >= n_in) break;
+        if ((alive >> k) & 1u) {
+          if (!lbp_window_stages<GUARD, COUNT>(t, Pg, lbp_origin(a, sc, first + k * 256u + tid), a.limit_bytes, s_prev, e, &evals))
+            alive &= ~(1u << k);
+        }
+      }
+      const unsigned mine = wave_sum((unsigned)__popc(alive));
+      if ((tid & 63u) == 0 && mine) atomicAdd(&alive_count, mine);
+      __syncthreads();
+      const unsigned c = alive_count;
+      __syncthreads();
+      if (tid == 0) alive_count = 0;
+      if (e >= a.nstages || c == 0 || c * 10u <= ph.adaptive_tenths * n_in || e >= ph.adaptive_max) {
+        if (e >= a.nstages) { /* small cascade: the dense phase was the whole cascade */
+          for (unsigned k = 0; k < kChunkItems / 256u; k++)
+            if ((alive >> k) & 1u) atomicOr(&bits[(k * 256u + tid) >> 5], 1u << ((k * 256u + tid) & 31u));
+          n_in = 0;
+        } else { /* re-pack the survivors: same queue format as the fixed phases */
+          uint16_t *qout = queue + (cur ^ 1u) * kChunkItems;
+          for (unsigned k = 0; k < kChunkItems / 256u; k++) {
+            if (k * 256u >= n_in) break;
+            const bool pass = (alive >> k) & 1u;
+            const uint64_t m = ballot(pass);
+            if (m) {
+              const unsigned lane = lane_id();
+              unsigned base = 0;
+              if (lane == 0) base = atomicAdd(&qn[cur ^ 1u], (unsigned)__popcll(m));
+              base = readlane0(base);
+              if (pass) qout[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(k * 256u + tid);
+            }
+          }
+          __syncthreads();
+          n_in = qn[cur ^ 1u];
+          __syncthreads();
+          if (tid == 0) qn[cur] = 0;
+          cur ^= 1u;
+        }
+        break;
+      }
+      s_prev = e, e = e + 1u;
+    }
+    /* the remaining phases: +2, +5 stages, then the rest */
+    np = 0, ends[np++] = e;
+    if (e + 2u < a.nstages) ends[np++] = e + 2u;
+    if (e + 5u < a.nstages) ends[np++] = e + 5u;
+    if (e < a.nstages) ends[np++] = a.nstages;
+    pstart = 1;
+    if (n_in == 0) pstart = np; /* nothing left (or already final) */
+  }
+  for (unsigned p = pstart; p < np; p++) {
+    const unsigned s0 = p ? ends[p - 1] : 0u, s1 = ends[p];
+    const bool lastp = p + 1 == np;
     const uint16_t *qin = queue + cur * kChunkItems;
     uint16_t *qout = queue + (cur ^ 1u) * kChunkItems;
     for (unsigned i0 = 0; i0 < n_in; i0 += 256u) { /* block-uniform trip count */

@@ -253,6 +253,24 @@ def test_lbp_survivor_repacking_never_changes_results(emu, oracle, cascade, pres
         emu.tune(4, 0)
 
 
+@pytest.mark.parametrize("knob", [3 + 16 * 10, 6 + 16 * 0, 15 + 16 * 0, 4 + 16 * 5, 1000 + 3 + 32 * 5])
+def test_lbp_adaptive_first_repack_never_changes_results(emu, oracle, cascade, knob):
+    """default preset: the first re-packing point is chosen per block from the survivor count (k_lbp.h
+    LbpPhases::adaptive_max); key 9 = max stages + 16 * tenths forces early, late and never-early choices,
+    key 4 >= 1000 a custom fixed split -- rectangles are the oracle's for all of them"""
+    edges = oracle.sobel(oracle.blur(Oracle.synth(128, 96, 1000), 2))
+    try:
+        if knob >= 1000: emu.tune(4, knob)
+        else: emu.tune(9, knob)
+        pc.lbp(emu, oracle, edges, MEM, cascade, params=((4096, 1.1, 1.0, 4.0, 1),))
+        pc.lbp(emu, oracle, Oracle.synth(96, 80, 7), MEM, cascade, params=((4096, 1.1, 1.0, 4.0, 1),))
+        pc.lbp(emu, oracle, Oracle.synth(64, 48, 9), MEM, random_cascade(1), params=((4096, 1.25, 1.0, 2.0, 2),))
+        pc.lbp(emu, oracle, Oracle.synth(80, 60, 11), MEM, random_cascade(4, nstages=3, weaks_per_stage=2),
+               params=((500, 1.2, 1.0, 2.5, 1),))
+    finally:
+        emu.tune(4, 0); emu.tune(9, 0)
+
+
 def test_lbp_cap_reached_in_early_scales(emu, oracle, cascade):
     """config-5 style input (sobel edge map): many hits, max_rects reached before the last scale --
     later scales are skipped on the GPU exactly because they cannot contribute (ref :819-823)"""

@@ -689,6 +689,24 @@ def test_lbp_caps_on_edge_maps(hip, oracle, cascade):
                     "random cascade, cap %d" % cap)
 
 
+@pytest.mark.parametrize("knob", [0, 3 + 16 * 10, 15 + 16 * 0, 4 + 16 * 5, 1000 + 4 + 32 * 6 + 1024 * 9])
+def test_lbp_adaptive_first_repack(hip, oracle, cascade, knob):
+    """the per-block choice of the first survivor re-packing point (default) against forced early / never-early
+    choices and a fixed split: same rectangles as the oracle on an edge map and on block noise"""
+    import torch
+    edges = oracle.sobel(oracle.blur(Oracle.synth(1280, 720, 1002), 2))
+    try:
+        if knob >= 1000: hip.tune(4, knob)
+        elif knob: hip.tune(9, knob)
+        for img in (edges, Oracle.synth(1280, 720, 12)):
+            ii = oracle.integral(img)
+            dii = torch.from_numpy(ii.view(np.int32)).cuda()
+            assert_same(hip.lbp_detect(cascade, dii, 4096, 1.1, 1.0, 4.0, 1), oracle.lbp_detect(cascade, ii, 4096, 1.1, 1.0, 4.0, 1),
+                        "knob %d" % knob)
+    finally:
+        hip.tune(4, 0); hip.tune(9, 0)
+
+
 def test_70000_frame_fast_batch(hip, oracle):
     """more frames than a grid dimension holds (65535) in ONE gsh_fast_batch call"""
     import torch
