@@ -252,7 +252,7 @@ dim3 grid2d(unsigned w, unsigned h, unsigned n) { return dim3((w + 63) / 64, (h 
 inline bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 /* ---- launch tuning (gsh_tune): 0 rows per band (0 = auto), 1 block shape, 2 prefetch depth */
-int g_tune[10] = {0, 1, 1, 0, 0, 0, 0, 0, 0, 0};
+int g_tune[12] = {0, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 /* gsh_lbp_count_evaluated: device counter that receives the windows the cascade really evaluated */
 thread_local unsigned long long *g_lbp_evaluated = nullptr;
 
@@ -452,14 +452,37 @@ void launch_blur(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsig
 }
 
 /* ------------------------------------------------------------------ histogram / otsu / threshold */
-unsigned hist_bpf(size_t frame_bytes) {
-  size_t b = (frame_bytes + (256 * 16 * 8 - 1)) / (256 * 16 * 8);
-  return (unsigned)std::max<size_t>(1, std::min<size_t>(b, 64));
+/* blocks per frame of k_hist_partial.  A block pays for zeroing and folding its 32 KB of LDS counters and for
+ * filling its load queue, so it should run ~64 trips of 16 B per lane (512 4K frames: 4.9 Tpx/s at 31 trips,
+ * 5.8 at 63; profiles/r02i_hist.log, r02i_hist_trips.log); a handful of frames is spread over the CUs
+ * (256 CUs x 5 resident blocks) down to 16 trips per block, at most 256 blocks per frame for k_hist_reduce. */
+unsigned hist_bpf(size_t frame_bytes, unsigned n) {
+  if (g_tune[11] > 0) return (unsigned)g_tune[11];
+  const size_t chunks = frame_bytes / 16 + 1, trips = g_tune[10] > 0 ? (size_t)g_tune[10] : 64;
+  const size_t by_size = (chunks + 256 * trips - 1) / (256 * trips);
+  const size_t by_fill = std::min<size_t>(std::min<size_t>((1280 + n - 1) / n, chunks / (256 * 16)), 256);
+  return (unsigned)std::max<size_t>(1, std::min<size_t>(std::max(by_size, by_fill), 2048));
 }
 void launch_histogram(const uint8_t *img, size_t frame_bytes, unsigned n, unsigned *hist) {
   if (n == 0) return;
   hipStream_t st = ctx().s();
-  const unsigned bpf = hist_bpf(frame_bytes);
+  if (frame_bytes > kHistMaxFrame) { /* k_hist_partial addresses a frame with 32-bit offsets: count a huge image in pieces */
+    const unsigned pieces = (unsigned)(frame_bytes / kHistMaxFrame);
+    const size_t rest = frame_bytes - (size_t)pieces * kHistMaxFrame;
+    const unsigned bpf = hist_bpf(kHistMaxFrame, pieces), bpr = rest ? hist_bpf(rest, 1) : 0;
+    unsigned *partial = (unsigned *)ctx().scratch(SL_HISTP, ((size_t)pieces * bpf + bpr) * 256 * 4);
+    for (unsigned f = 0; f < n; f++) {
+      const uint8_t *p = img + frame_bytes * f;
+      GS_LAUNCH(k_hist_partial, dim3(bpf, pieces), dim3(256), 0, st, p, kHistMaxFrame, partial);
+      if (rest)
+        GS_LAUNCH(k_hist_partial, dim3(bpr, 1), dim3(256), 0, st, p + (size_t)pieces * kHistMaxFrame, rest,
+                  partial + (size_t)pieces * bpf * 256);
+      GS_LAUNCH(k_hist_reduce, dim3(1), dim3(256), 0, st, (const unsigned *)partial, pieces * bpf + bpr,
+                hist + (size_t)f * 256, 0u);
+    }
+    return;
+  }
+  const unsigned bpf = hist_bpf(frame_bytes, n);
   for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
     const unsigned nn = std::min(kMaxZ, n - f0);
     unsigned *partial = (unsigned *)ctx().scratch(SL_HISTP, (size_t)nn * bpf * 256 * 4);
@@ -974,7 +997,7 @@ unsigned gsh_profile_read(double *total_ms) {
   return n;
 }
 void gsh_tune(int key, int value) {
-  if (key >= 0 && key < 10) g_tune[key] = value;
+  if (key >= 0 && key < 12) g_tune[key] = value;
 }
 void gsh_probe_strip_copy(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned n) {
   GS_ASSERT(dst && src && w % 16 == 0 && al16(dst) && al16(src));

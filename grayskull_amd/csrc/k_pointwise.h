@@ -75,27 +75,67 @@ __global__ __launch_bounds__(256) void k_threshold(uint8_t *img, size_t frame_by
  * wave's 64 ds_add_u32 never collide on a bank whatever the pixel values are (flat image
  * regions would otherwise serialise 64-way).  grid (bpf, n frames); each block writes its
  * 256 partial counts to partial[(frame*bpf + block)*256 ..]; k_hist_reduce sums them
- * (no global atomics, deterministic). */
+ * (no global atomics, deterministic).
+ *   The LDS atomic unit takes a ds_add_u32 every ~4.1 cycles per CU whatever the lanes' bins are
+ * (9.4 T pixel/s chip-wide, profiles/r02i_ubench_new_ops.log), above what HBM delivers at 1 B/px; the
+ * first form of this kernel (load 16 B, wait, 16 atomics) sat at 4.2 Tpx/s on the load latency, with only
+ * 20 waves per CU next to the 32 KB table.  So the loads are software-pipelined: every lane keeps DEPTH
+ * 16-byte loads in flight ahead of the one whose bytes it is counting. */
+#ifndef GS_HIST_DEPTH
+#define GS_HIST_DEPTH 3
+#endif
+constexpr unsigned kHistDepth = GS_HIST_DEPTH;
+constexpr size_t kHistMaxFrame = (size_t)1 << 30; /* bytes per k_hist_partial frame (32-bit buffer offsets) */
+GS_DEV void hist_count16(unsigned *lh, unsigned copy, const U4 &v, unsigned inc) {
+  const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int k = 0; k < 16; k++) atomicAdd(&lh[((d[k >> 2] >> (8 * (k & 3))) & 0xffu) * 32u + copy], inc);
+}
 __global__ __launch_bounds__(256) void k_hist_partial(const uint8_t *img, size_t frame_bytes,
                                                       unsigned *partial) {
   __shared__ unsigned lh[256 * 32];
   const unsigned tid = threadIdx.x, copy = tid & 31u;
-  for (unsigned i = tid; i < 256 * 32; i += 256) lh[i] = 0;
+  for (unsigned i = tid; i < 256 * 32 / 4; i += 256) ((U4 *)lh)[i] = U4{0, 0, 0, 0};
   __syncthreads();
   const uint8_t *base = img + (size_t)blockIdx.y * frame_bytes;
   const Chunking c = make_chunking(base, frame_bytes);
-  for (size_t i = (size_t)blockIdx.x * 256u + tid; i < c.nchunks; i += (size_t)gridDim.x * 256u) {
-    const size_t b0 = i * 16, b1 = b0 + 16;
-    if (b0 >= c.lo && b1 <= c.hi) {
-      const U4 v = *(const U4 *)(c.a0 + b0);
-      const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+  /* whole 16-byte chunks [c0, c1); the (at most two) partial ones at the ends of the frame go byte by byte */
+  const size_t c0 = c.lo ? 1 : 0, c1 = c.hi / 16;
+  const size_t stride = (size_t)gridDim.x * 256u, first = c0 + (size_t)blockIdx.x * 256u;
+  if (first < c1) { /* block-uniform */
+    /* The loop is branch-free and the loads are buffer loads (vmcnt only; a flat load would also tick the
+     * LDS counter) so that the compiler's s_waitcnt leaves DEPTH - 1 loads in flight instead of draining
+     * them: trips are padded to a multiple of DEPTH, loads past the last whole chunk return 0 from the
+     * buffer bounds check, and the lanes (or padded trips) without a chunk of their own add 0.
+     * kHistMaxFrame keeps every offset of the padded trips below 2^31. */
+    const uintptr_t b0 = c.a0 + c0 * 16; /* block-uniform, but 64-bit selects end up in VGPRs: say so (else: waterfall loops) */
+    const uint32_t end = uniform((uint32_t)(c1 - c0) * 16u);
+    const BufRsrc src = make_buf((const void *)(((uintptr_t)uniform((uint32_t)(b0 >> 32)) << 32) | uniform((uint32_t)b0)), end);
+    const unsigned iters = (unsigned)((c1 - first + stride - 1) / stride);
+    const unsigned padded = (iters + kHistDepth - 1) / kHistDepth * kHistDepth;
+    const uint32_t mine = ((uint32_t)blockIdx.x * 256u + tid) * 16u, step = (uint32_t)stride * 16u;
+    U4 q[kHistDepth];
 #pragma unroll
-      for (int k = 0; k < 16; k++)
-        atomicAdd(&lh[((d[k >> 2] >> (8 * (k & 3))) & 0xffu) * 32u + copy], 1u);
-    } else {
-      const size_t s = b0 < c.lo ? c.lo : b0, e = b1 > c.hi ? c.hi : b1;
-      for (size_t k = s; k < e; k++) atomicAdd(&lh[(unsigned)*(const uint8_t *)(c.a0 + k) * 32u + copy], 1u);
+    for (unsigned k = 0; k < kHistDepth; k++) {
+      q[k] = buf_load16(src, mine + k * step);
+      sched_fence(); /* issue order = consumption order, or the first trip (hence every trip) waits for all of them */
     }
+    uint32_t off = mine;
+    for (unsigned it = 0; it < padded; it += kHistDepth) {
+#pragma unroll
+      for (unsigned k = 0; k < kHistDepth; k++) { /* static register names: the queue is a rotation of q[] */
+        hist_count16(lh, copy, q[k], off < end ? 1u : 0u);
+        q[k] = buf_load16(src, off + kHistDepth * step); /* straight into the slot just consumed: no copies to wait for */
+        off += step;
+        sched_fence(); /* keep the steps apart: the scheduler would otherwise hoist all 48 address computations above
+                          one wait for every load */
+      }
+    }
+  }
+  if (blockIdx.x == 0 && tid < 16) { /* ragged ends: head [lo, min(16, hi)) when lo > 0, tail [16 c1, hi) when c1 >= c0 */
+    const size_t head_end = c.hi < 16 ? c.hi : 16;
+    if (c.lo && c.lo + tid < head_end) atomicAdd(&lh[(unsigned)*(const uint8_t *)(c.a0 + c.lo + tid) * 32u + copy], 1u);
+    if (c1 >= c0 && c1 * 16 + tid < c.hi) atomicAdd(&lh[(unsigned)*(const uint8_t *)(c.a0 + c1 * 16 + tid) * 32u + copy], 1u);
   }
   __syncthreads();
   unsigned s = 0;
@@ -104,13 +144,19 @@ __global__ __launch_bounds__(256) void k_hist_partial(const uint8_t *img, size_t
   partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256u + tid] = s;
 }
 
-/* grid n frames, block 256 */
+/* grid n frames, block 256: 8 independent partial sums per thread keep 8 loads in flight (a dependent chain over
+ * a few hundred partial histograms would be ~1 us per step) */
 __global__ __launch_bounds__(256) void k_hist_reduce(const unsigned *partial, unsigned bpf,
                                                      unsigned *hist, unsigned extra0) {
   const unsigned *p = partial + (size_t)blockIdx.x * bpf * 256u + threadIdx.x;
-  unsigned s = threadIdx.x == 0 ? extra0 : 0u; /* pixels known to be 0 that nobody counted */
-  for (unsigned b = 0; b < bpf; b++) s += p[(size_t)b * 256u];
-  hist[(size_t)blockIdx.x * 256u + threadIdx.x] = s;
+  unsigned acc[8] = {threadIdx.x == 0 ? extra0 : 0u, 0, 0, 0, 0, 0, 0, 0}; /* extra0: pixels known to be 0 that nobody counted */
+  unsigned b = 0;
+  for (; b + 8 <= bpf; b += 8) {
+#pragma unroll
+    for (unsigned k = 0; k < 8; k++) acc[k] += p[(size_t)(b + k) * 256u];
+  }
+  for (; b < bpf; b++) acc[0] += p[(size_t)b * 256u];
+  hist[(size_t)blockIdx.x * 256u + threadIdx.x] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
 }
 
 /* ref :205-223.  The reference's scan is a chain of float32 adds (sum / sumB) followed, per t,

@@ -114,6 +114,29 @@
 #define sub_co_LINE(i) "v_sub_co_u32 %" #i ", vcc, %" #i ", %8\n"
 #define cmp_cnd_LINE(i) "v_cmp_lt_u32 vcc, %" #i ", %8\nv_cndmask_b32 %" #i ", %" #i ", %9, vcc\n"
 
+/* round 2 (gs_fast / histogram questions): byte -> float conversion, float class flags, carries */
+#define cvt_f32_ubyte0_LINE(i) "v_cvt_f32_ubyte0 %" #i ", %" #i "\n"
+#define cvt_f32_ubyte2_LINE(i) "v_cvt_f32_ubyte2 %" #i ", %" #i "\n"
+#define cvt_u32_f32_LINE(i) "v_cvt_u32_f32 %" #i ", %" #i "\n"
+#define sub_f32_clamp_LINE(i) "v_sub_f32_e64 %" #i ", %" #i ", %8 clamp\n"
+#define min_f32_LINE(i) L2("v_min_f32", i)
+#define min_f32_abs_LINE(i) "v_min_f32_e64 %" #i ", %" #i ", |%8|\n"
+#define fmac_f32_LINE(i) "v_fmac_f32 %" #i ", %8, %9\n"
+#define addc_co_LINE(i) "v_addc_co_u32 %" #i ", vcc, %" #i ", %" #i ", vcc\n"
+#define cmp_only_LINE(i) "v_cmp_gt_u32 vcc, %" #i ", %8\n"
+#define cmp_addc_LINE(i) "v_cmp_gt_u32 vcc, %8, %9\nv_addc_co_u32 %" #i ", vcc, %" #i ", %" #i ", vcc\n"
+#define min_u16_LINE(i) L2("v_min_u16", i)
+#define max_i16_LINE(i) L2("v_max_i16", i)
+#define min_i32_LINE(i) L2("v_min_i32", i)
+#define or_b32_LINE(i) L2("v_or_b32", i)
+#define lshrrev_b32_LINE(i) "v_lshrrev_b32 %" #i ", 1, %" #i "\n"
+#define sub_u32_sdwa_b0_LINE(i) \
+  "v_sub_u32_sdwa %" #i ", %" #i ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n"
+#define NEW(X)                                                                                   \
+  X(cvt_f32_ubyte0) X(cvt_f32_ubyte2) X(cvt_u32_f32) X(sub_f32_clamp) X(min_f32) X(min_f32_abs)   \
+  X(fmac_f32) X(addc_co) X(cmp_only) X(cmp_addc) X(min_u16) X(max_i16) X(min_i32) X(or_b32)       \
+  X(lshrrev_b32) X(sub_u32_sdwa_b0)
+
 #define ALL(X)                                                                                    \
   X(add_u32) X(sub_u32) X(and_b32) X(xor_b32) X(lshlrev_b32) X(add3_u32) X(lshl_add_u32)          \
   X(add_lshl_u32) X(and_or_b32) X(or3_b32) X(lshl_or_b32) X(xad_u32) X(bfe_u32) X(bfi_b32)        \
@@ -127,6 +150,7 @@
 
 #define X(n) DEFK(k_##n, n##_LINE)
 ALL(X)
+NEW(X)
 #undef X
 
 // v_cndmask_b32 with the mask in VCC written by a VALU compare before the loop / in an SGPR pair
@@ -186,6 +210,37 @@ __global__ __launch_bounds__(256) void k_ds_add(uint32_t *out, int iters, unsign
   out[blockIdx.x * blockDim.x + threadIdx.x] = lh[threadIdx.x] + v;
 }
 
+// LDS atomic rate without any VALU in between: 16 precomputed addresses per lane (conflict-free copies),
+// `active` lanes of every wave take part (the rest are masked off by EXEC)
+__global__ __launch_bounds__(256) void k_ds_add_pure(uint32_t *out, int iters, unsigned long long *cyc, int active, int samebank) {
+  __shared__ unsigned lh[256 * 32];
+  for (unsigned i = threadIdx.x; i < 256 * 32; i += 256) lh[i] = 0;
+  __syncthreads();
+  unsigned v = threadIdx.x * 2654435761u + blockIdx.x;
+  const unsigned copy = samebank ? 0u : (threadIdx.x & 31u);
+  uint32_t ad[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    v = v * 1664525u + 1013904223u;
+    ad[k] = (uint32_t)(size_t)&lh[(v >> 24) * 32u + copy];
+  }
+  const uint32_t one = 1;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  if ((int)(threadIdx.x & 63u) < active) {
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+      for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int k = 0; k < 16; k++) asm volatile("ds_add_u32 %0, %1" ::"v"(ad[k]), "v"(one) : "memory");
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x == 0) cyc[0] = t1 - t0;
+  out[blockIdx.x * blockDim.x + threadIdx.x] = lh[threadIdx.x] + v;
+}
+
 struct Entry {
   const char *name;
   void (*fn)(uint32_t *, int, unsigned long long *);
@@ -206,8 +261,13 @@ int main(int argc, char **argv) {
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
 #define X(n) {#n, k_##n},
-  const Entry tab[] = {ALL(X){"cndmask_vcc_set_once", k_cnd_vcc_once}, {"cndmask_e64_sgprmask", k_cnd_sgpr}, {"bfi_select", k_bfi_select}};
+  const Entry tab_all[] = {ALL(X){"cndmask_vcc_set_once", k_cnd_vcc_once}, {"cndmask_e64_sgprmask", k_cnd_sgpr}, {"bfi_select", k_bfi_select}};
+  const Entry tab_new[] = {NEW(X)};
 #undef X
+  const bool only_new = argc > 2 && strcmp(argv[2], "new") == 0; /* ubench_valu <iters> new: the round-2 additions + LDS atomics */
+  std::vector<Entry> tab;
+  if (!only_new) tab.assign(tab_all, tab_all + sizeof(tab_all) / sizeof(tab_all[0]));
+  tab.insert(tab.end(), tab_new, tab_new + sizeof(tab_new) / sizeof(tab_new[0]));
   printf("%-18s %6s %14s %14s %12s\n", "instruction", "w/SIMD", "Gwave-inst/s", "cyc/inst/SIMD", "ns/launch");
   for (const Entry &e : tab) {
     for (int wps : {1, 2, 4, 8}) {
@@ -228,9 +288,9 @@ int main(int argc, char **argv) {
           CK(hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost));
         }
       }
-      const double ninst = (double)blocks * 4 * iters * 32.0 * (strcmp(e.name, "cmp_cnd") == 0 ? 2 : 1);
+      const double ninst = (double)blocks * 4 * iters * 32.0 * ((strcmp(e.name, "cmp_cnd") == 0 || strcmp(e.name, "cmp_addc") == 0) ? 2 : 1);
       /* cycles per wave-instruction per SIMD = wave cycles / (instructions of that wave * waves sharing the SIMD) */
-      const double cpi = (double)c / (iters * 32.0 * (strcmp(e.name, "cmp_cnd") == 0 ? 2 : 1)) / wps;
+      const double cpi = (double)c / (iters * 32.0 * ((strcmp(e.name, "cmp_cnd") == 0 || strcmp(e.name, "cmp_addc") == 0) ? 2 : 1)) / wps;
       printf("%-18s %6d %14.1f %14.2f %12.0f\n", e.name, wps, ninst / best / 1e6, cpi, best * 1e6);
     }
   }
@@ -251,5 +311,23 @@ int main(int argc, char **argv) {
              mode, mode == 0 ? "random bins" : mode == 1 ? "same bin per wave, own copy" : "16 bins", wps, ninst / ms / 1e6,
              ninst * 64 / ms / 1e9);
     }
+  for (int samebank = 0; samebank < 2; samebank++)
+    for (int active : {64, 32, 16, 8})
+      for (int wps : {2, 4}) {
+        const int blocks = cus * wps;
+        const int it = iters / 8;
+        hipLaunchKernelGGL(k_ds_add_pure, dim3(blocks), dim3(256), 0, 0, out, 2, cyc, active, samebank);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(k_ds_add_pure, dim3(blocks), dim3(256), 0, 0, out, it, cyc, active, samebank);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        const double ninst = (double)blocks * 4 * it * 32.0;
+        printf("ds_add_u32 pure stream, %2d active lanes, %s, %d w/SIMD: %.1f Gwave-inst/s = %.2f Tlane-atomics/s = %.2f LDS cycles per wave-inst per CU\n",
+               active, samebank ? "every lane in copy 0 (bank conflicts by value)" : "lane-private copies", wps, ninst / ms / 1e6,
+               ninst * active / ms / 1e9, (double)cus * prop.clockRate * 1e3 / (ninst / (ms * 1e-3)));
+      }
   return 0;
 }

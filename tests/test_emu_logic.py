@@ -421,3 +421,18 @@ def test_fast_with_a_score_map_of_another_size(emu, reference):
         exp, sm_exp = reference.fast(img, 500, 20, scoremap=sm0)
         assert_same(got, exp, "keypoints with a %dx%d map" % (sw, sh))
         assert_same(sm, sm_exp, "score map %dx%d after the call" % (sw, sh))
+
+
+def test_histogram_ragged_frames_every_alignment(emu, oracle):
+    """k_hist_partial counts whole 16-byte chunks from a queue of loads in flight and the bytes before the
+    first / after the last whole chunk one by one: frames of 1 .. 70 bytes and 4 KB +- a few at every base
+    alignment (frame f of a batch starts at f * w * h bytes)"""
+    rng = np.random.RandomState(11)
+    for w, h in [(1, 1), (3, 1), (5, 3), (1, 16), (17, 1), (31, 1), (11, 3), (1, 33), (7, 9), (70, 1), (4099, 1), (37, 111),
+                 (256 * 16 * 3 + 5, 1)]:
+        n = 17 if w * h < 5000 else 3
+        a = rng.randint(0, 256, (n, h, w)).astype(np.uint8)
+        hist = np.zeros((n, 256), np.uint32)
+        emu.histogram_batch(a, hist)
+        for f in range(n):
+            assert np.array_equal(hist[f], oracle.histogram(a[f])), (w, h, f)
