@@ -56,6 +56,22 @@ def time_stream(torch, fn, reps):
     return e0.elapsed_time(e1) / reps
 
 
+LDS_ATOMIC_TLANE_S = 9.4  # ds_add_u32, lane-private copies, any number of active lanes: 148 G wave-inst/s (r02i_ubench_new_ops.log)
+
+
+def fast_valu_block(npx_launch, ms_score):
+    """VALU issue pricing of the gs_fast score kernel from its SQ_INSTS_VALU count (profiles/fast_valu_pmc.json)"""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "fast_valu_pmc.json")))
+    except Exception:
+        return None
+    insts = d["valu_wave_insts_per_px"] * npx_launch
+    sec = insts * d["avg_issue_cycles"] / (1024 * 2.4e9)  # 1024 SIMDs, one VALU issue port each
+    return {"valu_wave_insts_per_px": d["valu_wave_insts_per_px"], "avg_issue_cycles": d["avg_issue_cycles"],
+            "score_kernel_ms": round(ms_score, 4), "valu_ms_at_issue_rate": round(sec * 1e3, 4),
+            "valu_frac": round(sec * 1e3 / ms_score, 4), "source": d.get("source")}
+
+
 def hbm_block(nbytes, ms, **extra):
     """physical HBM roofline block of one launch (or launch group): bytes really moved / time / peak"""
     gbs = nbytes / ms / 1e6
@@ -305,6 +321,10 @@ def main():
         ktab[name] = hbm_block(moved, ms)
         if percall != moved:
             ktab[name]["percall_equivalent_GB/s"] = round(percall / ms / 1e6, 1)
+        if name.startswith("gs_histogram"):  # one ds_add_u32 per pixel: the other physical ceiling of this kernel
+            ktab[name]["lds_atomic_frac"] = round(npx / ms / 1e9 / LDS_ATOMIC_TLANE_S / 1e3, 4)
+            ktab[name]["lds_atomic_note"] = ("pixels/s / %.1f T lane-atomics/s, the chip's measured ds_add_u32 rate "
+                                             "(profiles/r02i_ubench_new_ops.log, pure stream, 4.1 cycles per wave per CU)" % LDS_ATOMIC_TLANE_S)
     del ii_buf
     # The fused kernel itself: average over ALL its launches inside the timed region above (HIP events
     # recorded by the library on the launch stream, gsh_profile).  A step launches it once per
@@ -477,6 +497,7 @@ def extras(g, torch, np, src, tmp, dst, w, h, reps):
     kp7 = torch.zeros((nf, 2000, 12), dtype=torch.int32, device="cuda")
     cn7 = torch.zeros(nf, dtype=torch.int32, device="cuda")
     ms_fast = time_stream(torch, lambda: g.fast_batch(f7, sm7, kp7, cn7, 2000, 20), 5)
+    ms_fast_score = time_stream(torch, lambda: g.probe_fast_score(sm7, f7, 20), 5)
     # device-resident gs_orb_extract (GS_NO_STDLIB trig, no host round trip), same 32 frames, 500 keypoints each
     ko7 = torch.zeros((nf, 500, 12), dtype=torch.int32, device="cuda")
     ms_orb_dev = time_stream(torch, lambda: g.orb_extract_batch_nostdlib(f7, sm7, ko7, cn7, 500, 20), 5)
@@ -488,7 +509,9 @@ def extras(g, torch, np, src, tmp, dst, w, h, reps):
         "device_resident_note": "gsh_orb_extract_batch_nostdlib, %d frames per call, the reference's GS_NO_STDLIB trig "
                                 "(ref :70-88), no host round trip; bit-exact vs the -DGS_NO_STDLIB reference build" % nf,
         "gs_fast_roofline": hbm_block(3.0 * nf * 720 * 1280, ms_fast, bytes_per_px=3, frames=nf, limited_by="valu",
-                                      note="score pass 1 R + 1 W, NMS 1 R; the score pass is ~140 lane-ops per candidate pixel"),
+                                      score_pass_valu=fast_valu_block(nf * 720 * 1280, ms_fast_score),
+                                      note="score pass 1 R + 1 W, NMS 1 R; the score pass (LDS-tile kernel) is VALU work on "
+                                           "real candidates, the NMS / scan / emit passes behind it are latency-bound"),
         "reference_1core": "70 ms extract, 48.6 ms match (BASELINE.md)"}
     del s3, ii3, rc, cn, f7, sm7, kp7, ko7
     # configs[4], one GPU's share: per frame gs_blur(2) -> gs_sobel -> gs_integral -> gs_lbp_detect on 4K

@@ -90,6 +90,7 @@ _SIGS = {
     "gsh_profile": (None, [C.c_int]),
     "gsh_profile_read": (C.c_uint, [C.POINTER(C.c_double)]),
     "gsh_probe_strip_copy": (None, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint]),
+    "gsh_probe_fast_score": (None, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_uint]),
     "gsh_shutdown": (None, []),
     "gsh_malloc": (C.c_void_p, [C.c_size_t]),
     "gsh_free": (None, [C.c_void_p]),
@@ -227,6 +228,10 @@ class Grayskull:
         ms = C.c_double(0.0)
         n = self.c.gsh_profile_read(C.byref(ms))
         return int(n), float(ms.value)
+
+    def probe_fast_score(self, score, img, threshold):
+        n, h, w = self._nhw(img)
+        self.c.gsh_probe_fast_score(_ptr(score), _ptr(img), w, h, n, threshold)
 
     def probe_strip_copy(self, dst, src):
         n, h, w = self._nhw(src)

@@ -517,9 +517,9 @@ void launch_otsu(const uint8_t *img, unsigned w, unsigned h, unsigned n, unsigne
 /* ------------------------------------------------------------------ ordered compaction driver */
 template <bool QUAD = false, class F>
 void run_compaction(unsigned long long *mask, unsigned *cnt, unsigned nchunks, unsigned n,
-                    unsigned cap, unsigned *totals_dev, F emit) {
-  hipStream_t st = ctx().s();
-  unsigned *pfx = (unsigned *)ctx().scratch(SL_PFX, (size_t)n * nchunks * 4);
+                    unsigned cap, unsigned *totals_dev, F emit, hipStream_t on = nullptr, unsigned *pfx_in = nullptr) {
+  hipStream_t st = on ? on : ctx().s();
+  unsigned *pfx = pfx_in ? pfx_in : (unsigned *)ctx().scratch(SL_PFX, (size_t)n * nchunks * 4);
   GS_LAUNCH(k_chunk_scan, dim3(n), dim3(1024), 0, st, (const unsigned *)cnt, nchunks, pfx,
             totals_dev, cap);
   GS_LAUNCH((k_emit<F, QUAD>), dim3((nchunks + 3) / 4, n), dim3(256), 0, st,
@@ -528,6 +528,31 @@ void run_compaction(unsigned long long *mask, unsigned *cnt, unsigned nchunks, u
 }
 
 /* ------------------------------------------------------------------ FAST */
+/* gs_fast pass 1 (w, h >= 7, n <= kMaxZ): the LDS-tile kernel by default.  The strip kernel (gsh_tune key 7 = 1)
+ * decides per 256-px row span instead of per 64 px: on 32 x 720p (profiles/r02i_fast_tile.log) it is 1.25x faster on
+ * flat frames (1.6 vs 2.0 us per frame), equal on bright frames and 1.1-1.4x SLOWER on texture and on frames with
+ * large p < t regions (the block-noise frames of configs[3]: there every pixel is a candidate under the reference's
+ * unsigned wrap, and a 256-px span almost always touches one).  Key 7 = 2: one global byte load per ring pixel
+ * (the round-1 form: texture-addresser bound, 4.9 vs 4.2 us per frame). */
+void launch_fast_score(hipStream_t on, const uint8_t *img, uint8_t *score, unsigned w, unsigned h, unsigned n,
+                       unsigned threshold) {
+  const size_t fb = (size_t)w * h;
+  if (g_tune[7] == 1 && w % 4 == 0 && fb < 0x7fffffffull && ((uintptr_t)img & 3) == 0 && ((uintptr_t)score & 3) == 0 &&
+      threshold <= 0xffffff00u) {
+    /* strip kernel: ~6 waves per SIMD when the batch allows, bands of >= 8 rows */
+    const unsigned cw = (w + 255) / 256, rows = h - 6;
+    unsigned long long T = ((unsigned long long)rows * cw * n + 6143) / 6144;
+    T = T < 8 ? 8 : T > 64 ? 64 : T;
+    const unsigned nb = (rows + (unsigned)T - 1) / (unsigned)T;
+    GS_LAUNCH(k_fast_score4, dim3(cw, (nb + 3) / 4, n), dim3(64, 4), 0, on, img, score, w, h, (unsigned)T, fb, threshold);
+  } else if (g_tune[7] == 2) {
+    GS_LAUNCH(k_fast_score_px, grid2d(w - 6, h - 6, n), dim3(64, 4), 0, on, img, score, w, h, fb, threshold);
+  } else {
+    GS_LAUNCH(k_fast_score_tile, dim3((w - 6 + 63) / 64, (h - 6 + kFastTileRows - 1) / kFastTileRows, n), dim3(64, 4), 0, on,
+              img, score, w, h, fb, threshold);
+  }
+}
+
 /* clip_w / clip_h (single frame only): the caller's score map is smaller than the image; positions
  * outside it read 0 in the NMS pass like gs_get does (ref :524) */
 void launch_fast(const uint8_t *img, uint8_t *score, unsigned w, unsigned h, unsigned n,
@@ -548,42 +573,31 @@ void launch_fast(const uint8_t *img, uint8_t *score, unsigned w, unsigned h, uns
   const size_t fb = (size_t)w * h;
   const unsigned nitems = (w - 6) * (h - 6);
   const unsigned nchunks = (nitems + kChunkItems - 1) / kChunkItems;
-  /* Score pass: per-pixel kernel with the wave-level compass filter by default.  The strip kernel
-   * (gsh_tune key 7 = 1) decides per 256-px row span instead of per 64 px: measured on 32 x 720p
-   * (profiles/r01i_fast_strip_vs_px.log) it is 1.5-2.3x faster on flat / bright frames (23 vs 53 us,
-   * 52 vs 75 us), equal on texture (lena, random) and 1.4x SLOWER on frames with large p < t
-   * regions (135 vs 95 us on the block-noise frames of configs[3]: there every pixel is a
-   * candidate under the reference's unsigned wrap, and a 256-px span almost always touches one). */
-  if (g_tune[7] == 1 && w % 4 == 0 && fb < 0x7fffffffull && ((uintptr_t)img & 3) == 0 && ((uintptr_t)score & 3) == 0 &&
-      threshold <= 0xffffff00u) {
-    /* strip kernel: ~6 waves per SIMD when the batch allows, bands of >= 8 rows */
-    const unsigned cw = (w + 255) / 256, rows = h - 6;
-    unsigned long long T = ((unsigned long long)rows * cw * n + 6143) / 6144;
-    T = T < 8 ? 8 : T > 64 ? 64 : T;
-    const unsigned nb = (rows + (unsigned)T - 1) / (unsigned)T;
-    for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
-      const unsigned nn = std::min(kMaxZ, n - f0);
-      GS_LAUNCH(k_fast_score4, dim3(cw, (nb + 3) / 4, nn), dim3(64, 4), 0, st, img + fb * f0, score + fb * f0, w, h,
-                (unsigned)T, fb, threshold);
-    }
-  } else {
-    GS_LAUNCH(k_fast_score_px, grid2d(w - 6, h - 6, n), dim3(64, 4), 0, st, img, score, w, h, fb,
-              threshold);
-  }
-  if (clip_w && n == 1 && (clip_w < w || clip_h < h))
-    GS_LAUNCH(k_fast_clip, grid2d(w, h, 1), dim3(64, 4), 0, st, score, w, h, clip_w, clip_h);
+  launch_fast_score(st, img, score, w, h, n, threshold);
   unsigned long long *mask =
       (unsigned long long *)ctx().scratch(SL_MASK, (size_t)n * nchunks * kChunkWords * 8);
   unsigned *cnt = (unsigned *)ctx().scratch(SL_CNT, (size_t)n * nchunks * 4);
-  GS_HIP(hipMemsetAsync(cnt, 0, (size_t)n * nchunks * 4, st));
+  unsigned *pfx = (unsigned *)ctx().scratch(SL_PFX, (size_t)n * nchunks * 4);
   /* row = item / (w-6) by multiplication where the magic fits (see div_by) */
   const unsigned iw = w - 6;
   const unsigned magic = (iw > 256 && iw <= 8192 && (unsigned long long)iw * (h - 6) <= (1ull << 26))
                              ? (unsigned)(((1ull << 40) + iw - 1) / iw) : 0u;
-  GS_LAUNCH(k_fast_nms, dim3(nchunks, n), dim3(256), 0, st, (const uint8_t *)score, w, h, fb, mask,
-            cnt, nchunks, magic);
-  run_compaction</*QUAD=*/true>(mask, cnt, nchunks, n, nkps, counts, /* k_fast_nms: 4 items per lane */
-                                FastEmit{score, w, fb, kps, nkps});
+  /* NMS flags, chunk scan, ordered emit of frames [f0, f0 + nn) on stream `on` */
+  auto rest = [&](hipStream_t on, unsigned f0, unsigned nn) {
+    if (clip_w && n == 1 && (clip_w < w || clip_h < h))
+      GS_LAUNCH(k_fast_clip, grid2d(w, h, 1), dim3(64, 4), 0, on, score, w, h, clip_w, clip_h);
+    unsigned *c = cnt + (size_t)f0 * nchunks;
+    GS_HIP(hipMemsetAsync(c, 0, (size_t)nn * nchunks * 4, on));
+    GS_LAUNCH(k_fast_nms, dim3(nchunks, nn), dim3(256), 0, on, (const uint8_t *)score + fb * f0, w, h, fb,
+              mask + (size_t)f0 * nchunks * kChunkWords, c, nchunks, magic);
+    run_compaction</*QUAD=*/true>(mask + (size_t)f0 * nchunks * kChunkWords, c, nchunks, nn, nkps, counts + f0, /* k_fast_nms: 4 items per lane */
+                                  FastEmit{score + fb * f0, w, fb, kps + (size_t)f0 * nkps * 12, nkps}, on,
+                                  pfx + (size_t)f0 * nchunks);
+  };
+  /* Tried and not kept: cutting a batch into 2-8 groups of frames and running group i's NMS / scan / emit on the side
+   * stream under group i+1's score pass.  The cross-stream event hops cost more than the ~60 us of small passes
+   * they could hide: 32 x 720p 4.2 us per frame in one piece, 5.1 in two, 6.8 in four (profiles/r02i_fast_groups_not_kept.log). */
+  rest(st, 0, n);
 }
 
 /* ------------------------------------------------------------------ LBP cascade */
@@ -1003,6 +1017,10 @@ void gsh_probe_strip_copy(uint8_t *dst, const uint8_t *src, unsigned w, unsigned
   GS_ASSERT(dst && src && w % 16 == 0 && al16(dst) && al16(src));
   const StripCfg c = strip_cfg(w, h, n);
   GS_LAUNCH(k_strip_copy, c.grid, c.block, 0, ctx().s(), dst, src, w, h, c.T, (size_t)w * h);
+}
+void gsh_probe_fast_score(uint8_t *score, const uint8_t *img, unsigned w, unsigned h, unsigned n, unsigned threshold) {
+  GS_ASSERT(score && img && w >= 7 && h >= 7 && n >= 1 && n <= kMaxZ);
+  launch_fast_score(ctx().s(), img, score, w, h, n, threshold);
 }
 void gsh_sync(void) { ctx().sync(); }
 void gsh_shutdown(void) { ctx().release(); }

@@ -106,6 +106,57 @@ __global__ __launch_bounds__(256) void k_fast_score_px(const uint8_t *img, uint8
   if (in) score[(size_t)blockIdx.z * frame_bytes + (size_t)y * w + x] = (uint8_t)s;
 }
 
+/* pass 1, default: the same per-pixel evaluation, but the 17 bytes of a pixel come from an LDS tile instead of
+ * 17 global byte loads.  k_fast_score_px spends its time in the texture addresser: 4.5 M wave-level byte loads per
+ * 32 x 720p launch at ~8 cycles each are ~90 % of its 98 us, while its VALU is 54 % busy
+ * (profiles/r02i_pmc_features.txt).  Here a block of 256 threads copies the (16 + 6) x (64 + 6) pixel region of
+ * its 64 x 16 output tile with ~1.5 (unaligned) dword loads per thread and every ring pixel is a ds_read_u8
+ * (consecutive lanes read consecutive bytes: conflict-free).  grid (ceil((w-6)/64), ceil((h-6)/16), n), block (64,4);
+ * thread (tx, ty) scores rows ty, ty+4, ty+8, ty+12 of the tile. */
+constexpr unsigned kFastTileRows = 16, kFastTileDw = 18; /* 72 bytes per tile row: 64 + 6, rounded up to dwords */
+__global__ __launch_bounds__(256) void k_fast_score_tile(const uint8_t *img, uint8_t *score, unsigned w, unsigned h,
+                                                         size_t frame_bytes, unsigned threshold) {
+  __shared__ uint32_t tile32[(kFastTileRows + 6) * kFastTileDw];
+  const uint8_t *frame = img + (size_t)blockIdx.z * frame_bytes;
+  const unsigned tid = threadIdx.y * 64u + threadIdx.x;
+  const unsigned x_t = blockIdx.x * 64u, y_t = blockIdx.y * kFastTileRows; /* image position of tile byte (0, 0) */
+  for (unsigned i = tid; i < (kFastTileRows + 6) * kFastTileDw; i += 256u) {
+    const unsigned r = i / kFastTileDw, c = i - r * kFastTileDw;
+    /* rows / columns past the image are only ever ring pixels of positions that are not scored: whatever the
+     * frame holds there will do, but the last bytes of the frame are real ring pixels -- byte by byte */
+    const size_t off = (size_t)(y_t + r) * w + x_t + c * 4u;
+    uint32_t v = 0;
+    if (off + 4 <= frame_bytes) {
+      v = load_u32_unaligned(frame + off);
+    } else {
+      for (unsigned b = 0; b < 4; b++)
+        if (off + b < frame_bytes) v |= (uint32_t)frame[off + b] << (8 * b);
+    }
+    tile32[i] = v;
+  }
+  __syncthreads();
+  const uint8_t *tb = (const uint8_t *)tile32;
+  constexpr int S = (int)kFastTileDw * 4; /* tile row stride in bytes */
+  const unsigned x = 3 + x_t + threadIdx.x;
+#pragma unroll
+  for (unsigned k = 0; k < kFastTileRows / 4; k++) {
+    const unsigned ry = threadIdx.y + 4u * k, y = 3 + y_t + ry;
+    const bool in = x + 3 < w && y + 3 < h;
+    const uint8_t *c = tb + (ry + 3) * S + threadIdx.x + 3;
+    const unsigned p = c[0], v0 = c[-3 * S], v4 = c[3], v8 = c[3 * S], v12 = c[-3];
+    const bool cand = in && fast_compass_candidate(p, v0, v4, v8, v12, threshold);
+    unsigned sc = 0;
+    if (ballot(cand) != 0) { /* wave-uniform */
+      const unsigned v[16] = {v0,  c[-3 * S + 1], c[-2 * S + 2], c[-S + 3],
+                              v4,  c[S + 3],      c[2 * S + 2],  c[3 * S + 1],
+                              v8,  c[3 * S - 1],  c[2 * S - 2],  c[S - 3],
+                              v12, c[-S - 3],     c[-2 * S - 2], c[-3 * S - 1]};
+      sc = fast_score(p, v, threshold);
+    }
+    if (in) score[(size_t)blockIdx.z * frame_bytes + (size_t)y * w + x] = (uint8_t)sc;
+  }
+}
+
 /* pass 1, strips (w % 4 == 0, 4-byte aligned frames, threshold <= 0xffffff00): a lane owns 4
  * consecutive pixels (one dword per row), a wave 256 px of a row, and walks DOWN a band of T rows
  * with the 7 image rows y-3..y+3 in registers as 12-byte windows (L, C, R: the neighbour lanes'

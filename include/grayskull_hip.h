@@ -52,6 +52,8 @@ void gsh_profile(int on);
 unsigned gsh_profile_read(double *total_ms);
 /* diagnostic: strip-kernel traffic pattern with no arithmetic (access-pattern ceiling) */
 void gsh_probe_strip_copy(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned n);
+/* diagnostic: pass 1 of gs_fast alone (the score map of n frames; w, h >= 7), for timing / counter runs */
+void gsh_probe_fast_score(uint8_t *score, const uint8_t *img, unsigned w, unsigned h, unsigned n, unsigned threshold);
 void gsh_shutdown(void);                  /* free this thread's scratch + stream        */
 
 void *gsh_malloc(size_t bytes);           /* hipMalloc; aborts on failure               */

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""gsh_fast_batch: per-pixel score kernel with the compass filter (default) vs strip kernel k_fast_score4 (gsh_tune key 7 = 1), 32 x 1280x720"""
+"""gsh_fast_batch: LDS-tile score kernel (default) vs strip kernel k_fast_score4 (gsh_tune key 7 = 1) vs the per-pixel kernel with one
+global byte load per ring pixel (key 7 = 2), 32 x 1280x720"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -21,8 +22,8 @@ from tests.util import lena
 L = lena(); inputs["lena_tiled"] = np.tile(L, ((H + 127) // 128, (W + 127) // 128))[:H, :W].copy()
 for name, img in inputs.items():
     src = torch.from_numpy(np.stack([img] * F)).cuda(); sm = torch.zeros_like(src)
-    for px in (0, 1):
+    for px in (0, 1, 2):
         g.tune(7, px)
         ms = timeit(lambda: g.fast_batch(src, sm, kps, cnt, 5000, 20))
-        print("%-28s %-6s %.4f ms per frame  (%.0f Gpx/s)  n0=%d" % (name, "strip" if px else "px", ms / F, F * W * H / ms / 1e6, int(cnt[0])))
+        print("%-28s %-6s %.4f ms per frame  (%.0f Gpx/s)  n0=%d" % (name, ("tile", "strip", "px")[px], ms / F, F * W * H / ms / 1e6, int(cnt[0])))
     g.tune(7, 0)

@@ -60,7 +60,7 @@ def test_next_rows(emu, oracle, shape):
 @pytest.mark.parametrize("shape", [(67, 45), (96, 80), (7, 7), (6, 30), (40, 8), (300, 12), (260, 17), (8, 8), (516, 9)])
 def test_fast(emu, oracle, shape):
     w, h = shape
-    for strip in ((0, 1) if w % 4 == 0 else (0,)):  # gsh_tune key 7 = 1: strip score kernel
+    for strip in ((0, 1, 2) if w % 4 == 0 else (0, 2)):  # gsh_tune key 7: 0 LDS-tile score kernel (default), 1 strip kernel, 2 one global byte load per ring pixel
         emu.tune(7, strip)
         try:
             pc.fast(emu, oracle, Oracle.synth(w, h, 5), MEM)
@@ -75,19 +75,21 @@ def test_fast(emu, oracle, shape):
 
 
 def test_fast_strip_kernel_equals_per_pixel_kernel(emu, oracle):
-    """k_fast_score4 (w % 4 == 0: lane = 4 px, rows in registers, compass filter) against k_fast_score_px
-    (the default) and the oracle; gsh_tune key 7 = 1 selects the strip kernel: block corners, noise and a p < t region, two waves wide"""
+    """k_fast_score4 (w % 4 == 0: lane = 4 px, rows in registers, compass filter) against k_fast_score_tile
+    (the default), k_fast_score_px and the oracle; gsh_tune key 7 = 1 selects the strip kernel, 2 the per-pixel global-load kernel:
+    block corners, noise and a p < t region, two waves wide"""
     rs = np.random.RandomState(11)
     img = Oracle.synth(264, 40, 9)
     img[8:20, 100:140] = rs.randint(0, 12, (12, 40))       # p < threshold: the unsigned-wrap class
     img[25:33, 250:264] = rs.randint(0, 256, (8, 14))      # texture up to the right border
     for t in (20, 3, 200):
         pc.fast(emu, oracle, img, MEM, threshold=t, caps=(5000,))
-        emu.tune(7, 1)
-        try:
-            pc.fast(emu, oracle, img, MEM, threshold=t, caps=(5000,))
-        finally:
-            emu.tune(7, 0)
+        for mode in (1, 2):
+            emu.tune(7, mode)
+            try:
+                pc.fast(emu, oracle, img, MEM, threshold=t, caps=(5000,))
+            finally:
+                emu.tune(7, 0)
 
 
 def test_fast_quirk(emu, oracle):

@@ -115,7 +115,7 @@ def test_next_rows(hip, oracle, shape, mem):
 @pytest.mark.parametrize("shape", [(67, 45), (96, 80), (7, 7), (6, 30), (40, 8), (640, 480), (1283, 517), (260, 17), (8, 8), (1284, 100)])
 def test_fast(hip, oracle, shape, mem):
     w, h = shape
-    for strip in ((0, 1) if w % 4 == 0 else (0,)):  # gsh_tune key 7 = 1: strip score kernel
+    for strip in ((0, 1, 2) if w % 4 == 0 else (0, 2)):  # gsh_tune key 7: 0 LDS-tile score kernel (default), 1 strip kernel, 2 global byte loads
         hip.tune(7, strip)
         try:
             pc.fast(hip, oracle, Oracle.synth(w, h, 5), mem)
@@ -127,14 +127,14 @@ def test_fast(hip, oracle, shape, mem):
 
 
 def test_fast_strip_kernel_equals_per_pixel_kernel(hip, oracle):
-    """k_fast_score4 (gsh_tune key 7 = 1) and k_fast_score_px (default) against the oracle on a 1280x720 frame with a
+    """k_fast_score4 (gsh_tune key 7 = 1), k_fast_score_px (2) and k_fast_score_tile (default) against the oracle on a 1280x720 frame with a
     dark (p < t) region and random texture, thresholds incl. one that puts every pixel in the wrap class"""
     rs = np.random.RandomState(11)
     img = Oracle.synth(1280, 720, 9)
     img[80:200, 100:400] = rs.randint(0, 12, (120, 300))
     img[500:620, 1100:1280] = rs.randint(0, 256, (120, 180))
     for t in (20, 3, 200, 300):
-        for force_px in (0, 1):
+        for force_px in (0, 1, 2):
             hip.tune(7, force_px)
             try:
                 pc.fast(hip, oracle, img, DEV, threshold=t, caps=(5000,))
