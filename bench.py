@@ -322,7 +322,7 @@ def main():
         if percall != moved:
             ktab[name]["percall_equivalent_GB/s"] = round(percall / ms / 1e6, 1)
         if name.startswith("gs_histogram"):  # one ds_add_u32 per pixel: the other physical ceiling of this kernel
-            ktab[name]["lds_atomic_frac"] = round(npx / ms / 1e9 / LDS_ATOMIC_TLANE_S / 1e3, 4)
+            ktab[name]["lds_atomic_frac"] = round(npx / ms / 1e9 / LDS_ATOMIC_TLANE_S, 4)
             ktab[name]["lds_atomic_note"] = ("pixels/s / %.1f T lane-atomics/s, the chip's measured ds_add_u32 rate "
                                              "(profiles/r02i_ubench_new_ops.log, pure stream, 4.1 cycles per wave per CU)" % LDS_ATOMIC_TLANE_S)
     del ii_buf

@@ -20,16 +20,17 @@ __global__ __launch_bounds__(256) void k_gather(const unsigned *tab, unsigned nd
                                                 int iters, unsigned *out) {
   const unsigned lane = threadIdx.x & 63u, wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
   unsigned acc = 0;
-  unsigned base = (wave * 4099u) % (ndw / 2);
+  const unsigned lanepart = lane * W * lane_stride + mis;
+  unsigned base = (wave * 4099u) & (ndw / 2 - 1u);
   for (int i = 0; i < iters; i++) {
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-      const unsigned off = (base + (unsigned)k * pitch + lane * W * lane_stride + mis) % (ndw - 8);
+      const unsigned off = (base + (unsigned)k * pitch + lanepart) & (ndw - 1u); /* ndw is a power of two; the table has 8 spare dwords */
       if (W == 1) acc += tab[off];
       else if (W == 2) { const u32x2 v = *(const u32x2_u *)(tab + off); acc += v.x ^ v.y; }
       else { const u32x4 v = *(const u32x4_u *)(tab + off); acc += v.x ^ v.y ^ v.z ^ v.w; }
     }
-    base = (base + 977u * 64u) % (ndw / 2);
+    base = (base + 977u * 64u) & (ndw / 2 - 1u);
   }
   out[blockIdx.x * 256u + threadIdx.x] = acc;
 }
@@ -56,7 +57,7 @@ int main() {
   const int cus = prop.multiProcessorCount, mhz = prop.clockRate / 1000;
   const unsigned ndw = 2u << 20; /* 8 MB: L2 / MALL resident */
   unsigned *tab, *out;
-  CK(hipMalloc(&tab, (size_t)ndw * 4)); CK(hipMemset(tab, 1, (size_t)ndw * 4));
+  CK(hipMalloc(&tab, (size_t)ndw * 4 + 64)); CK(hipMemset(tab, 1, (size_t)ndw * 4 + 64));
   CK(hipMalloc(&out, (size_t)cus * 8 * 256 * 4));
   printf("# %s, %d CUs @ %d MHz; 16 loads per iteration at row offsets k * 1921 dwords, 8 blocks of 4 waves per CU\n", prop.name, cus, mhz);
   run<1>("dword, consecutive lanes (256 B per wave-load)", tab, ndw, 0, 1, out, cus, mhz);
