@@ -519,12 +519,18 @@ template <bool QUAD = false, class F>
 void run_compaction(unsigned long long *mask, unsigned *cnt, unsigned nchunks, unsigned n,
                     unsigned cap, unsigned *totals_dev, F emit, hipStream_t on = nullptr, unsigned *pfx_in = nullptr) {
   hipStream_t st = on ? on : ctx().s();
+  if (nchunks <= kEmitSelfScan) { /* FAST on video frames, match: one launch less on a latency-bound tail */
+    GS_LAUNCH((k_emit<F, QUAD>), dim3((nchunks + 3) / 4, n), dim3(256), 0, st,
+              (const unsigned long long *)mask, (const unsigned *)cnt, (const unsigned *)nullptr, nchunks,
+              cap, emit, totals_dev);
+    return;
+  }
   unsigned *pfx = pfx_in ? pfx_in : (unsigned *)ctx().scratch(SL_PFX, (size_t)n * nchunks * 4);
   GS_LAUNCH(k_chunk_scan, dim3(n), dim3(1024), 0, st, (const unsigned *)cnt, nchunks, pfx,
             totals_dev, cap);
   GS_LAUNCH((k_emit<F, QUAD>), dim3((nchunks + 3) / 4, n), dim3(256), 0, st,
             (const unsigned long long *)mask, (const unsigned *)cnt, (const unsigned *)pfx, nchunks,
-            cap, emit);
+            cap, emit, (unsigned *)nullptr);
 }
 
 /* ------------------------------------------------------------------ FAST */
@@ -586,8 +592,7 @@ void launch_fast(const uint8_t *img, uint8_t *score, unsigned w, unsigned h, uns
   auto rest = [&](hipStream_t on, unsigned f0, unsigned nn) {
     if (clip_w && n == 1 && (clip_w < w || clip_h < h))
       GS_LAUNCH(k_fast_clip, grid2d(w, h, 1), dim3(64, 4), 0, on, score, w, h, clip_w, clip_h);
-    unsigned *c = cnt + (size_t)f0 * nchunks;
-    GS_HIP(hipMemsetAsync(c, 0, (size_t)nn * nchunks * 4, on));
+    unsigned *c = cnt + (size_t)f0 * nchunks; /* k_fast_nms stores every chunk's count: no zeroing */
     GS_LAUNCH(k_fast_nms, dim3(nchunks, nn), dim3(256), 0, on, (const uint8_t *)score + fb * f0, w, h, fb,
               mask + (size_t)f0 * nchunks * kChunkWords, c, nchunks, magic);
     run_compaction</*QUAD=*/true>(mask + (size_t)f0 * nchunks * kChunkWords, c, nchunks, nn, nkps, counts + f0, /* k_fast_nms: 4 items per lane */

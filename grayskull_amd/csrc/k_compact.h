@@ -6,7 +6,8 @@
  *
  *   1. the producing kernel publishes one 64-bit ballot word per wave (item i = bit i%64 of
  *      word i/64) and adds popcount(word) to the counter of its chunk (kChunkWords words);
- *   2. k_chunk_scan: exclusive prefix sum of the chunk counters (one block per frame);
+ *   2. k_chunk_scan: exclusive prefix sum of the chunk counters (one block per frame) -- or, for frames of at
+ *      most kEmitSelfScan chunks, no pass at all: each k_emit wave adds up the counters before its own chunk;
  *   3. k_emit<F>: one wave per non-empty chunk walks its words in order and writes the hits
  *      of a word in parallel, hit number r (< cap) through the functor F(frame, item, r).
  */
@@ -18,6 +19,7 @@ namespace gs {
 
 constexpr unsigned kChunkWords = 32;                  /* 2048 items per chunk */
 constexpr unsigned kChunkItems = kChunkWords * 64u;
+constexpr unsigned kEmitSelfScan = 1024;             /* chunks per frame up to which k_emit does its own prefix sums */
 
 /* called by ALL lanes of a wave, `word` wave-uniform */
 GS_DEV void publish_flags(bool flag, unsigned long long *mask, unsigned *chunk_count,
@@ -69,13 +71,30 @@ __global__ __launch_bounds__(1024) void k_chunk_scan(const unsigned *count, unsi
 template <class F, bool QUAD = false>
 __global__ __launch_bounds__(256) void k_emit(const unsigned long long *mask,
                                               const unsigned *count, const unsigned *prefix,
-                                              unsigned nchunks, unsigned cap, F emit) {
+                                              unsigned nchunks, unsigned cap, F emit, unsigned *total = nullptr) {
   const unsigned lane = threadIdx.x & 63u;
   const unsigned c = uniform(blockIdx.x * 4u + (threadIdx.x >> 6));
   if (c >= nchunks) return; /* whole wave */
   const size_t fc = (size_t)blockIdx.y * nchunks + c;
-  if (uniform(count[fc]) == 0) return;
-  unsigned r = uniform(prefix[fc]);
+  unsigned r;
+  if (prefix) {
+    if (uniform(count[fc]) == 0) return;
+    r = uniform(prefix[fc]);
+  } else {
+    /* no scan pass (few chunks per frame): the wave sums the counters of the chunks before its own; the wave of
+     * chunk 0 also leaves the frame's total */
+    const unsigned *cf = count + (size_t)blockIdx.y * nchunks;
+    if (c == 0) {
+      unsigned t = 0;
+      for (unsigned i = lane; i < nchunks; i += 64u) t += cf[i];
+      t = wave_sum(t);
+      if (lane == 0) total[blockIdx.y] = t < cap ? t : cap;
+    }
+    if (uniform(cf[c]) == 0) return;
+    unsigned before = 0;
+    for (unsigned i = lane; i < c; i += 64u) before += cf[i];
+    r = wave_sum(before);
+  }
   if (r >= cap) return;
   const unsigned long long mine = lane < kChunkWords ? mask[fc * kChunkWords + lane] : 0ull;
   const uint32_t mlo = (uint32_t)mine, mhi = (uint32_t)(mine >> 32);

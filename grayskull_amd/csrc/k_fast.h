@@ -304,6 +304,8 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t *score, unsigned
   const unsigned tid = threadIdx.x, wv = tid >> 6;
   const size_t chunk = (size_t)blockIdx.y * nchunks + blockIdx.x;
   const long W = (long)w;
+  __shared__ unsigned wave_hits[4];
+  unsigned hits = 0; /* this wave's share of the chunk's count */
   for (unsigned k = 0; k < kChunkItems / 1024u; k++) {
     const unsigned idx = blockIdx.x * kChunkItems + k * 1024u + tid * 4u;
     bool kp[4] = {false, false, false, false};
@@ -343,12 +345,16 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t *score, unsigned
     const uint64_t b0 = ballot(kp[0]), b1 = ballot(kp[1]), b2 = ballot(kp[2]), b3 = ballot(kp[3]);
     /* the four ballots are the group's four mask words in slot-major form (k_emit<F, QUAD>) */
     const unsigned total = (unsigned)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
+    hits += total;
     if (lane_id() == 0) {
       const size_t w0 = chunk * kChunkWords + k * 16u + wv * 4u;
       mask[w0] = b0, mask[w0 + 1] = b1, mask[w0 + 2] = b2, mask[w0 + 3] = b3;
-      if (total) atomicAdd(&chunk_count[chunk], total);
     }
   }
+  /* one block = one chunk: its count is a plain store (no atomics on a zeroed array, no zeroing pass) */
+  if (lane_id() == 0) wave_hits[wv] = hits;
+  __syncthreads();
+  if (tid == 0) chunk_count[chunk] = wave_hits[0] + wave_hits[1] + wave_hits[2] + wave_hits[3];
 }
 
 /* compaction functor: item -> gs_keypoint {{x,y}, score, 0, {0}} (ref :530), 48 B = 12 dwords */
