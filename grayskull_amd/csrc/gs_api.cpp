@@ -509,8 +509,8 @@ void launch_otsu(const uint8_t *img, unsigned w, unsigned h, unsigned n, unsigne
   launch_histogram(img, (size_t)(w * h), n, hist);
   for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
     const unsigned nn = std::min(kMaxZ, n - f0);
-    GS_LAUNCH(k_otsu, dim3(nn), dim3(256), 0, ctx().s(), (const unsigned *)hist + (size_t)f0 * 256,
-              w * h, thr + f0);
+    GS_LAUNCH(k_otsu, dim3(nn), dim3(256), 0, ctx().s(), hist + (size_t)f0 * 256, w * h, thr + f0,
+              (const unsigned *)nullptr, 0u, 0u);
   }
 }
 
@@ -1176,15 +1176,19 @@ void gsh_edge_pipeline_batch(uint8_t *dst, uint8_t *tmp, const uint8_t *src, uns
       for (unsigned g0 = f0; g0 < f0 + nn; g0 += kMaxZ) {
         const unsigned m = std::min(kMaxZ, f0 + nn - g0);
         const unsigned *pp = partial + (size_t)g0 * bpf_max * 256;
-        /* the 2w + 2(h-2) frame pixels are 0 in the result and were not counted by the kernel */
-        GS_LAUNCH(k_hist_reduce, dim3(m), dim3(256), 0, on, pp, bpf, hist_scratch + (size_t)g0 * 256,
+        /* the 2w + 2(h-2) frame pixels are 0 in the result and were not counted by the kernel; the threshold pass
+         * below waits for this launch only (k_otsu folds the blocks' partial histograms itself) */
+        GS_LAUNCH(k_otsu, dim3(m), dim3(256), 0, on, hist_scratch + (size_t)g0 * 256, w * h, thr + g0, pp, bpf,
                   2 * w + 2 * (h - 2));
-        GS_LAUNCH(k_otsu, dim3(m), dim3(256), 0, on, (const unsigned *)hist_scratch + (size_t)g0 * 256,
-                  w * h, thr + g0);
-        /* gs_sobel ran "into a zeroed image": only its 1-px frame is left to zero */
-        GS_LAUNCH(k_zero_frame, dim3((2 * w + 2 * h + 255) / 256, m), dim3(256), 0, on, dst + fb * g0, w, h, fb);
       }
       launch_threshold(dst + fb * f0, fb, nn, thr + f0, 0, on);
+      /* gs_sobel ran "into a zeroed image": only its 1-px frame is left to zero.  AFTER the threshold pass (which
+       * turns whatever the fused kernel left there into 0 / 255): the frame is then 0 either way, and the
+       * threshold pass need not wait for this launch. */
+      for (unsigned g0 = f0; g0 < f0 + nn; g0 += kMaxZ) {
+        const unsigned m = std::min(kMaxZ, f0 + nn - g0);
+        GS_LAUNCH(k_zero_frame, dim3((2 * w + 2 * h + 255) / 256, m), dim3(256), 0, on, dst + fb * g0, w, h, fb);
+      }
     };
 #ifdef GS_EMU
     const bool split = false;

@@ -166,7 +166,11 @@ __global__ __launch_bounds__(256) void k_hist_reduce(const unsigned *partial, un
  * same order), then all 256 between-class variances are evaluated in parallel and reduced with
  * "greater wins, first index on ties" == the reference's strict `>` update.  No FMA contraction;
  * IEEE add/mul/div are correctly rounded on gfx950 as on x86-64.  grid n frames, block 256. */
-__global__ __launch_bounds__(256) void k_otsu(const unsigned *hist, unsigned npix, uint8_t *thr) {
+/* partial != nullptr: the histogram is first folded from `bpf` per-block partial histograms (what k_hist_reduce
+ * does, saved as a launch: the pipeline's threshold pass waits for this kernel) and written to `hist` as well;
+ * extra0 = pixels known to be 0 that no block counted. */
+__global__ __launch_bounds__(256) void k_otsu(unsigned *hist, unsigned npix, uint8_t *thr,
+                                              const unsigned *partial = nullptr, unsigned bpf = 0, unsigned extra0 = 0) {
 #ifndef GS_EMU
 #pragma clang fp contract(off)
 #endif
@@ -176,16 +180,36 @@ __global__ __launch_bounds__(256) void k_otsu(const unsigned *hist, unsigned npi
   __shared__ float bv[4];
   __shared__ unsigned bt[4];
   const unsigned t = threadIdx.x, lane = t & 63u, wv = t >> 6;
-  const unsigned hv = hist[(size_t)blockIdx.x * 256u + t];
+  unsigned hv;
+  if (partial) {
+    const unsigned *p = partial + (size_t)blockIdx.x * bpf * 256u + t;
+    unsigned acc[8] = {t == 0 ? extra0 : 0u, 0, 0, 0, 0, 0, 0, 0};
+    unsigned b = 0;
+    for (; b + 8 <= bpf; b += 8) {
+#pragma unroll
+      for (unsigned k = 0; k < 8; k++) acc[k] += p[(size_t)(b + k) * 256u];
+    }
+    for (; b < bpf; b++) acc[0] += p[(size_t)b * 256u];
+    hv = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    hist[(size_t)blockIdx.x * 256u + t] = hv;
+  } else {
+    hv = hist[(size_t)blockIdx.x * 256u + t];
+  }
   prod[t] = (float)t * (float)hv;
   const unsigned inc = wave_incl_scan(hv);
   if (lane == 63) wsum[wv] = inc;
   __syncthreads();
-  if (t == 0) {
+  if (t == 0) { /* the reference's add chain, in its order; 8 LDS reads are in flight ahead of the 8 dependent adds */
     float s = 0;
-    for (int i = 0; i < 256; i++) {
-      s += prod[i];
-      pre[i] = s;
+    for (int i = 0; i < 256; i += 8) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) v[k] = prod[i + k];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        s += v[k];
+        pre[i + k] = s;
+      }
     }
   }
   unsigned wb = inc;

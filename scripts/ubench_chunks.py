@@ -5,7 +5,11 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import grayskull_amd as gs
-g = gs.lib(); g.use_torch_stream()
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TAG = os.environ.get("UB_TAG", "")
+g = gs.Grayskull(os.path.join(ROOT, "build_variants", "libgs_%s.so" % TAG)) if TAG else gs.lib()
+g.use_torch_stream()
+print("# library:", TAG or "this tree")
 W, H = 3840, 2160
 def timeit(fn, reps=10):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
