@@ -252,7 +252,7 @@ dim3 grid2d(unsigned w, unsigned h, unsigned n) { return dim3((w + 63) / 64, (h 
 inline bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 /* ---- launch tuning (gsh_tune): 0 rows per band (0 = auto), 1 block shape, 2 prefetch depth */
-int g_tune[12] = {0, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+int g_tune[13] = {0, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 /* gsh_lbp_count_evaluated: device counter that receives the windows the cascade really evaluated */
 thread_local unsigned long long *g_lbp_evaluated = nullptr;
 
@@ -466,16 +466,19 @@ unsigned hist_bpf(size_t frame_bytes, unsigned n) {
 void launch_histogram(const uint8_t *img, size_t frame_bytes, unsigned n, unsigned *hist) {
   if (n == 0) return;
   hipStream_t st = ctx().s();
-  if (frame_bytes > kHistMaxFrame) { /* k_hist_partial addresses a frame with 32-bit offsets: count a huge image in pieces */
-    const unsigned pieces = (unsigned)(frame_bytes / kHistMaxFrame);
-    const size_t rest = frame_bytes - (size_t)pieces * kHistMaxFrame;
-    const unsigned bpf = hist_bpf(kHistMaxFrame, pieces), bpr = rest ? hist_bpf(rest, 1) : 0;
+  /* k_hist_partial addresses a frame with 32-bit offsets: count a huge image in pieces (key 12: piece size in
+   * bytes, so that tests reach this path with small images) */
+  const size_t piece_bytes = g_tune[12] > 0 ? (size_t)g_tune[12] : kHistMaxFrame;
+  if (frame_bytes > piece_bytes) {
+    const unsigned pieces = (unsigned)(frame_bytes / piece_bytes);
+    const size_t rest = frame_bytes - (size_t)pieces * piece_bytes;
+    const unsigned bpf = hist_bpf(piece_bytes, pieces), bpr = rest ? hist_bpf(rest, 1) : 0;
     unsigned *partial = (unsigned *)ctx().scratch(SL_HISTP, ((size_t)pieces * bpf + bpr) * 256 * 4);
     for (unsigned f = 0; f < n; f++) {
       const uint8_t *p = img + frame_bytes * f;
-      GS_LAUNCH(k_hist_partial, dim3(bpf, pieces), dim3(256), 0, st, p, kHistMaxFrame, partial);
+      GS_LAUNCH(k_hist_partial, dim3(bpf, pieces), dim3(256), 0, st, p, piece_bytes, partial);
       if (rest)
-        GS_LAUNCH(k_hist_partial, dim3(bpr, 1), dim3(256), 0, st, p + (size_t)pieces * kHistMaxFrame, rest,
+        GS_LAUNCH(k_hist_partial, dim3(bpr, 1), dim3(256), 0, st, p + (size_t)pieces * piece_bytes, rest,
                   partial + (size_t)pieces * bpf * 256);
       GS_LAUNCH(k_hist_reduce, dim3(1), dim3(256), 0, st, (const unsigned *)partial, pieces * bpf + bpr,
                 hist + (size_t)f * 256, 0u);
@@ -1016,7 +1019,7 @@ unsigned gsh_profile_read(double *total_ms) {
   return n;
 }
 void gsh_tune(int key, int value) {
-  if (key >= 0 && key < 12) g_tune[key] = value;
+  if (key >= 0 && key < 13) g_tune[key] = value;
 }
 void gsh_probe_strip_copy(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned n) {
   GS_ASSERT(dst && src && w % 16 == 0 && al16(dst) && al16(src));

@@ -438,3 +438,24 @@ def test_histogram_ragged_frames_every_alignment(emu, oracle):
         emu.histogram_batch(a, hist)
         for f in range(n):
             assert np.array_equal(hist[f], oracle.histogram(a[f])), (w, h, f)
+
+
+def test_histogram_of_an_image_larger_than_one_launch_frame(emu, oracle):
+    """images above 1 GB are counted in pieces (k_hist_partial addresses a frame with 32-bit offsets); gsh_tune key 12
+    lowers the piece size so that 1000 .. 70000-byte images take that path: whole pieces + a remainder, odd piece sizes
+    (every piece starts at another alignment), batches"""
+    rng = np.random.RandomState(5)
+    try:
+        for piece, (n, h, w) in [(4096, (1, 37, 300)), (1000, (2, 70, 1000)), (333, (3, 9, 111)), (999, (1, 1, 999)), (999, (1, 2, 999)),
+                                 (5000, (1, 1, 4999))]:
+            emu.tune(12, piece)
+            a = rng.randint(0, 256, (n, h, w)).astype(np.uint8)
+            hist = np.zeros((n, 256), np.uint32)
+            emu.histogram_batch(a, hist)
+            for f in range(n):
+                assert np.array_equal(hist[f], oracle.histogram(a[f])), (piece, n, h, w, f)
+            thr = np.zeros(n, np.uint8)
+            emu.otsu_batch(a, hist, thr)
+            assert [int(t) for t in thr] == [oracle.otsu_threshold(a[f]) for f in range(n)]
+    finally:
+        emu.tune(12, 0)

@@ -766,3 +766,24 @@ def test_two_threads_share_one_cascade_handle(hip, oracle, cascade):
         t.join()
     dc.close()
     assert not errors, errors
+
+
+def test_histogram_of_a_1_2_gigabyte_image(hip):
+    """gs_histogram on one 40000 x 30000 image (1.2e9 bytes): more than one k_hist_partial frame (32-bit offsets), so it is
+    counted as one 1 GiB piece + the remainder; against torch.bincount"""
+    import torch
+    w, h = 40000, 30000
+    img = torch.empty((1, h, w), dtype=torch.uint8, device="cuda")
+    hip.synth_batch(img[:, :2160, :3840].contiguous(), 3)  # warm the library; the big image is filled by torch below
+    torch.manual_seed(1)
+    chunk = torch.randint(0, 256, (1000, w), dtype=torch.uint8, device="cuda")
+    for y in range(0, h, 1000):
+        img[0, y:y + 1000] = chunk.roll(y // 1000, 1)
+    img[0, -1, -7:] = 255
+    hist = torch.zeros((1, 256), dtype=torch.int32, device="cuda")
+    hip.histogram_batch(img, hist)
+    ref = torch.zeros(256, dtype=torch.int64, device="cuda")
+    for y in range(0, h, 5000):
+        ref += torch.bincount(img[0, y:y + 5000].flatten().to(torch.int64), minlength=256)
+    assert bool((hist[0].to(torch.int64) == ref).all())
+    assert int(hist.sum()) == w * h
