@@ -39,9 +39,12 @@ void gsh_sync(void);                      /* hipStreamSynchronize(current stream
  * gsh_edge_pipeline_batch's internal overlap (0 = default 32, negative = never split),
  * 6 comparison switches: 1 = generic two-pass gs_integral, 2 = block-per-band gs_integral,
  * 3 = integral-image route for gs_blur(radius > 3) / gs_adaptive_threshold instead of the sliding
- * box kernel, 7 set to 1: gs_fast scores with the strip kernel (lane = 4 px, image rows in
- * registers; faster on flat / bright frames, slower where large regions are darker than the
- * threshold).  Results never change. */
+ * box kernel, 7 score kernel of gs_fast: 0 = LDS tile (default), 1 = strip kernel (lane = 4 px, image
+ * rows in registers; faster on flat frames only), 2 = one global byte load per ring pixel (round 1),
+ * 8 frames per launch (test hook for the batch splitting of every launcher), 9 LBP: stages / survivor
+ * share at which a block first re-packs (max stages + 16 * tenths; key 4 >= 1000 = custom fixed split),
+ * 10 trips per block gs_histogram aims at, 11 its blocks per frame, 12 bytes per histogram piece (test
+ * hook for images above 1 GiB).  Results never change. */
 void gsh_tune(int key, int value);
 /* measurement aid for bench.py: while on, gsh_edge_pipeline_batch brackets every launch of its
  * fused blur+sobel+histogram kernel with HIP events on the stream it is launched on (up to 4096
