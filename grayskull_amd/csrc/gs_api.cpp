@@ -776,8 +776,12 @@ void launch_lbp_padded(const gsh_cascade *dc, const LbpGeomCache &gc, const unsi
     /* preset 0 (default): first re-packing point chosen per block between stages 2 and 6 (k_lbp.h) */
     ph.adaptive_max = (g_tune[4] == 0 && dc->nstages > 2) ? 6u : 0u;
     ph.adaptive_tenths = 2u;
-    if (ph.adaptive_max && g_tune[9] > 0) /* experiments: key 9 = max + 16 * tenths */
-      ph.adaptive_max = (unsigned)g_tune[9] & 15u, ph.adaptive_tenths = (unsigned)g_tune[9] >> 4;
+    ph.adaptive_next[0] = 2u, ph.adaptive_next[1] = 5u, ph.adaptive_next[2] = 0u;
+    if (ph.adaptive_max && g_tune[9] > 0) { /* experiments: key 9 = max + 16 * tenths (+ 256 d1 + 4096 d2 + 65536 d3: later points) */
+      const unsigned v = (unsigned)g_tune[9];
+      ph.adaptive_max = v & 15u, ph.adaptive_tenths = (v >> 4) & 15u;
+      if (v >> 8) ph.adaptive_next[0] = (v >> 8) & 15u, ph.adaptive_next[1] = (v >> 12) & 15u, ph.adaptive_next[2] = (v >> 16) & 15u;
+    }
   }
   const size_t lds_all = ((lds + 15) & ~(size_t)15) + 2 * kChunkItems * 2 + 64 * 4 + 16;
   if (a.evaluated) { /* counting build: the same kernel + one register that counts classifier evaluations */

@@ -198,6 +198,7 @@ struct LbpPhases { /* phase p = stages [end[p-1], end[p]) */
    * profiles/r02h_lbp_splits.log).  The later re-packing points follow at +2 and +5 stages. */
   unsigned adaptive_max;
   unsigned adaptive_tenths; /* re-pack once alive <= tenths/10 of the chunk */
+  unsigned adaptive_next[3]; /* later re-packing points, in stages after the first one (0 = none) */
 };
 
 /* grid (max chunks per scale, nscales, n frames), block 256;
@@ -306,8 +307,9 @@ __global__ __launch_bounds__(256) void k_lbp_cascade(LbpArgs a, LbpPhases ph) {
     }
     /* the remaining phases: +2, +5 stages, then the rest */
     np = 0, ends[np++] = e;
-    if (e + 2u < a.nstages) ends[np++] = e + 2u;
-    if (e + 5u < a.nstages) ends[np++] = e + 5u;
+#pragma unroll
+    for (unsigned i = 0; i < 3; i++)
+      if (ph.adaptive_next[i] && e + ph.adaptive_next[i] < a.nstages) ends[np++] = e + ph.adaptive_next[i];
     if (e < a.nstages) ends[np++] = a.nstages;
     pstart = 1;
     if (n_in == 0) pstart = np; /* nothing left (or already final) */

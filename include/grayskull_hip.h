@@ -42,7 +42,7 @@ void gsh_sync(void);                      /* hipStreamSynchronize(current stream
  * box kernel, 7 score kernel of gs_fast: 0 = LDS tile (default), 1 = strip kernel (lane = 4 px, image
  * rows in registers; faster on flat frames only), 2 = one global byte load per ring pixel (round 1),
  * 8 frames per launch (test hook for the batch splitting of every launcher), 9 LBP: stages / survivor
- * share at which a block first re-packs (max stages + 16 * tenths; key 4 >= 1000 = custom fixed split),
+ * share at which a block first re-packs (max stages + 16 * tenths [+ later points]; key 4 >= 1000 = custom fixed split),
  * 10 trips per block gs_histogram aims at, 11 its blocks per frame, 12 bytes per histogram piece (test
  * hook for images above 1 GiB).  Results never change. */
 void gsh_tune(int key, int value);
