@@ -456,12 +456,22 @@ void launch_blur(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsig
  * filling its load queue, so it should run ~64 trips of 16 B per lane (512 4K frames: 4.9 Tpx/s at 31 trips,
  * 5.8 at 63; profiles/r02i_hist.log, r02i_hist_trips.log); a handful of frames is spread over the CUs
  * (256 CUs x 5 resident blocks) down to 16 trips per block, at most 256 blocks per frame for k_hist_reduce. */
+constexpr unsigned kHistThreads = 256;
+unsigned hist_threads() { return g_tune[10] >= 1000 ? (unsigned)(g_tune[10] / 1000) * 256u : kHistThreads; } /* experiments: key 10 = 1000 * (threads / 256) + trips */
 unsigned hist_bpf(size_t frame_bytes, unsigned n) {
   if (g_tune[11] > 0) return (unsigned)g_tune[11];
-  const size_t chunks = frame_bytes / 16 + 1, trips = g_tune[10] > 0 ? (size_t)g_tune[10] : 64;
-  const size_t by_size = (chunks + 256 * trips - 1) / (256 * trips);
-  const size_t by_fill = std::min<size_t>(std::min<size_t>((1280 + n - 1) / n, chunks / (256 * 16)), 256);
+  const size_t bt = hist_threads();
+  const size_t chunks = frame_bytes / 16 + 1, trips = g_tune[10] % 1000 > 0 ? (size_t)(g_tune[10] % 1000) : 64 * 256 / bt;
+  const size_t by_size = (chunks + bt * trips - 1) / (bt * trips);
+  const size_t by_fill = std::min<size_t>(std::min<size_t>((1280 + n - 1) / n, chunks / (bt * 16)), 256);
   return (unsigned)std::max<size_t>(1, std::min<size_t>(std::max(by_size, by_fill), 2048));
+}
+void launch_hist_partial(dim3 grid, hipStream_t st, const uint8_t *img, size_t frame_bytes, unsigned *partial) {
+  switch (hist_threads()) {
+    case 512: GS_LAUNCH(k_hist_partial<512>, grid, dim3(512), 0, st, img, frame_bytes, partial); break;
+    case 1024: GS_LAUNCH(k_hist_partial<1024>, grid, dim3(1024), 0, st, img, frame_bytes, partial); break;
+    default: GS_LAUNCH(k_hist_partial<256>, grid, dim3(256), 0, st, img, frame_bytes, partial);
+  }
 }
 void launch_histogram(const uint8_t *img, size_t frame_bytes, unsigned n, unsigned *hist) {
   if (n == 0) return;
@@ -476,10 +486,9 @@ void launch_histogram(const uint8_t *img, size_t frame_bytes, unsigned n, unsign
     unsigned *partial = (unsigned *)ctx().scratch(SL_HISTP, ((size_t)pieces * bpf + bpr) * 256 * 4);
     for (unsigned f = 0; f < n; f++) {
       const uint8_t *p = img + frame_bytes * f;
-      GS_LAUNCH(k_hist_partial, dim3(bpf, pieces), dim3(256), 0, st, p, piece_bytes, partial);
+      launch_hist_partial(dim3(bpf, pieces), st, p, piece_bytes, partial);
       if (rest)
-        GS_LAUNCH(k_hist_partial, dim3(bpr, 1), dim3(256), 0, st, p + (size_t)pieces * piece_bytes, rest,
-                  partial + (size_t)pieces * bpf * 256);
+        launch_hist_partial(dim3(bpr, 1), st, p + (size_t)pieces * piece_bytes, rest, partial + (size_t)pieces * bpf * 256);
       GS_LAUNCH(k_hist_reduce, dim3(1), dim3(256), 0, st, (const unsigned *)partial, pieces * bpf + bpr,
                 hist + (size_t)f * 256, 0u);
     }
@@ -489,8 +498,7 @@ void launch_histogram(const uint8_t *img, size_t frame_bytes, unsigned n, unsign
   for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
     const unsigned nn = std::min(kMaxZ, n - f0);
     unsigned *partial = (unsigned *)ctx().scratch(SL_HISTP, (size_t)nn * bpf * 256 * 4);
-    GS_LAUNCH(k_hist_partial, dim3(bpf, nn), dim3(256), 0, st, img + frame_bytes * f0, frame_bytes,
-              partial);
+    launch_hist_partial(dim3(bpf, nn), st, img + frame_bytes * f0, frame_bytes, partial);
     GS_LAUNCH(k_hist_reduce, dim3(nn), dim3(256), 0, st, (const unsigned *)partial, bpf,
               hist + (size_t)f0 * 256, 0u);
   }

@@ -91,17 +91,19 @@ GS_DEV void hist_count16(unsigned *lh, unsigned copy, const U4 &v, unsigned inc)
 #pragma unroll
   for (int k = 0; k < 16; k++) atomicAdd(&lh[((d[k >> 2] >> (8 * (k & 3))) & 0xffu) * 32u + copy], inc);
 }
-__global__ __launch_bounds__(256) void k_hist_partial(const uint8_t *img, size_t frame_bytes,
-                                                      unsigned *partial) {
+/* BT threads share the block's 32 KB of counters: more waves per CU next to the same LDS footprint */
+template <unsigned BT>
+__global__ __launch_bounds__(BT) void k_hist_partial(const uint8_t *img, size_t frame_bytes,
+                                                     unsigned *partial) {
   __shared__ unsigned lh[256 * 32];
   const unsigned tid = threadIdx.x, copy = tid & 31u;
-  for (unsigned i = tid; i < 256 * 32 / 4; i += 256) ((U4 *)lh)[i] = U4{0, 0, 0, 0};
+  for (unsigned i = tid; i < 256 * 32 / 4; i += BT) ((U4 *)lh)[i] = U4{0, 0, 0, 0};
   __syncthreads();
   const uint8_t *base = img + (size_t)blockIdx.y * frame_bytes;
   const Chunking c = make_chunking(base, frame_bytes);
   /* whole 16-byte chunks [c0, c1); the (at most two) partial ones at the ends of the frame go byte by byte */
   const size_t c0 = c.lo ? 1 : 0, c1 = c.hi / 16;
-  const size_t stride = (size_t)gridDim.x * 256u, first = c0 + (size_t)blockIdx.x * 256u;
+  const size_t stride = (size_t)gridDim.x * BT, first = c0 + (size_t)blockIdx.x * BT;
   if (first < c1) { /* block-uniform */
     /* The loop is branch-free and the loads are buffer loads (vmcnt only; a flat load would also tick the
      * LDS counter) so that the compiler's s_waitcnt leaves DEPTH - 1 loads in flight instead of draining
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(256) void k_hist_partial(const uint8_t *img, size_t
     const BufRsrc src = make_buf((const void *)(((uintptr_t)uniform((uint32_t)(b0 >> 32)) << 32) | uniform((uint32_t)b0)), end);
     const unsigned iters = (unsigned)((c1 - first + stride - 1) / stride);
     const unsigned padded = (iters + kHistDepth - 1) / kHistDepth * kHistDepth;
-    const uint32_t mine = ((uint32_t)blockIdx.x * 256u + tid) * 16u, step = (uint32_t)stride * 16u;
+    const uint32_t mine = ((uint32_t)blockIdx.x * BT + tid) * 16u, step = (uint32_t)stride * 16u;
     U4 q[kHistDepth];
 #pragma unroll
     for (unsigned k = 0; k < kHistDepth; k++) {
@@ -138,10 +140,12 @@ __global__ __launch_bounds__(256) void k_hist_partial(const uint8_t *img, size_t
     if (c1 >= c0 && c1 * 16 + tid < c.hi) atomicAdd(&lh[(unsigned)*(const uint8_t *)(c.a0 + c1 * 16 + tid) * 32u + copy], 1u);
   }
   __syncthreads();
-  unsigned s = 0;
+  if (tid < 256u) {
+    unsigned s = 0;
 #pragma unroll 8
-  for (unsigned k = 0; k < 32; k++) s += lh[tid * 32u + ((k + tid) & 31u)]; /* rotated: conflict-free */
-  partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256u + tid] = s;
+    for (unsigned k = 0; k < 32; k++) s += lh[tid * 32u + ((k + tid) & 31u)]; /* rotated: conflict-free */
+    partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256u + tid] = s;
+  }
 }
 
 /* grid n frames, block 256: 8 independent partial sums per thread keep 8 loads in flight (a dependent chain over

@@ -20,7 +20,7 @@ for (n, h, w) in [(512, 2160, 3840), (64, 4096, 4096), (32, 720, 1280), (1, 2160
     src = torch.empty((n, h, w), dtype=torch.uint8, device="cuda"); g.synth_batch(src, 1000)
     hist = torch.zeros((n, 256), dtype=torch.int32, device="cuda"); thr = torch.zeros(n, dtype=torch.uint8, device="cuda")
     ref = torch.stack([torch.bincount(src[i].flatten().to(torch.int64), minlength=256) for i in (0, n - 1)]).to(torch.int32)
-    for bpf in [int(x) for x in os.environ.get("UB_TRIPS", "0").split(",")]:
+    for bpf in [int(x) for x in os.environ.get("UB_TRIPS", "0").split(",")]:  # >= 1000: 1000 * (threads per block / 256) + trips
         g.tune(10, bpf)
         ms = timeit(lambda: g.histogram_batch(src, hist))
         ok = bool((hist[[0, n - 1]] == ref).all())
