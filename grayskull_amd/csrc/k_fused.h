@@ -132,9 +132,9 @@ __global__ __launch_bounds__(256) GS_FUSED_VGPR_ATTR void k_blur_sobel_hist16(ui
     /* per-lane increments, fixed for the kernel: lanes outside the image and the two frame columns count 0 */
     const unsigned inc_in = inimg ? 1u : 0u, inc_first = (inimg && !first) ? 1u : 0u, inc_last = (inimg && !last) ? 1u : 0u;
 
-    /* The histogram of row i is added during row i+1 (software pipelining): an LDS atomic costs the
-     * CU's LDS pipe ~8-13 cycles per wave-instruction (scripts/ubench_valu.cpp), 16 of them per row and
-     * wave -- about as much LDS time per CU as the row's VALU time per SIMD.  Issued in a burst after
+    /* The histogram of row i is added during row i+1 (software pipelining): an LDS atomic takes the
+     * CU's LDS pipe ~4 cycles per wave-instruction (scripts/ubench_valu.cpp, pure stream), 16 of them per
+     * row and wave.  Issued in a burst after
      * the row's last results (hipcc sinks instructions nobody waits for to the end of the block),
      * they fill the LDS queue and stall the wave.  So the previous row's 16 atomics are threaded
      * through values of THIS row's arithmetic (lds_add_through): the even pixels' through the new
