@@ -415,3 +415,30 @@ def _body_fast_any_scoremap(g, reference, w, h, sw, sh, seed, threshold):
        threshold=st.sampled_from([0, 5, 20, 100]))
 def test_fast_any_scoremap_size(emu, reference, w, h, sw, sh, seed, threshold):
     _body_fast_any_scoremap(emu, reference, w=w, h=h, sw=sw, sh=sh, seed=seed, threshold=threshold)
+
+
+# ---- histogram / Otsu of a batch: any frame size (every base alignment occurs inside a batch), any piece size of the
+# ---- huge-image path (gsh_tune key 12), any blocks-per-frame choice (key 11)
+def _body_histogram_batch(g, oracle, n, w, h, seed, kind, piece, bpf):
+    rs = np.random.RandomState(seed)
+    a = np.stack([_img(rs, w, h, kind) for _ in range(n)])
+    hist = np.zeros((n, 256), np.uint32)
+    thr = np.zeros(n, np.uint8)
+    try:
+        g.tune(12, piece)
+        g.tune(11, bpf)
+        g.histogram_batch(a, hist)
+        for f in range(n):
+            assert_same(hist[f], oracle.histogram(a[f]), "histogram frame %d of %d, %dx%d, piece %d, bpf %d" % (f, n, w, h, piece, bpf))
+        g.otsu_batch(a, hist, thr)
+        assert [int(t) for t in thr] == [oracle.otsu_threshold(a[f]) for f in range(n)]
+    finally:
+        g.tune(12, 0)
+        g.tune(11, 0)
+
+
+@_cfg(30)
+@given(n=st.integers(1, 4), w=st.integers(1, 300), h=st.integers(1, 40), seed=st.integers(0, 2 ** 16), kind=st.integers(0, 2),
+       piece=st.sampled_from([0, 0, 17, 100, 999, 4096]), bpf=st.sampled_from([0, 0, 1, 2, 5]))
+def test_histogram_batch_any_shape(emu, oracle, n, w, h, seed, kind, piece, bpf):
+    _body_histogram_batch(emu, oracle, n, w, h, seed, kind, piece, bpf)
