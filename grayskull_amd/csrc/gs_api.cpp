@@ -607,7 +607,7 @@ void launch_fast(const uint8_t *img, uint8_t *score, unsigned w, unsigned h, uns
     GS_LAUNCH(k_fast_nms, dim3(nchunks, nn), dim3(256), 0, on, (const uint8_t *)score + fb * f0, w, h, fb,
               mask + (size_t)f0 * nchunks * kChunkWords, c, nchunks, magic);
     run_compaction</*QUAD=*/true>(mask + (size_t)f0 * nchunks * kChunkWords, c, nchunks, nn, nkps, counts + f0, /* k_fast_nms: 4 items per lane */
-                                  FastEmit{score + fb * f0, w, fb, kps + (size_t)f0 * nkps * 12, nkps}, on,
+                                  FastEmit{score + fb * f0, w, fb, kps + (size_t)f0 * nkps * 12, nkps, ((uintptr_t)kps & 15) == 0}, on,
                                   pfx + (size_t)f0 * nchunks);
   };
   /* Tried and not kept: cutting a batch into 2-8 groups of frames and running group i's NMS / scan / emit on the side

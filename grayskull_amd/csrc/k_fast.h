@@ -391,14 +391,20 @@ struct FastEmit {
   size_t frame_bytes;
   unsigned *kps; /* n frames x nkps x 12 u32 */
   unsigned nkps;
+  bool aligned16; /* kps is 16-byte aligned: a 48-byte record is three dwordx4 stores instead of twelve 4-byte ones */
   GS_DEV void operator()(unsigned frame, size_t item, unsigned r) const {
     const unsigned iw = w - 6;
     const unsigned it = (unsigned)item; /* (w-6)*(h-6) fits 32 bits (checked by the launcher's item count) */
     const unsigned yy = it / iw, x = 3 + (it - yy * iw), y = 3 + yy;
     unsigned *o = kps + ((size_t)frame * nkps + r) * 12u;
-    o[0] = x, o[1] = y, o[2] = score[(size_t)frame * frame_bytes + (size_t)y * w + x];
+    const unsigned sc = score[(size_t)frame * frame_bytes + (size_t)y * w + x];
+    if (aligned16) {
+      store_u32x4(o, U4{x, y, sc, 0}), store_u32x4(o + 4, U4{0, 0, 0, 0}), store_u32x4(o + 8, U4{0, 0, 0, 0});
+    } else {
+      o[0] = x, o[1] = y, o[2] = sc;
 #pragma unroll
-    for (int i = 3; i < 12; i++) o[i] = 0;
+      for (int i = 3; i < 12; i++) o[i] = 0;
+    }
   }
 };
 

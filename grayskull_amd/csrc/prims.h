@@ -98,6 +98,7 @@ GS_DEV uint32_t buf_load4(const BufRsrc &b, uint32_t off) {
   if (off < b.n) memcpy(&v, b.base + off, 4);
   return v;
 }
+GS_DEV void store_u32x4(void *p, const U4 &v) { memcpy(p, &v, 16); }
 GS_DEV void buf_store16(const BufRsrc &b, uint32_t off, const U4 &v) {
   emu_buf_check(b, off, 16);
   if (off < b.n) memcpy(b.base + off, &v, 16);
@@ -206,6 +207,8 @@ GS_DEV uint32_t buf_gather4(const BufRsrc &b, uint32_t voff, uint32_t soff) {
   return __builtin_amdgcn_raw_buffer_load_b32(b.r, (int)voff, (int)soff, 0);
 }
 GS_DEV uint32_t uniform(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+/* one global_store_dwordx4 at a 16-byte aligned address */
+GS_DEV void store_u32x4(void *p, const U4 &v) { *(gs_u32x4 *)p = gs_u32x4{v.x, v.y, v.z, v.w}; }
 GS_DEV void buf_store16(const BufRsrc &b, uint32_t off, const U4 &v) { /* buffer_store_dwordx4 offen */
   __builtin_amdgcn_raw_buffer_store_b128(gs_u32x4{v.x, v.y, v.z, v.w}, b.r, (int)off, 0, GS_STORE_AUX);
 }
