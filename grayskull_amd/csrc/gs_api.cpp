@@ -252,7 +252,7 @@ dim3 grid2d(unsigned w, unsigned h, unsigned n) { return dim3((w + 63) / 64, (h 
 inline bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 /* ---- launch tuning (gsh_tune): 0 rows per band (0 = auto), 1 block shape, 2 prefetch depth */
-int g_tune[13] = {0, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+int g_tune[14] = {0, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 /* gsh_lbp_count_evaluated: device counter that receives the windows the cascade really evaluated */
 thread_local unsigned long long *g_lbp_evaluated = nullptr;
 
@@ -749,7 +749,11 @@ void launch_lbp_padded(const gsh_cascade *dc, const LbpGeomCache &gc, const unsi
   a.subsets = dc->d_subsets;
   a.mask = mask, a.chunk_count = cnt, a.total_chunks = nch;
   const unsigned nsc = (unsigned)gc.scales.size();
-  const dim3 g(gc.max_chunks, nsc, n);
+  /* XCD-aware chunk mapping (k_lbp.h) once the integral image no longer fits one XCD's 4 MB L2: 1080p -3 %, 4K block
+   * noise -4 %, 4K edge maps -12 % (5.76 -> 5.08 ms per frame); 720p (3.7 MB) is 1-4 % better off in dispatch order
+   * (profiles/r02l_lbp_xcd.log).  Key 13: 1 = never, 2 = always. */
+  a.xcd_swizzle = g_tune[13] == 1 ? 0u : g_tune[13] == 2 ? 1u : (a.frame_stride * 4 >= (size_t)6 << 20 ? 1u : 0u);
+  const dim3 g(a.xcd_swizzle ? (gc.max_chunks + 7u) & ~7u : gc.max_chunks, nsc, n);
   const size_t lds = (size_t)dc->nstages * sizeof(LbpStage) +
                      (size_t)dc->nweaks * (sizeof(LbpWeak) + sizeof(LbpGeom)) + (size_t)dc->nsub * 4;
   GS_ASSERT(lds <= 60 * 1024 && "cascade tables must fit the block's LDS");
@@ -1031,7 +1035,7 @@ unsigned gsh_profile_read(double *total_ms) {
   return n;
 }
 void gsh_tune(int key, int value) {
-  if (key >= 0 && key < 13) g_tune[key] = value;
+  if (key >= 0 && key < 14) g_tune[key] = value;
 }
 void gsh_probe_strip_copy(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned n) {
   GS_ASSERT(dst && src && w % 16 == 0 && al16(dst) && al16(src));

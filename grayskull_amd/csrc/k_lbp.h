@@ -54,6 +54,7 @@ struct LbpArgs {
   unsigned *hits_super;         /* n frames x nsupers   (pre-zeroed) */
   unsigned ngroups, nsupers;
   unsigned nscales, cap;        /* cap = max_rects */
+  unsigned xcd_swizzle;         /* 1: chunk = (blockIdx.x % 8) * ceil(nchunks / 8) + blockIdx.x / 8 */
   unsigned long long *evaluated; /* optional (COUNT kernels): [0] += windows of every chunk that was not
                                     skipped, [1] += weak classifiers evaluated, summed over windows */
 };
@@ -214,7 +215,18 @@ __global__ __launch_bounds__(256) void k_lbp_cascade(LbpArgs a, LbpPhases ph) {
 #endif
   GS_DYN_LDS(smem);
   const LbpScale sc = a.scales[blockIdx.y];
-  if (blockIdx.x >= sc.nchunks) return; /* whole block */
+  /* XCD-aware chunk mapping (a.xcd_swizzle; gridDim.x is then a multiple of 8): the dispatcher places block b on
+   * XCD b % 8, each with its own 4 MB L2.  Handing consecutive chunks to consecutive XCDs makes every XCD sweep
+   * the whole integral image of every scale (one L2 request in three missed: 134 M misses per 4 x 1080p,
+   * profiles/r02l_pmc_tcc.txt); instead XCD k takes the k-th eighth of the scale's chunks, i.e. one band of
+   * window rows whose table rows stay in its L2.  Results do not depend on it (mask words are indexed by chunk). */
+  unsigned cx = blockIdx.x;
+  if (a.xcd_swizzle) {
+    const unsigned per = (sc.nchunks + 7u) >> 3, j = blockIdx.x >> 3;
+    if (j >= per) return; /* whole block */
+    cx = (blockIdx.x & 7u) * per + j;
+  }
+  if (cx >= sc.nchunks) return; /* whole block */
   const unsigned tid = threadIdx.x;
   /* The reference stops scanning once max_rects detections exist (ref :819-823), and the output is
    * the FIRST max_rects hits in (scale, y, x) order.  Detections published by chunks that precede
@@ -224,7 +236,7 @@ __global__ __launch_bounds__(256) void k_lbp_cascade(LbpArgs a, LbpPhases ph) {
    * partial sum only skips less, so the result is exact for any dispatch order -- and blocks are
    * dispatched in (scale, chunk) order, so on frames that reach the cap nearly everything after
    * that point is skipped. */
-  const unsigned lin = sc.chunk_base + blockIdx.x;
+  const unsigned lin = sc.chunk_base + cx;
   __shared__ unsigned before_s;
   if (tid < 64u) { /* one wave sums; the decision must be the same for the whole block */
     const unsigned g1 = lin >> kLbpGroupShift, g2 = lin >> kLbpSuperShift;
@@ -247,7 +259,7 @@ __global__ __launch_bounds__(256) void k_lbp_cascade(LbpArgs a, LbpPhases ph) {
   if (tid < 64) bits[tid] = 0;
   if (tid < 2) qn[tid] = 0;
   __syncthreads();
-  const unsigned nwin = sc.nx * sc.ny, first = blockIdx.x * kChunkItems;
+  const unsigned nwin = sc.nx * sc.ny, first = cx * kChunkItems;
   const unsigned *Pg = a.padded + (size_t)blockIdx.z * a.frame_stride;
   unsigned n_in = nwin - first < kChunkItems ? nwin - first : kChunkItems;
   unsigned cur = 0, evals = 0;
@@ -351,7 +363,7 @@ __global__ __launch_bounds__(256) void k_lbp_cascade(LbpArgs a, LbpPhases ph) {
   }
   __syncthreads();
   /* publish this chunk: 32 words of 64 bits + their total */
-  const size_t chunk = (size_t)blockIdx.z * a.total_chunks + sc.chunk_base + blockIdx.x;
+  const size_t chunk = (size_t)blockIdx.z * a.total_chunks + sc.chunk_base + cx;
   if (tid < 64) { /* one wave */
     unsigned c = 0;
     if (tid < kChunkWords) {

@@ -459,3 +459,17 @@ def test_histogram_of_an_image_larger_than_one_launch_frame(emu, oracle):
             assert [int(t) for t in thr] == [oracle.otsu_threshold(a[f]) for f in range(n)]
     finally:
         emu.tune(12, 0)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_lbp_chunk_to_xcd_mapping_never_changes_results(emu, oracle, cascade, mode):
+    """gsh_tune key 13: 1 = chunks in dispatch order, 2 = XCD-aware mapping (chunk = (block % 8) * ceil(nchunks / 8) + block / 8,
+    grid padded to a multiple of 8) -- forced on small images: scales with 1, 7, 9 and a few dozen chunks, caps reached early"""
+    edges = oracle.sobel(oracle.blur(Oracle.synth(200, 150, 1000), 2))
+    try:
+        emu.tune(13, mode)
+        pc.lbp(emu, oracle, edges, MEM, cascade, params=((4096, 1.1, 1.0, 4.0, 1), (7, 1.1, 1.0, 4.0, 1), (300, 1.3, 1.0, 3.0, 2)))
+        pc.lbp(emu, oracle, Oracle.synth(96, 80, 7), MEM, cascade, params=((4096, 1.1, 1.0, 4.0, 1),))
+        pc.lbp(emu, oracle, Oracle.synth(64, 48, 9), MEM, random_cascade(1), params=((4096, 1.25, 1.0, 2.0, 2), (3, 1.25, 1.0, 2.0, 1)))
+    finally:
+        emu.tune(13, 0)
