@@ -785,8 +785,8 @@ void launch_lbp_padded(const gsh_cascade *dc, const LbpGeomCache &gc, const unsi
     }
     if (ph.n == 0) ph.n = 1, ph.end[0] = dc->nstages;
     ph.end[ph.n - 1] = dc->nstages;
-    /* preset 0 (default): first re-packing point chosen per block between stages 2 and 6 (k_lbp.h) */
-    ph.adaptive_max = (g_tune[4] == 0 && dc->nstages > 2) ? 6u : 0u;
+    /* preset 0 (default): first re-packing point chosen per block between stages 2 and 8 (k_lbp.h) */
+    ph.adaptive_max = (g_tune[4] == 0 && dc->nstages > 2) ? 8u : 0u; /* 6 .. 15 within 1.5 % (profiles/r02l_lbp_adaptive_xcd.log) */
     ph.adaptive_tenths = 2u;
     ph.adaptive_next[0] = 2u, ph.adaptive_next[1] = 5u, ph.adaptive_next[2] = 0u;
     if (ph.adaptive_max && g_tune[9] > 0) { /* experiments: key 9 = max + 16 * tenths (+ 256 d1 + 4096 d2 + 65536 d3: later points) */

@@ -25,7 +25,7 @@ rects = torch.zeros((n, 4096, 4), dtype=torch.int32, device="cuda"); counts = to
 splits = [(2, 4, 7), (3, 6, 10), (4, 8), (3, 5, 8), (4, 6, 9)]
 for name, ii in (("noise", ii_n), ("edges", ii_e)):
     ref = None
-    for sp in [("adaptive", 6, 2)] + [("adaptive", 6, 2, a, b, c) for (a, b, c) in ((2, 5, 0), (1, 3, 6), (2, 4, 7), (1, 2, 4), (3, 6, 0), (2, 5, 9), (1, 3, 0), (2, 0, 0), (3, 7, 0), (2, 6, 0))] + splits[:1]:
+    for sp in [("adaptive", 6, 2), ("adaptive", 8, 2), ("adaptive", 10, 2), ("adaptive", 12, 2), ("adaptive", 15, 2), ("adaptive", 10, 2, 2, 4, 0), ("adaptive", 10, 2, 1, 3, 6)] + splits[:1]:
         if sp[0] == "adaptive": g.tune(4, 0); g.tune(9, sp[1] + 16 * sp[2] + (256 * sp[3] + 4096 * sp[4] + 65536 * sp[5] if len(sp) > 3 else 0))
         else: g.tune(4, 1000 + sum(e << (5 * i) for i, e in enumerate(sp)))
         ms = timeit(lambda: g.lbp_detect_batch(dc, ii, rects, counts, 4096, 1.1, 1.0, 4.0, 1))
