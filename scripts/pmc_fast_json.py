@@ -14,7 +14,7 @@ for r in csv.DictReader(open(f)):
         acc[k].append(float(r["Counter_Value"]))
 npx = 32 * 1280 * 720
 out = {"workload": "32 x 1280x720 synth(seed 4), threshold 20 (scripts/pmc_probe_features.py)", "avg_issue_cycles": round((48 * 2 + 114 * 4) / 162.0, 3),
-       "source": "rocprofv3 --pmc SQ_INSTS_VALU (profiles/r02k_pmc_features.txt); issue cycles from profiles/r02a_ubench_valu.log classes",
+       "source": "rocprofv3 --pmc SQ_INSTS_VALU (profiles/r02l_pmc_features.txt); issue cycles from profiles/r02a_ubench_valu.log classes",
        "kernels": {k: {"valu_wave_insts_per_launch": sum(v) / len(v), "valu_wave_insts_per_px": sum(v) / len(v) / npx} for k, v in acc.items()}}
 tile = [v for k, v in out["kernels"].items() if "tile" in k]
 out["valu_wave_insts_per_px"] = tile[0]["valu_wave_insts_per_px"] if tile else None
