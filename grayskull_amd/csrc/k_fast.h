@@ -10,7 +10,9 @@
  * bound wraps and every non-brighter pixel counts as darker (ref :496-498).
  *
  * Algorithmic traffic is 3 B/px (score pass 1 R + 1 W, NMS pass 1 R), but the score pass is
- * VALU-bound (~140 lane-ops per pixel: 16 ring pixels x two class masks + the minimum |v - p|).
+ * VALU-bound (16 ring pixels x two class masks + the minimum |v - p|: ~1.3 VALU wave-instructions per
+ * pixel on textured frames); three score kernels: k_fast_score_tile (default: ring bytes from an LDS
+ * tile), k_fast_score4 (strip form), k_fast_score_px (one global byte load per ring pixel).
  */
 #ifndef GS_K_FAST_H
 #define GS_K_FAST_H

@@ -234,8 +234,9 @@ __global__ __launch_bounds__(256) void k_lbp_cascade(LbpArgs a, LbpPhases ph) {
    * be among the first max_rects: skip the block (its mask words and counter stay zero).  The
    * counters are read with returning atomics (served where the adds are performed); a stale or
    * partial sum only skips less, so the result is exact for any dispatch order -- and blocks are
-   * dispatched in (scale, chunk) order, so on frames that reach the cap nearly everything after
-   * that point is skipped. */
+   * dispatched scale by scale (inside a scale: in chunk order, or as eight bands side by side with the
+   * XCD-aware mapping), so on frames that reach the cap every later scale is skipped, and most of the
+   * scale in which it happens when the chunks run in order. */
   const unsigned lin = sc.chunk_base + cx;
   __shared__ unsigned before_s;
   if (tid < 64u) { /* one wave sums; the decision must be the same for the whole block */
