@@ -55,3 +55,43 @@ def test_no_respawn_under_torchrun_or_for_one_gpu(monkeypatch):
     b.spawn_ranks_if_needed(argparse.Namespace(gpus=8))  # one of the driver's ranks
     monkeypatch.delenv("WORLD_SIZE")
     b.spawn_ranks_if_needed(argparse.Namespace(gpus=1))
+
+
+def _walk(d, path=""):
+    if isinstance(d, dict):
+        for k, v in d.items():
+            yield from _walk(v, path + "/" + str(k))
+    elif isinstance(d, list):
+        for i, v in enumerate(d):
+            yield from _walk(v, path + "/%d" % i)
+    else:
+        yield path, d
+
+
+def test_latest_committed_bench_line_honours_the_contract():
+    """the newest profiles/r*_bench.json (what `python bench.py` printed on the GPU box): the driver's keys are there,
+    the metric is BASELINE.json's, every fraction in the line is physical (<= 1), the dominant-kernel roofline carries
+    achieved / peak / frac / traffic, the CPU baseline says how it was taken"""
+    import glob
+    import json
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_bench.json")) if "rank" not in f)
+    d = json.loads(open(files[-1]).read().strip().splitlines()[-1])
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"] == base["metric"] and d["unit"] == "Mpix/s" and d["vs_baseline"] is None
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["dtype"] == "u8" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - d["config"]["global_frames"] * 3840 * 2160 / d["ms_per_step"] / 1e3) / d["value"] < 1e-3
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["traffic"] is None or 0.9 < r["traffic"] / (2 * 32 * 3840 * 2160) < 1.2  # PMC bytes per 32-frame launch vs 2 B/px
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    for path, v in _walk(d):
+        leaf = path.rsplit("/", 1)[-1]
+        # frac_of_copy_ceiling relates to the guide's measured 6.29 TB/s two-buffer copy (the in-place threshold stream
+        # passes it); every other fraction is against a physical peak and cannot exceed 1
+        if isinstance(v, (int, float)) and "frac" in leaf and "copy_ceiling" not in leaf and "percall" not in path:
+            assert 0 <= v <= 1.0, (path, v)
