@@ -136,15 +136,26 @@ __global__ __launch_bounds__(256) void k_box16(uint8_t *dst, const uint8_t *src,
     const float rcy = 1.0f / (float)cy;
     uint32_t od[4] = {0, 0, 0, 0};
     const uint32_t cd[4] = {cen.x, cen.y, cen.z, cen.w};
+    /* MODE 1 without the division: px > floor(V / cnt) - c  <=>  px + c >= floor(V / cnt) + 1  <=>  (px + c) * cnt > V
+     * (cnt > 0).  k = px + c <= 0 can never exceed V >= 0, k >= 256 always does (V <= 255 cnt), in between the
+     * product fits 32 bits (cnt <= 255^2).  Only for |c| < 2^30: beyond that the reference's unsigned `mean - c`
+     * wraps and the literal form below reproduces it. */
+    const bool by_product = MODE == 1 && c > -(1 << 30) && c < (1 << 30);
 #pragma unroll
     for (int j = 0; j < 16; j++) {
-      const unsigned q = box_div(V[j], cx[j], cy, rcx[j], rcy);
       unsigned o;
-      if (MODE == 0) o = q & 0xffu;
-      else {
-        const int thr = (int)(q - (unsigned)c);
-        const int px = (int)((cd[j >> 2] >> (8 * (j & 3))) & 0xffu);
-        o = px > thr ? 255u : 0u;
+      if (MODE == 1 && by_product) {
+        const int k = (int)((cd[j >> 2] >> (8 * (j & 3))) & 0xffu) + c;
+        const unsigned kc = (unsigned)(k < 0 ? 0 : k > 256 ? 256 : k);
+        o = kc * (cx[j] * cy) > V[j] ? 255u : 0u;
+      } else {
+        const unsigned q = box_div(V[j], cx[j], cy, rcx[j], rcy);
+        if (MODE == 0) o = q & 0xffu;
+        else {
+          const int thr = (int)(q - (unsigned)c);
+          const int px = (int)((cd[j >> 2] >> (8 * (j & 3))) & 0xffu);
+          o = px > thr ? 255u : 0u;
+        }
       }
       od[j >> 2] |= o << (8 * (j & 3));
     }
