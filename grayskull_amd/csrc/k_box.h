@@ -4,12 +4,16 @@
  *
  * The integral-image route (k_integral_* + k_box_px) moves ~16 B/px.  This one moves 3-4: a
  * 256-thread block owns a band of rows of one frame and spans the whole row (thread = 16 px,
- * w <= 4096).  It keeps the vertical window sum V[16] (u32) of HORIZONTAL window sums in
- * registers and slides it down one row per step:  V += H(y+r+1) - H(y-r).  The horizontal sums of
- * the entering and the leaving source row are formed on the fly: both rows are staged as bytes in
- * LDS (zero halo of 128 px either side = the clipped sum), each thread adds up its first window
- * and slides it 15 times (two LDS byte reads per step).  Every step reads two source rows
- * (2 B/px; + the centre row for the adaptive compare) and writes one output row.
+ * w <= 4096).  VERTICAL FIRST (round 2): a thread keeps the column sums Vc of its 16 pixels over the
+ * rows y-r .. y+r in registers (8 packed u16 pairs, <= 255 * 255) and slides them down one row per step,
+ * Vc += row(y+r+1) - row(y-r): two 16-byte loads and byte unpacking, nobody else's data.  The box sums
+ * of row y are then ONE horizontal pass over the block's Vc row, staged in LDS as u16 with a zero halo
+ * of 128 entries either side (= the clipped sum): each thread adds up its first window and slides it
+ * 15 times (two u16 reads per step at offsets that depend on the radius only and are computed once).
+ * Round 1 kept a u32 vertical sum of horizontal sums instead and formed the horizontal sums of the
+ * entering and of the leaving row every step: two LDS passes over byte rows per output row, their
+ * offsets recomputed every time (435 VALU + 389 SALU instructions and 100 ds_read_u8 per 16-px row).
+ * Every step reads two source rows (2 B/px; + the centre row for the adaptive compare) and writes one.
  *
  * Division by the number of in-image taps (cx * cy): estimate with two float multiplies by
  * precomputed reciprocals, then make it exact with the integer remainder (the estimate is within
@@ -21,11 +25,11 @@
 
 namespace gs {
 
-/* LDS row layout: pixel x lives at byte kBoxPad + x + 4*floor(x/16): every thread's 16-px segment
- * starts 20 bytes after its neighbour's, so the byte reads of a wave (one per lane, same k) fall
- * into 32 different banks (5 dwords of stride; 16-byte stride would be an 8-way conflict). */
-constexpr unsigned kBoxPad = 160, kBoxRowBytes = kBoxPad + 4096 + 4096 / 4 + kBoxPad + 16;
-GS_DEV int box_off(int x) { return x + 4 * (x >> 4); } /* arithmetic shift = floor for x < 0 */
+/* LDS row layout (u16 entries): column x lives at BYTE kBoxPad + 2 x + 4 floor(x / 16): every thread's
+ * 16-entry segment starts 36 bytes = 9 dwords after its neighbour's, so the reads of a wave (one per
+ * lane, same k) fall into different banks (9 is odd); 32-byte stride would be a 4-way conflict. */
+constexpr unsigned kBoxPad = 320, kBoxRowBytes = kBoxPad + 36 * 256 + kBoxPad;
+GS_DEV int box_off(int x) { return 2 * x + 4 * (x >> 4); } /* arithmetic shift = floor for x < 0 */
 
 /* floor(sum / (cx * cy)) for sum < 2^24 given rx ~ 1/cx, ry ~ 1/cy */
 GS_DEV unsigned box_div(unsigned sum, unsigned cx, unsigned cy, float rx, float ry) {
@@ -45,7 +49,7 @@ GS_DEV unsigned box_div(unsigned sum, unsigned cx, unsigned cy, float rx, float 
 template <int MODE>
 __global__ __launch_bounds__(256) void k_box16(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h,
                                                unsigned T, size_t frame_bytes, unsigned r, int c) {
-  __shared__ __attribute__((aligned(16))) uint8_t rows[2][2][kBoxRowBytes]; /* [phase][enter/leave] */
+  __shared__ __attribute__((aligned(16))) uint8_t rows[2][kBoxRowBytes]; /* [phase]: the block's column sums as u16 */
   const unsigned tid = threadIdx.x, x0 = tid * 16u;
   const bool act = x0 < w;
   const BufRsrc S = make_buf(src + (size_t)blockIdx.z * frame_bytes, frame_bytes);
@@ -53,9 +57,8 @@ __global__ __launch_bounds__(256) void k_box16(uint8_t *dst, const uint8_t *src,
   const int y0 = (int)(blockIdx.y * T);
   if (y0 >= (int)h) return; /* whole block */
   const int nrows = ((int)h - y0) < (int)T ? ((int)h - y0) : (int)T;
-  /* zero all four row buffers once: the halos and the 4 pad bytes after every 16 px are never
-   * written again (rows are only ever stored inside the image span) */
-  for (unsigned i = tid; i < 4u * kBoxRowBytes / 4u; i += 256u) ((uint32_t *)&rows[0][0][0])[i] = 0;
+  /* zero both row buffers once: the halos and the pad bytes after every 16 entries are never written again */
+  for (unsigned i = tid; i < 2u * kBoxRowBytes / 4u; i += 256u) ((uint32_t *)&rows[0][0])[i] = 0;
   /* per-pixel column counts and their reciprocals */
   unsigned cx[16];
   float rcx[16];
@@ -69,68 +72,62 @@ __global__ __launch_bounds__(256) void k_box16(uint8_t *dst, const uint8_t *src,
   auto row_load = [&](int yy) { /* this thread's 16 B of row yy, zeros outside the image */
     return buf_load16(S, (act && yy >= 0 && yy < (int)h) ? (uint32_t)yy * w + x0 : kOOB);
   };
-  const unsigned seg = kBoxPad + 20u * tid; /* = kBoxPad + box_off(x0) */
-  auto row_stage = [&](unsigned phase, unsigned which, const U4 &v) {
-    if (act) {
-      uint32_t *q = (uint32_t *)&rows[phase][which][seg]; /* 4-byte aligned (20 * tid) */
-      q[0] = v.x, q[1] = v.y, q[2] = v.z, q[3] = v.w;
-    }
+  /* column sums += / -= one row (bytes -> u16 pairs; fields cannot carry or borrow: 0 <= Vc <= 255 * 255) */
+  uint32_t Vc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto vc_add = [&](const U4 &v) {
+    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; q++) Vc[2 * q] += unpack_lo(d[q]), Vc[2 * q + 1] += unpack_hi(d[q]);
   };
-  /* horizontal window sums of this thread's 16 px from a staged row */
-  auto hsum = [&](unsigned phase, unsigned which, unsigned (&H)[16]) {
-    const uint8_t *p = &rows[phase][which][seg]; /* p[box_off(k)] = pixel x0 + k, zero outside the image */
-    /* first window x0-r .. x0+r: single bytes up to the next multiple of 4, then whole dwords
-     * (v_dot4 with ones; the 4 pad bytes after every 16 px are zero), then the last bytes.
-     * All bounds depend on r only: wave-uniform control flow. */
+  auto vc_sub = [&](const U4 &v) {
+    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; q++) Vc[2 * q] -= unpack_lo(d[q]), Vc[2 * q + 1] -= unpack_hi(d[q]);
+  };
+  /* LDS byte offsets of the horizontal pass, relative to the thread's segment: they depend on r only
+   * (wave-uniform, computed once): the first window's dword range and, for slide j, the entering entry
+   * j + r and the leaving entry j - r - 1 */
+  int ohi[16], olo[16];
+#pragma unroll
+  for (int j = 1; j < 16; j++) ohi[j] = (int)uniform((uint32_t)box_off(j + (int)r)), olo[j] = (int)uniform((uint32_t)box_off(j - (int)r - 1));
+  const unsigned seg = kBoxPad + 36u * tid; /* = kBoxPad + box_off(x0) */
+  auto hsum = [&](unsigned phase, unsigned (&H)[16]) {
+    const uint8_t *p = &rows[phase][seg]; /* *(u16 *)(p + box_off(k)) = column sum at x0 + k, zero outside the image */
+    /* first window x0-r .. x0+r: a single entry up to the next even k, then pairs (one dword = two entries, both
+     * halves added by v_dot2 with ones; k even => 4-byte aligned, and a pair never straddles the 4 pad bytes
+     * after 16 entries), then the last entry.  All bounds depend on r only: wave-uniform control flow. */
     unsigned s = 0;
     int k = -(int)r;
-    for (; (k & 3) != 0 && k <= (int)r; k++) s += p[box_off(k)];
-    for (; k + 3 <= (int)r; k += 4) s = udot4(*(const uint32_t *)(p + box_off(k)), 0x01010101u, s);
-    for (; k <= (int)r; k++) s += p[box_off(k)];
-    /* two running byte offsets for the slide: `hi` = entering pixel, `lo` = leaving pixel */
-    int lo = box_off(-(int)r), hi = box_off((int)r + 1);
-    H[0] = s; /* hi = box_off(r + 1) */
+    if (k & 1) s += *(const uint16_t *)(p + box_off(k)), k++;
+    for (; k + 1 <= (int)r; k += 2) s = udot2_ones(*(const uint32_t *)(p + box_off(k)), s);
+    if (k <= (int)r) s += *(const uint16_t *)(p + box_off(k));
+    H[0] = s;
 #pragma unroll
     for (int j = 1; j < 16; j++) {
-      s += p[hi];
-      s -= p[lo];
-      hi += ((j + (int)r + 1) & 15) == 0 ? 5 : 1; /* from pixel j+r to j+r+1 */
-      lo += ((j - (int)r) & 15) == 0 ? 5 : 1;     /* from pixel j-1-r to j-r */
+      s += *(const uint16_t *)(p + ohi[j]);
+      s -= *(const uint16_t *)(p + olo[j]);
       H[j] = s;
     }
   };
-  unsigned V[16];
-#pragma unroll
-  for (int j = 0; j < 16; j++) V[j] = 0;
-  __syncthreads();
-  /* prologue: V = sum of H(yy), yy = y0-r .. y0+r, two rows per barrier pair */
-  for (int yy = y0 - (int)r; yy <= y0 + (int)r; yy += 2) { /* block-uniform */
-    const bool two = yy + 1 <= y0 + (int)r;
-    row_stage(0, 0, row_load(yy));
-    if (two) row_stage(0, 1, row_load(yy + 1));
-    __syncthreads();
-    unsigned H[16];
-    hsum(0, 0, H);
-#pragma unroll
-    for (int j = 0; j < 16; j++) V[j] += H[j];
-    if (two) {
-      hsum(0, 1, H);
-#pragma unroll
-      for (int j = 0; j < 16; j++) V[j] += H[j];
-    }
-    __syncthreads();
-  }
-  /* main loop: finish row y, then V += H(y+r+1) - H(y-r) */
+  /* prologue: Vc = rows y0-r .. y0+r (no LDS, no barrier) */
+  for (int yy = y0 - (int)r; yy <= y0 + (int)r; yy++) vc_add(row_load(yy)); /* block-uniform trip count */
+  __syncthreads(); /* the zeroing above */
   U4 nin = row_load(y0 + (int)r + 1), nout = row_load(y0 - (int)r), ncen = MODE ? row_load(y0) : U4{0, 0, 0, 0};
   for (int i = 0; i < nrows; i++) { /* block-uniform */
     const int y = y0 + i;
     const unsigned ph = (unsigned)i & 1u;
-    row_stage(ph, 0, nin), row_stage(ph, 1, nout);
-    const U4 cen = ncen;
+    if (act) { /* this thread's 16 column sums of the window around row y: 32 bytes at a 4-byte aligned address */
+      uint32_t *q = (uint32_t *)&rows[ph][seg];
+#pragma unroll
+      for (int k = 0; k < 8; k++) q[k] = Vc[k];
+    }
+    const U4 cen = ncen, in = nin, out = nout;
     __syncthreads(); /* also orders this phase's writes after the reads of two iterations ago */
     nin = row_load(y + (int)r + 2), nout = row_load(y - (int)r + 1);
     if (MODE) ncen = row_load(y + 1);
-    /* finish row y */
+    unsigned H[16];
+    hsum(ph, H);
+    vc_add(in), vc_sub(out); /* the window around row y + 1 */
     const int ya = y - (int)r < 0 ? 0 : y - (int)r, yb = y + (int)r > (int)h - 1 ? (int)h - 1 : y + (int)r;
     const unsigned cy = (unsigned)(yb - ya + 1);
     const float rcy = 1.0f / (float)cy;
@@ -147,9 +144,9 @@ __global__ __launch_bounds__(256) void k_box16(uint8_t *dst, const uint8_t *src,
       if (MODE == 1 && by_product) {
         const int k = (int)((cd[j >> 2] >> (8 * (j & 3))) & 0xffu) + c;
         const unsigned kc = (unsigned)(k < 0 ? 0 : k > 256 ? 256 : k);
-        o = kc * (cx[j] * cy) > V[j] ? 255u : 0u;
+        o = kc * (cx[j] * cy) > H[j] ? 255u : 0u;
       } else {
-        const unsigned q = box_div(V[j], cx[j], cy, rcx[j], rcy);
+        const unsigned q = box_div(H[j], cx[j], cy, rcx[j], rcy);
         if (MODE == 0) o = q & 0xffu;
         else {
           const int thr = (int)(q - (unsigned)c);
@@ -160,11 +157,6 @@ __global__ __launch_bounds__(256) void k_box16(uint8_t *dst, const uint8_t *src,
       od[j >> 2] |= o << (8 * (j & 3));
     }
     buf_store16(D, act ? (uint32_t)y * w + x0 : kOOB, U4{od[0], od[1], od[2], od[3]});
-    /* slide */
-    unsigned Hin[16], Hout[16];
-    hsum(ph, 0, Hin), hsum(ph, 1, Hout);
-#pragma unroll
-    for (int j = 0; j < 16; j++) V[j] += Hin[j] - Hout[j];
   }
 }
 

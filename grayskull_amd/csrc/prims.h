@@ -118,6 +118,7 @@ GS_DEV uint32_t udot4(uint32_t a, uint32_t b, uint32_t c) {
   for (int i = 0; i < 4; i++) c += ((a >> (8 * i)) & 0xffu) * ((b >> (8 * i)) & 0xffu);
   return c;
 }
+GS_DEV uint32_t udot2_ones(uint32_t a, uint32_t c) { return (a & 0xffffu) + (a >> 16) + c; }
 GS_DEV uint32_t load_u32_unaligned(const uint8_t *p) {
   uint32_t v;
   memcpy(&v, p, 4);
@@ -268,6 +269,11 @@ GS_DEV uint32_t pk_mad_u16_s(uint32_t a, uint32_t b, uint32_t c) {
 }
 /* sum of the four u8 x u8 products + c (v_dot4_u32_u8) */
 GS_DEV uint32_t udot4(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_udot4(a, b, c, false); }
+/* lo16(a) + hi16(a) + c: one v_dot2_u32_u16 */
+GS_DEV uint32_t udot2_ones(uint32_t a, uint32_t c) {
+  typedef unsigned short gs_u16x2 __attribute__((ext_vector_type(2)));
+  return __builtin_amdgcn_udot2(__builtin_bit_cast(gs_u16x2, a), gs_u16x2{1, 1}, c, false);
+}
 /* dword at any byte address (global memory handles unaligned dwords in hardware) */
 GS_DEV uint32_t load_u32_unaligned(const uint8_t *p) {
   typedef uint32_t u32_unaligned __attribute__((aligned(1)));
