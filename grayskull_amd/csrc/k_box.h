@@ -69,6 +69,14 @@ __global__ __launch_bounds__(256) void k_box16(uint8_t *dst, const uint8_t *src,
     cx[j] = act ? (unsigned)(xb - xa + 1) : 1u;
     rcx[j] = 1.0f / (float)cx[j];
   }
+  /* MODE 0, rows whose window is not clipped vertically (cy = 2r + 1), r <= 31: the quotient is ONE v_mul_hi_u32 with
+   * M = ceil(2^32 / cnt).  mul_hi(H, M) = floor(H / cnt + H (M cnt - 2^32) / (cnt 2^32)) and the excess is below
+   * H / 2^32 <= 255 cnt / 2^32, which is less than the 1 / cnt that separates H / cnt from the next integer as long
+   * as 255 cnt^2 < 2^32, i.e. cnt <= 4103 >= 63^2. */
+  const bool magic_ok = MODE == 0 && r <= 31u;
+  unsigned Mi[16];
+#pragma unroll
+  for (int j = 0; j < 16; j++) Mi[j] = MODE == 0 ? 0xffffffffu / (cx[j] * (2u * r + 1u)) + 1u : 0u; /* cnt >= 4 */
   auto row_load = [&](int yy) { /* this thread's 16 B of row yy, zeros outside the image */
     return buf_load16(S, (act && yy >= 0 && yy < (int)h) ? (uint32_t)yy * w + x0 : kOOB);
   };
@@ -138,10 +146,13 @@ __global__ __launch_bounds__(256) void k_box16(uint8_t *dst, const uint8_t *src,
      * product fits 32 bits (cnt <= 255^2).  Only for |c| < 2^30: beyond that the reference's unsigned `mean - c`
      * wraps and the literal form below reproduces it. */
     const bool by_product = MODE == 1 && c > -(1 << 30) && c < (1 << 30);
+    const bool by_magic = magic_ok && cy == 2u * r + 1u; /* block-uniform */
 #pragma unroll
     for (int j = 0; j < 16; j++) {
       unsigned o;
-      if (MODE == 1 && by_product) {
+      if (MODE == 0 && by_magic) {
+        o = __umulhi(H[j], Mi[j]) & 0xffu;
+      } else if (MODE == 1 && by_product) {
         const int k = (int)((cd[j >> 2] >> (8 * (j & 3))) & 0xffu) + c;
         const unsigned kc = (unsigned)(k < 0 ? 0 : k > 256 ? 256 : k);
         o = kc * (cx[j] * cy) > H[j] ? 255u : 0u;
