@@ -398,16 +398,30 @@ void launch_box_generic(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h
   hipStream_t st = ctx().s();
   const size_t fp = (size_t)w * h;
   const unsigned r = std::min(radius, std::max(w, h)); /* larger windows clip identically */
-  if (g_tune[6] != 3 && r >= 1 && r <= 56 && w <= 4096 && strip_ok(w, h, dst, src)) {
-    /* sliding box sums straight from the source rows (k_box.h): 3-4 B/px instead of ~16; the
-     * per-band start-up grows with the radius, and from r ~ 60 the integral-image route (whose
-     * cost does not depend on r) is faster: 64 4K frames, r = 15: 0.73 vs 2.83 ms, r = 64: 2.7 vs 2.8 */
+  if (g_tune[6] != 3 && r >= 1 && r <= 127 && w <= 4096 && strip_ok(w, h, dst, src)) {
+    /* sliding box sums straight from the source rows (k_box.h): 3-4 B/px instead of the ~16 of the integral-image
+     * route below (64 4K frames: 2.8 ms whatever the radius; this one: r = 16 0.36 ms, r = 40 0.63 ms); the kernel's
+     * u16 column sums and LDS halo hold up to r = 127 */
     for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
       const unsigned nn = std::min(kMaxZ, n - f0);
-      /* band height: ~2K blocks in flight, but at least four window heights per band (each band
-       * first sums 2r+1 rows it does not output) */
-      const unsigned want = std::max(1u, 2048u / nn);
-      const unsigned T = std::min(h, std::max(4u * (2u * r + 1u), (h + want - 1) / want));
+      /* band height: the launch should be whole rounds of the ~1024 blocks the chip holds (4 per CU), and a band
+       * first loads 2r+1 rows it does not output -- loads and adds only since the vertical-first form, ~0.3 of an
+       * output row each.  Pick the band count with the smallest rounds x (T + 0.3 (2r+1)): 64 4K frames -> 16 bands
+       * of 135 rows (r = 16: 0.50 -> 0.36 ms, r = 40: 1.11 -> 0.63), 8 frames -> 128 bands (r = 40: 1.0 -> 0.16 ms;
+       * profiles/r02l_box_T.log).  Round 1's "at least four window heights per band" dates from a prologue that
+       * cost more than the rows it preceded. */
+      unsigned T = h;
+      if (g_tune[0] > 0) {
+        T = (unsigned)g_tune[0];
+      } else {
+        double best = 1e30;
+        for (unsigned nbc = 1; nbc <= std::max(1u, h / 8u); nbc++) {
+          const unsigned t = (h + nbc - 1) / nbc;
+          const double rounds = (double)(((unsigned long long)nn * ((h + t - 1) / t) + 1023) / 1024);
+          const double cost = rounds * ((double)t + 0.3 * (2.0 * r + 1.0));
+          if (cost < best - 1e-9) best = cost, T = t;
+        }
+      }
       const unsigned nb = (h + T - 1) / T;
       GS_LAUNCH(k_box16<MODE>, dim3(1, nb, nn), dim3(256), 0, st, dst + fp * f0, src + fp * f0, w, h, T, fp,
                 r, c);

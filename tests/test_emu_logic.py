@@ -50,7 +50,7 @@ def test_otsu_scan_float_order(emu, oracle):
         assert emu.otsu_threshold(img) == oracle.otsu_threshold(img)
 
 
-@pytest.mark.parametrize("shape", [(67, 45), (40, 24), (64, 40), (48, 9), (32, 3), (1040, 5), (32, 1)])
+@pytest.mark.parametrize("shape", [(67, 45), (40, 24), (64, 40), (48, 9), (32, 3), (1040, 5), (32, 1), (272, 150)])
 def test_next_rows(emu, oracle, shape):
     w, h = shape
     pc.next_rows(emu, oracle, Oracle.synth(w, h, 21), MEM)
@@ -473,3 +473,20 @@ def test_lbp_chunk_to_xcd_mapping_never_changes_results(emu, oracle, cascade, mo
         pc.lbp(emu, oracle, Oracle.synth(64, 48, 9), MEM, random_cascade(1), params=((4096, 1.25, 1.0, 2.0, 2), (3, 1.25, 1.0, 2.0, 1)))
     finally:
         emu.tune(13, 0)
+
+
+def test_box_radii_around_the_quotient_switch_and_up_to_127(emu, oracle):
+    """k_box16: the quotient of unclipped rows is one multiply up to r = 31 and the float estimate + fix-up beyond; the
+    sliding route serves radii up to 127 (u16 column sums, 128-entry LDS halo).  gs_blur and gs_adaptive_threshold on
+    images with a bright half (large sums)"""
+    rng = np.random.RandomState(3)
+    for (w, h) in ((96, 80), (272, 90)):
+        img = rng.randint(0, 256, (h, w)).astype(np.uint8)
+        img[:, :w // 2] |= 0xF0
+        for r in (30, 31, 32, 33, 56, 57, 100, 127):
+            d = np.zeros_like(img)
+            emu.blur(d, img.copy(), r)
+            assert_same(d, oracle.blur(img, r), "gs_blur r=%d %dx%d" % (r, w, h))
+            d = np.zeros_like(img)
+            emu.adaptive_threshold(d, img.copy(), r, -3)
+            assert_same(d, oracle.adaptive_threshold(img, r, -3), "gs_adaptive_threshold r=%d %dx%d" % (r, w, h))

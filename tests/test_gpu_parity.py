@@ -374,7 +374,7 @@ def test_box_and_filter_kernels_at_frame_sizes(hip, oracle):
     hip.synth_batch(big, 77)
     a, b = torch.zeros_like(big), torch.zeros_like(big)
     try:
-        for r in (4, 15, 56):
+        for r in (4, 15, 31, 32, 56, 100, 127):  # 31 / 32: last radius of the one-multiply quotient / first of the float one
             hip.tune(6, 0)
             hip.blur_batch(a, big, r)
             hip.tune(6, 3)

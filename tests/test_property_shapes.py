@@ -189,14 +189,14 @@ def _body_orb_drivers_any(emu, oracle, w, h, seed, nkps, threshold, levels, n):
 
 # ---- the same properties through the emulator (CPU suite) and on the real GPU (-m gpu) ----------
 @_cfg(40)
-@given(w=widths, h=heights, seed=st.integers(0, 2 ** 16), kind=st.integers(0, 2), radius=st.integers(0, 40))
+@given(w=widths, h=heights, seed=st.integers(0, 2 ** 16), kind=st.integers(0, 2), radius=st.one_of(st.integers(0, 40), st.integers(41, 140)))
 def test_stencils_any_shape(emu, oracle, w, h, seed, kind, radius):
     _body_stencils_any_shape(emu, oracle, w=w, h=h, seed=seed, kind=kind, radius=radius)
 
 
 @pytest.mark.gpu
 @_cfg(40)
-@given(w=widths, h=heights, seed=st.integers(0, 2 ** 16), kind=st.integers(0, 2), radius=st.integers(0, 40))
+@given(w=widths, h=heights, seed=st.integers(0, 2 ** 16), kind=st.integers(0, 2), radius=st.one_of(st.integers(0, 40), st.integers(41, 140)))
 def test_gpu_stencils_any_shape(hip, oracle, w, h, seed, kind, radius):
     _body_stencils_any_shape(hip, oracle, w=w, h=h, seed=seed, kind=kind, radius=radius)
 
