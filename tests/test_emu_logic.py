@@ -490,3 +490,29 @@ def test_box_radii_around_the_quotient_switch_and_up_to_127(emu, oracle):
             d = np.zeros_like(img)
             emu.adaptive_threshold(d, img.copy(), r, -3)
             assert_same(d, oracle.adaptive_threshold(img, r, -3), "gs_adaptive_threshold r=%d %dx%d" % (r, w, h))
+
+
+def test_box_kernel_any_band_height_and_full_width(emu, oracle):
+    """k_box16 with bands of 1 .. 200 rows (gsh_tune key 0; the launcher itself picks 8 .. h) on a batch, and on rows as
+    wide as the kernel goes (4096 = 256 threads x 16 px) with radii on both sides of every switch"""
+    rng = np.random.RandomState(11)
+    img = rng.randint(0, 256, (3, 50, 64)).astype(np.uint8)
+    try:
+        for T in (1, 2, 3, 8, 17, 50, 200):
+            emu.tune(0, T)
+            for r in (4, 9, 20):
+                d = np.zeros_like(img)
+                emu.blur_batch(d, img, r)
+                for f in range(3):
+                    assert_same(d[f], oracle.blur(img[f], r), "band height %d, r=%d, frame %d" % (T, r, f))
+    finally:
+        emu.tune(0, 0)
+    for (w, h) in ((4096, 4), (4080, 3)):
+        wide = rng.randint(0, 256, (h, w)).astype(np.uint8)
+        for r in (4, 31, 32, 127):
+            d = np.zeros_like(wide)
+            emu.blur(d, wide.copy(), r)
+            assert_same(d, oracle.blur(wide, r), "gs_blur r=%d %dx%d" % (r, w, h))
+            d = np.zeros_like(wide)
+            emu.adaptive_threshold(d, wide.copy(), r, 3)
+            assert_same(d, oracle.adaptive_threshold(wide, r, 3), "gs_adaptive_threshold r=%d %dx%d" % (r, w, h))
