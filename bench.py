@@ -61,15 +61,14 @@ LDS_ATOMIC_TLANE_S = 9.4  # ds_add_u32, lane-private copies, any number of activ
 
 def fast_valu_block(npx_launch, ms_score):
     """VALU issue pricing of the gs_fast score kernel from its SQ_INSTS_VALU count (profiles/fast_valu_pmc.json)"""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "fast_valu_pmc.json")))
-    except Exception:
-        return None
+    d, stamp = measurement(os.path.join(ROOT, "profiles", "fast_valu_pmc.json"))
+    if d is None:
+        return {"stale_or_missing": stamp}
     insts = d["valu_wave_insts_per_px"] * npx_launch
     sec = insts * d["avg_issue_cycles"] / (1024 * 2.4e9)  # 1024 SIMDs, one VALU issue port each
     return {"valu_wave_insts_per_px": d["valu_wave_insts_per_px"], "avg_issue_cycles": d["avg_issue_cycles"],
             "score_kernel_ms": round(ms_score, 4), "valu_ms_at_issue_rate": round(sec * 1e3, 4),
-            "valu_frac": round(sec * 1e3 / ms_score, 4), "source": d.get("source")}
+            "valu_frac": round(sec * 1e3 / ms_score, 4), "source": d.get("source"), "taken_at": stamp}
 
 
 def hbm_block(nbytes, ms, **extra):
@@ -81,34 +80,93 @@ def hbm_block(nbytes, ms, **extra):
     return d
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def usable_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
 def cpu_baseline(w, h, radius, frames_target=48):
+    """SURVEY 8(d) / BASELINE.md 4: the unmodified reference on this box's host cores, (i) one thread -- the
+    reference's native mode -- and (ii) one thread per usable core, each looping over its own frames (the
+    reference code itself stays single-threaded).  `value` / `cores` are the all-cores figure."""
     import threading
     from oracle import pyoracle
     kind = "reference" if pyoracle.have_reference() else "port"
-    cores = max(1, min(os.cpu_count() or 1, 32))
+    cores = usable_cores()
     per = max(1, frames_target // cores)
     frames = per * cores
-    imgs = [pyoracle.Oracle.synth(w, h, 1000 + i) for i in range(cores)]
+    imgs = [pyoracle.Oracle.synth(w, h, 1000 + i) for i in range(min(cores, 16))]  # shared, read-only
 
-    def work(i):
+    def work(i, n):
         o = pyoracle.Oracle(kind)  # ctypes releases the GIL inside the C calls
-        for _ in range(per):
-            s = o.sobel(o.blur(imgs[i], radius))
+        for _ in range(n):
+            s = o.sobel(o.blur(imgs[i % len(imgs)], radius))
             o.threshold(s, o.otsu_threshold(s))
 
-    ths = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+    t0 = time.time()
+    work(0, 2)
+    dt1 = time.time() - t0
+    ths = [threading.Thread(target=work, args=(i, per)) for i in range(cores)]
     t0 = time.time()
     for t in ths:
         t.start()
     for t in ths:
         t.join()
     dt = time.time() - t0
+    what = ("unmodified reference C (oracle/_ref, gcc -std=c99 -O2)" if kind == "reference"
+            else "C restatement (oracle/gs_oracle.c)")
     return {"value": round(frames * w * h / dt / 1e6, 2), "unit": "Mpix/s", "cores": cores,
-            "kind": kind, "seconds": round(dt, 2),
-            "sample": "%d frames %dx%d, blur(r=%d)->sobel->otsu->threshold, %d threads x %d frames, "
-                      "unmodified reference C (gcc -std=c99 -O2)" % (frames, w, h, radius, cores, per)
-            if kind == "reference" else
-            "%d frames %dx%d, same chain, C restatement (oracle/gs_oracle.c)" % (frames, w, h)}
+            "kind": kind, "seconds": round(dt + dt1, 2),
+            "single_thread": {"value": round(2 * w * h / dt1 / 1e6, 2), "unit": "Mpix/s", "cores": 1, "frames": 2,
+                              "seconds": round(dt1, 2)},
+            "cpu_model": cpu_model(), "nproc": os.cpu_count(), "usable_cores": cores,
+            "sample": "%d frames %dx%d, blur(r=%d)->sobel->otsu->threshold, %d threads x %d frames (+ 2 frames on one "
+                      "thread), %s" % (frames, w, h, radius, cores, per, what)}
+
+
+def measurement(path):
+    """a committed measurement file of profiles/ plus whether the kernel sources it was taken from are still the
+    ones in the tree (scripts/stamp.py): returns (dict or None, stamp) -- a STALE file is not used"""
+    try:
+        d = json.load(open(path))
+    except Exception:
+        return None, None
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    from stamp import fresh
+    ok = fresh(d)
+    stamp = {"file": os.path.relpath(path, ROOT), "commit": d.get("stamped_at_commit"),
+             "kernel_sources_unchanged": ok}
+    return (None if ok is False else d), stamp
+
+
+GOLDEN_BATCH = os.path.join(ROOT, "tests", "golden", "batch_checksums.json")
+
+
+def load_golden_batch(w, h, r):
+    """tests/golden/batch_checksums.json (reference-generated, tests/golden/make_batch_golden.py) when it covers this shape"""
+    try:
+        gold = json.load(open(GOLDEN_BATCH))
+    except Exception:
+        return None
+    return gold if (gold["w"], gold["h"], gold["radius"]) == (w, h, r) else None
+
+
+def wsum_bytes(np, a):
+    """sum (i+1)*(byte+1) mod 2^64 over raw bytes: the host twin of gsh_checksum_batch, for KB-sized result lists"""
+    b = np.ascontiguousarray(a).view(np.uint8).reshape(-1).astype(np.uint64)
+    return int(np.sum(np.arange(1, b.size + 1, dtype=np.uint64) * (b + np.uint64(1)), dtype=np.uint64))
 
 
 def free_port():
@@ -138,16 +196,18 @@ def spawn_ranks_if_needed(args):
 def run_cfg4(args, sh, g, torch, np, w, h, F, r, lo):
     """BASELINE configs[4]: every frame goes through gs_blur(r) -> gs_sobel (zeroed dst) -> gs_integral ->
     gs_lbp_detect(frontalface, sf 1.1, scales 1..4, step 1, max_rects 4096) on the GPU that owns it; frames
-    are sharded by index, nothing but the barrier / max / a count gather crosses GPUs."""
+    are sharded by index.  What crosses GPUs: the cascade blob broadcast from rank 0, the timing
+    barrier / max, the per-frame counts and the packed variable-length gs_rect lists -- never a pixel plane."""
     from grayskull_amd.cascade import Cascade
-    casc = Cascade.from_blob(os.path.join(ROOT, "tests", "golden", "frontalface_cascade.bin"))
+    blob = open(os.path.join(ROOT, "tests", "golden", "frontalface_cascade.bin"), "rb").read() if sh.rank == 0 else b""
+    casc = Cascade.from_bytes(sh.broadcast_bytes(blob, root=0), "broadcast from rank 0")
     G = 16  # frames per inner group (bounds the u32 integral scratch: 16 x 33 MB)
     src = torch.empty((G, h, w), dtype=torch.uint8, device="cuda")
     a, b = torch.empty_like(src), torch.empty_like(src)
     ii = torch.zeros((G, h, w), dtype=torch.int32, device="cuda")
-    rects = torch.zeros((G, 4096, 4), dtype=torch.int32, device="cuda")
+    rects = torch.zeros((F, 4096, 4), dtype=torch.int32, device="cuda")  # 64 KB per frame: every frame's list is kept
     counts = torch.zeros(F, dtype=torch.int32, device="cuda")
-    evaluated = torch.zeros(2, dtype=torch.int64, device="cuda")
+    evaluated = torch.zeros(4, dtype=torch.int64, device="cuda")
     dc = g.cascade_create(casc)
 
     def step():
@@ -158,7 +218,7 @@ def run_cfg4(args, sh, g, torch, np, w, h, F, r, lo):
             b[:n].zero_()
             g.sobel_batch(b[:n], a[:n])
             g.integral_batch(b[:n], ii[:n])
-            g.lbp_detect_batch(dc, ii[:n], rects[:n], counts[f0:f0 + n], 4096, 1.1, 1.0, 4.0, 1)
+            g.lbp_detect_batch(dc, ii[:n], rects[f0:f0 + n], counts[f0:f0 + n], 4096, 1.1, 1.0, 4.0, 1)
 
     for _ in range(args.warmup):
         step()
@@ -174,9 +234,42 @@ def run_cfg4(args, sh, g, torch, np, w, h, F, r, lo):
     step()
     torch.cuda.synchronize()
     g.lbp_count_evaluated(None)
-    all_counts = sh.all_gather_frames(counts, F * sh.world)
+    total = F * sh.world
+    all_counts, all_rects = sh.gather_varlen(counts, rects, total)  # every frame's rect list, global frame order
     ev_total = sh.sum_over_ranks(float(evaluated[0].item())) * args.steps
     nwin = g.lbp_window_count(casc, w, h, 1.1, 1.0, 4.0, 1)
+    # ---- verification (outside the timed region): reference-generated golden lists, every rank's frames ----
+    parity = "skipped"
+    if not args.no_verify:
+        gold = load_golden_batch(w, h, r)
+        starts = torch.cumsum(all_counts, 0) - all_counts
+        checked, bad = [], []
+        if gold and sh.rank == 0:
+            rc = all_rects.cpu().numpy()
+            for fs, want in sorted(gold["cfg4"]["frames"].items(), key=lambda kv: int(kv[0])):
+                f = int(fs)
+                if f >= total:
+                    continue
+                n0, s0 = int(all_counts[f]), int(starts[f])
+                got = {"n": n0, "wsum": "%016x" % wsum_bytes(np, rc[s0:s0 + n0])}
+                checked.append(f)
+                if got != want:
+                    bad.append(f)
+        live = None
+        if sh.rank == 0 and args.verify_live:  # frame 0 against the CPU oracle itself (~30 s of one host core at 4K)
+            from oracle import pyoracle
+            o = pyoracle.Oracle("reference" if pyoracle.have_reference() else "port")
+            e = o.sobel(o.blur(pyoracle.Oracle.synth(w, h, 1000), r))
+            want = o.lbp_detect(casc, o.integral(e), 4096, 1.1, 1.0, 4.0, 1)
+            n0 = int(all_counts[0])
+            got = all_rects[:n0].cpu().numpy().astype(np.uint32)
+            live = n0 == len(want) and np.array_equal(got.reshape(-1), want.view(np.uint32).reshape(-1))
+            if not live:
+                bad.append("live:0")
+        if sh.rank == 0:
+            parity = ("MISMATCH at frames %s" % bad if bad else
+                      "rect lists of frames %s (of %d, all ranks) == reference golden (count + checksum)%s"
+                      % (checked, total, "; frame 0 bit-exact vs %s oracle live" % o.kind if live else ""))
     if sh.rank == 0:
         print(json.dumps({
             "metric": "frames/s for gs_blur->gs_sobel->gs_integral->gs_lbp_detect on 4K uint8 (BASELINE configs[4])",
@@ -189,7 +282,10 @@ def run_cfg4(args, sh, g, torch, np, w, h, F, r, lo):
             "windows_per_frame_full_scan": nwin,
             "windows_evaluated_per_frame": round(ev_total / (sh.world * F * args.steps), 1),
             "Gwindows/s_evaluated": round(ev_total / dt / 1e9, 2),
-            "rccl_ranks_seen": sh.ranks_seen(),
+            "rccl_ranks_seen": sh.ranks_seen(), "backend": sh.backend,
+            "collectives": ["broadcast(cascade blob, %d B)" % len(blob), "barrier", "all_reduce(max, sum)",
+                            "all_gather(counts)", "all_gather(packed gs_rect lists, %d records)" % int(all_rects.shape[0])],
+            "parity": parity,
             "detections_total": int(all_counts.sum()), "detections_first_frames": all_counts[:4].cpu().tolist()}))
     dc.close()
     sh.close()
@@ -198,14 +294,13 @@ def run_cfg4(args, sh, g, torch, np, w, h, F, r, lo):
 def fused_valu_block(lpx, w, fms):
     """VALU pricing of one fused-kernel launch: wave-instructions by issue class / measured issue rate.
     lpx pixels per launch -> wave-rows = lpx / 1024 * (columns of waves cover ceil(w/1024)*1024 px per row)."""
-    try:
-        mix = json.load(open(FUSED_OPS_PER_ROW_FILE))
-    except Exception:
-        return None
+    mix, stamp = measurement(FUSED_OPS_PER_ROW_FILE)
+    if mix is None:
+        return {"stale_or_missing": stamp}
     wave_rows = lpx / w * ((w + 1023) // 1024)
     sec = {k: wave_rows * mix["per_wave_row"][k] / (VALU_RATE_GINST[k] * 1e9) for k in ("full", "half")}
     t = sec["full"] + sec["half"]
-    return {"wave_instructions_per_wave_row": mix["per_wave_row"], "source": mix.get("source"),
+    return {"wave_instructions_per_wave_row": mix["per_wave_row"], "source": mix.get("source"), "taken_at": stamp,
             "issue_rate_Gwaveinst_s": VALU_RATE_GINST, "valu_ms_at_measured_issue_rate": round(t * 1e3, 4),
             "valu_frac": round(t * 1e3 / fms, 4),
             "lds_atomics_per_wave_row": mix["per_wave_row"].get("ds_add"),
@@ -227,6 +322,7 @@ def main():
                          "gs_blur(2) -> gs_sobel -> gs_integral -> gs_lbp_detect, frames sharded over the GPUs")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--verify-live", action="store_true", help="cfg4: also run frame 0 through the CPU oracle (~30 s)")
     ap.add_argument("--no-other", action="store_true", help="skip the other_configs / per-kernel extras (profiling runs)")
     args = ap.parse_args()
     spawn_ranks_if_needed(args)
@@ -245,7 +341,8 @@ def main():
     if device >= torch.cuda.device_count():
         sys.exit("bench.py: rank %d wants cuda:%d but only %d GPU(s) are visible" % (sh.rank, device, torch.cuda.device_count()))
     torch.cuda.set_device(device)
-    g = gs.lib()
+    # GS_BENCH_LIB: an experiment build of the library (build_variants/, A/B runs only)
+    g = gs.Grayskull(os.environ["GS_BENCH_LIB"]) if os.environ.get("GS_BENCH_LIB") else gs.lib()
     g.set_device(device)
     g.use_torch_stream()
 
@@ -307,10 +404,10 @@ def main():
     n_ii = min(64, F)
     ii_buf = torch.empty((n_ii, h, w), dtype=torch.int32, device="cuda")
     moved_ii = 5.0 * n_ii * w * h
+    pt_all, pt_stamp = measurement(os.path.join(ROOT, "profiles", "pmc_traffic.json"))
     try:
-        pt_ii = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["per_launch"]
-        if (w, h, n_ii) == (3840, 2160, 64):
-            moved_ii = float(sum(v["total_bytes"] for k, v in pt_ii.items() if k.startswith("gs::k_integral_")))
+        if pt_all and (w, h, n_ii) == (3840, 2160, 64):
+            moved_ii = float(sum(v["total_bytes"] for k, v in pt_all["per_launch"].items() if k.startswith("gs::k_integral")))
     except Exception:
         pass
     kernels["gs_integral (3 launches: colsum, colbase, wave), %d frames" % n_ii] = (
@@ -338,7 +435,7 @@ def main():
                          note="per launch, HIP events on the launch stream over the timed region; 1 R + 1 W per pixel")
     pmc = None
     try:
-        pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        pt = pt_all
         # the kernel's printed name carries its template arguments ("<2>" or "<2, true>"): match by prefix
         names = [k for k in pt["per_launch"] if k.startswith("gs::k_blur_sobel_hist16<2") and "false" not in k]
         if (w, h, r) == (3840, 2160, 2) and names and pt.get("fused_frames_per_launch") == fpl:
@@ -362,39 +459,58 @@ def main():
                                "frac_of_copy_ceiling": round(4.0 * npx / ms_step / 1e6 / HBM_COPY_GBS, 4),
                                "note": "whole timed step: fused pass 1 R + 1 W, threshold pass 1 R + 1 W per pixel"},
             "per_call_kernels": {k: ktab[k]["frac"] for k in ktab if k != fk},
-            "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc, corrected per MI355X_MICROARCH.md)" if pmc else None}
+            "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc, corrected per MI355X_MICROARCH.md)" if pmc else None,
+            "traffic_taken_at": pt_stamp}
 
     ns = other = None
     if sh.world == 1 and not args.no_other:
         ns, other = extras(g, torch, np, src, tmp, dst, w, h, reps)
 
-    # ---- verification against the oracle (outside the timed region) -------------------------
-    parity = "skipped"
-    if not args.no_verify and sh.rank == 0:
-        from oracle.pyoracle import Oracle
-        o = Oracle("port")
-        step()
-        torch.cuda.synchronize()
-        ok = True
-        vf = sorted({0, min(31, F - 1), min(32, F - 1), F // 2, F - 1})  # both sides of a chunk boundary
-        for f in vf:
-            img = Oracle.synth(w, h, 1000 + lo + f)
-            s = o.sobel(o.blur(img, r))
-            t = o.otsu_threshold(s)
-            ok &= int(thr[f]) == t and np.array_equal(dst[f].cpu().numpy(), o.threshold(s, t))
-        parity = "bit-exact vs oracle on frames %s" % vf if ok else "MISMATCH"
-    thr_all = sh.all_gather_frames(thr, F * sh.world)  # KB-scale result exchange (RCCL when N>1)
-    # per-frame output checksums (sum of the bytes of each thresholded frame, computed on the owning GPU), gathered
-    # in global frame order: SURVEY 8(e)'s "checksum of checksums" -- the same number whatever N is for the same
-    # global frames; pixel planes never cross GPUs
+    # ---- verification (outside the timed region) ----------------------------------------------
+    # (1) EVERY rank checks sample frames of its own shard bit for bit against the CPU oracle (the compiled
+    #     reference when oracle/_ref is there, else the C restatement); the verdicts are AND-ed over ranks.
+    # (2) every rank checksums ALL its output frames on its GPU; the per-frame checksums and Otsu thresholds are
+    #     gathered in global frame order (KB-scale, RCCL when N > 1) and rank 0 compares every one of them with
+    #     tests/golden/batch_checksums.json, which the unmodified reference generated for all 4096 frames.
+    total = F * sh.world
     step()
+    torch.cuda.synchronize()
+    thr_all = sh.all_gather_frames(thr, total)
     sums = torch.zeros(F, dtype=torch.int64, device="cuda")
     g.checksum_batch(dst, sums)
     torch.cuda.synchronize()
-    sums_all = sh.all_gather_frames(sums, F * sh.world)
+    sums_all = sh.all_gather_frames(sums, total)
+    sums_list = [v & 0xffffffffffffffff for v in sums_all.cpu().tolist()]
+    parity, golden_note, oracle_kind = "skipped", None, None
+    if not args.no_verify:
+        from oracle import pyoracle
+        oracle_kind = "reference" if pyoracle.have_reference() else "port"
+        o = pyoracle.Oracle(oracle_kind)
+        ok = True
+        vf = sorted({0, min(31, F - 1), min(32, F - 1), F // 2, F - 1})  # both sides of a chunk boundary
+        for f in vf:
+            img = pyoracle.Oracle.synth(w, h, 1000 + lo + f)
+            e = o.sobel(o.blur(img, r))
+            t = o.otsu_threshold(e)
+            ok &= int(thr[f]) == t and np.array_equal(dst[f].cpu().numpy(), o.threshold(e, t))
+        ok_all = sh.min_over_ranks(1.0 if ok else 0.0) > 0.5
+        parity = ("bit-exact vs %s oracle on local frames %s of every rank (%d ranks)" % (oracle_kind, vf, sh.world)
+                  if ok_all else "MISMATCH vs oracle")
+        gold = load_golden_batch(w, h, r)
+        if gold and sh.rank == 0:
+            nchk = min(total, gold["frames"])
+            bad = [f for f in range(nchk) if "%016x" % sums_list[f] != gold["cfg1"]["wsum"][f]
+                   or int(thr_all[f]) != gold["cfg1"]["otsu"][f]]
+            golden_note = ("%d/%d checksums + otsu thresholds match golden (reference-generated, all ranks' frames)"
+                           % (nchk - len(bad), nchk))
+            if bad:
+                parity = "MISMATCH vs golden at global frames %s" % bad[:16]
+            else:
+                parity = golden_note + "; " + parity
+    # SURVEY 8(e)'s "checksum of checksums": the same number whatever N is for the same global frames
     digest = 1469598103934665603
-    for v in sums_all.cpu().tolist():
-        digest = ((digest ^ (v & 0xffffffffffffffff)) * 1099511628211) & 0xffffffffffffffff
+    for v in sums_list:
+        digest = ((digest ^ v) * 1099511628211) & 0xffffffffffffffff
     ranks_seen = sh.ranks_seen()
 
     out = {
@@ -421,6 +537,7 @@ def main():
             "percall_equivalent_GB/s (4 B/px)": ktab[bs].get("percall_equivalent_GB/s"), "limited_by": "valu"},
         "roofline": roof, "kernels": ktab, "sobel_4096x4096": ns, "other_configs": other, "parity": parity,
         "otsu_thresholds_gathered": int(thr_all.numel()),
+        "parity_golden": golden_note, "parity_oracle_kind": oracle_kind,
         "output_checksum_of_checksums": "%016x" % digest, "output_checksums_gathered": int(sums_all.numel()),
     }
     if sh.rank == 0 and sh.world == 1 and not args.no_cpu:
@@ -434,7 +551,6 @@ def extras(g, torch, np, src, tmp, dst, w, h, reps):
     """north-star shape and the other single-GPU configs of BASELINE.json, each with its own physical
     roofline block (not the headline metric)"""
     from grayskull_amd.cascade import Cascade
-    from oracle.pyoracle import Oracle as _O
     # north-star shape: gs_sobel alone on 4096x4096, rotating over 64 distinct frames (1 GiB/plane)
     n4 = 64
     a4 = torch.empty((n4, 4096, 4096), dtype=torch.uint8, device="cuda")
@@ -454,7 +570,7 @@ def extras(g, torch, np, src, tmp, dst, w, h, reps):
     ii3 = torch.zeros((n3, h3, w3), dtype=torch.int32, device="cuda")
     rc = torch.zeros((n3, 4096, 4), dtype=torch.int32, device="cuda")
     cn = torch.zeros(n3, dtype=torch.int32, device="cuda")
-    ev = torch.zeros(2, dtype=torch.int64, device="cuda")
+    ev = torch.zeros(4, dtype=torch.int64, device="cuda")
     dc = g.cascade_create(casc)
     ms_ii = time_stream(torch, lambda: g.integral_batch(s3, ii3), 5)
     ms_lbp = time_stream(torch, lambda: g.lbp_detect_batch(dc, ii3, rc, cn, 4096, 1.1, 1.0, 4.0, 1), 3)
@@ -474,10 +590,11 @@ def extras(g, torch, np, src, tmp, dst, w, h, reps):
         "lbp_roofline": lbp_gather_block(nweak, ms_lbp),
         "reference_1core": "5.98 s/frame, 4.83 Mwin/s (BASELINE.md)"}
     dc.close()
-    A = _O.synth(1280, 720, 4)
-    B = np.zeros_like(A)
-    B[:717, :1275] = A[3:, 5:]
-    dA, dB = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
+    dA = torch.empty((1, 720, 1280), dtype=torch.uint8, device="cuda")
+    g.synth_batch(dA, 4)  # frame A = synth(1280, 720, seed 4) generated on the device; B = A shifted by (+5, +3), zero fill
+    dA = dA[0]
+    dB = torch.zeros_like(dA)
+    dB[:717, :1275] = dA[3:, 5:]
     sm = torch.zeros_like(dA)
     ka = g.orb_extract_dev(dA, sm, 500, 20)
     t1 = time.perf_counter()

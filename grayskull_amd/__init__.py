@@ -395,8 +395,9 @@ class Grayskull:
                                     max_rects, scale_factor, min_scale, max_scale, step)
 
     def lbp_count_evaluated(self, counter):
-        """counter: two-element int64 device tensor (zeroed by the caller): [windows evaluated, weak
-        classifiers evaluated]; None switches the counting kernels off"""
+        """counter: FOUR-element int64 device tensor (zeroed by the caller): [windows of chunks that were not
+        skipped, weak classifiers evaluated, dword table loads issued, windows through the prefilter]; None
+        switches the counting kernels off"""
         self.c.gsh_lbp_count_evaluated(_ptr(counter) if counter is not None else None)
 
     def lbp_window_count(self, cascade, iw, ih, scale_factor, min_scale, max_scale, step):

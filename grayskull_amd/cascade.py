@@ -34,16 +34,24 @@ class Cascade:
 
     @classmethod
     def from_blob(cls, path):
-        raw = open(path, "rb").read()
+        return cls.from_bytes(open(path, "rb").read(), path)
+
+    @classmethod
+    def from_bytes(cls, raw, origin="<bytes>"):
+        """the blob as a byte string (what Sharder.broadcast_bytes hands every rank)"""
+        if len(raw) < 20:
+            raise ValueError("not a cascade blob: %r" % origin)
         magic, ww, wh, nf, nw, ns, _, nsub = struct.unpack_from("<4sHHHHHHI", raw, 0)
         if magic != b"LBPC":
-            raise ValueError("not a cascade blob: %r" % path)
+            raise ValueError("not a cascade blob: %r" % origin)
         counts = dict(features=nf * 4, weak_feature_idx=nw, weak_left_val=nw, weak_right_val=nw,
                       weak_subset_offset=nw, weak_num_subsets=nw, subsets=nsub,
                       stage_weak_start=ns, stage_nweaks=ns, stage_threshold=ns)
         off, arrays = 20, {}
         for name, dt in _FIELDS:
             n = counts[name]
+            if off + n * np.dtype(dt).itemsize > len(raw):
+                raise ValueError("truncated cascade blob: %r" % origin)
             arrays[name] = np.frombuffer(raw, dtype=dt, count=n, offset=off).copy()
             off += (n * np.dtype(dt).itemsize + 3) & ~3
         return cls(ww, wh, **arrays)

@@ -24,6 +24,7 @@
 #include "k_geom.h"
 #include "k_integral.h"
 #include "k_lbp.h"
+#include "k_lbp_dense.h"
 #include "k_orb.h"
 #include "k_pointwise.h"
 #include "k_stencil.h"
@@ -61,7 +62,7 @@ using namespace gs;
 namespace {
 
 /* ------------------------------------------------------------------ per-thread context */
-enum Slot { SL_IN = 0, SL_OUT, SL_AUX, SL_AUX2, SL_II, SL_PAD, SL_MASK, SL_CNT, SL_PFX, SL_TOT,
+enum Slot { SL_IN = 0, SL_OUT, SL_AUX, SL_AUX2, SL_II, SL_PAD, SL_MASK, SL_CNT, SL_PFX, SL_TOT, SL_PRE, SL_NOTII,
             SL_HISTP, SL_HIST, SL_THR, SL_KPS, SL_MOM, SL_KIN, SL_DESC, SL_TAB, SL_JUMP, SL_LEV,
             SL_BEST, SL_COUNT };
 
@@ -82,6 +83,12 @@ struct LbpGeomCache {
   unsigned total_chunks = 0, max_chunks = 0;
   bool guard = false;
   unsigned long long nwindows = 0;
+  /* prefilter geometry (k_lbp_dense.h), only built for step == 1 */
+  LbpPreScale *d_pre = nullptr;
+  size_t d_pre_cap = 0;
+  unsigned long long pre_words = 0; /* u64 words of one frame's "alive" bitmap */
+  unsigned long long max_cell_px = 0; /* largest fw x fh over all (scale, classifier) */
+  unsigned max_tiles = 0;
 };
 struct gsh_cascade_tables_deleter { void operator()(struct ::gsh_cascade *dc) const; };
 /* Events that order the library's own streams on ONE device need no system-scope fence: a plain
@@ -93,7 +100,16 @@ struct gsh_cascade_tables_deleter { void operator()(struct ::gsh_cascade *dc) co
 #ifndef GS_EVENT_FLAGS
 #define GS_EVENT_FLAGS hipEventDisableSystemFence
 #endif
-inline unsigned sync_event_flags() { return GS_EVENT_FLAGS; }
+inline unsigned sync_event_flags() { return GS_EVENT_FLAGS; } /* timing-only events (gsh_profile) */
+/* The events that ORDER the side stream against the caller's stream (ev_join / ev_chunk) carry the data
+ * dependence of dst / thr / the partial histograms between the two streams, so they keep HIP's documented
+ * semantics (a release the waiting stream is guaranteed to observe) -- hipEventDisableSystemFence is documented
+ * for timing-only events and worked for ordering only through ROCclr's kernel-boundary release.
+ * GS_ORDER_EVENT_FLAGS (experiment hook) adds flags to them. */
+#ifndef GS_ORDER_EVENT_FLAGS
+#define GS_ORDER_EVENT_FLAGS 0
+#endif
+inline unsigned order_event_flags() { return hipEventDisableTiming | GS_ORDER_EVENT_FLAGS; }
 #endif
 struct Ctx {
   int device = 0;
@@ -111,6 +127,7 @@ struct Ctx {
     for (auto &kv : geom_cache) {
       if (kv.second.d_scales) (void)hipFree(kv.second.d_scales);
       if (kv.second.d_geom) (void)hipFree(kv.second.d_geom);
+      if (kv.second.d_pre) (void)hipFree(kv.second.d_pre);
     }
     geom_cache.clear();
   }
@@ -146,8 +163,8 @@ struct Ctx {
       if (hipStreamGetPriority(s(), &mine) != hipSuccess) mine = 0;
       GS_HIP(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, mine == lo && lo != hi ? hi : lo));
     }
-    GS_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming | sync_event_flags()));
-    for (auto &e : ev_chunk) GS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming | sync_event_flags()));
+    GS_HIP(hipEventCreateWithFlags(&ev_join, order_event_flags()));
+    for (auto &e : ev_chunk) GS_HIP(hipEventCreateWithFlags(&e, order_event_flags()));
   }
 #endif
 
@@ -252,7 +269,7 @@ dim3 grid2d(unsigned w, unsigned h, unsigned n) { return dim3((w + 63) / 64, (h 
 inline bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 /* ---- launch tuning (gsh_tune): 0 rows per band (0 = auto), 1 block shape, 2 prefetch depth */
-int g_tune[14] = {0, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+int g_tune[16] = {0, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 /* gsh_lbp_count_evaluated: device counter that receives the windows the cascade really evaluated */
 thread_local unsigned long long *g_lbp_evaluated = nullptr;
 
@@ -414,12 +431,22 @@ void launch_box_generic(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h
       if (g_tune[0] > 0) {
         T = (unsigned)g_tune[0];
       } else {
-        double best = 1e30;
-        for (unsigned nbc = 1; nbc <= std::max(1u, h / 8u); nbc++) {
-          const unsigned t = (h + nbc - 1) / nbc;
-          const double rounds = (double)(((unsigned long long)nn * ((h + t - 1) / t) + 1023) / 1024);
-          const double cost = rounds * ((double)t + 0.3 * (2.0 * r + 1.0));
-          if (cost < best - 1e-9) best = cost, T = t;
+        /* once the launch is several full rounds, more bands only add prologues (cost ~ nn h / 1024 + nn nbc k / 1024
+         * grows with nbc), so the search stops at 4 rounds' worth of blocks: at most 4096 candidates however tall
+         * the image is; the last answer is kept per (h, nn, r) */
+        static thread_local struct { unsigned h, nn, r, T; } memo = {0, 0, 0, 0};
+        if (memo.h == h && memo.nn == nn && memo.r == r) {
+          T = memo.T;
+        } else {
+          double best = 1e30;
+          const unsigned nbc_max = std::max(1u, std::min(h / 8u, std::max(1u, 4096u / nn)));
+          for (unsigned nbc = 1; nbc <= nbc_max; nbc++) {
+            const unsigned t = (h + nbc - 1) / nbc;
+            const double rounds = (double)(((unsigned long long)nn * ((h + t - 1) / t) + 1023) / 1024);
+            const double cost = rounds * ((double)t + 0.3 * (2.0 * r + 1.0));
+            if (cost < best - 1e-9) best = cost, T = t;
+          }
+          memo = {h, nn, r, T};
         }
       }
       const unsigned nb = (h + T - 1) / T;
@@ -640,13 +667,15 @@ struct gsh_cascade {
   LbpWeak *d_weak = nullptr;
   LbpStage *d_stage = nullptr;
   int32_t *d_subsets = nullptr;
+  unsigned *d_pass_lut = nullptr; /* per stage: truth table of the stage decision over its match bits (k_lbp_dense.h) */
+  unsigned pre_max = 0;           /* leading stages with <= kPreMaxWeaks weak classifiers */
   unsigned long long id = 0; /* unique per handle: key of the calling threads' geometry caches */
 };
 
 namespace {
 /* the device tables of a handle, without touching any context (used while a context is being released) */
 void gsh_cascade_tables_deleter::operator()(gsh_cascade *dc) const {
-  (void)hipFree(dc->d_weak), (void)hipFree(dc->d_stage), (void)hipFree(dc->d_subsets);
+  (void)hipFree(dc->d_weak), (void)hipFree(dc->d_stage), (void)hipFree(dc->d_subsets), (void)hipFree(dc->d_pass_lut);
   delete dc;
 }
 }  // namespace
@@ -656,7 +685,8 @@ namespace {
 /* The reference's scale loop and per-feature truncation (ref :819-821, :799-804), float32. */
 void build_scales(const gsh_cascade &c, unsigned iw, unsigned ih, float scale_factor,
                   float min_scale, float max_scale, int step, std::vector<LbpScale> &scales,
-                  std::vector<LbpGeom> &geom, bool &guard, unsigned long long &nwin) {
+                  std::vector<LbpGeom> &geom, bool &guard, unsigned long long &nwin,
+                  unsigned long long *max_cell_px = nullptr) {
   scales.clear();
   geom.clear();
   guard = false;
@@ -683,7 +713,8 @@ void build_scales(const gsh_cascade &c, unsigned iw, unsigned ih, float scale_fa
       if (fw < 1) fw = 1;
       if (fh < 1) fh = 1;
       if (fx < 0 || fy < 0 || fx + 3 * fw > win_w || fy + 3 * fh > win_h) guard = true;
-      geom.push_back(LbpGeom{(fy * (int)S + fx) * 4, fw * 4, fh * (int)S * 4, 0});
+      geom.push_back(LbpGeom{(fy * (int)S + fx) * 4, fw * 4, fh * (int)S * 4, fh});
+      if (max_cell_px) *max_cell_px = std::max(*max_cell_px, (unsigned long long)fw * (unsigned long long)fh);
     }
     scales.push_back(sc);
     if (scales.size() >= 4096 || !(scale_factor > 1.0f)) break; /* the reference would not terminate */
@@ -701,7 +732,8 @@ LbpGeomCache &cascade_prepare(const gsh_cascade *dc, unsigned iw, unsigned ih, f
   if (gc.iw == iw && gc.ih == ih && gc.sf == sf && gc.mn == mn && gc.mx == mx && gc.step == step && gc.d_scales)
     return gc;
   std::vector<LbpGeom> geom;
-  build_scales(*dc, iw, ih, sf, mn, mx, step, gc.scales, geom, gc.guard, gc.nwindows);
+  gc.max_cell_px = 0;
+  build_scales(*dc, iw, ih, sf, mn, mx, step, gc.scales, geom, gc.guard, gc.nwindows, &gc.max_cell_px);
   cx.sync(); /* tables may be in use by an earlier launch of this thread */
   const size_t sb = std::max<size_t>(1, gc.scales.size()) * sizeof(LbpScale);
   const size_t gb = std::max<size_t>(1, geom.size()) * sizeof(LbpGeom);
@@ -724,6 +756,26 @@ LbpGeomCache &cascade_prepare(const gsh_cascade *dc, unsigned iw, unsigned ih, f
     gc.total_chunks += sc.nchunks;
     gc.max_chunks = std::max(gc.max_chunks, sc.nchunks);
   }
+  /* prefilter layout: one bit per window, window rows padded to whole u64 words; 64 x 64-window tiles */
+  gc.pre_words = 0, gc.max_tiles = 0;
+  if (step == 1 && !gc.scales.empty()) {
+    std::vector<LbpPreScale> pre;
+    for (auto &sc : gc.scales) {
+      LbpPreScale ps;
+      ps.word_base = gc.pre_words, ps.wpr = (sc.nx + 63u) / 64u, ps.tiles_x = ps.wpr;
+      ps.ntiles = ps.tiles_x * ((sc.ny + kPreTile - 1u) / kPreTile), ps.pad = 0;
+      gc.pre_words += (unsigned long long)ps.wpr * sc.ny;
+      gc.max_tiles = std::max(gc.max_tiles, ps.ntiles);
+      pre.push_back(ps);
+    }
+    const size_t pb = pre.size() * sizeof(LbpPreScale);
+    if (gc.d_pre_cap < pb) {
+      if (gc.d_pre) GS_HIP(hipFree(gc.d_pre));
+      GS_HIP(hipMalloc((void **)&gc.d_pre, pb));
+      gc.d_pre_cap = pb;
+    }
+    GS_HIP(hipMemcpy(gc.d_pre, pre.data(), pb, hipMemcpyHostToDevice));
+  }
   gc.iw = iw, gc.ih = ih, gc.sf = sf, gc.mn = mn, gc.mx = mx, gc.step = step;
   return gc;
 }
@@ -731,7 +783,7 @@ LbpGeomCache &cascade_prepare(const gsh_cascade *dc, unsigned iw, unsigned ih, f
 /* padded: n frames of (iw+1)*(ih+1) u32 on device */
 void launch_lbp_padded(const gsh_cascade *dc, const LbpGeomCache &gc, const unsigned *padded, unsigned iw,
                        unsigned ih, unsigned n, unsigned *rects, unsigned *counts, unsigned max_rects,
-                       int step) {
+                       int step, const unsigned *not_integral) {
   hipStream_t st = ctx().s();
   if (gc.scales.empty() || max_rects == 0) {
     GS_HIP(hipMemsetAsync(counts, 0, (size_t)n * 4, st));
@@ -743,13 +795,15 @@ void launch_lbp_padded(const gsh_cascade *dc, const LbpGeomCache &gc, const unsi
   const unsigned nsc0 = (unsigned)gc.scales.size();
   /* chunk counters, then the early-exit counters: one per group of 32 chunks, one per 1024 */
   const unsigned ngroups = (nch >> kLbpGroupShift) + 1, nsupers = (nch >> kLbpSuperShift) + 1;
-  const size_t ncnt = (size_t)n * nch + (size_t)n * ngroups + (size_t)n * nsupers;
+  const size_t ncnt = (size_t)n * nch + (size_t)n * ngroups + (size_t)n * nsupers + n;
   unsigned *cnt = (unsigned *)ctx().scratch(SL_CNT, ncnt * 4);
   GS_HIP(hipMemsetAsync(cnt, 0, ncnt * 4, st));
   GS_HIP(hipMemsetAsync(mask, 0, (size_t)n * nch * kChunkWords * 8, st));
   LbpArgs a;
   a.hits_group = cnt + (size_t)n * nch;
   a.hits_super = a.hits_group + (size_t)n * ngroups;
+  a.hits_total = a.hits_super + (size_t)n * nsupers;
+  a.scale0 = 0;
   a.ngroups = ngroups, a.nsupers = nsupers;
   a.evaluated = g_lbp_evaluated;
   a.nscales = nsc0, a.cap = max_rects;
@@ -762,12 +816,12 @@ void launch_lbp_padded(const gsh_cascade *dc, const LbpGeomCache &gc, const unsi
   a.scales = gc.d_scales, a.geom = gc.d_geom, a.weak = dc->d_weak, a.stage = dc->d_stage;
   a.subsets = dc->d_subsets;
   a.mask = mask, a.chunk_count = cnt, a.total_chunks = nch;
+  a.pre_bitmap = nullptr, a.pre_scales = gc.d_pre, a.pre_words = gc.pre_words, a.pre_stages = 0;
   const unsigned nsc = (unsigned)gc.scales.size();
   /* XCD-aware chunk mapping (k_lbp.h) once the integral image no longer fits one XCD's 4 MB L2: 1080p -3 %, 4K block
    * noise -4 %, 4K edge maps -12 % (5.76 -> 5.08 ms per frame); 720p (3.7 MB) is 1-4 % better off in dispatch order
    * (profiles/r02l_lbp_xcd.log).  Key 13: 1 = never, 2 = always. */
   a.xcd_swizzle = g_tune[13] == 1 ? 0u : g_tune[13] == 2 ? 1u : (a.frame_stride * 4 >= (size_t)6 << 20 ? 1u : 0u);
-  const dim3 g(a.xcd_swizzle ? (gc.max_chunks + 7u) & ~7u : gc.max_chunks, nsc, n);
   const size_t lds = (size_t)dc->nstages * sizeof(LbpStage) +
                      (size_t)dc->nweaks * (sizeof(LbpWeak) + sizeof(LbpGeom)) + (size_t)dc->nsub * 4;
   GS_ASSERT(lds <= 60 * 1024 && "cascade tables must fit the block's LDS");
@@ -810,11 +864,57 @@ void launch_lbp_padded(const gsh_cascade *dc, const LbpGeomCache &gc, const unsi
     }
   }
   const size_t lds_all = ((lds + 15) & ~(size_t)15) + 2 * kChunkItems * 2 + 64 * 4 + 16;
-  if (a.evaluated) { /* counting build: the same kernel + one register that counts classifier evaluations */
-    if (gc.guard) GS_LAUNCH((k_lbp_cascade<true, true>), g, dim3(256), lds_all, st, a, ph);
-    else GS_LAUNCH((k_lbp_cascade<false, true>), g, dim3(256), lds_all, st, a, ph);
-  } else if (gc.guard) GS_LAUNCH(k_lbp_cascade<true>, g, dim3(256), lds_all, st, a, ph);
-  else GS_LAUNCH(k_lbp_cascade<false>, g, dim3(256), lds_all, st, a, ph);
+  /* Prefilter (k_lbp_dense.h): stages [0, pre) for every window with the table rows shared down the columns of
+   * 64 x 64-window tiles; the cascade kernel then starts from the surviving set.  Key 14: 0 = default (2 stages),
+   * -1 = off, k = that many stages.  Needs unit step, in-window geometry, the adaptive preset and stages of
+   * <= 5 weak classifiers.
+   * The prefilter cannot see detections of its own launch, so the scales are issued in GROUPS (prefilter, then
+   * cascade, group after group on the stream): a group's tiles skip once the groups before it hold max_rects
+   * detections -- the reference stops scanning there (ref :819-823) -- while the chunk-granular exit inside the
+   * cascade kernel stays as it was.  A group is at least ~16 M windows (key 15 overrides, a test hook), so a
+   * launch always fills the chip: 8 x 4K = one scale per group, one 1080p frame = two groups. */
+  const int k14 = g_tune[14] >= 100 ? g_tune[14] - 100 : g_tune[14];
+  unsigned pre = k14 < 0 ? 0u : k14 > 0 ? (unsigned)k14 : 2u;
+  pre = std::min(pre, std::min(dc->pre_max, dc->nstages > 0 ? dc->nstages - 1u : 0u));
+  if (step != 1 || gc.guard || !ph.adaptive_max || !gc.d_pre || !dc->d_pass_lut || a.frame_stride * 4 >= (1ull << 31)) pre = 0;
+  LbpPreArgs pa;
+  pa.pass_lut = dc->d_pass_lut, pa.bitmap = nullptr, pa.xcd_swizzle = a.xcd_swizzle;
+  pa.not_integral = not_integral;
+  /* sign-bit compares (k_lbp_dense.h: lbp_code8) need every cell sum < 2^31: cells of the prefiltered classifiers
+   * cover at most max_cell_px pixels of <= 255 each.  Key 14 + 100 forces the general compare (A/B, tests). */
+  pa.small_cells = (not_integral && gc.max_cell_px < (1ull << 31) / 255ull && g_tune[14] < 100) ? 1u : 0u;
+  if (pre) {
+    pa.bitmap = (unsigned long long *)ctx().scratch(SL_PRE, (size_t)n * gc.pre_words * 8);
+    a.pre_bitmap = pa.bitmap, a.pre_stages = pre;
+  }
+  const unsigned long long group_windows = g_tune[15] > 0 ? (unsigned long long)g_tune[15] : 16ull << 20;
+  for (unsigned s0 = 0; s0 < nsc;) {
+    unsigned s1 = s0;
+    unsigned long long wsum = 0;
+    unsigned mc = 0, mt = 0;
+    do {
+      wsum += (unsigned long long)n * gc.scales[s1].nx * gc.scales[s1].ny;
+      mc = std::max(mc, gc.scales[s1].nchunks);
+      mt = std::max(mt, (gc.scales[s1].nx + 63u) / 64u * ((gc.scales[s1].ny + kPreTile - 1u) / kPreTile));
+      s1++;
+    } while (pre && s1 < nsc && wsum < group_windows);
+    if (!pre) /* no prefilter: one launch over all scales, as before */
+      for (; s1 < nsc; s1++) mc = std::max(mc, gc.scales[s1].nchunks);
+    a.scale0 = s0;
+    if (pre) {
+      const unsigned nblk = (mt + 3u) / 4u;
+      const dim3 gd(pa.xcd_swizzle ? (nblk + 7u) & ~7u : nblk, s1 - s0, n);
+      if (a.evaluated) GS_LAUNCH(k_lbp_dense<true>, gd, dim3(256), lds + 16, st, a, pa);
+      else GS_LAUNCH(k_lbp_dense<false>, gd, dim3(256), lds + 16, st, a, pa);
+    }
+    const dim3 g(a.xcd_swizzle ? (mc + 7u) & ~7u : mc, s1 - s0, n);
+    if (a.evaluated) { /* counting build: the same kernel + one register that counts classifier evaluations */
+      if (gc.guard) GS_LAUNCH((k_lbp_cascade<true, true>), g, dim3(256), lds_all, st, a, ph);
+      else GS_LAUNCH((k_lbp_cascade<false, true>), g, dim3(256), lds_all, st, a, ph);
+    } else if (gc.guard) GS_LAUNCH(k_lbp_cascade<true>, g, dim3(256), lds_all, st, a, ph);
+    else GS_LAUNCH(k_lbp_cascade<false>, g, dim3(256), lds_all, st, a, ph);
+    s0 = s1;
+  }
   run_compaction(mask, cnt, nch, n, max_rects, counts,
                  LbpEmit{gc.d_scales, (unsigned)gc.scales.size(), step, rects, max_rects});
 }
@@ -831,10 +931,12 @@ void launch_lbp_unpadded(const gsh_cascade *dc, const unsigned *ii, unsigned iw,
   for (unsigned f0 = 0; f0 < n; f0 += kLbpGroup) {
     const unsigned nn = std::min(kLbpGroup, n - f0);
     unsigned *padded = (unsigned *)ctx().scratch(SL_PAD, pp * 4 * nn);
+    unsigned *notii = (unsigned *)ctx().scratch(SL_NOTII, (size_t)nn * 4);
+    GS_HIP(hipMemsetAsync(notii, 0, (size_t)nn * 4, st));
     GS_LAUNCH(k_integral_pad, dim3((iw + 64) / 64, (ih + 4) / 4, nn), dim3(64, 4), 0, st,
-              ii + fp * f0, iw, ih, padded);
+              ii + fp * f0, iw, ih, padded, notii);
     launch_lbp_padded(dc, gc, padded, iw, ih, nn, rects + (size_t)f0 * max_rects * 4, counts + f0,
-                      max_rects, step);
+                      max_rects, step, notii);
   }
 }
 
@@ -1049,7 +1151,7 @@ unsigned gsh_profile_read(double *total_ms) {
   return n;
 }
 void gsh_tune(int key, int value) {
-  if (key >= 0 && key < 14) g_tune[key] = value;
+  if (key >= 0 && key < 16) g_tune[key] = value;
 }
 void gsh_probe_strip_copy(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned n) {
   GS_ASSERT(dst && src && w % 16 == 0 && al16(dst) && al16(src));
@@ -1306,6 +1408,29 @@ gsh_cascade *gsh_cascade_create(const struct gs_lbp_cascade *c) {
   GS_HIP(hipMemcpy(dc->d_weak, wk.data(), wk.size() * sizeof(LbpWeak), hipMemcpyHostToDevice));
   GS_HIP(hipMemcpy(dc->d_stage, stg.data(), stg.size() * sizeof(LbpStage), hipMemcpyHostToDevice));
   GS_HIP(hipMemcpy(dc->d_subsets, c->subsets, (size_t)nsub * 4, hipMemcpyHostToDevice));
+  /* Truth tables of the stage decisions (k_lbp_dense.h): for every combination b of a stage's match bits the
+   * reference's own sequence -- sum = 0.0f; sum += match ? left : right in weak order; pass unless
+   * sum < threshold (ref :796-810) -- evaluated here in float32 (this file is built -ffp-contract=off). */
+  std::vector<unsigned> lut(std::max<size_t>(1, stg.size()), 0u);
+  dc->pre_max = 0;
+  bool leading = true;
+  for (unsigned si = 0; si < c->nstages; si++) {
+    if (stg[si].count > kPreMaxWeaks) {
+      leading = false;
+      continue;
+    }
+    for (unsigned b = 0; b < (1u << stg[si].count); b++) {
+      volatile float sum = 0.0f;
+      for (unsigned k = 0; k < stg[si].count; k++) {
+        const LbpWeak &w = wk[stg[si].first + k];
+        sum = sum + (((b >> k) & 1u) ? w.left : w.right);
+      }
+      if (!(sum < stg[si].threshold)) lut[si] |= 1u << b;
+    }
+    if (leading) dc->pre_max = si + 1;
+  }
+  GS_HIP(hipMalloc((void **)&dc->d_pass_lut, lut.size() * 4));
+  GS_HIP(hipMemcpy(dc->d_pass_lut, lut.data(), lut.size() * 4, hipMemcpyHostToDevice));
   return dc;
 }
 void gsh_cascade_destroy(gsh_cascade *dc) {

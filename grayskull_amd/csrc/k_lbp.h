@@ -26,7 +26,10 @@ struct LbpScale {          /* one entry per visited scale (host-computed, float3
   unsigned chunk_base;     /* first chunk of this scale in the frame's chunk array */
   unsigned nchunks;
 };
-struct LbpGeom { int off0, fw, fh_stride, pad; };      /* per (scale, weak): BYTE offsets in the padded table */
+struct LbpGeom { int off0, fw, fh_stride, pad; };      /* per (scale, weak): BYTE offsets in the padded table; pad = fh in rows */
+/* per scale: where its windows' "alive after the prefiltered stages" bits live (k_lbp_dense.h): window
+ * (xi, yi) is bit xi % 64 of word word_base + yi * wpr + xi / 64; tiles of 64 x 64 windows, row-major */
+struct LbpPreScale { unsigned long long word_base; unsigned wpr, tiles_x, ntiles, pad; };
 struct LbpWeak { float left, right; unsigned sub_off, nsub; };
 struct LbpStage { unsigned first, count; float threshold, pad; };
 
@@ -52,11 +55,23 @@ struct LbpArgs {
    * precede it in the reference's scan order -- and skips when that reaches the cap. */
   unsigned *hits_group;         /* n frames x ngroups   (pre-zeroed) */
   unsigned *hits_super;         /* n frames x nsupers   (pre-zeroed) */
+  unsigned *hits_total;         /* n frames (pre-zeroed): all detections published so far; the launcher issues the
+                                   scales in groups, and a group's prefilter tiles skip once the groups before it
+                                   (complete by stream order) reached the cap */
+  unsigned scale0;              /* first scale of this launch (blockIdx.y counts from it) */
   unsigned ngroups, nsupers;
   unsigned nscales, cap;        /* cap = max_rects */
   unsigned xcd_swizzle;         /* 1: chunk = (blockIdx.x % 8) * ceil(nchunks / 8) + blockIdx.x / 8 */
   unsigned long long *evaluated; /* optional (COUNT kernels): [0] += windows of every chunk that was not
-                                    skipped, [1] += weak classifiers evaluated, summed over windows */
+                                    skipped, [1] += weak classifiers evaluated, summed over windows, [2] += dword
+                                    corner loads issued, summed over lanes, [3] += windows that went through the
+                                    prefilter (k_lbp_dense) */
+  /* prefilter (k_lbp_dense.h): when pre_stages > 0 the windows' starting set is the bitmap written by
+   * k_lbp_dense (alive after stages [0, pre_stages)) and the cascade resumes at stage pre_stages */
+  const unsigned long long *pre_bitmap; /* n frames x pre_words */
+  const LbpPreScale *pre_scales;
+  unsigned long long pre_words;
+  unsigned pre_stages;
 };
 constexpr unsigned kLbpGroupShift = 5, kLbpSuperShift = 10; /* chunks per group / super-group (log2) */
 
@@ -214,7 +229,8 @@ __global__ __launch_bounds__(256) void k_lbp_cascade(LbpArgs a, LbpPhases ph) {
 #pragma clang fp contract(off)
 #endif
   GS_DYN_LDS(smem);
-  const LbpScale sc = a.scales[blockIdx.y];
+  const unsigned si = blockIdx.y + a.scale0;
+  const LbpScale sc = a.scales[si];
   /* XCD-aware chunk mapping (a.xcd_swizzle; gridDim.x is then a multiple of 8): the dispatcher places block b on
    * XCD b % 8, each with its own 4 MB L2.  Handing consecutive chunks to consecutive XCDs makes every XCD sweep
    * the whole integral image of every scale (one L2 request in three missed: 134 M misses per 4 x 1080p,
@@ -252,7 +268,7 @@ __global__ __launch_bounds__(256) void k_lbp_cascade(LbpArgs a, LbpPhases ph) {
   }
   __syncthreads();
   if (before_s >= a.cap) return;
-  const LbpLds t = lbp_stage_tables(smem, a, a.geom + (size_t)blockIdx.y * a.nweaks, tid, 256u);
+  const LbpLds t = lbp_stage_tables(smem, a, a.geom + (size_t)si * a.nweaks, tid, 256u);
   char *extra = smem + ((lbp_lds_bytes(a.nstages, a.nweaks, a.nsub) + 15) & ~(size_t)15);
   uint16_t *queue = (uint16_t *)extra;                       /* [2][kChunkItems] */
   uint32_t *bits = (uint32_t *)(extra + 2 * kChunkItems * 2); /* [64] */
@@ -268,27 +284,45 @@ __global__ __launch_bounds__(256) void k_lbp_cascade(LbpArgs a, LbpPhases ph) {
 #pragma unroll
   for (unsigned i = 0; i < kLbpMaxPhases; i++) ends[i] = ph.end[i];
   if (ph.adaptive_max) { /* dense pre-phase with a block-local choice of the first re-packing point */
-    __shared__ unsigned alive_count;
-    if (tid == 0) alive_count = 0;
+    /* three rotating counters, one barrier per iteration: iteration i adds into slot i % 3 and reads it behind
+     * the barrier; slot (i + 1) % 3 is cleared BEFORE that barrier -- its last readers (iteration i - 2) are all
+     * past barrier i - 1, its next writers (iteration i + 1) all behind barrier i, so no add can be wiped */
+    __shared__ unsigned alive_count[3];
+    if (tid < 3) alive_count[tid] = 0;
     __syncthreads();
+    unsigned slot = 0;
     unsigned alive = 0; /* bit k: window k * 256 + tid of the chunk is still alive */
+    if (a.pre_stages) { /* starting set = what k_lbp_dense left alive */
+      const LbpPreScale ps = a.pre_scales[si];
+      const unsigned long long *bm = a.pre_bitmap + (size_t)blockIdx.z * a.pre_words + ps.word_base;
 #pragma unroll
-    for (unsigned k = 0; k < kChunkItems / 256u; k++) alive |= (k * 256u + tid < n_in ? 1u : 0u) << k;
-    unsigned s_prev = 0, e = ph.end[0] < a.nstages ? ph.end[0] : a.nstages;
-    for (;;) { /* block-uniform */
-      for (unsigned k = 0; k < kChunkItems / 256u; k++) { /* uniform trip count; dead lanes idle */
-        if (k * 256u >= n_in) break;
-        if ((alive >> k) & 1u) {
-          if (!lbp_window_stages<GUARD, COUNT>(t, Pg, lbp_origin(a, sc, first + k * 256u + tid), a.limit_bytes, s_prev, e, &evals))
-            alive &= ~(1u << k);
+      for (unsigned k = 0; k < kChunkItems / 256u; k++)
+        if (k * 256u + tid < n_in) {
+          const unsigned idx = first + k * 256u + tid, yi = idx / sc.nx, xi = idx - yi * sc.nx;
+          alive |= (unsigned)((bm[(size_t)yi * ps.wpr + (xi >> 6)] >> (xi & 63u)) & 1ull) << k;
         }
-      }
+    } else {
+#pragma unroll
+      for (unsigned k = 0; k < kChunkItems / 256u; k++) alive |= (k * 256u + tid < n_in ? 1u : 0u) << k;
+    }
+    /* stages [s_prev, e) are evaluated per iteration; with a prefilter the first iteration only counts */
+    unsigned s_prev = a.pre_stages, e = a.pre_stages ? a.pre_stages : (ph.end[0] < a.nstages ? ph.end[0] : a.nstages);
+    for (;;) { /* block-uniform */
+      if (e > s_prev)
+        for (unsigned k = 0; k < kChunkItems / 256u; k++) { /* uniform trip count; dead lanes idle */
+          if (k * 256u >= n_in) break;
+          if ((alive >> k) & 1u) {
+            if (!lbp_window_stages<GUARD, COUNT>(t, Pg, lbp_origin(a, sc, first + k * 256u + tid), a.limit_bytes, s_prev, e, &evals))
+              alive &= ~(1u << k);
+          }
+        }
       const unsigned mine = wave_sum((unsigned)__popc(alive));
-      if ((tid & 63u) == 0 && mine) atomicAdd(&alive_count, mine);
+      const unsigned nslot = slot == 2u ? 0u : slot + 1u;
+      if ((tid & 63u) == 0 && mine) atomicAdd(&alive_count[slot], mine);
+      if (tid == 0) alive_count[nslot] = 0;
       __syncthreads();
-      const unsigned c = alive_count;
-      __syncthreads();
-      if (tid == 0) alive_count = 0;
+      const unsigned c = alive_count[slot];
+      slot = nslot;
       if (e >= a.nstages || c == 0 || c * 10u <= ph.adaptive_tenths * n_in || e >= ph.adaptive_max) {
         if (e >= a.nstages) { /* small cascade: the dense phase was the whole cascade */
           for (unsigned k = 0; k < kChunkItems / 256u; k++)
@@ -377,12 +411,14 @@ __global__ __launch_bounds__(256) void k_lbp_cascade(LbpArgs a, LbpPhases ph) {
       a.chunk_count[chunk] = c;
       atomicAdd(&a.hits_group[(size_t)blockIdx.z * a.ngroups + (lin >> kLbpGroupShift)], c);
       atomicAdd(&a.hits_super[(size_t)blockIdx.z * a.nsupers + (lin >> kLbpSuperShift)], c);
+      atomicAdd(&a.hits_total[blockIdx.z], c);
     }
   }
   if constexpr (COUNT) { /* measurement build of the kernel (gsh_lbp_count_evaluated) */
     const unsigned ev = wave_sum(evals);
-    if ((tid & 63u) == 0) atomicAdd(a.evaluated + 1, (unsigned long long)ev);
-    if (tid == 0) atomicAdd(a.evaluated, (unsigned long long)(nwin - first < kChunkItems ? nwin - first : kChunkItems));
+    if ((tid & 63u) == 0) atomicAdd(a.evaluated + 1, (unsigned long long)ev), atomicAdd(a.evaluated + 2, 16ull * ev);
+    if (tid == 0)
+      atomicAdd(a.evaluated, (unsigned long long)(nwin - first < kChunkItems ? nwin - first : kChunkItems));
   }
 }
 

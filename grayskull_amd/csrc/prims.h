@@ -256,10 +256,24 @@ GS_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 template <class T> GS_DEV uint32_t lds_address(T *p) { /* byte address inside the block's LDS */
   return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)p;
 }
+/* -DGS_PLAIN_LDS_ATOMICS: the same adds as compiler-visible atomicAdd (hipcc's own lgkmcnt bookkeeping, its own
+ * placement) -- the fallback should a hipcc update stop tolerating LDS traffic it cannot see; `make variant
+ * TAG=plain_lds EXTRA=-DGS_PLAIN_LDS_ATOMICS` is one of the A/B builds (scripts/gpu_variants.sh) and must
+ * produce the same bytes.  Contract of the threaded form: between the first lds_add_through and lds_drain()
+ * the caller performs NO compiler-visible access to the table (k_fused.h: the only LDS object is `lh`, cleared
+ * before a __syncthreads() ahead of the row loop, read after lds_drain() + __syncthreads() behind it). */
+#ifdef GS_PLAIN_LDS_ATOMICS
+GS_DEV void lds_add_through(unsigned *lds_base, uint32_t byte_off, uint32_t value, uint32_t &through) {
+  (void)through;
+  atomicAdd((unsigned *)((char *)lds_base + byte_off), value);
+}
+GS_DEV void lds_drain() {}
+#else
 GS_DEV void lds_add_through(unsigned *lds_base, uint32_t byte_off, uint32_t value, uint32_t &through) {
   asm volatile("ds_add_u32 %1, %2" : "+v"(through) : "v"(lds_address(lds_base) + byte_off), "v"(value) : "memory");
 }
 GS_DEV void lds_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#endif
 /* a*b + c per half with a wave-uniform multiplier pair b (SGPR): kept as one v_pk_mad_u16 even
  * when b is a power of two */
 GS_DEV uint32_t pk_mad_u16_s(uint32_t a, uint32_t b, uint32_t c) {

@@ -361,6 +361,19 @@ struct cascade_file {
   struct gs_lbp_cascade c;
   uint8_t *raw;
 };
+static int cascade_tables_ok(const struct gs_lbp_cascade *c, uint32_t nsub) {
+  /* every index array must stay inside the table it points into: gsh_cascade_create and the kernels trust them */
+  unsigned i;
+  if (c->window_w == 0 || c->window_h == 0) return 0;
+  for (i = 0; i < c->nweaks; i++) {
+    if (c->weak_feature_idx[i] >= c->nfeatures) return 0;
+    if ((uint32_t)c->weak_subset_offset[i] + c->weak_num_subsets[i] > nsub) return 0;
+  }
+  for (i = 0; i < c->nstages; i++)
+    if ((unsigned)c->stage_weak_start[i] + c->stage_nweaks[i] > c->nweaks) return 0;
+  return 1;
+}
+
 static int load_cascade(const char *path, struct cascade_file *cf) {
   FILE *fp = fopen(path, "rb");
   long sz;
@@ -369,28 +382,38 @@ static int load_cascade(const char *path, struct cascade_file *cf) {
   size_t off = 20, cnt[10], esz[10] = {1, 2, 4, 4, 2, 2, 4, 2, 2, 4};
   const void *arr[10];
   int i;
+  cf->raw = NULL;
   if (!fp) return -1;
   if (fseek(fp, 0, SEEK_END) != 0 || (sz = ftell(fp)) < 20 || fseek(fp, 0, SEEK_SET) != 0) return fclose(fp), -1;
   cf->raw = (uint8_t *)malloc((size_t)sz);
-  if (!cf->raw || fread(cf->raw, 1, (size_t)sz, fp) != (size_t)sz) return fclose(fp), -1;
+  if (!cf->raw || fread(cf->raw, 1, (size_t)sz, fp) != (size_t)sz) {
+    fclose(fp);
+    goto bad;
+  }
   fclose(fp);
-  if (memcmp(cf->raw, "LBPC", 4) != 0) return -1;
+  if (memcmp(cf->raw, "LBPC", 4) != 0) goto bad;
   memcpy(hdr, cf->raw + 4, sizeof hdr); /* window_w, window_h, nfeatures, nweaks, nstages, pad */
   memcpy(&nsub, cf->raw + 16, 4);
   cnt[0] = (size_t)hdr[2] * 4, cnt[1] = cnt[2] = cnt[3] = cnt[4] = cnt[5] = hdr[3], cnt[6] = nsub;
   cnt[7] = cnt[8] = cnt[9] = hdr[4];
   for (i = 0; i < 10; i++) {
     arr[i] = cf->raw + off;
+    if (cnt[i] > ((size_t)sz - off) / esz[i]) goto bad; /* also keeps `off` from wrapping on a hostile nsub */
     off += (cnt[i] * esz[i] + 3) & ~(size_t)3;
+    if (off > (size_t)sz && i < 9) goto bad;
   }
-  if (off > (size_t)sz) return -1;
   cf->c.window_w = hdr[0], cf->c.window_h = hdr[1], cf->c.nfeatures = hdr[2], cf->c.nweaks = hdr[3], cf->c.nstages = hdr[4];
   cf->c.features = (const int8_t *)arr[0], cf->c.weak_feature_idx = (const uint16_t *)arr[1];
   cf->c.weak_left_val = (const float *)arr[2], cf->c.weak_right_val = (const float *)arr[3];
   cf->c.weak_subset_offset = (const uint16_t *)arr[4], cf->c.weak_num_subsets = (const uint16_t *)arr[5];
   cf->c.subsets = (const int32_t *)arr[6], cf->c.stage_weak_start = (const uint16_t *)arr[7];
   cf->c.stage_nweaks = (const uint16_t *)arr[8], cf->c.stage_threshold = (const float *)arr[9];
+  if (!cascade_tables_ok(&cf->c, nsub)) goto bad;
   return 0;
+bad:
+  free(cf->raw);
+  cf->raw = NULL;
+  return -1;
 }
 
 /* nanomagick.c:172-184, restated: Bresenham with clipping */

@@ -113,10 +113,13 @@ void gsh_cascade_destroy(gsh_cascade *dc);
 void gsh_lbp_detect_batch(const gsh_cascade *dc, const unsigned *ii, unsigned iw, unsigned ih,
                           unsigned n, struct gs_rect *rects, unsigned *counts, unsigned max_rects,
                           float scale_factor, float min_scale, float max_scale, int step);
-/* Measurement aid: while `counter_dev` (TWO device u64, caller-zeroed) is set, every cascade launch
+/* Measurement aid: while `counter_dev` (FOUR device u64, caller-zeroed) is set, every cascade launch
  * of this thread adds [0] the number of windows it really evaluated -- chunks skipped because
- * max_rects detections precede them in scan order (ref :819-823) are not counted -- and [1] the
- * number of weak classifiers evaluated, summed over windows.  NULL = off (the default kernels). */
+ * max_rects detections precede them in scan order (ref :819-823) are not counted --, [1] the
+ * number of weak classifiers evaluated, summed over windows (every window pays the classifiers of the stages
+ * it enters, like the reference), [2] the dword table loads the kernels issued, summed over lanes (the
+ * prefilter k_lbp_dense shares table rows between windows, so this is less than 16 x [1]), [3] the windows
+ * that went through the prefilter.  NULL = off (the default kernels). */
 void gsh_lbp_count_evaluated(unsigned long long *counter_dev);
 /* number of windows gs_lbp_detect visits for this geometry (for Mwin/s reporting) */
 uint64_t gsh_lbp_window_count(const struct gs_lbp_cascade *c, unsigned iw, unsigned ih,

@@ -273,6 +273,66 @@ def test_lbp_adaptive_first_repack_never_changes_results(emu, oracle, cascade, k
         emu.tune(4, 0); emu.tune(9, 0)
 
 
+@pytest.mark.parametrize("pre,group", [(-1, 0), (1, 0), (2, 1), (3, 0), (7, 1), (5, 40000), (102, 0)])
+def test_lbp_prefilter_never_changes_results(emu, oracle, cascade, pre, group):
+    """k_lbp_dense (key 14: prefiltered stages, -1 = off; key 15: windows per scale group, 1 = every scale its own
+    prefilter + cascade launch pair): the first stages for all windows with shared table rows + truth-table stage
+    decisions give the oracle's rectangles for any number of prefiltered stages, any grouping and any cap --
+    tiles with ragged right / bottom edges (sizes that are not multiples of 64), images smaller than a tile,
+    cascades whose stages are too long for the truth table (prefilter switches itself off there)"""
+    edges = oracle.sobel(oracle.blur(Oracle.synth(200, 150, 1000), 2))
+    try:
+        emu.tune(14, pre), emu.tune(15, group)
+        pc.lbp(emu, oracle, edges, MEM, cascade, params=((4096, 1.1, 1.0, 4.0, 1), (7, 1.1, 1.0, 4.0, 1), (60, 1.3, 1.0, 3.0, 1)))
+        pc.lbp(emu, oracle, Oracle.synth(96, 80, 7), MEM, cascade, params=((4096, 1.1, 1.0, 4.0, 1),))
+        pc.lbp(emu, oracle, Oracle.synth(40, 30, 3), MEM, cascade, params=((4096, 1.1, 1.0, 4.0, 1),))
+        pc.lbp(emu, oracle, Oracle.synth(130, 70, 9), MEM, random_cascade(1), params=((4096, 1.25, 1.0, 2.0, 1), (37, 1.25, 1.0, 2.0, 1)))
+        pc.lbp(emu, oracle, Oracle.synth(80, 60, 11), MEM, random_cascade(4, nstages=6, weaks_per_stage=2), params=((500, 1.2, 1.0, 2.5, 1),))
+        pc.lbp(emu, oracle, Oracle.synth(80, 60, 12), MEM, random_cascade(5, nstages=3, weaks_per_stage=5), params=((500, 1.2, 1.0, 2.5, 1),))
+        pc.lbp(emu, oracle, Oracle.synth(80, 60, 13), MEM, random_cascade(6, nstages=2, weaks_per_stage=7), params=((500, 1.2, 1.0, 2.5, 1),))
+        pc.lbp(emu, oracle, Oracle.synth(80, 60, 13), MEM, random_cascade(7, nstages=3, weaks_per_stage=3, permissive=False), params=((500, 1.2, 1.0, 2.5, 1),))
+        # a table that is NOT an integral image (arbitrary u32 words, what the reference would happily index):
+        # k_integral_pad flags it and the prefilter falls back to full unsigned compares
+        rnd = np.random.RandomState(5).randint(0, 2 ** 32, (90, 130), dtype=np.uint64).astype(np.uint32)
+        for casc in (cascade, random_cascade(1)):
+            assert_same(emu.lbp_detect(casc, rnd.copy(), 4096, 1.2, 1.0, 3.0, 1), oracle.lbp_detect(casc, rnd, 4096, 1.2, 1.0, 3.0, 1),
+                        "non-integral table")
+        wrap = oracle.integral(np.full((70, 100), 255, np.uint8)) + np.uint32(0xfffffff0)  # wraps mod 2^32 inside the table
+        assert_same(emu.lbp_detect(cascade, wrap.copy(), 4096, 1.2, 1.0, 3.0, 1), oracle.lbp_detect(cascade, wrap, 4096, 1.2, 1.0, 3.0, 1),
+                    "table offset by a constant: not an integral image at its first row / column")
+    finally:
+        emu.tune(14, 0), emu.tune(15, 0)
+
+
+def test_lbp_prefilter_counters_and_group_exit(emu, oracle, cascade):
+    """the counting build: with the prefilter every window of a non-skipped scale group goes through k_lbp_dense
+    ([3]), the dword loads ([2]) are fewer than 16 per evaluated weak classifier ([1]) because table rows are
+    shared, and once a group of scales has reached the cap the prefilter of the later groups is skipped"""
+    edges = oracle.sobel(oracle.blur(Oracle.synth(352, 288, 1000), 2))
+    ii = oracle.integral(edges)
+    total = emu.lbp_window_count(cascade, 352, 288, 1.1, 1.0, 4.0, 1)
+
+    def run(cap, pre, group):
+        cnt = np.zeros(4, np.uint64)
+        emu.tune(14, pre), emu.tune(15, group)
+        emu.lbp_count_evaluated(cnt)
+        try:
+            r = emu.lbp_detect(cascade, ii.copy(), cap, 1.1, 1.0, 4.0, 1)
+        finally:
+            emu.lbp_count_evaluated(None)
+            emu.tune(14, 0), emu.tune(15, 0)
+        assert_same(r, oracle.lbp_detect(cascade, ii, cap, 1.1, 1.0, 4.0, 1), "cap %d pre %d group %d" % (cap, pre, group))
+        return [int(v) for v in cnt]
+    off = run(4096, -1, 0)
+    on = run(4096, 2, 0)
+    assert off[3] == 0 and off[2] == 16 * off[1] and off[0] == total
+    assert on[3] == total and on[0] == total
+    assert on[2] < 0.85 * off[2], (on, off)          # shared rows: fewer table loads (lane-level; the old dense phase also
+    assert on[1] == off[1]                            # issues its stage-1 gathers for waves with few live lanes) for the same classifiers
+    one = run(1, 2, 1)                                # every scale its own group: the cap is reached in the first
+    assert one[3] < 0.2 * total, one
+
+
 def test_lbp_cap_reached_in_early_scales(emu, oracle, cascade):
     """config-5 style input (sobel edge map): many hits, max_rects reached before the last scale --
     later scales are skipped on the GPU exactly because they cannot contribute (ref :819-823)"""
@@ -291,7 +351,7 @@ def test_lbp_chunk_granular_early_exit(emu, oracle, cascade):
     total = emu.lbp_window_count(cascade, 352, 288, 1.1, 1.0, 4.0, 1)
     evaluated = {}
     for cap in (1, 20, 60, 4096):
-        cnt = np.zeros(2, np.uint64)
+        cnt = np.zeros(4, np.uint64)
         emu.lbp_count_evaluated(cnt)
         try:
             r = emu.lbp_detect(cascade, ii.copy(), cap, 1.1, 1.0, 4.0, 1)

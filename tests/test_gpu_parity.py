@@ -499,6 +499,58 @@ def test_pipeline_chunk_overlap(hip, oracle):
         hip.use_torch_stream()
 
 
+def test_pipeline_chunk_ordering_big_batch_and_pinned_host_buffers(hip):
+    """the side stream is ordered against the caller's stream by events alone: every frame of a
+    multi-chunk batch equals the unsplit path -- on a batch big enough that chunks really overlap (128 x 1080p,
+    32-frame chunks) and with src / dst / thr in page-locked HOST memory (host-coherent buffers, where a missing
+    release would show first)"""
+    import ctypes as C
+    import torch
+    n, h, w = 128, 1080, 1920
+    src = torch.empty((n, h, w), dtype=torch.uint8, device="cuda")
+    hip.synth_batch(src, 777)
+    hist = torch.zeros((n, 256), dtype=torch.int32, device="cuda")
+    ref, tref = torch.zeros_like(src), torch.zeros(n, dtype=torch.uint8, device="cuda")
+    try:
+        hip.tune(5, -1)
+        hip.edge_pipeline_batch(ref, None, src, 2, hist, tref)
+        hip.sync()
+        hip.tune(5, 0)
+        for rep in range(3):
+            out, thr = torch.full_like(src, 9), torch.zeros(n, dtype=torch.uint8, device="cuda")
+            hip.edge_pipeline_batch(out, None, src, 2, hist, thr)
+            hip.sync()
+            bad = (out != ref).flatten(1).any(1).nonzero().flatten().tolist()
+            assert not bad and bool((thr == tref).all()), "32-frame chunks, call %d: frames %s differ" % (rep, bad[:8])
+        # page-locked host buffers, small frames, 8-frame chunks
+        m, hh, ww = 40, 96, 256
+        nb = m * hh * ww
+        hsrc, hdst, hthr = hip.c.gsh_host_alloc(nb), hip.c.gsh_host_alloc(nb), hip.c.gsh_host_alloc(m)
+        try:
+            a_src = np.ctypeslib.as_array(C.cast(hsrc, C.POINTER(C.c_uint8)), (m, hh, ww))
+            a_dst = np.ctypeslib.as_array(C.cast(hdst, C.POINTER(C.c_uint8)), (m, hh, ww))
+            a_thr = np.ctypeslib.as_array(C.cast(hthr, C.POINTER(C.c_uint8)), (m,))
+            small = src[:m, :hh, :ww].contiguous()
+            a_src[:] = small.cpu().numpy()
+            hs = torch.zeros((m, 256), dtype=torch.int32, device="cuda")
+            r2, t2 = torch.zeros_like(small), torch.zeros(m, dtype=torch.uint8, device="cuda")
+            hip.tune(5, -1)
+            hip.edge_pipeline_batch(r2, None, small, 2, hs, t2)
+            hip.sync()
+            for per in (8, 3):
+                hip.tune(5, per)
+                a_dst[:] = 5
+                a_thr[:] = 0
+                hip.c.gsh_edge_pipeline_batch(hdst, None, hsrc, ww, hh, m, 2, hs.data_ptr(), hthr)
+                hip.sync()
+                assert np.array_equal(a_dst, r2.cpu().numpy()) and np.array_equal(a_thr, t2.cpu().numpy()), \
+                    "pinned host buffers, %d-frame chunks" % per
+        finally:
+            hip.c.gsh_host_free(hsrc), hip.c.gsh_host_free(hdst), hip.c.gsh_host_free(hthr)
+    finally:
+        hip.tune(5, 0)
+
+
 def test_batch_integral_lbp_fast(hip, oracle, cascade):
     import torch
     n, h, w = 3, 480, 640
@@ -644,7 +696,7 @@ def test_config4_chain_on_one_4k_frame(hip, oracle, cascade):
     ii = torch.zeros((1, h, w), dtype=torch.int32, device="cuda")
     rects = torch.zeros((1, 4096, 4), dtype=torch.int32, device="cuda")
     counts = torch.zeros(1, dtype=torch.int32, device="cuda")
-    ev = torch.zeros(2, dtype=torch.int64, device="cuda")
+    ev = torch.zeros(4, dtype=torch.int64, device="cuda")
     dc = hip.cascade_create(cascade)
     hip.blur_batch(a, src, 2)
     hip.sobel_batch(b, a)

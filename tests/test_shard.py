@@ -117,3 +117,74 @@ def test_gloo_world2_sharded_pipeline_equals_oracle_on_every_frame():
     for rank, thr, sums in res:
         assert thr == exp_thr, "rank %d thresholds" % rank
         assert sums == exp_sum, "rank %d output hashes" % rank
+
+
+def _collectives_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from grayskull_amd.shard import Sharder, frame_range
+    sh = Sharder(backend="gloo")
+    blob = sh.broadcast_bytes(b"LBPC" + bytes(range(200)) if rank == 0 else b"", root=0)
+    total, cap = 5, 6
+    lo, hi = frame_range(rank, world, total)
+    counts = torch.tensor([(3 * f) % (cap + 1) for f in range(lo, hi)], dtype=torch.int32)
+    recs = torch.full((hi - lo, cap, 4), -1, dtype=torch.int32)        # rows past counts[f] hold junk (-1)
+    for i, f in enumerate(range(lo, hi)):
+        for k in range(int(counts[i])):
+            recs[i, k] = torch.tensor([f, k, f * 100 + k, 7])
+    call, rall = sh.gather_varlen(counts, recs, total)
+    ok = sh.min_over_ranks(1.0 if rank == 0 else 0.0)
+    q.put((rank, blob, call.tolist(), rall.tolist(), ok))
+    sh.close()
+
+
+def test_gloo_world2_cascade_broadcast_and_variable_length_gather():
+    """SURVEY 8(e) collectives (1) and (3): every rank ends up with rank 0's blob and with every frame's
+    result list, packed, in global frame order -- whatever the per-frame lengths are (incl. 0)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    ps = [ctx.Process(target=_collectives_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    exp_counts = [(3 * f) % 7 for f in range(5)]
+    exp_recs = [[f, k, f * 100 + k, 7] for f in range(5) for k in range(exp_counts[f])]
+    for rank, blob, call, rall, ok in res:
+        assert blob == b"LBPC" + bytes(range(200))
+        assert call == exp_counts and rall == exp_recs
+        assert ok == 0.0
+
+
+def test_forced_world1_uses_the_same_collectives(monkeypatch):
+    """GS_BENCH_FORCE_DIST=1: a process group even at world 1 (gloo here, nccl == RCCL on the GPU box)"""
+    from grayskull_amd.shard import Sharder
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("GS_BENCH_FORCE_DIST", "1")
+    sh = Sharder(backend="gloo")
+    try:
+        assert sh.dist is not None and sh.world == 1 and sh.backend == "gloo" and sh.ranks_seen() == 1
+        assert sh.broadcast_bytes(b"abc") == b"abc"
+        c, r = sh.gather_varlen(torch.tensor([2, 0, 1]), torch.arange(3 * 4 * 2).reshape(3, 4, 2), 3)
+        assert c.tolist() == [2, 0, 1] and r.tolist() == [[0, 1], [2, 3], [16, 17]]
+        assert sh.all_gather_frames(torch.tensor([5, 6, 7]), 3).tolist() == [5, 6, 7]
+    finally:
+        sh.close()
+
+
+def test_cascade_roundtrips_through_bytes():
+    from grayskull_amd.cascade import Cascade
+    path = os.path.join(ROOT, "tests", "golden", "frontalface_cascade.bin")
+    raw = open(path, "rb").read()
+    a, b = Cascade.from_blob(path), Cascade.from_bytes(raw)
+    assert (a.nfeatures, a.nweaks, a.nstages) == (b.nfeatures, b.nweaks, b.nstages) == (136, 139, 20)
+    assert bytes(a.subsets) == bytes(b.subsets) and bytes(a.stage_threshold) == bytes(b.stage_threshold)
+    with pytest.raises(ValueError):
+        Cascade.from_bytes(raw[:1000])
+    with pytest.raises(ValueError):
+        Cascade.from_bytes(b"nope")
