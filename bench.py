@@ -105,23 +105,29 @@ def cpu_baseline(w, h, radius, frames_target=48):
     from oracle import pyoracle
     kind = "reference" if pyoracle.have_reference() else "port"
     cores = usable_cores()
-    per = max(1, frames_target // cores)
+    per = max(2, frames_target // cores)
     frames = per * cores
     imgs = [pyoracle.Oracle.synth(w, h, 1000 + i) for i in range(min(cores, 16))]  # shared, read-only
+    oracles = [pyoracle.Oracle(kind) for _ in range(cores)]  # library handles made outside the timed region
+    gate = threading.Barrier(cores + 1)
 
-    def work(i, n):
-        o = pyoracle.Oracle(kind)  # ctypes releases the GIL inside the C calls
+    def chain(o, img, n):  # ctypes releases the GIL inside the C calls
         for _ in range(n):
-            s = o.sobel(o.blur(imgs[i % len(imgs)], radius))
+            s = o.sobel(o.blur(img, radius))
             o.threshold(s, o.otsu_threshold(s))
 
+    def work(i):
+        gate.wait()
+        chain(oracles[i], imgs[i % len(imgs)], per)
+
     t0 = time.time()
-    work(0, 2)
+    chain(oracles[0], imgs[0], 2)
     dt1 = time.time() - t0
-    ths = [threading.Thread(target=work, args=(i, per)) for i in range(cores)]
-    t0 = time.time()
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
     for t in ths:
         t.start()
+    gate.wait()  # every thread exists and waits: the clock starts with the work
+    t0 = time.time()
     for t in ths:
         t.join()
     dt = time.time() - t0

@@ -21,6 +21,7 @@
 
 #include "k_box.h"
 #include "k_fast.h"
+#include "k_fast_nms.h"
 #include "k_geom.h"
 #include "k_integral.h"
 #include "k_lbp.h"
@@ -269,11 +270,15 @@ dim3 grid2d(unsigned w, unsigned h, unsigned n) { return dim3((w + 63) / 64, (h 
 inline bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 /* ---- launch tuning (gsh_tune): 0 rows per band (0 = auto), 1 block shape, 2 prefetch depth */
-int g_tune[16] = {0, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+int g_tune[20] = {0, 3, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 /* gsh_lbp_count_evaluated: device counter that receives the windows the cascade really evaluated */
 thread_local unsigned long long *g_lbp_evaluated = nullptr;
 
-struct StripCfg { dim3 grid, block; unsigned T; };
+struct StripCfg {
+  dim3 grid, block;
+  unsigned T;
+  size_t xcd_flag = 0; /* OR into the kernel's frame_bytes argument: XCD-aware band mapping (k_strip.h) */
+};
 /* rows: output rows per frame.  One wave per (1024-px column block, band, frame).
  * HBM-bound per-call kernels (waves_per_simd >= 5) take SHORT bands of 8 rows (more for wide halos):
  * blocks are dispatched in band order, so the few thousand waves that are resident at any time work
@@ -320,11 +325,24 @@ StripCfg strip_cfg(unsigned w, unsigned rows, unsigned n, unsigned waves_per_sim
   }
   c.T = (unsigned)t;
   const unsigned nb = (rows + c.T - 1) / c.T;
+  /* block shape: 256 threads = 4 waves; a wave is 1024 px of a row.  Frames narrower than 4096 px put the spare
+   * waves on further BANDS (64 x 4 up to 1024 px, 128 x 2 up to 2048 px) instead of columns that do not exist --
+   * a 1920-px row kept two of a 256 x 1 block's four waves busy computing on zero fill (8 x 1080p gs_sobel at 0.21
+   * of the HBM peak).  Key 1: 0 / 1 / 2 force 64 x 4 / 256 x 1 / 128 x 2, anything else = by width. */
   unsigned bx = 256, by = 1;
-  if (g_tune[1] == 0) bx = 64, by = 4;
-  else if (g_tune[1] == 2) bx = 128, by = 2;
+  if (g_tune[1] == 0 || (g_tune[1] > 2 && strips <= 64)) bx = 64, by = 4;
+  else if (g_tune[1] == 2 || (g_tune[1] > 2 && strips <= 128)) bx = 128, by = 2;
   c.block = dim3(bx, by);
   c.grid = dim3((strips + bx - 1) / bx, (nb + by - 1) / by, n);
+  /* XCD-aware band mapping for the short-band (HBM-bound) kernels: one block per band row (w <= 4096), the band
+   * count padded to a multiple of 8 (blocks past the last band return at once).  Key 18: 1 = off, 2 = always. */
+  /* measured (profiles/r03g_strip_xcd_bands.log): 512 x 4K gs_blur(2) +3.1 %, gs_erode +2.6 %, gs_sobel +2.0 %,
+   * 64 x 4096^2 copy +2 %, sobel -1 % (noise); gs_filter (waves_per_simd 6) -3.5 %: not for that one */
+  const bool want = g_tune[18] == 2 || (g_tune[18] == 0 && waves_per_simd == 5 && nb >= 64);
+  if (want && c.grid.x == 1 && by == 1) {
+    c.grid.y = (nb + 7u) & ~7u;
+    c.xcd_flag = kStripXcdFlag;
+  }
   return c;
 }
 inline bool strip_ok(unsigned w, unsigned h, const void *a, const void *b) {
@@ -350,8 +368,8 @@ void launch_sobel(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsi
     const uint8_t *s = src + fb * f0;
     if (strip_ok(w, h, d, s) && w >= 32) {
       const StripCfg c = strip_cfg(w, h - 2, nn);
-      if (keep_cols) GS_LAUNCH(k_sobel16<true>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb);
-      else GS_LAUNCH(k_sobel16<false>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb);
+      if (keep_cols) GS_LAUNCH(k_sobel16<true>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
+      else GS_LAUNCH(k_sobel16<false>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
     } else {
       GS_LAUNCH(k_sobel_px, grid2d(w, h, nn), dim3(64, 4), 0, st, d, s, w, h, fb);
     }
@@ -369,7 +387,7 @@ void launch_morph(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsi
     const uint8_t *s = src + fb * f0;
     if (strip_ok(w, h, d, s)) {
       const StripCfg c = strip_cfg(w, h, nn);
-      GS_LAUNCH(k_morph16<DILATE>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb);
+      GS_LAUNCH(k_morph16<DILATE>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
     } else {
       GS_LAUNCH(k_morph_px<DILATE>, grid2d(w, h, nn), dim3(64, 4), 0, st, d, s, w, h, fb);
     }
@@ -476,9 +494,9 @@ void launch_blur(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsig
       const StripCfg c = strip_cfg(w, h, nn, 5, 2 * radius);
       uint8_t *d = dst + fb * f0;
       const uint8_t *s = src + fb * f0;
-      if (radius == 1) GS_LAUNCH(k_blur16<1>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb);
-      else if (radius == 2) GS_LAUNCH(k_blur16<2>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb);
-      else GS_LAUNCH(k_blur16<3>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb);
+      if (radius == 1) GS_LAUNCH(k_blur16<1>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
+      else if (radius == 2) GS_LAUNCH(k_blur16<2>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
+      else GS_LAUNCH(k_blur16<3>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
       /* the 2*radius vertically clipped rows of each frame get their true divisors */
       GS_LAUNCH(k_blur_edge_rows, dim3((w + 255) / 256, 2 * radius, nn), dim3(256), 0, st, d, s, w, h,
                 (int)radius, fb);
@@ -629,9 +647,29 @@ void launch_fast(const uint8_t *img, uint8_t *score, unsigned w, unsigned h, uns
     return;
   }
   const size_t fb = (size_t)w * h;
+  launch_fast_score(st, img, score, w, h, n, threshold);
+  /* pass 2 in strip form (k_fast_nms.h) when the score map qualifies for the strip machinery: items numbered over
+   * rows padded to whole mask words.  Key 19 = 1: the item-by-item kernel k_fast_nms (round 2). */
+  if (g_tune[19] != 1 && strip_ok(w, h, score, score) && w >= 32 && (unsigned long long)((w + 63) / 64) * 64 * h < (1ull << 32)) {
+    const unsigned wpr = (w + 63) / 64, nwords = wpr * h, nchunks = (nwords + kChunkWords - 1) / kChunkWords;
+    unsigned long long *mask = (unsigned long long *)ctx().scratch(SL_MASK, (size_t)n * nchunks * kChunkWords * 8);
+    unsigned *cnt = (unsigned *)ctx().scratch(SL_CNT, (size_t)n * nchunks * 4);
+    unsigned *pfx = (unsigned *)ctx().scratch(SL_PFX, (size_t)n * nchunks * 4);
+    if (clip_w && n == 1 && (clip_w < w || clip_h < h))
+      GS_LAUNCH(k_fast_clip, grid2d(w, h, 1), dim3(64, 4), 0, st, score, w, h, clip_w, clip_h);
+    GS_HIP(hipMemsetAsync(cnt, 0, (size_t)n * nchunks * 4, st));
+    for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
+      const unsigned nn = std::min(kMaxZ, n - f0);
+      const StripCfg c = strip_cfg(w, h - 6, nn);
+      GS_LAUNCH(k_fast_nms16, c.grid, c.block, 0, st, (const uint8_t *)score + fb * f0, w, h, c.T, fb | c.xcd_flag,
+                mask + (size_t)f0 * nchunks * kChunkWords, cnt + (size_t)f0 * nchunks, wpr, nchunks);
+    }
+    run_compaction(mask, cnt, nchunks, n, nkps, counts,
+                   FastEmitPadded{score, w, wpr * 64u, fb, kps, nkps, ((uintptr_t)kps & 15) == 0}, st, pfx);
+    return;
+  }
   const unsigned nitems = (w - 6) * (h - 6);
   const unsigned nchunks = (nitems + kChunkItems - 1) / kChunkItems;
-  launch_fast_score(st, img, score, w, h, n, threshold);
   unsigned long long *mask =
       (unsigned long long *)ctx().scratch(SL_MASK, (size_t)n * nchunks * kChunkWords * 8);
   unsigned *cnt = (unsigned *)ctx().scratch(SL_CNT, (size_t)n * nchunks * 4);
@@ -807,6 +845,7 @@ void launch_lbp_padded(const gsh_cascade *dc, const LbpGeomCache &gc, const unsi
   a.ngroups = ngroups, a.nsupers = nsupers;
   a.evaluated = g_lbp_evaluated;
   a.nscales = nsc0, a.cap = max_rects;
+  a.nwindows_cap = (unsigned)std::min<unsigned long long>(gc.nwindows, 0xffffffffull);
   a.padded = padded;
   a.frame_stride = (size_t)(iw + 1) * (ih + 1);
   a.S = iw + 1;
@@ -856,7 +895,8 @@ void launch_lbp_padded(const gsh_cascade *dc, const LbpGeomCache &gc, const unsi
     /* preset 0 (default): first re-packing point chosen per block between stages 2 and 8 (k_lbp.h) */
     ph.adaptive_max = (g_tune[4] == 0 && dc->nstages > 2) ? 8u : 0u; /* 6 .. 15 within 1.5 % (profiles/r02l_lbp_adaptive_xcd.log) */
     ph.adaptive_tenths = 2u;
-    ph.adaptive_next[0] = 2u, ph.adaptive_next[1] = 5u, ph.adaptive_next[2] = 0u;
+    ph.quad = g_tune[17] == 1 ? 0u : 1u; /* key 17 = 1: one lane per re-packed window (the round-2 form) */
+    ph.adaptive_next[0] = 1u, ph.adaptive_next[1] = 3u, ph.adaptive_next[2] = 6u; /* with quad-lane survivors: profiles/r03f_lbp_adaptive_quad.log */
     if (ph.adaptive_max && g_tune[9] > 0) { /* experiments: key 9 = max + 16 * tenths (+ 256 d1 + 4096 d2 + 65536 d3: later points) */
       const unsigned v = (unsigned)g_tune[9];
       ph.adaptive_max = v & 15u, ph.adaptive_tenths = (v >> 4) & 15u;
@@ -864,17 +904,20 @@ void launch_lbp_padded(const gsh_cascade *dc, const LbpGeomCache &gc, const unsi
     }
   }
   const size_t lds_all = ((lds + 15) & ~(size_t)15) + 2 * kChunkItems * 2 + 64 * 4 + 16;
-  /* Prefilter (k_lbp_dense.h): stages [0, pre) for every window with the table rows shared down the columns of
-   * 64 x 64-window tiles; the cascade kernel then starts from the surviving set.  Key 14: 0 = default (2 stages),
-   * -1 = off, k = that many stages.  Needs unit step, in-window geometry, the adaptive preset and stages of
-   * <= 5 weak classifiers.
+  /* Prefilter (k_lbp_dense.h, OPTIONAL, key 14 = k > 0: that many stages; default off): stages [0, pre) for every
+   * window with the table rows shared down the columns of 64 x 64-window tiles; the cascade kernel then starts from
+   * the surviving set.  Needs unit step, in-window geometry, the adaptive preset and stages of <= 5 weak classifiers.
+   * Measured (profiles/r03a_lbp_prefilter_first.log, r03d_pmc_lbp.txt): 2.8x fewer gather instructions per weak
+   * classifier, but 0.22 ms per classifier and 4K frame against 0.18 for the dense phase of k_lbp_cascade -- ~1000
+   * tiles per XCD walk 64-row bands of the table at once, half their L2 requests miss (the cascade kernel's chunks
+   * stay inside a 3 MB band: 1 % misses) and the texture path stalls on pending misses half the time.
    * The prefilter cannot see detections of its own launch, so the scales are issued in GROUPS (prefilter, then
    * cascade, group after group on the stream): a group's tiles skip once the groups before it hold max_rects
    * detections -- the reference stops scanning there (ref :819-823) -- while the chunk-granular exit inside the
    * cascade kernel stays as it was.  A group is at least ~16 M windows (key 15 overrides, a test hook), so a
    * launch always fills the chip: 8 x 4K = one scale per group, one 1080p frame = two groups. */
   const int k14 = g_tune[14] >= 100 ? g_tune[14] - 100 : g_tune[14];
-  unsigned pre = k14 < 0 ? 0u : k14 > 0 ? (unsigned)k14 : 2u;
+  unsigned pre = k14 > 0 ? (unsigned)k14 : 0u; /* off by default: measured slower than the dense phase it replaces (see above) */
   pre = std::min(pre, std::min(dc->pre_max, dc->nstages > 0 ? dc->nstages - 1u : 0u));
   if (step != 1 || gc.guard || !ph.adaptive_max || !gc.d_pre || !dc->d_pass_lut || a.frame_stride * 4 >= (1ull << 31)) pre = 0;
   LbpPreArgs pa;
@@ -915,6 +958,7 @@ void launch_lbp_padded(const gsh_cascade *dc, const LbpGeomCache &gc, const unsi
     else GS_LAUNCH(k_lbp_cascade<false>, g, dim3(256), lds_all, st, a, ph);
     s0 = s1;
   }
+  if (g_tune[16] == 1) return; /* timing aid (scripts/bench_lbp_stages.py): the cascade kernels alone, no rect emission */
   run_compaction(mask, cnt, nch, n, max_rects, counts,
                  LbpEmit{gc.d_scales, (unsigned)gc.scales.size(), step, rects, max_rects});
 }
@@ -1151,12 +1195,12 @@ unsigned gsh_profile_read(double *total_ms) {
   return n;
 }
 void gsh_tune(int key, int value) {
-  if (key >= 0 && key < 16) g_tune[key] = value;
+  if (key >= 0 && key < 20) g_tune[key] = value;
 }
 void gsh_probe_strip_copy(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned n) {
   GS_ASSERT(dst && src && w % 16 == 0 && al16(dst) && al16(src));
   const StripCfg c = strip_cfg(w, h, n);
-  GS_LAUNCH(k_strip_copy, c.grid, c.block, 0, ctx().s(), dst, src, w, h, c.T, (size_t)w * h);
+  GS_LAUNCH(k_strip_copy, c.grid, c.block, 0, ctx().s(), dst, src, w, h, c.T, (size_t)w * h | c.xcd_flag);
 }
 void gsh_probe_fast_score(uint8_t *score, const uint8_t *img, unsigned w, unsigned h, unsigned n, unsigned threshold) {
   GS_ASSERT(score && img && w >= 7 && h >= 7 && n >= 1 && n <= kMaxZ);
@@ -1442,6 +1486,7 @@ void gsh_cascade_destroy(gsh_cascade *dc) {
   if (it != ctx().geom_cache.end()) {
     if (it->second.d_scales) (void)hipFree(it->second.d_scales);
     if (it->second.d_geom) (void)hipFree(it->second.d_geom);
+    if (it->second.d_pre) (void)hipFree(it->second.d_pre);
     ctx().geom_cache.erase(it);
   }
   gsh_cascade_tables_deleter()(dc);
@@ -1681,7 +1726,7 @@ void gsh_filter_batch(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, 
     for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
       const unsigned nn = std::min(kMaxZ, n - f0);
       const StripCfg c = strip_cfg(w, h, nn, 6);
-      GS_LAUNCH(k_filter16, c.grid, c.block, 0, st, dst + fb * f0, src + fb * f0, w, h, c.T, fb, fk);
+      GS_LAUNCH(k_filter16, c.grid, c.block, 0, st, dst + fb * f0, src + fb * f0, w, h, c.T, fb | c.xcd_flag, fk);
     }
     return;
   }

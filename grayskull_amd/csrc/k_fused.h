@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) GS_FUSED_VGPR_ATTR void k_blur_sobel_hist16(ui
   }
   const Strip<> S(src, dst, w, h, frame_bytes);
   const int y0 = 1 + (int)(S.band * T);
-  if (y0 < (int)h - 1) { /* wave-uniform; no early return: every wave reaches the barrier */
+  if (y0 < (int)h - 1 && !S.wave_outside()) { /* wave-uniform; no early return: every wave reaches the barrier */
     const int nrows = ((int)h - 1 - y0) < (int)T ? ((int)h - 1 - y0) : (int)T;
     const bool first = S.x0 == 0, last = S.x0 + 16 == w, inimg = S.x0 < w;
     /* N+1 ring slots: the new row lands in the free slot and the unroll period N+1 is even, so

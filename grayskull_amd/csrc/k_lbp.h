@@ -61,6 +61,7 @@ struct LbpArgs {
   unsigned scale0;              /* first scale of this launch (blockIdx.y counts from it) */
   unsigned ngroups, nsupers;
   unsigned nscales, cap;        /* cap = max_rects */
+  unsigned nwindows_cap;        /* min(windows of the whole scan, 2^32 - 1): a cap >= this can never be reached */
   unsigned xcd_swizzle;         /* 1: chunk = (blockIdx.x % 8) * ceil(nchunks / 8) + blockIdx.x / 8 */
   unsigned long long *evaluated; /* optional (COUNT kernels): [0] += windows of every chunk that was not
                                     skipped, [1] += weak classifiers evaluated, summed over windows, [2] += dword
@@ -184,6 +185,68 @@ GS_DEV bool lbp_window_stages(const LbpLds &t, const unsigned *Pg, unsigned orig
   return true;
 }
 
+/* The same stages with FOUR lanes per window (a DPP quad): lane ci of the quad loads column ci of the 4 x 4 corner
+ * grid, one gather instruction per grid ROW.  Why: the cascade is bound by the texture path (TA busy 95 %,
+ * profiles/r03d_pmc_lbp.txt), which pays per 64-byte line a gather touches once the lanes scatter -- and re-packed
+ * survivors do: one window per lane makes every gather visit 64 unrelated places (~27 TA cycles per gather in the
+ * survivor phases against ~4 in the dense phase), although the four corners of one window's grid row lie only
+ * 3 fw dwords apart, mostly inside one or two lines.  With a quad per window a gather covers 16 windows x one grid
+ * row: the same 16 gather instructions per 64 windows and classifier, but 16 x (1..4) lines each instead of up
+ * to 64.  The cells come from the neighbour lane through quad_perm (c = D[lane + 1] - D[lane]), the centre is
+ * broadcast from lane 1, every lane contributes the code bits of its column and two quad ORs assemble the code;
+ * the lookup and the float sum run redundantly in all four lanes, so the quad decides as one.
+ * Control flow stays wave-uniform (a dead quad's loads are masked, its arithmetic runs on garbage): `live` says
+ * whether this lane's window exists; returns the window's verdict in all four lanes. */
+template <bool GUARD, bool COUNT = false>
+GS_DEV bool lbp_quad_stages(const LbpLds &t, const unsigned *Pg, unsigned origin, unsigned ci, bool live,
+                            unsigned limit, unsigned s0, unsigned s1, unsigned *evals = nullptr) {
+  /* code bit of this lane's cell in the top / middle / bottom cell row (tl tc tr r br bc bl l = bits 7..0,
+   * ref :780-782); lane 1's middle cell is the centre, lane 3 holds no cell */
+  const unsigned sh0 = ci == 0u ? 7u : ci == 1u ? 6u : 5u, sh1 = ci == 0u ? 0u : 4u, sh2 = ci == 0u ? 1u : ci == 1u ? 2u : 3u;
+  const unsigned use02 = ci < 3u ? 1u : 0u, use1 = (ci == 0u || ci == 2u) ? 1u : 0u;
+  const unsigned wend = uniform(t.stage[s1 - 1].first) + uniform(t.stage[s1 - 1].count);
+  unsigned wi = uniform(t.stage[s0].first);
+  bool alive = live;
+  auto gather = [&](unsigned w, unsigned (&G)[4]) {
+    const LbpGeom g = t.geom[w];
+    const unsigned col = origin + uniform((unsigned)g.off0) + ci * uniform((unsigned)g.fw), fhs = uniform((unsigned)g.fh_stride);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      unsigned idx = col + (unsigned)j * fhs;
+      if (GUARD) idx = idx > limit ? limit : idx;
+      G[j] = *(const unsigned *)((const char *)Pg + idx);
+    }
+  };
+  unsigned q[4] = {0, 0, 0, 0};
+  if (alive) gather(wi, q);
+  for (unsigned s = s0; s < s1; s++) {
+    const LbpStage st = t.stage[s];
+    const unsigned count = uniform(st.count);
+    float sum = 0.0f;
+    for (unsigned k = 0; k < count; k++, wi++) {
+      const unsigned G0 = q[0], G1 = q[1], G2 = q[2], G3 = q[3];
+      if constexpr (COUNT) {
+        if (alive && ci == 0u) ++*evals;
+      }
+      const LbpWeak wk = t.weak[wi];
+      if (wi + 1u < wend && alive) gather(wi + 1u, q); /* the next classifier's corners fly during this one's arithmetic */
+      const unsigned D0 = G1 - G0, D1 = G2 - G1, D2 = G3 - G2;
+      const unsigned c0 = quad_perm<1, 2, 3, 3>(D0) - D0, c1 = quad_perm<1, 2, 3, 3>(D1) - D1, c2 = quad_perm<1, 2, 3, 3>(D2) - D2;
+      const unsigned ctr = quad_perm<1, 1, 1, 1>(c1);
+      unsigned code = ((c0 >= ctr ? use02 : 0u) << sh0) | ((c1 >= ctr ? use1 : 0u) << sh1) | ((c2 >= ctr ? use02 : 0u) << sh2);
+      code |= quad_perm<1, 0, 3, 2>(code);
+      code |= quad_perm<2, 3, 0, 1>(code);
+      const unsigned word = code >> 5, bit = code & 31u;
+      bool hit = false;
+      if (word < wk.nsub) hit = ((uint32_t)t.subsets[wk.sub_off + word] >> bit) & 1u;
+      sum += hit ? wk.left : wk.right;
+    }
+    if (sum < st.threshold) alive = false;
+    if (!ballot(alive)) break; /* wave-uniform */
+  }
+  return alive;
+}
+
 GS_DEV unsigned lbp_origin(const LbpArgs &a, const LbpScale &sc, unsigned idx) {
   const unsigned yi = idx / sc.nx, xi = idx - yi * sc.nx;
   return ((yi * (unsigned)a.step) * a.S + xi * (unsigned)a.step) * 4u;
@@ -215,6 +278,7 @@ struct LbpPhases { /* phase p = stages [end[p-1], end[p]) */
   unsigned adaptive_max;
   unsigned adaptive_tenths; /* re-pack once alive <= tenths/10 of the chunk */
   unsigned adaptive_next[3]; /* later re-packing points, in stages after the first one (0 = none) */
+  unsigned quad;             /* 1: re-packed survivors are evaluated four lanes per window (lbp_quad_stages) */
 };
 
 /* grid (max chunks per scale, nscales, n frames), block 256;
@@ -344,8 +408,8 @@ __global__ __launch_bounds__(256) void k_lbp_cascade(LbpArgs a, LbpPhases ph) {
           }
           __syncthreads();
           n_in = qn[cur ^ 1u];
+          if (tid == 0) qn[cur] = 0; /* nobody reads it any more; cleared BEFORE the barrier that releases the next phase's adds */
           __syncthreads();
-          if (tid == 0) qn[cur] = 0;
           cur ^= 1u;
         }
         break;
@@ -366,6 +430,27 @@ __global__ __launch_bounds__(256) void k_lbp_cascade(LbpArgs a, LbpPhases ph) {
     const bool lastp = p + 1 == np;
     const uint16_t *qin = queue + cur * kChunkItems;
     uint16_t *qout = queue + (cur ^ 1u) * kChunkItems;
+    if (ph.quad && p > 0u) { /* re-packed survivors: a quad of lanes per window, 64 windows per block iteration */
+      for (unsigned i0 = 0; i0 < n_in; i0 += 64u) { /* block-uniform trip count */
+        const unsigned i = i0 + (tid >> 2), ci = tid & 3u;
+        const bool live = i < n_in;
+        const unsigned local = qin[live ? i : n_in - 1u];
+        const bool pass = lbp_quad_stages<GUARD, COUNT>(t, Pg, lbp_origin(a, sc, first + local), ci, live, a.limit_bytes, s0, s1, &evals);
+        const bool lead = pass && ci == 0u;
+        if (lastp) {
+          if (lead) atomicOr(&bits[local >> 5], 1u << (local & 31u));
+        } else {
+          const uint64_t m = ballot(lead);
+          if (m) {
+            const unsigned lane = lane_id();
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(&qn[cur ^ 1u], (unsigned)__popcll(m));
+            base = readlane0(base);
+            if (lead) qout[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)local;
+          }
+        }
+      }
+    } else
     for (unsigned i0 = 0; i0 < n_in; i0 += 256u) { /* block-uniform trip count */
       const unsigned i = i0 + tid;
       bool pass = false;
@@ -390,8 +475,10 @@ __global__ __launch_bounds__(256) void k_lbp_cascade(LbpArgs a, LbpPhases ph) {
     __syncthreads();
     if (!lastp) {
       n_in = qn[cur ^ 1u];
+      /* this phase's input counter becomes the output counter of the next phase: cleared before the barrier that
+       * lets the next phase's atomics start (cleared behind it, a fast wave's first add could be wiped) */
+      if (tid == 0) qn[cur] = 0;
       __syncthreads();
-      if (tid == 0) qn[cur] = 0; /* becomes the output counter of the phase after next */
       cur ^= 1u;
       if (n_in == 0) break; /* block-uniform */
     }
@@ -409,9 +496,12 @@ __global__ __launch_bounds__(256) void k_lbp_cascade(LbpArgs a, LbpPhases ph) {
     c = wave_sum(c);
     if (tid == 0 && c) { /* hits are rare: few atomics */
       a.chunk_count[chunk] = c;
-      atomicAdd(&a.hits_group[(size_t)blockIdx.z * a.ngroups + (lin >> kLbpGroupShift)], c);
-      atomicAdd(&a.hits_super[(size_t)blockIdx.z * a.nsupers + (lin >> kLbpSuperShift)], c);
-      atomicAdd(&a.hits_total[blockIdx.z], c);
+      if (a.cap < a.nwindows_cap) { /* a cap no scan can reach needs no early-exit bookkeeping (thousands of chunks
+                                       adding to ONE counter serialise: +1.4 ms per 4K frame when every chunk has hits) */
+        atomicAdd(&a.hits_group[(size_t)blockIdx.z * a.ngroups + (lin >> kLbpGroupShift)], c);
+        atomicAdd(&a.hits_super[(size_t)blockIdx.z * a.nsupers + (lin >> kLbpSuperShift)], c);
+        atomicAdd(&a.hits_total[blockIdx.z], c);
+      }
     }
   }
   if constexpr (COUNT) { /* measurement build of the kernel (gsh_lbp_count_evaluated) */

@@ -27,6 +27,8 @@
  */
 #ifndef GS_K_LBP_DENSE_H
 #define GS_K_LBP_DENSE_H
+#include <utility>
+
 #include "k_lbp.h"
 
 namespace gs {
@@ -42,7 +44,14 @@ struct LbpPreArgs {
   unsigned xcd_swizzle;
 };
 
-struct LbpRowRing { unsigned G[3][4], R[3][3]; };
+/* Rows in flight ahead of the arithmetic.  The table of a 4K frame (33 MB) does not stay in an XCD's 4 MB L2 while
+ * ~1000 tiles per XCD walk it, so a row comes from the Infinity Cache / HBM (~0.7 us): with one row ahead the
+ * kernel sat on that latency (204 SIMD-cycles per step against ~96 of VALU work, first measurement of round 3). */
+#ifndef GS_LBP_DENSE_PD
+#define GS_LBP_DENSE_PD 2
+#endif
+constexpr int kPreRing = GS_LBP_DENSE_PD + 2; /* raw rows t-1, t, t+1 .. t+PD; the walk is unrolled by this */
+struct LbpRowRing { unsigned G[kPreRing][4], R[kPreRing][3]; };
 
 /* the 4 corners of one table row of this residue class: 64 consecutive dwords per gather.  Buffer loads: the
  * lane's constant column offset is the VGPR offset, everything else -- tile row, residue class, feature offset,
@@ -89,15 +98,17 @@ GS_DEV unsigned lbp_code8(const unsigned (&n)[8], unsigned ctr, bool small_cells
   return code;
 }
 
-/* one step of the walk: row `tstep` is in slot NEW, row tstep-1 in PRV; prefetch row tstep+1 into NXT, form
- * cell row tstep-1, and evaluate window tstep-3 of the class from cell rows tstep-3 (slot NEW), tstep-2 (NXT),
- * tstep-1 (PRV) */
+/* one step of the walk: row `tstep` is in slot NEW, row tstep-1 in PRV; prefetch row tstep+PD into the slot row
+ * tstep-2 just left, form cell row tstep-1, and evaluate window tstep-3 of the class from cell rows tstep-3,
+ * tstep-2, tstep-1 */
 template <int U, bool SMALL>
 GS_DEV void lbp_dense_step(LbpRowRing &q, const LbpLds &t, const LbpTable &T, unsigned base, unsigned tstep, unsigned last,
                            unsigned nwin, unsigned fhS, unsigned colB, unsigned fwB, unsigned r, unsigned fh,
                            unsigned sub_off, unsigned nsub, uint64_t rowany, uint64_t &bits) {
-  constexpr int NEW = (1 + U) % 3, PRV = (NEW + 2) % 3, NXT = (NEW + 1) % 3;
-  lbp_dense_load<NXT>(q, T, base, tstep + 1, last, fhS, colB, fwB);
+  /* step t = 1 + kPreRing * q + U: raw row t in slot t % ring, cell row c in slot c % ring */
+  constexpr int NG = kPreRing, NEW = (1 + U) % NG, PRV = (NEW + NG - 1) % NG, FAR = (NEW + GS_LBP_DENSE_PD) % NG;
+  constexpr int TOP = (NEW + NG - 3) % NG, MID = (NEW + NG - 2) % NG; /* cell rows t-3, t-2; t-1 goes to PRV */
+  lbp_dense_load<FAR>(q, T, base, tstep + GS_LBP_DENSE_PD, last, fhS, colB, fwB);
   unsigned V[4]; /* vertical differences first: 4 + 3 subtractions per cell row */
 #pragma unroll
   for (int i = 0; i < 4; i++) V[i] = q.G[NEW][i] - q.G[PRV][i];
@@ -106,9 +117,9 @@ GS_DEV void lbp_dense_step(LbpRowRing &q, const LbpLds &t, const LbpTable &T, un
   if (tstep >= 3u && tstep - 3u < nwin) { /* wave-uniform */
     const unsigned ybit = r + (tstep - 3u) * fh;
     if ((rowany >> ybit) & 1ull) { /* some lane's window of this row is still alive */
-      const unsigned nb[8] = {q.R[NEW][0], q.R[NEW][1], q.R[NEW][2], q.R[NXT][2],
-                              q.R[PRV][2], q.R[PRV][1], q.R[PRV][0], q.R[NXT][0]};
-      const unsigned code = lbp_code8(nb, q.R[NXT][1], SMALL);
+      const unsigned nb[8] = {q.R[TOP][0], q.R[TOP][1], q.R[TOP][2], q.R[MID][2],
+                              q.R[PRV][2], q.R[PRV][1], q.R[PRV][0], q.R[MID][0]};
+      const unsigned code = lbp_code8(nb, q.R[MID][1], SMALL);
       /* subset bit, branch-free: words past the classifier's subset count read word 0 and are masked */
       const unsigned word = code >> 5;
       const unsigned v = (uint32_t)t.subsets[sub_off + (word < nsub ? word : 0u)];
@@ -116,6 +127,18 @@ GS_DEV void lbp_dense_step(LbpRowRing &q, const LbpLds &t, const LbpTable &T, un
       bits |= (uint64_t)hit << ybit;
     }
   }
+}
+
+template <int... I>
+GS_DEV void lbp_dense_prologue(LbpRowRing &q, const LbpTable &T, unsigned base, unsigned last, unsigned fhS, unsigned colB,
+                               unsigned fwB, std::integer_sequence<int, I...>) {
+  (lbp_dense_load<I>(q, T, base, (unsigned)I, last, fhS, colB, fwB), ...); /* rows 0 .. PD */
+}
+template <bool SMALL, int... U>
+GS_DEV void lbp_dense_steps(LbpRowRing &q, const LbpLds &t, const LbpTable &T, unsigned base, unsigned tstep, unsigned last,
+                            unsigned nwin, unsigned fhS, unsigned colB, unsigned fwB, unsigned r, unsigned fh,
+                            unsigned sub_off, unsigned nsub, uint64_t rowany, uint64_t &bits, std::integer_sequence<int, U...>) {
+  (lbp_dense_step<U, SMALL>(q, t, T, base, tstep + (unsigned)U, last, nwin, fhS, colB, fwB, r, fh, sub_off, nsub, rowany, bits), ...);
 }
 
 /* weak classifier wi for every window of the tile: bit y of the result = match of window row y0 + y */
@@ -134,14 +157,11 @@ GS_DEV uint64_t lbp_dense_weak(const LbpLds &t, const LbpTable &T, unsigned wi, 
     const unsigned last = nwin + 2u;                  /* they need table rows 0 .. nwin + 2 of the class */
     const unsigned base = tile_rowB + r * rowB + off0; /* byte offset in the frame's table (< 2 GiB, launcher) */
     LbpRowRing q;
-    lbp_dense_load<0>(q, T, base, 0u, last, fhS, colB, fwB);
-    lbp_dense_load<1>(q, T, base, 1u, last, fhS, colB, fwB);
-    for (unsigned tstep = 1u; tstep <= last; tstep += 3u) {
-      lbp_dense_step<0, SMALL>(q, t, T, base, tstep, last, nwin, fhS, colB, fwB, r, fh, sub_off, nsub, rowany, bits);
-      lbp_dense_step<1, SMALL>(q, t, T, base, tstep + 1u, last, nwin, fhS, colB, fwB, r, fh, sub_off, nsub, rowany, bits);
-      lbp_dense_step<2, SMALL>(q, t, T, base, tstep + 2u, last, nwin, fhS, colB, fwB, r, fh, sub_off, nsub, rowany, bits);
-    }
-    if (loads) *loads += 4u * (2u + 3u * ((last + 2u) / 3u));
+    lbp_dense_prologue(q, T, base, last, fhS, colB, fwB, std::make_integer_sequence<int, GS_LBP_DENSE_PD + 1>());
+    for (unsigned tstep = 1u; tstep <= last; tstep += (unsigned)kPreRing)
+      lbp_dense_steps<SMALL>(q, t, T, base, tstep, last, nwin, fhS, colB, fwB, r, fh, sub_off, nsub, rowany, bits,
+                             std::make_integer_sequence<int, kPreRing>());
+    if (loads) *loads += 4u * ((unsigned)GS_LBP_DENSE_PD + 1u + (unsigned)kPreRing * ((last + (unsigned)kPreRing - 1u) / (unsigned)kPreRing));
   }
   return bits;
 }

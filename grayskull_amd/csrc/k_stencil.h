@@ -31,6 +31,7 @@ template <bool KEEP_COLS>
 __global__ __launch_bounds__(256) void k_sobel16(uint8_t *dst, const uint8_t *src, unsigned w,
                                                  unsigned h, unsigned T, size_t frame_bytes) {
   const Strip<> S(src, dst, w, h, frame_bytes);
+  if (S.wave_outside()) return; /* block wider than the frame */
   const int y0 = 1 + (int)(S.band * T);
   if (y0 >= (int)h - 1) return; /* whole wave */
   const int nrows = ((int)h - 1 - y0) < (int)T ? ((int)h - 1 - y0) : (int)T;
@@ -65,6 +66,7 @@ __global__ __launch_bounds__(256) void k_blur16(uint8_t *dst, const uint8_t *src
                                                 unsigned h, unsigned T, size_t frame_bytes) {
   constexpr int N = 2 * R + 1;
   const Strip<> S(src, dst, w, h, frame_bytes);
+  if (S.wave_outside()) return; /* block wider than the frame */
   const bool first = S.x0 == 0, last = S.x0 + 16 == w;
   const int y0 = (int)(S.band * T);
   if (y0 >= (int)h) return;
@@ -142,6 +144,7 @@ template <bool DILATE>
 __global__ __launch_bounds__(256) void k_morph16(uint8_t *dst, const uint8_t *src, unsigned w,
                                                  unsigned h, unsigned T, size_t frame_bytes) {
   const Strip<!DILATE> S(src, dst, w, h, frame_bytes);
+  if (S.wave_outside()) return; /* block wider than the frame */
   const int y0 = (int)(S.band * T);
   if (y0 >= (int)h) return;
   const int nrows = ((int)h - y0) < (int)T ? ((int)h - y0) : (int)T;
@@ -175,6 +178,7 @@ __global__ __launch_bounds__(256) void k_morph16(uint8_t *dst, const uint8_t *sr
 __global__ __launch_bounds__(256) void k_strip_copy(uint8_t *dst, const uint8_t *src, unsigned w,
                                                     unsigned h, unsigned T, size_t frame_bytes) {
   const Strip<> S(src, dst, w, h, frame_bytes);
+  if (S.wave_outside()) return; /* block wider than the frame */
   const int y0 = (int)(S.band * T);
   if (y0 >= (int)h) return;
   const int nrows = ((int)h - y0) < (int)T ? ((int)h - y0) : (int)T;
@@ -209,6 +213,7 @@ GS_DEV void filter_hrow(const uint32_t (&U)[12], const uint32_t (&kr)[3], uint32
 __global__ __launch_bounds__(256) void k_filter16(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h,
                                                   unsigned T, size_t frame_bytes, FilterK fk) {
   const Strip<> S(src, dst, w, h, frame_bytes);
+  if (S.wave_outside()) return; /* block wider than the frame */
   const int y0 = (int)(S.band * T);
   if (y0 >= (int)h) return;
   const int nrows = ((int)h - y0) < (int)T ? ((int)h - y0) : (int)T;

@@ -41,21 +41,31 @@ struct RawRow { U4 v; uint32_t hh; };
  * and lanes are encoded in the summands themselves: kRowOOB + any valid column and any valid row +
  * kOOB both land beyond the frame (< 2^31 - 1 bytes, see strip_ok), and kRowOOB + kOOB = 2^32 - 1. */
 constexpr uint32_t kRowOOB = 0x7fffffffu;
+/* XCD-aware band mapping, requested by the launcher through the top bit of frame_bytes (gridDim.x == 1,
+ * blockDim.y == 1, gridDim.y a multiple of 8).  The dispatcher places block b on XCD b % 8; with bands in
+ * dispatch order the two halo rows a band shares with its neighbour are fetched by ANOTHER XCD, i.e. past the
+ * L2 (k_sobel16 read 1.22x its algorithmic bytes, k_blur16<2> 1.31x: profiles/pmc_traffic.json round 2).
+ * Mapped, XCD k walks the k-th eighth of every frame top to bottom, so a band's halo rows are the rows its
+ * own L2 fetched for the previous band. */
+constexpr size_t kStripXcdFlag = (size_t)1 << 63;
 template <bool INVERT = false> struct Strip {
   BufRsrc src, dst;
   unsigned w, h, x0, lane, band;
   uint32_t col_off, halo_off; /* this lane's 16 B / its halo dword inside a row (kOOB: none) */
   GS_DEV Strip(const uint8_t *s, uint8_t *d, unsigned w_, unsigned h_, size_t frame_bytes)
-      : src(make_buf(s + (size_t)blockIdx.z * frame_bytes, frame_bytes)),
-        dst(make_buf(d + (size_t)blockIdx.z * frame_bytes, frame_bytes)), w(w_), h(h_) {
+      : src(make_buf(s + (size_t)blockIdx.z * (frame_bytes & ~kStripXcdFlag), frame_bytes & ~kStripXcdFlag)),
+        dst(make_buf(d + (size_t)blockIdx.z * (frame_bytes & ~kStripXcdFlag), frame_bytes & ~kStripXcdFlag)), w(w_), h(h_) {
     lane = threadIdx.x & 63u;
     x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 16u;
     band = uniform(blockIdx.y * blockDim.y + threadIdx.y); /* same for the wave's 64 lanes: SGPR */
+    if (frame_bytes & kStripXcdFlag) band = (blockIdx.y & 7u) * (gridDim.y >> 3) + (blockIdx.y >> 3);
     col_off = x0 < w ? x0 : kOOB;
     halo_off = kOOB;
     if (lane == 0 && x0 > 0 && x0 < w) halo_off = x0 - 4;
     if (lane == 63 && x0 + 16 < w) halo_off = x0 + 16;
   }
+  /* the whole wave lies right of the image (its block is wider than the frame): nothing to load, compute or store */
+  GS_DEV bool wave_outside() const { return uniform(x0 - lane * 16u) >= w; }
   GS_DEV uint32_t row_off(int y, bool ok = true) const { /* y, ok wave-uniform */
     return (ok && (unsigned)y < h) ? (uint32_t)y * w : kRowOOB;
   }

@@ -351,6 +351,18 @@ GS_DEV unsigned absdiff_u16(unsigned a, unsigned b) {
   return __builtin_amdgcn_sad_u16(a, b, 0u);
 #endif
 }
+/* lane (4 * (lane / 4) + S[lane % 4])'s value: v_mov_b32_dpp quad_perm:[S0,S1,S2,S3] (no LDS crossbar).  Every lane
+ * of a quad has to execute it together (on the GPU a disabled source lane yields 0; the emulator's exchange is a
+ * rendezvous of the quad's live lanes). */
+template <int S0, int S1, int S2, int S3>
+GS_DEV uint32_t quad_perm(uint32_t x) {
+#ifdef GS_EMU
+  const int sel[4] = {S0, S1, S2, S3};
+  return (uint32_t)emu::quad_exchange(x, (unsigned)sel[lane_id() & 3u]);
+#else
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, S0 | (S1 << 2) | (S2 << 4) | (S3 << 6), 0xf, 0xf, false);
+#endif
+}
 GS_DEV uint32_t readlane0(uint32_t x) { return shfl(x, 0); }
 
 /* inclusive add-scan across the wave.  gfx950: six DPP adds -- row_shr 1/2/4/8 inside each row of

@@ -44,8 +44,12 @@ void gsh_sync(void);                      /* hipStreamSynchronize(current stream
  * 8 frames per launch (test hook for the batch splitting of every launcher), 9 LBP: stages / survivor
  * share at which a block first re-packs (max stages + 16 * tenths [+ later points]; key 4 >= 1000 = custom fixed split),
  * 10 trips per block gs_histogram aims at, 11 its blocks per frame, 12 bytes per histogram piece (test
- * hook for images above 1 GiB), 13 chunk-to-XCD mapping of the LBP cascade (1 = dispatch order, 2 = XCD-aware always).
- * Results never change. */
+ * hook for images above 1 GiB), 13 chunk-to-XCD mapping of the LBP cascade (1 = dispatch order, 2 = XCD-aware always),
+ * 14 stages the optional LBP prefilter k_lbp_dense takes (0 = off, the default; k = k stages; + 100 = full unsigned compares),
+ * 15 windows per scale group of gs_lbp_detect (test hook; 0 = default 16 M), 16 = 1: gs_lbp_detect runs its cascade
+ * kernels but emits nothing (timing aid; counts / rects are NOT written), 17 = 1: the cascade evaluates re-packed windows
+ * one per lane instead of one per quad of lanes.
+ * Results never change (key 16 excepted). */
 void gsh_tune(int key, int value);
 /* measurement aid for bench.py: while on, gsh_edge_pipeline_batch brackets every launch of its
  * fused blur+sobel+histogram kernel with HIP events on the stream it is launched on (up to 4096

@@ -19,6 +19,7 @@
 #error "hip_emu.h is only for -DGS_EMU builds"
 #endif
 
+#include <setjmp.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -51,7 +52,9 @@ constexpr int WAVE = 64;
 constexpr size_t STACK = 256 * 1024;
 
 struct Fiber {
-  ucontext_t ctx;
+  ucontext_t ctx; /* first entry only; afterwards fibers switch through jb (no signal-mask system call per switch) */
+  jmp_buf jb;
+  bool started = false;
   char *stack = nullptr;
   bool done = true;
   emu_idx tid;
@@ -63,6 +66,7 @@ struct State {
   dim3 bdim, gdim;
   std::vector<Fiber> fibers;
   ucontext_t sched;
+  jmp_buf sched_jb;
   int cur = -1;
   unsigned nthreads = 0, alive = 0;
   /* block barrier */
@@ -72,8 +76,16 @@ struct State {
     unsigned count = 0, gen = 0, alive = 0;
     uint64_t slot[WAVE];
     bool valid[WAVE];
+    unsigned arrived[WAVE] = {}; /* generation + 1 of the rendezvous a lane is waiting in */
   };
   std::vector<WaveX> waves;
+  /* per-quad exchange (DPP quad_perm): double-buffered slots, one rendezvous per exchange, and a lane that has
+   * to wait hands the CPU straight to a sibling that has not arrived (not a full round of the block's fibers) */
+  struct QuadX {
+    unsigned count = 0, gen = 0;
+    uint64_t slot[2][4];
+  };
+  std::vector<QuadX> quads;
   const std::function<void()> *body = nullptr;
   char *dyn_lds = nullptr;
   ~State() { /* one State per host thread: give the fiber stacks back when the thread ends */
@@ -91,6 +103,8 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &bo
 inline unsigned lane_id() { return S().fibers[S().cur].lin % WAVE; }
 inline unsigned wave_id() { return S().fibers[S().cur].lin / WAVE; }
 void wave_rendezvous();
+/* the four lanes of the calling lane's quad swap `v`: returns the value published by lane (quad base + sel) */
+uint64_t quad_exchange(uint64_t v, unsigned sel);
 }  // namespace emu
 
 #define threadIdx (emu::S().tidx)

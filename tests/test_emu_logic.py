@@ -57,7 +57,8 @@ def test_next_rows(emu, oracle, shape):
     pc.next_rows(emu, oracle, np.random.RandomState(w + h).randint(0, 256, (h, w)).astype(np.uint8), MEM)
 
 
-@pytest.mark.parametrize("shape", [(67, 45), (96, 80), (7, 7), (6, 30), (40, 8), (300, 12), (260, 17), (8, 8), (516, 9)])
+@pytest.mark.parametrize("shape", [(67, 45), (96, 80), (7, 7), (6, 30), (40, 8), (300, 12), (260, 17), (8, 8), (516, 9),
+                                   (64, 40), (48, 7), (32, 16), (1040, 9), (2064, 8)])
 def test_fast(emu, oracle, shape):
     w, h = shape
     for strip in ((0, 1, 2) if w % 4 == 0 else (0, 2)):  # gsh_tune key 7: 0 LDS-tile score kernel (default), 1 strip kernel, 2 one global byte load per ring pixel
@@ -90,6 +91,27 @@ def test_fast_strip_kernel_equals_per_pixel_kernel(emu, oracle):
                 pc.fast(emu, oracle, img, MEM, threshold=t, caps=(5000,))
             finally:
                 emu.tune(7, 0)
+
+
+@pytest.mark.parametrize("shape", [(96, 80), (64, 40), (1040, 9), (32, 7), (272, 33)])
+def test_fast_nms_strip_kernel_equals_item_kernel(emu, oracle, shape):
+    """pass 2 of gs_fast: k_fast_nms16 (strip form, items over word-padded rows; default when w % 16 == 0) and
+    k_fast_nms (item by item, gsh_tune key 19 = 1) give the oracle's keypoints in the oracle's order -- plateaus
+    (ties survive), peaks next to the never-written 3-px frame of a caller's non-zero score map, caps that cut the
+    list inside a row, every strip band height"""
+    w, h = shape
+    rs = np.random.RandomState(w + h)
+    flat = np.full((h, w), 100, np.uint8)
+    flat[::3, ::3] = 140                      # a lattice of equal corners: plateaus / ties everywhere
+    imgs = [Oracle.synth(w, h, 8), rs.randint(0, 256, (h, w)).astype(np.uint8), flat]
+    for key19 in (0, 1):
+        for T in (0, 1, 3):
+            try:
+                emu.tune(19, key19), emu.tune(0, T)
+                for img in imgs:
+                    pc.fast(emu, oracle, img, MEM, threshold=12, caps=(5000, 9, 1))
+            finally:
+                emu.tune(19, 0), emu.tune(0, 0)
 
 
 def test_fast_quirk(emu, oracle):
@@ -216,7 +238,7 @@ def test_strip_launch_tuning_never_changes_results(emu, oracle, geom, pf):
             for (w, h) in ((2064, 11), (64, 23), (4112, 4)):
                 pc.stencils(emu, oracle, Oracle.synth(w, h, w + h + T), MEM, radii=(1, 2, 3))
     finally:
-        emu.tune(0, 0), emu.tune(1, 1), emu.tune(2, 2)
+        emu.tune(0, 0), emu.tune(1, 3), emu.tune(2, 2)
 
 
 @pytest.mark.parametrize("radius", [1, 2, 3])
@@ -273,9 +295,9 @@ def test_lbp_adaptive_first_repack_never_changes_results(emu, oracle, cascade, k
         emu.tune(4, 0); emu.tune(9, 0)
 
 
-@pytest.mark.parametrize("pre,group", [(-1, 0), (1, 0), (2, 1), (3, 0), (7, 1), (5, 40000), (102, 0)])
+@pytest.mark.parametrize("pre,group", [(0, 0), (1, 0), (2, 1), (3, 0), (7, 1), (5, 40000), (102, 0)])
 def test_lbp_prefilter_never_changes_results(emu, oracle, cascade, pre, group):
-    """k_lbp_dense (key 14: prefiltered stages, -1 = off; key 15: windows per scale group, 1 = every scale its own
+    """k_lbp_dense (key 14: prefiltered stages, 0 = off (default); key 15: windows per scale group, 1 = every scale its own
     prefilter + cascade launch pair): the first stages for all windows with shared table rows + truth-table stage
     decisions give the oracle's rectangles for any number of prefiltered stages, any grouping and any cap --
     tiles with ragged right / bottom edges (sizes that are not multiples of 64), images smaller than a tile,
@@ -323,7 +345,7 @@ def test_lbp_prefilter_counters_and_group_exit(emu, oracle, cascade):
             emu.tune(14, 0), emu.tune(15, 0)
         assert_same(r, oracle.lbp_detect(cascade, ii, cap, 1.1, 1.0, 4.0, 1), "cap %d pre %d group %d" % (cap, pre, group))
         return [int(v) for v in cnt]
-    off = run(4096, -1, 0)
+    off = run(4096, 0, 0)
     on = run(4096, 2, 0)
     assert off[3] == 0 and off[2] == 16 * off[1] and off[0] == total
     assert on[3] == total and on[0] == total
