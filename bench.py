@@ -585,7 +585,7 @@ def extras(g, torch, np, src, tmp, dst, w, h, reps):
     torch.cuda.synchronize()
     g.lbp_count_evaluated(None)
     nwin = g.lbp_window_count(casc, w3, h3, 1.1, 1.0, 4.0, 1)
-    nev, nweak = int(ev[0]), int(ev[1])
+    nev, nweak, nload = int(ev[0]), int(ev[1]), int(ev[2])
     other["configs[2] gs_integral + gs_lbp_detect(frontalface) 1920x1080 sf=1.1 scales 1..4 step 1"] = {
         "frames": n3, "integral_ms_per_frame": round(ms_ii / n3, 4), "lbp_ms_per_frame": round(ms_lbp / n3, 3),
         "windows_per_frame": nwin, "windows_evaluated_per_frame": nev // n3,
@@ -593,7 +593,7 @@ def extras(g, torch, np, src, tmp, dst, w, h, reps):
         "detections_frame0": int(cn[0]), "expected_frame0 (reference KAT)": 158,
         "integral_roofline": hbm_block(5.0 * n3 * h3 * w3, ms_ii, bytes_per_px=5,
                                        note="algorithmic 1 R + 4 W per px; the three-launch form moves ~6.1 (PMC)"),
-        "lbp_roofline": lbp_gather_block(nweak, ms_lbp),
+        "lbp_roofline": lbp_gather_block(nweak, nload, ms_lbp),
         "reference_1core": "5.98 s/frame, 4.83 Mwin/s (BASELINE.md)"}
     dc.close()
     dA = torch.empty((1, 720, 1280), dtype=torch.uint8, device="cuda")
@@ -652,32 +652,40 @@ def extras(g, torch, np, src, tmp, dst, w, h, reps):
         g.integral_batch(b5, ii5)
         g.lbp_detect_batch(dc5, ii5, rc5, cn5, 4096, 1.1, 1.0, 4.0, 1)
     ms5 = time_stream(torch, chain5, 2)
+    ms5_lbp_plain = time_stream(torch, lambda: g.lbp_detect_batch(dc5, ii5, rc5, cn5, 4096, 1.1, 1.0, 4.0, 1), 2)
     ev.zero_()
-    g.lbp_count_evaluated(ev)
-    ms5_lbp = time_stream(torch, lambda: g.lbp_detect_batch(dc5, ii5, rc5, cn5, 4096, 1.1, 1.0, 4.0, 1), 1)
+    g.lbp_count_evaluated(ev)  # one untimed run of the counting build of the kernels
+    g.lbp_detect_batch(dc5, ii5, rc5, cn5, 4096, 1.1, 1.0, 4.0, 1)
+    torch.cuda.synchronize()
     g.lbp_count_evaluated(None)
-    nev5, nweak5 = int(ev[0]) // 2, int(ev[1]) // 2  # time_stream runs fn twice (warm-up + 1 rep)
+    nev5, nweak5, nload5 = int(ev[0]), int(ev[1]), int(ev[2])
     nwin5 = g.lbp_window_count(casc, w, h, 1.1, 1.0, 4.0, 1)
     other["configs[4] per-GPU share: gs_blur(2) -> gs_sobel -> gs_integral -> gs_lbp_detect per 3840x2160 frame"] = {
         "frames": n5, "ms_per_frame": round(ms5 / n5, 3), "frames_per_s_per_gpu": round(n5 / ms5 * 1e3, 1),
         "windows_per_frame_full_scan": nwin5, "windows_evaluated_per_frame": nev5 // n5,
-        "Gwindows/s_evaluated": round(nev5 / ms5_lbp / 1e6, 2), "detections": cn5.cpu().tolist()[:4],
-        "lbp_roofline": lbp_gather_block(nweak5, ms5_lbp),
+        "Gwindows/s_evaluated": round(nev5 / ms5_lbp_plain / 1e6, 2), "lbp_ms_per_frame": round(ms5_lbp_plain / n5, 3), "detections": cn5.cpu().tolist()[:4],
+        "lbp_roofline": lbp_gather_block(nweak5, nload5, ms5_lbp_plain),
         "note": "frames shard across GPUs with no exchange: 4096 frames on 8 GPUs = 512 per GPU; the cascade dominates "
                 "(120 M windows per frame; chunks behind the 4096th detection are skipped like the reference stops there)"}
     dc5.close()
     return ns, other
 
 
-def lbp_gather_block(weak_evals, ms):
-    """gather-bytes model of the cascade: every weak classifier a window evaluates reads
-    16 integral-image corners = 64 B through the texture path; ceiling = the 37 B/clk/CU measured in
-    profiles/r01h_gather_cost_microbench.txt x 256 CUs x 2.4 GHz."""
-    peak = 37.0 * 256 * 2.4  # GB/s
-    gbs = weak_evals * 64.0 / ms / 1e6
-    return {"bound": "L1/TA gather bytes", "weak_classifier_evaluations": weak_evals, "bytes": weak_evals * 64.0,
-            "ms": round(ms, 4), "GB/s": round(gbs, 1), "peak_GB/s": round(peak, 1), "frac": round(gbs / peak, 4),
-            "note": "16 dword corners per evaluated weak classifier (lane-level count, gsh_lbp_count_evaluated[1])"}
+L1_LINE_GBS = 64.0 * 256 * 2.4  # one 64-byte line per clock per CU (vector L1 -> texture path), 256 CUs at 2.4 GHz
+
+
+def lbp_gather_block(weak_evals, dword_loads, ms):
+    """The cascade is bound by the texture path (TA busy 95 %, profiles/r03d_pmc_lbp.txt), so its roofline is the rate
+    at which the vector L1 hands lines to it: ONE peak, 64 B per clock and CU = 39.3 TB/s (the dense phase, whose gathers
+    are 64 consecutive dwords, runs at that width: 4 cycles per 256-byte gather).  achieved = the dwords the lanes really
+    loaded (gsh_lbp_count_evaluated[2]) x 4 B / time -- scattered survivor gathers fetch a whole line per dword or two,
+    which is exactly what the fraction shows."""
+    gbs = dword_loads * 4.0 / ms / 1e6
+    return {"bound": "vector L1 / texture path line rate", "weak_classifier_evaluations": weak_evals,
+            "dword_loads": dword_loads, "bytes": dword_loads * 4.0, "ms": round(ms, 4), "GB/s": round(gbs, 1),
+            "peak_GB/s": round(L1_LINE_GBS, 1), "frac": round(gbs / L1_LINE_GBS, 4),
+            "note": "bytes = table dwords loaded by the lanes (lane-level count of the counting build) x 4; peak = 64 B/clk/CU "
+                    "x 256 CUs x 2.4 GHz; 16 dwords per evaluated weak classifier"}
 
 
 if __name__ == "__main__":

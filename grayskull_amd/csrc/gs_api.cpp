@@ -623,6 +623,12 @@ void launch_fast_score(hipStream_t on, const uint8_t *img, uint8_t *score, unsig
     GS_LAUNCH(k_fast_score4, dim3(cw, (nb + 3) / 4, n), dim3(64, 4), 0, on, img, score, w, h, (unsigned)T, fb, threshold);
   } else if (g_tune[7] == 2) {
     GS_LAUNCH(k_fast_score_px, grid2d(w - 6, h - 6, n), dim3(64, 4), 0, on, img, score, w, h, fb, threshold);
+  } else if (g_tune[7] == 3) {
+    /* LDS tile + block-local candidate queue: measured and NOT the default (profiles/r03i_fast_candidate_queue.log, 32 x 720p
+     * score pass): block noise 72.7 -> 69.9 us, tiled lena 109 -> 92, but +8 % on bright noise, flat and random frames --
+     * half of the pass is the tile load, the compass filter and the byte stores, which the queue does not touch */
+    GS_LAUNCH(k_fast_score_cq, dim3((w - 6 + 63) / 64, (h - 6 + kFastTileRows - 1) / kFastTileRows, n), dim3(64, 4), 0, on,
+              img, score, w, h, fb, threshold);
   } else {
     GS_LAUNCH(k_fast_score_tile, dim3((w - 6 + 63) / 64, (h - 6 + kFastTileRows - 1) / kFastTileRows, n), dim3(64, 4), 0, on,
               img, score, w, h, fb, threshold);
@@ -896,7 +902,9 @@ void launch_lbp_padded(const gsh_cascade *dc, const LbpGeomCache &gc, const unsi
     ph.adaptive_max = (g_tune[4] == 0 && dc->nstages > 2) ? 8u : 0u; /* 6 .. 15 within 1.5 % (profiles/r02l_lbp_adaptive_xcd.log) */
     ph.adaptive_tenths = 2u;
     ph.quad = g_tune[17] == 1 ? 0u : 1u; /* key 17 = 1: one lane per re-packed window (the round-2 form) */
-    ph.adaptive_next[0] = 1u, ph.adaptive_next[1] = 3u, ph.adaptive_next[2] = 6u; /* with quad-lane survivors: profiles/r03f_lbp_adaptive_quad.log */
+    /* with quad-lane survivors (profiles/r03f_lbp_adaptive_quad.log, r03k_lbp_adaptive_next.log): +1 +2 +4 is best on
+     * block noise (8 x 1080p 0.76 vs 0.80 ms for +1 +3 +6, 4K 3.15 vs 3.17) and within 0.5 % of the best on edge maps */
+    ph.adaptive_next[0] = 1u, ph.adaptive_next[1] = 2u, ph.adaptive_next[2] = 4u;
     if (ph.adaptive_max && g_tune[9] > 0) { /* experiments: key 9 = max + 16 * tenths (+ 256 d1 + 4096 d2 + 65536 d3: later points) */
       const unsigned v = (unsigned)g_tune[9];
       ph.adaptive_max = v & 15u, ph.adaptive_tenths = (v >> 4) & 15u;

@@ -159,6 +159,94 @@ __global__ __launch_bounds__(256) void k_fast_score_tile(const uint8_t *img, uin
   }
 }
 
+/* pass 1 with block-local candidate compaction.  k_fast_score_tile is VALU-bound (0.70 of the issue rate,
+ * profiles/fast_valu_pmc.json) and a wave scores all 64 of its pixels as soon as ONE passes the compass filter;
+ * on the block-noise frames of configs[3] nearly every wave holds one, but only a quarter of the pixels do.  Here
+ * the 1024 pixels of the tile go through the compass filter first (5 LDS bytes each); those that pass are queued
+ * in LDS (one ds_add per wave row, order irrelevant) and the queue is scored 64 candidates to a wave -- every lane
+ * of every fast_score is a real candidate; the others' score is 0 and is stored right away.  Tiles in which most
+ * pixels pass (regions with p < threshold: the reference's unsigned wrap makes every pixel a candidate) gain
+ * nothing and lose the queue round trip, so from half the tile on the rows are scored in place like
+ * k_fast_score_tile does.  Same scores, same stores.  grid / block as k_fast_score_tile. */
+__global__ __launch_bounds__(256) void k_fast_score_cq(const uint8_t *img, uint8_t *score, unsigned w, unsigned h,
+                                                       size_t frame_bytes, unsigned threshold) {
+  __shared__ uint32_t tile32[(kFastTileRows + 6) * kFastTileDw];
+  __shared__ uint16_t queue[64 * kFastTileRows];
+  __shared__ unsigned qn;
+  const uint8_t *frame = img + (size_t)blockIdx.z * frame_bytes;
+  uint8_t *out = score + (size_t)blockIdx.z * frame_bytes;
+  const unsigned tid = threadIdx.y * 64u + threadIdx.x;
+  const unsigned x_t = blockIdx.x * 64u, y_t = blockIdx.y * kFastTileRows;
+  if (tid == 0) qn = 0;
+  for (unsigned i = tid; i < (kFastTileRows + 6) * kFastTileDw; i += 256u) {
+    const unsigned r = i / kFastTileDw, c = i - r * kFastTileDw;
+    const size_t off = (size_t)(y_t + r) * w + x_t + c * 4u;
+    uint32_t v = 0;
+    if (off + 4 <= frame_bytes) {
+      v = load_u32_unaligned(frame + off);
+    } else {
+      for (unsigned b = 0; b < 4; b++)
+        if (off + b < frame_bytes) v |= (uint32_t)frame[off + b] << (8 * b);
+    }
+    tile32[i] = v;
+  }
+  __syncthreads();
+  const uint8_t *tb = (const uint8_t *)tile32;
+  constexpr int S = (int)kFastTileDw * 4;
+  auto score_at = [&](const uint8_t *c) {
+    const unsigned v[16] = {c[-3 * S],     c[-3 * S + 1], c[-2 * S + 2], c[-S + 3], c[3],  c[S + 3],  c[2 * S + 2],  c[3 * S + 1],
+                            c[3 * S],      c[3 * S - 1],  c[2 * S - 2],  c[S - 3],  c[-3], c[-S - 3], c[-2 * S - 2], c[-3 * S - 1]};
+    return fast_score(c[0], v, threshold);
+  };
+  const unsigned x = 3 + x_t + threadIdx.x;
+  unsigned mine = 0; /* bit k: this thread's pixel of row ty + 4k passed the compass filter */
+#pragma unroll
+  for (unsigned k = 0; k < kFastTileRows / 4; k++) {
+    const unsigned ry = threadIdx.y + 4u * k, y = 3 + y_t + ry;
+    const bool in = x + 3 < w && y + 3 < h;
+    const uint8_t *c = tb + (ry + 3) * S + threadIdx.x + 3;
+    const bool cand = in && fast_compass_candidate(c[0], c[-3 * S], c[3], c[3 * S], c[-3], threshold);
+    mine |= (cand ? 1u : 0u) << k;
+    if (in && !cand) out[(size_t)y * w + x] = 0;
+  }
+  const unsigned total = wave_sum((unsigned)__popc(mine)); /* this wave's candidates */
+  __shared__ unsigned wtot[4];
+  if ((tid & 63u) == 0) wtot[tid >> 6] = total;
+  __syncthreads();
+  const unsigned ncand = wtot[0] + wtot[1] + wtot[2] + wtot[3]; /* block-uniform */
+  if (ncand == 0) return;
+  if (ncand * 2u >= 64u * kFastTileRows) { /* dense tile: in place, a whole wave row at a time */
+#pragma unroll
+    for (unsigned k = 0; k < kFastTileRows / 4; k++) {
+      const unsigned ry = threadIdx.y + 4u * k, y = 3 + y_t + ry;
+      if (ballot((mine >> k) & 1u) != 0) { /* wave-uniform */
+        const unsigned sc = score_at(tb + (ry + 3) * S + threadIdx.x + 3);
+        if ((mine >> k) & 1u) out[(size_t)y * w + x] = (uint8_t)sc;
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (unsigned k = 0; k < kFastTileRows / 4; k++) {
+    const bool cand = (mine >> k) & 1u;
+    const uint64_t m = ballot(cand);
+    if (m) {
+      const unsigned lane = lane_id();
+      unsigned base = 0;
+      if (lane == 0) base = atomicAdd(&qn, (unsigned)__popcll(m));
+      base = readlane0(base);
+      if (cand) queue[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)((threadIdx.y + 4u * k) * 64u + threadIdx.x);
+    }
+  }
+  __syncthreads();
+  for (unsigned i0 = 0; i0 < ncand; i0 += 256u) { /* block-uniform trip count */
+    const unsigned i = i0 + tid;
+    const unsigned e = queue[i < ncand ? i : ncand - 1u], ry = e >> 6, tx = e & 63u;
+    const unsigned sc = score_at(tb + (ry + 3) * S + tx + 3);
+    if (i < ncand) out[(size_t)(3 + y_t + ry) * w + 3 + x_t + tx] = (uint8_t)sc;
+  }
+}
+
 /* pass 1, strips (w % 4 == 0, 4-byte aligned frames, threshold <= 0xffffff00): a lane owns 4
  * consecutive pixels (one dword per row), a wave 256 px of a row, and walks DOWN a band of T rows
  * with the 7 image rows y-3..y+3 in registers as 12-byte windows (L, C, R: the neighbour lanes'

@@ -209,7 +209,9 @@ GS_DEV bool lbp_quad_stages(const LbpLds &t, const unsigned *Pg, unsigned origin
   bool alive = live;
   auto gather = [&](unsigned w, unsigned (&G)[4]) {
     const LbpGeom g = t.geom[w];
-    const unsigned col = origin + uniform((unsigned)g.off0) + ci * uniform((unsigned)g.fw), fhs = uniform((unsigned)g.fh_stride);
+    /* ci * fw without a 32-bit multiply (quarter rate): ci is 0..3 */
+    const unsigned fw = uniform((unsigned)g.fw), cfw = ((ci & 1u) ? fw : 0u) + ((ci & 2u) ? 2u * fw : 0u);
+    const unsigned col = origin + uniform((unsigned)g.off0) + cfw, fhs = uniform((unsigned)g.fh_stride);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       unsigned idx = col + (unsigned)j * fhs;
@@ -236,9 +238,10 @@ GS_DEV bool lbp_quad_stages(const LbpLds &t, const unsigned *Pg, unsigned origin
       unsigned code = ((c0 >= ctr ? use02 : 0u) << sh0) | ((c1 >= ctr ? use1 : 0u) << sh1) | ((c2 >= ctr ? use02 : 0u) << sh2);
       code |= quad_perm<1, 0, 3, 2>(code);
       code |= quad_perm<2, 3, 0, 1>(code);
-      const unsigned word = code >> 5, bit = code & 31u;
-      bool hit = false;
-      if (word < wk.nsub) hit = ((uint32_t)t.subsets[wk.sub_off + word] >> bit) & 1u;
+      /* subset bit, branch-free: words past the classifier's subset count read word 0 and are masked */
+      const unsigned word = code >> 5, nsub = uniform(wk.nsub);
+      const unsigned v = (uint32_t)t.subsets[uniform(wk.sub_off) + (word < nsub ? word : 0u)];
+      const bool hit = word < nsub && ((v >> (code & 31u)) & 1u);
       sum += hit ? wk.left : wk.right;
     }
     if (sum < st.threshold) alive = false;

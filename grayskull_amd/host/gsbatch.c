@@ -770,6 +770,17 @@ int main(int argc, char **argv) {
       ngpus = atoi(argv[pos + 1]), pos += 2;
     } else if (strcmp(argv[pos], "--cascade") == 0 && pos + 1 < argc) {
       cascade_path = argv[pos + 1], pos += 2;
+    } else if (strcmp(argv[pos], "--shard-table") == 0 && pos + 2 < argc) {
+      /* diagnostic (no GPU needed): the file ranges `--gpus W` gives its workers for a group of T files, one
+       * "rank lo hi" line each -- tests/test_shard.py holds them against grayskull_amd/shard.py frame_range */
+      const unsigned W = (unsigned)atoi(argv[pos + 1]), T = (unsigned)atoi(argv[pos + 2]);
+      unsigned r, lo, hi;
+      if (W < 1) return 1;
+      for (r = 0; r < W; r++) {
+        frame_range(r, W, T, &lo, &hi);
+        printf("%u %u %u\n", r, lo, hi);
+      }
+      return 0;
     } else {
       usage(argv[0]);
       return 1;

@@ -39,8 +39,8 @@ void gsh_sync(void);                      /* hipStreamSynchronize(current stream
  * gsh_edge_pipeline_batch's internal overlap (0 = default 32, negative = never split),
  * 6 comparison switches: 1 = generic two-pass gs_integral, 2 = block-per-band gs_integral,
  * 3 = integral-image route for gs_blur(radius > 3) / gs_adaptive_threshold instead of the sliding
- * box kernel, 7 score kernel of gs_fast: 0 = LDS tile (default), 1 = strip kernel (lane = 4 px, image
- * rows in registers; faster on flat frames only), 2 = one global byte load per ring pixel (round 1),
+ * box kernel, 7 score kernel of gs_fast: 0 = LDS tile (default), 1 = strip kernel (lane = 4 px, image rows in registers; faster
+ * on flat frames only), 2 = one global byte load per ring pixel (round 1), 3 = LDS tile + block-local candidate queue,
  * 8 frames per launch (test hook for the batch splitting of every launcher), 9 LBP: stages / survivor
  * share at which a block first re-packs (max stages + 16 * tenths [+ later points]; key 4 >= 1000 = custom fixed split),
  * 10 trips per block gs_histogram aims at, 11 its blocks per frame, 12 bytes per histogram piece (test
@@ -48,7 +48,8 @@ void gsh_sync(void);                      /* hipStreamSynchronize(current stream
  * 14 stages the optional LBP prefilter k_lbp_dense takes (0 = off, the default; k = k stages; + 100 = full unsigned compares),
  * 15 windows per scale group of gs_lbp_detect (test hook; 0 = default 16 M), 16 = 1: gs_lbp_detect runs its cascade
  * kernels but emits nothing (timing aid; counts / rects are NOT written), 17 = 1: the cascade evaluates re-packed windows
- * one per lane instead of one per quad of lanes.
+ * one per lane instead of one per quad of lanes, 18 band-to-XCD mapping of the strip kernels (1 = dispatch order, 2 = XCD-aware
+ * always), 19 = 1: pass 2 of gs_fast item by item (k_fast_nms, round 2) instead of the strip form.
  * Results never change (key 16 excepted). */
 void gsh_tune(int key, int value);
 /* measurement aid for bench.py: while on, gsh_edge_pipeline_batch brackets every launch of its

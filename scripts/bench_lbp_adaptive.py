@@ -14,14 +14,17 @@ def timeit(fn, reps=3):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
-w, h, n = 3840, 2160, 8
+w, h, n = int(os.environ.get("UB_W", 3840)), int(os.environ.get("UB_H", 2160)), int(os.environ.get("UB_F", 8))
 src = torch.empty((n, h, w), dtype=torch.uint8, device="cuda"); g.synth_batch(src, 1000)
 a, b = torch.empty_like(src), torch.zeros_like(src)
 g.blur_batch(a, src, 2); g.sobel_batch(b, a)
 rects = torch.zeros((n, 4096, 4), dtype=torch.int32, device="cuda"); counts = torch.zeros(n, dtype=torch.int32, device="cuda")
 g.tune(14, 0)
-combos = [(8, 2, 2, 5, 0)] + [(8, t, 2, 5, 0) for t in (1, 3, 4, 5, 7)] + [(m, 3, 2, 5, 0) for m in (4, 6, 12)] + \
-         [(8, 3, d1, d2, d3) for (d1, d2, d3) in ((1, 3, 6), (1, 2, 4), (2, 4, 8), (3, 6, 0), (1, 2, 3), (2, 0, 0), (1, 3, 0))]
+if len(sys.argv) > 1:
+    combos = [tuple(int(v) for v in c.split(",")) for c in sys.argv[1].split(";")]
+else:
+    combos = [(8, 2, 2, 5, 0)] + [(8, t, 2, 5, 0) for t in (1, 3, 4, 5, 7)] + [(m, 3, 2, 5, 0) for m in (4, 6, 12)] + \
+             [(8, 3, d1, d2, d3) for (d1, d2, d3) in ((1, 3, 6), (1, 2, 4), (2, 4, 8), (3, 6, 0), (1, 2, 3), (2, 0, 0), (1, 3, 0))]
 for name, img in (("noise", src), ("edges", b)):
     ii = torch.zeros((n, h, w), dtype=torch.int32, device="cuda"); g.integral_batch(img, ii)
     ref = None
@@ -30,6 +33,6 @@ for name, img in (("noise", src), ("edges", b)):
         ms = timeit(lambda: g.lbp_detect_batch(dc, ii, rects, counts, 4096, 1.1, 1.0, 4.0, 1)) / n
         crc = zlib.crc32(rects.cpu().numpy().tobytes()) ^ zlib.crc32(counts.cpu().numpy().tobytes())
         ref = ref or crc
-        print("%s 4K x%d adaptive max %2d tenths %d next +%d +%d +%d  %.3f ms/frame  same=%s" % (name, n, m, t, d1, d2, d3, ms, crc == ref), flush=True)
+        print("%s %dx%d x%d adaptive max %2d tenths %d next +%d +%d +%d  %.3f ms/frame  same=%s" % (name, w, h, n, m, t, d1, d2, d3, ms, crc == ref), flush=True)
     g.tune(9, 0)
 g.tune(14, 0); dc.close()

@@ -20,5 +20,11 @@ gauss = np.array([[1, 2, 1], [2, 4, 2], [1, 2, 1]], np.int8)
 for _ in range(3):
     g.filter_batch(dst, src, gauss, 16); g.adaptive_threshold_batch(dst, src, 15, 5); g.blur_batch(dst, src, 9)
     g.downsample_batch(half, src); g.integral_batch(src, ii)
+# gs_fast on 32 x 720p block-noise frames (configs[3]): score pass 1 R + 1 W, NMS 1 R
+f7 = torch.empty((32, 720, 1280), dtype=torch.uint8, device="cuda"); g.synth_batch(f7, 4)
+sm7 = torch.zeros_like(f7)
+kp7 = torch.zeros((32, 2000, 12), dtype=torch.int32, device="cuda"); cn7 = torch.zeros(32, dtype=torch.int32, device="cuda")
+for _ in range(3):
+    g.fast_batch(f7, sm7, kp7, cn7, 2000, 20)
 torch.cuda.synchronize()
 print("algorithmic bytes per launch: copy/blur/erode/threshold %d, sobel %d, hist %d" % (2*F*H*W, F*(H*W+(H-2)*(W-2)), F*H*W))

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""gsh_fast_batch: LDS-tile score kernel (default) vs strip kernel k_fast_score4 (gsh_tune key 7 = 1) vs the per-pixel kernel with one
+"""gsh_fast_batch: LDS-tile score kernel (default) / with the block-local candidate queue (key 7 = 3) vs strip kernel k_fast_score4 (gsh_tune key 7 = 1) vs the per-pixel kernel with one
 global byte load per ring pixel (key 7 = 2), 32 x 1280x720"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import grayskull_amd as gs
 from oracle.pyoracle import Oracle
-g = gs.lib(); g.use_torch_stream()
+g = gs.Grayskull(os.environ["UB_LIB"]) if os.environ.get("UB_LIB") else gs.lib(); g.use_torch_stream()
 W, H, F = int(os.environ.get("UB_W", 1280)), int(os.environ.get("UB_H", 720)), int(os.environ.get("UB_F", 32))
 def timeit(fn, reps=20):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -22,8 +22,10 @@ from tests.util import lena
 L = lena(); inputs["lena_tiled"] = np.tile(L, ((H + 127) // 128, (W + 127) // 128))[:H, :W].copy()
 for name, img in inputs.items():
     src = torch.from_numpy(np.stack([img] * F)).cuda(); sm = torch.zeros_like(src)
-    for px in (0, 1, 2):
+    for px in (0, 3, 1, 2):
         g.tune(7, px)
         ms = timeit(lambda: g.fast_batch(src, sm, kps, cnt, 5000, 20))
-        print("%-28s %-6s %.4f ms per frame  (%.0f Gpx/s)  n0=%d" % (name, ("tile", "strip", "px")[px], ms / F, F * W * H / ms / 1e6, int(cnt[0])))
+        ms_score = timeit(lambda: g.probe_fast_score(sm, src, 20))
+        print("%-28s %-10s %.4f ms per frame  (%.0f Gpx/s)  score pass alone %.1f us per batch  n0=%d"
+              % (name, ("tile", "strip", "px", "tile+queue")[px], ms / F, F * W * H / ms / 1e6, ms_score * 1e3, int(cnt[0])), flush=True)
     g.tune(7, 0)

@@ -95,3 +95,21 @@ def test_latest_committed_bench_line_honours_the_contract():
         # passes it); every other fraction is against a physical peak and cannot exceed 1
         if isinstance(v, (int, float)) and "frac" in leaf and "copy_ceiling" not in leaf and "percall" not in path:
             assert 0 <= v <= 1.0, (path, v)
+
+
+def test_stamped_measurement_files_describe_the_kernels_in_the_tree():
+    """profiles/*.json that bench.py reads carry the hashes of the kernel sources they were taken from
+    (scripts/stamp.py).  fused_isa_mix.json can be regenerated without a GPU (make -C grayskull_amd/csrc asm +
+    scripts/isa_count.py), so a stale one is an error; the PMC files need the GPU box -- bench.py reports their
+    numbers as null while they are stale, and this test only checks that the mechanism sees the change."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    from stamp import fresh
+    mix = json.load(open(os.path.join(ROOT, "profiles", "fused_isa_mix.json")))
+    assert fresh(mix) is True, "k_fused.h / gs_fused.cpp / k_strip.h changed after profiles/fused_isa_mix.json: regenerate it " \
+                               "(make -C grayskull_amd/csrc asm; scripts/isa_count.py ...; scripts/stamp.py ...)"
+    stale = dict(mix, kernel_sources={k: "0" * 40 for k in mix["kernel_sources"]})
+    assert fresh(stale) is False and fresh({}) is None
+    b = _bench()
+    d, stamp = b.measurement(os.path.join(ROOT, "profiles", "fused_isa_mix.json"))
+    assert d is not None and stamp["kernel_sources_unchanged"] is True

@@ -188,3 +188,18 @@ def test_cascade_roundtrips_through_bytes():
         Cascade.from_bytes(raw[:1000])
     with pytest.raises(ValueError):
         Cascade.from_bytes(b"nope")
+
+
+def test_gsbatch_shards_files_like_the_python_driver():
+    """the C99 driver's `--gpus N` split (grayskull_amd/host/gsbatch.c frame_range) is the rule bench.py uses
+    (grayskull_amd/shard.py): same ranges for every (workers, files), each file owned exactly once"""
+    import subprocess
+    from grayskull_amd.shard import frame_range
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "grayskull_amd", "csrc"), "tool"])
+    exe = os.path.join(ROOT, "grayskull_amd", "gsbatch")
+    for world in (1, 2, 3, 8):
+        for total in (0, 1, 7, 8, 9, 4096, 4099):
+            out = subprocess.run([exe, "--shard-table", str(world), str(total)], capture_output=True, text=True, check=True).stdout
+            got = [tuple(int(v) for v in line.split()) for line in out.splitlines()]
+            assert got == [(r,) + frame_range(r, world, total) for r in range(world)], (world, total)
+            assert [f for _, lo, hi in got for f in range(lo, hi)] == list(range(total))
