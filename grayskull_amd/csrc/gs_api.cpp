@@ -291,7 +291,8 @@ struct StripCfg {
  * 108 rows for 64 4K frames) and never tried bands below 16 rows.
  * The VALU-heavy fused kernels (waves_per_simd 3) keep long bands: each band first recomputes
  * 2R+2 rows of horizontal sums (8-row bands: 0.25 -> 0.38 ms per 64 frames). */
-StripCfg strip_cfg(unsigned w, unsigned rows, unsigned n, unsigned waves_per_simd = 5, unsigned halo_rows = 2) {
+StripCfg strip_cfg(unsigned w, unsigned rows, unsigned n, unsigned waves_per_simd = 5, unsigned halo_rows = 2,
+                   unsigned short_T = 8) {
   StripCfg c;
   const unsigned strips = (w + 15) / 16;
   const unsigned long long waves_x = (strips + 63) / 64;
@@ -299,7 +300,11 @@ StripCfg strip_cfg(unsigned w, unsigned rows, unsigned n, unsigned waves_per_sim
   if (g_tune[0] > 0) {
     t = (unsigned long long)g_tune[0];
   } else if (waves_per_simd >= 5) {
-    t = std::max(8u, 2u * halo_rows);
+    /* round 3, with the XCD-aware band mapping (a band's halo rows were just fetched by its own XCD) even shorter bands
+     * pay: gs_sobel 6 rows (4096^2 0.706 -> 0.720 of the peak, 512 x 4K 0.705 -> 0.722; odd heights break its 2-row
+     * unroll groups), gs_blur(2) 6 (0.671 -> 0.703 / 0.692 -> 0.705), gs_blur(1) and the morphology 4 (0.707 -> 0.730,
+     * 0.716 -> 0.738 / 0.728 -> 0.746); profiles/r03l_strip_band_height_xcd.log.  short_T is the caller's choice. */
+    t = std::max(short_T, 2u * halo_rows);
   } else {
     /* bands per frame: the launch should fill the chip's resident-wave capacity a whole number of
      * times.  One round when the batch is small enough; for big batches (512 4K frames: 2048 wave
@@ -367,7 +372,7 @@ void launch_sobel(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsi
     uint8_t *d = dst + fb * f0;
     const uint8_t *s = src + fb * f0;
     if (strip_ok(w, h, d, s) && w >= 32) {
-      const StripCfg c = strip_cfg(w, h - 2, nn);
+      const StripCfg c = strip_cfg(w, h - 2, nn, 5, 2, 6);
       if (keep_cols) GS_LAUNCH(k_sobel16<true>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
       else GS_LAUNCH(k_sobel16<false>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
     } else {
@@ -386,7 +391,7 @@ void launch_morph(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsi
     uint8_t *d = dst + fb * f0;
     const uint8_t *s = src + fb * f0;
     if (strip_ok(w, h, d, s)) {
-      const StripCfg c = strip_cfg(w, h, nn);
+      const StripCfg c = strip_cfg(w, h, nn, 5, 2, 4);
       GS_LAUNCH(k_morph16<DILATE>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
     } else {
       GS_LAUNCH(k_morph_px<DILATE>, grid2d(w, h, nn), dim3(64, 4), 0, st, d, s, w, h, fb);
@@ -491,7 +496,7 @@ void launch_blur(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsig
   if (radius >= 1 && radius <= 3 && strip_ok(w, h, dst, src) && h > 2 * radius && w > 2 * radius) {
     for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
       const unsigned nn = std::min(kMaxZ, n - f0);
-      const StripCfg c = strip_cfg(w, h, nn, 5, 2 * radius);
+      const StripCfg c = strip_cfg(w, h, nn, 5, radius, radius == 1 ? 4 : radius == 2 ? 6 : 12);
       uint8_t *d = dst + fb * f0;
       const uint8_t *s = src + fb * f0;
       if (radius == 1) GS_LAUNCH(k_blur16<1>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
@@ -670,6 +675,9 @@ void launch_fast(const uint8_t *img, uint8_t *score, unsigned w, unsigned h, uns
       GS_LAUNCH(k_fast_nms16, c.grid, c.block, 0, st, (const uint8_t *)score + fb * f0, w, h, c.T, fb | c.xcd_flag,
                 mask + (size_t)f0 * nchunks * kChunkWords, cnt + (size_t)f0 * nchunks, wpr, nchunks);
     }
+    /* (Tried and not kept: eight chunks per emit wave -- fewer waves, loads batched -- 19 -> 33 us per 32 x 720p: the pass is
+     * one wave's latency chain, and 14,464 small waves hide it better than 1,808 long ones.  Bands of 16 rows for the NMS
+     * kernel: 23.6 -> 25 us.  profiles/r03m_fast_emit_not_kept.log) */
     run_compaction(mask, cnt, nchunks, n, nkps, counts,
                    FastEmitPadded{score, w, wpr * 64u, fb, kps, nkps, ((uintptr_t)kps & 15) == 0}, st, pfx);
     return;
