@@ -11,6 +11,8 @@ echo "== bench under torch.distributed.run, 1 rank, GS_BENCH_FORCE_DIST=1 (nccl 
 GS_BENCH_FORCE_DIST=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29631 bench.py --gpus 1 --no-other --no-cpu --steps 20 2>gpurun_out/bench_rccl.err | grep '^{' | tee gpurun_out/bench_rccl_world1.json | cut -c1-300
 echo "== configs[4] workload, 64 frames, golden + live oracle check of frame 0"
 timeout 900 python bench.py --workload cfg4 --frames 64 --steps 2 --warmup 1 --verify-live 2>gpurun_out/cfg4.err | tee gpurun_out/cfg4_bench.json | cut -c1-900
+echo "== A/B build with compiler-visible LDS atomics in the fused kernel (-DGS_PLAIN_LDS_ATOMICS): same bytes (golden parity), time"
+[ -f build_variants/libgs_plain_lds.so ] && GS_BENCH_LIB=$R/build_variants/libgs_plain_lds.so timeout 600 python bench.py --no-cpu --no-other --steps 20 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('plain_lds', d['value'], d['ms_per_step'], d['parity'][:90])" | tee gpurun_out/plain_lds_ab.log
 echo "== --gpus 2 on a 1-GPU box must refuse"; python bench.py --gpus 2 --steps 2 2>&1 | tail -1
 echo "== rocprofv3 kernel stats (the full bench command)"
 cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o stats -- python $R/bench.py --no-cpu --no-verify > $R/gpurun_out/prof_bench.json 2> $R/gpurun_out/prof.err

@@ -65,6 +65,9 @@ def hip():
     import grayskull_amd as G
     g = G.lib()
     assert g.device_count() > 0, "no HIP device visible"
+    # GS_TUNE_KEY / GS_TUNE_VAL: run the GPU suite under a non-default launch-tuning key (results never change)
+    if os.environ.get("GS_TUNE_KEY"):
+        g.tune(int(os.environ["GS_TUNE_KEY"]), int(os.environ.get("GS_TUNE_VAL", "0")))
     return g
 
 

@@ -74,7 +74,9 @@ def test_latest_committed_bench_line_honours_the_contract():
     achieved / peak / frac / traffic, the CPU baseline says how it was taken"""
     import glob
     import json
-    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_bench.json")) if "rank" not in f)
+    import re
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_bench.json"))
+                   if re.fullmatch(r"r\d\d[a-z]_bench\.json", os.path.basename(f)))  # the default workload's line only
     d = json.loads(open(files[-1]).read().strip().splitlines()[-1])
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
