@@ -105,7 +105,7 @@ def cpu_baseline(w, h, radius, frames_target=48):
     from oracle import pyoracle
     kind = "reference" if pyoracle.have_reference() else "port"
     cores = usable_cores()
-    per = max(2, frames_target // cores)
+    per = max(1, frames_target // cores)  # the threads start together behind a barrier, so one frame each is a fair sample
     frames = per * cores
     imgs = [pyoracle.Oracle.synth(w, h, 1000 + i) for i in range(min(cores, 16))]  # shared, read-only
     oracles = [pyoracle.Oracle(kind) for _ in range(cores)]  # library handles made outside the timed region

@@ -437,6 +437,8 @@ __global__ __launch_bounds__(256) void k_lbp_cascade(LbpArgs a, LbpPhases ph) {
       for (unsigned i0 = 0; i0 < n_in; i0 += 64u) { /* block-uniform trip count */
         const unsigned i = i0 + (tid >> 2), ci = tid & 3u;
         const bool live = i < n_in;
+        if (i0 + (tid & ~63u) / 4u >= n_in) continue; /* this wave's 16 windows all lie past the queue's end (wave-uniform): the
+                                                         tail stages leave a chunk a handful of survivors, one wave's worth */
         const unsigned local = qin[live ? i : n_in - 1u];
         const bool pass = lbp_quad_stages<GUARD, COUNT>(t, Pg, lbp_origin(a, sc, first + local), ci, live, a.limit_bytes, s0, s1, &evals);
         const bool lead = pass && ci == 0u;
