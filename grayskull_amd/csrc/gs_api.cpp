@@ -634,8 +634,11 @@ void launch_fast_score(hipStream_t on, const uint8_t *img, uint8_t *score, unsig
      * half of the pass is the tile load, the compass filter and the byte stores, which the queue does not touch */
     GS_LAUNCH(k_fast_score_cq, dim3((w - 6 + 63) / 64, (h - 6 + kFastTileRows - 1) / kFastTileRows, n), dim3(64, 4), 0, on,
               img, score, w, h, fb, threshold);
-  } else {
+  } else if (g_tune[7] == 4 || threshold > 0xffffff00u) { /* round-2 default: one pixel per lane, whole wave rows scored */
     GS_LAUNCH(k_fast_score_tile, dim3((w - 6 + 63) / 64, (h - 6 + kFastTileRows - 1) / kFastTileRows, n), dim3(64, 4), 0, on,
+              img, score, w, h, fb, threshold);
+  } else { /* LDS tile, 4 px per thread through the compass filter, candidates queued (k_fast.h) */
+    GS_LAUNCH(k_fast_score_q4, dim3((w - 6 + 63) / 64, (h - 6 + kFastTileRows - 1) / kFastTileRows, n), dim3(64, 4), 0, on,
               img, score, w, h, fb, threshold);
   }
 }

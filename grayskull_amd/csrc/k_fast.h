@@ -247,6 +247,116 @@ __global__ __launch_bounds__(256) void k_fast_score_cq(const uint8_t *img, uint8
   }
 }
 
+/* pass 1, round 3 default (threshold <= 0xffffff00): LDS tile, FOUR pixels per thread for the compass filter, candidates
+ * queued and scored 64 to a wave.  Where k_fast_score_tile's time goes on the configs[3] frames (72 us per 32 x 720p):
+ * half of it is paid on flat frames too (38 us) -- one pixel per lane means 5 ds_read_u8, ~35 scalar-per-pixel VALU
+ * operations and a byte store for EVERY pixel -- and the 16-pixel ring is walked for whole wave rows although only
+ * 11 % of the pixels pass the filter (45 % of the wave rows hold at least one).  Here a thread takes 4 consecutive
+ * pixels of a tile row: 7 aligned LDS dwords (centre row 3, rows y -+ 3 two each; v_alignbit shifts them into
+ * place) feed the compass filter on packed u16 pairs exactly as in k_fast_score4 (second largest / second smallest
+ * of the four compass pixels against p +- t; p < t always passes: the reference's unsigned wrap, ref :496-498), the
+ * four scores are stored as ONE zero dword, and only the pixels that pass are queued (LDS, order irrelevant) and
+ * scored from the tile's bytes with fast_score -- the same function as every other score kernel, and a pixel the
+ * filter rejects has no run of 9, so the stored zero IS its score.  One pass over the 64 x 16 tile per block
+ * (256 threads x 4 px) instead of four.  grid / block as k_fast_score_tile. */
+typedef uint32_t gs_u32_unaligned __attribute__((aligned(1)));
+__global__ __launch_bounds__(256) void k_fast_score_q4(const uint8_t *img, uint8_t *score, unsigned w, unsigned h,
+                                                       size_t frame_bytes, unsigned threshold) {
+  __shared__ uint32_t tile32[(kFastTileRows + 6) * kFastTileDw + 2]; /* + 2: the last thread's third centre dword */
+  __shared__ uint16_t queue[64 * kFastTileRows];
+  __shared__ unsigned qn;
+  const uint8_t *frame = img + (size_t)blockIdx.z * frame_bytes;
+  uint8_t *out = score + (size_t)blockIdx.z * frame_bytes;
+  const unsigned tid = threadIdx.y * 64u + threadIdx.x;
+  const unsigned x_t = blockIdx.x * 64u, y_t = blockIdx.y * kFastTileRows;
+  if (tid == 0) qn = 0, tile32[(kFastTileRows + 6) * kFastTileDw] = 0, tile32[(kFastTileRows + 6) * kFastTileDw + 1] = 0;
+  for (unsigned i = tid; i < (kFastTileRows + 6) * kFastTileDw; i += 256u) {
+    const unsigned r = i / kFastTileDw, c = i - r * kFastTileDw;
+    const size_t off = (size_t)(y_t + r) * w + x_t + c * 4u;
+    uint32_t v = 0;
+    if (off + 4 <= frame_bytes) {
+      v = load_u32_unaligned(frame + off);
+    } else {
+      for (unsigned b = 0; b < 4; b++)
+        if (off + b < frame_bytes) v |= (uint32_t)frame[off + b] << (8 * b);
+    }
+    tile32[i] = v;
+  }
+  __syncthreads();
+  /* thread -> tile row ry, pixels 4 xg .. 4 xg + 3 of it (tile byte columns 4 xg + 3 .. 4 xg + 6) */
+  const unsigned ry = tid >> 4, xg = tid & 15u;
+  const unsigned x = 3 + x_t + 4u * xg, y = 3 + y_t + ry;
+  const uint32_t *rc = tile32 + (ry + 3) * kFastTileDw + xg, *ru = tile32 + ry * kFastTileDw + xg,
+                 *rd = tile32 + (ry + 6) * kFastTileDw + xg;
+  const uint32_t d0 = rc[0], d1 = rc[1], d2 = rc[2];
+  const uint32_t C = alignbit(d1, d0, 24), L = d0, Rr = alignbit(d2, d1, 16); /* p; (x - 3, y); (x + 3, y) */
+  const uint32_t U = alignbit(ru[1], ru[0], 24), D = alignbit(rd[1], rd[0], 24); /* (x, y - 3); (x, y + 3) */
+  const uint32_t t16 = threshold < 256u ? threshold : 256u, tt = t16 | (t16 << 16);
+  unsigned cand = 0; /* bit k: pixel k passes the compass filter */
+#pragma unroll
+  for (int hp = 0; hp < 2; hp++) {
+    const uint32_t P = hp ? unpack_hi(C) : unpack_lo(C), a = hp ? unpack_hi(U) : unpack_lo(U), c = hp ? unpack_hi(D) : unpack_lo(D);
+    const uint32_t b = hp ? unpack_hi(Rr) : unpack_lo(Rr), d = hp ? unpack_hi(L) : unpack_lo(L);
+    const uint32_t mx = pk_max_u16(a, b), mn = pk_min_u16(a, b), z = pk_max_u16(c, d), u = pk_min_u16(c, d);
+    const uint32_t mid_hi = pk_min_u16(mx, z), mid_lo = pk_max_u16(mn, u);
+    const uint32_t S2 = pk_max_u16(mid_hi, mid_lo), s2 = pk_min_u16(mid_hi, mid_lo); /* second largest / smallest */
+    const uint32_t pass = pk_subsat_u16(S2, pk_add_u16(P, tt)) | pk_subsat_u16(pk_subsat_u16(P, tt), s2) | pk_subsat_u16(tt, P);
+    cand |= ((pass & 0xffffu) ? 1u : 0u) << (2 * hp) | ((pass >> 16) ? 1u : 0u) << (2 * hp + 1);
+  }
+  /* pixels of the interior only (3 <= x < w - 3, 3 <= y < h - 3); the tile may stick out of it */
+  unsigned inmask = 0;
+#pragma unroll
+  for (unsigned k = 0; k < 4; k++) inmask |= (x + k + 3u < w && y + 3u < h ? 1u : 0u) << k;
+  cand &= inmask;
+  if (inmask == 15u) {
+    *(gs_u32_unaligned *)(out + (size_t)y * w + x) = 0u; /* candidates are overwritten behind the barrier */
+  } else {
+#pragma unroll
+    for (unsigned k = 0; k < 4; k++)
+      if ((inmask >> k) & 1u) out[(size_t)y * w + x + k] = 0;
+  }
+#pragma unroll
+  for (unsigned k = 0; k < 4; k++) { /* queue the candidates: one LDS atomic per wave and slot */
+    const bool ck = (cand >> k) & 1u;
+    const uint64_t m = ballot(ck);
+    if (m) {
+      const unsigned lane = lane_id();
+      unsigned base = 0;
+      if (lane == 0) base = atomicAdd(&qn, (unsigned)__popcll(m));
+      base = readlane0(base);
+      if (ck) queue[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(ry * 64u + 4u * xg + k);
+    }
+  }
+  __syncthreads(); /* orders the zero stores above before the candidates' stores below (workgroup-scope release / acquire) */
+  const unsigned ncand = qn;
+  const uint8_t *tb = (const uint8_t *)tile32;
+  constexpr int S = (int)kFastTileDw * 4;
+  if (ncand * 2u >= 64u * kFastTileRows) { /* most of the tile passes (noise, p < t regions): the queue would only add a round trip
+                                              and scatter the LDS reads -- every thread scores its own pixels (32 x 720p random
+                                              bytes: 138 us through the queue, 110 in place) */
+#pragma unroll
+    for (unsigned k = 0; k < 4; k++) {
+      if (ballot((cand >> k) & 1u) == 0) continue; /* wave-uniform */
+      const uint8_t *c = tb + (ry + 3) * S + 4u * xg + k + 3;
+      const unsigned v[16] = {c[-3 * S],     c[-3 * S + 1], c[-2 * S + 2], c[-S + 3], c[3],  c[S + 3],  c[2 * S + 2],  c[3 * S + 1],
+                              c[3 * S],      c[3 * S - 1],  c[2 * S - 2],  c[S - 3],  c[-3], c[-S - 3], c[-2 * S - 2], c[-3 * S - 1]};
+      const unsigned sc = fast_score(c[0], v, threshold);
+      if (((cand >> k) & 1u) && sc) out[(size_t)y * w + x + k] = (uint8_t)sc;
+    }
+    return;
+  }
+  for (unsigned i0 = 0; i0 < ncand; i0 += 256u) { /* block-uniform trip count */
+    const unsigned i = i0 + tid;
+    if (i0 + (tid & ~63u) >= ncand) continue; /* whole wave past the queue's end */
+    const unsigned e = queue[i < ncand ? i : ncand - 1u], qy = e >> 6, qx = e & 63u;
+    const uint8_t *c = tb + (qy + 3) * S + qx + 3;
+    const unsigned v[16] = {c[-3 * S],     c[-3 * S + 1], c[-2 * S + 2], c[-S + 3], c[3],  c[S + 3],  c[2 * S + 2],  c[3 * S + 1],
+                            c[3 * S],      c[3 * S - 1],  c[2 * S - 2],  c[S - 3],  c[-3], c[-S - 3], c[-2 * S - 2], c[-3 * S - 1]};
+    const unsigned sc = fast_score(c[0], v, threshold);
+    if (i < ncand && sc) out[(size_t)(3 + y_t + qy) * w + 3 + x_t + qx] = (uint8_t)sc;
+  }
+}
+
 /* pass 1, strips (w % 4 == 0, 4-byte aligned frames, threshold <= 0xffffff00): a lane owns 4
  * consecutive pixels (one dword per row), a wave 256 px of a row, and walks DOWN a band of T rows
  * with the 7 image rows y-3..y+3 in registers as 12-byte windows (L, C, R: the neighbour lanes'

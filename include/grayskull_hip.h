@@ -39,8 +39,9 @@ void gsh_sync(void);                      /* hipStreamSynchronize(current stream
  * gsh_edge_pipeline_batch's internal overlap (0 = default 32, negative = never split),
  * 6 comparison switches: 1 = generic two-pass gs_integral, 2 = block-per-band gs_integral,
  * 3 = integral-image route for gs_blur(radius > 3) / gs_adaptive_threshold instead of the sliding
- * box kernel, 7 score kernel of gs_fast: 0 = LDS tile (default), 1 = strip kernel (lane = 4 px, image rows in registers; faster
- * on flat frames only), 2 = one global byte load per ring pixel (round 1), 3 = LDS tile + block-local candidate queue,
+ * box kernel, 7 score kernel of gs_fast: 0 = LDS tile, 4 px per thread through the compass filter, candidates queued (default),
+ * 1 = strip kernel (lane = 4 px, image rows in registers), 2 = one global byte load per ring pixel (round 1), 3 = LDS tile, one
+ * pixel per lane + candidate queue, 4 = LDS tile, one pixel per lane, whole wave rows scored (round 2),
  * 8 frames per launch (test hook for the batch splitting of every launcher), 9 LBP: stages / survivor
  * share at which a block first re-packs (max stages + 16 * tenths [+ later points]; key 4 >= 1000 = custom fixed split),
  * 10 trips per block gs_histogram aims at, 11 its blocks per frame, 12 bytes per histogram piece (test

@@ -16,7 +16,7 @@ npx = 32 * 1280 * 720
 out = {"workload": "32 x 1280x720 synth(seed 4), threshold 20 (scripts/pmc_probe_features.py)", "avg_issue_cycles": round((48 * 2 + 114 * 4) / 162.0, 3),
        "source": "rocprofv3 --pmc SQ_INSTS_VALU (profiles/r02l_pmc_features.txt); issue cycles from profiles/r02a_ubench_valu.log classes",
        "kernels": {k: {"valu_wave_insts_per_launch": sum(v) / len(v), "valu_wave_insts_per_px": sum(v) / len(v) / npx} for k, v in acc.items()}}
-tile = [v for k, v in out["kernels"].items() if "tile" in k]
+tile = [v for k, v in out["kernels"].items() if "score_q4" in k] or [v for k, v in out["kernels"].items() if "tile" in k]
 out["valu_wave_insts_per_px"] = tile[0]["valu_wave_insts_per_px"] if tile else None
 for p in (os.path.join(root, "gpurun_out", "fast_valu_pmc.json"), os.path.join(root, "profiles", "fast_valu_pmc.json")):
     json.dump(out, open(p, "w"), indent=1)

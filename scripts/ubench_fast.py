@@ -22,10 +22,10 @@ from tests.util import lena
 L = lena(); inputs["lena_tiled"] = np.tile(L, ((H + 127) // 128, (W + 127) // 128))[:H, :W].copy()
 for name, img in inputs.items():
     src = torch.from_numpy(np.stack([img] * F)).cuda(); sm = torch.zeros_like(src)
-    for px in (0, 3, 1, 2):
+    for px in (0, 4, 3, 1, 2):
         g.tune(7, px)
         ms = timeit(lambda: g.fast_batch(src, sm, kps, cnt, 5000, 20))
         ms_score = timeit(lambda: g.probe_fast_score(sm, src, 20))
         print("%-28s %-10s %.4f ms per frame  (%.0f Gpx/s)  score pass alone %.1f us per batch  n0=%d"
-              % (name, ("tile", "strip", "px", "tile+queue")[px], ms / F, F * W * H / ms / 1e6, ms_score * 1e3, int(cnt[0])), flush=True)
+              % (name, ("tile4+queue", "strip", "px", "tile+queue", "tile")[px], ms / F, F * W * H / ms / 1e6, ms_score * 1e3, int(cnt[0])), flush=True)
     g.tune(7, 0)

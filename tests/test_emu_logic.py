@@ -61,7 +61,7 @@ def test_next_rows(emu, oracle, shape):
                                    (64, 40), (48, 7), (32, 16), (1040, 9), (2064, 8)])
 def test_fast(emu, oracle, shape):
     w, h = shape
-    for strip in ((0, 1, 2, 3) if w % 4 == 0 else (0, 2, 3)):  # gsh_tune key 7: 0 LDS tile (default), 1 strip kernel, 2 one global byte load per ring pixel, 3 LDS tile + candidate queue
+    for strip in ((0, 1, 2, 3, 4) if w % 4 == 0 else (0, 2, 3, 4)):  # gsh_tune key 7: 0 LDS tile, 4 px per thread + candidate queue (default), 1 strip kernel, 2 one global byte load per ring pixel, 3 LDS tile + candidate queue, 4 LDS tile (round 2)
         emu.tune(7, strip)
         try:
             pc.fast(emu, oracle, Oracle.synth(w, h, 5), MEM)
@@ -85,7 +85,7 @@ def test_fast_strip_kernel_equals_per_pixel_kernel(emu, oracle):
     img[25:33, 250:264] = rs.randint(0, 256, (8, 14))      # texture up to the right border
     for t in (20, 3, 200):
         pc.fast(emu, oracle, img, MEM, threshold=t, caps=(5000,))
-        for mode in (1, 2, 3):
+        for mode in (1, 2, 3, 4):
             emu.tune(7, mode)
             try:
                 pc.fast(emu, oracle, img, MEM, threshold=t, caps=(5000,))
