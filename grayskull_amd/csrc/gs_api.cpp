@@ -638,8 +638,12 @@ void launch_fast_score(hipStream_t on, const uint8_t *img, uint8_t *score, unsig
     GS_LAUNCH(k_fast_score_tile, dim3((w - 6 + 63) / 64, (h - 6 + kFastTileRows - 1) / kFastTileRows, n), dim3(64, 4), 0, on,
               img, score, w, h, fb, threshold);
   } else { /* LDS tile, 4 px per thread through the compass filter, candidates queued (k_fast.h) */
-    GS_LAUNCH(k_fast_score_q4, dim3((w - 6 + 63) / 64, (h - 6 + kFastTileRows - 1) / kFastTileRows, n), dim3(64, 4), 0, on,
-              img, score, w, h, fb, threshold);
+    const unsigned tx = (w - 6 + 63) / 64, ty = (h - 6 + kFastTileRows - 1) / kFastTileRows;
+    const unsigned long long nt = (unsigned long long)tx * ty * n;
+    GS_ASSERT(nt <= 0x7ffffff0ull); /* 2^31 tiles = 2^41 pixels in one call */
+    const unsigned share = g_tune[18] == 1 ? 0u : (unsigned)((nt + 7) / 8); /* key 18 = 1: tiles in launch order */
+    GS_LAUNCH(k_fast_score_q4, dim3(share ? share * 8u : (unsigned)nt), dim3(64, 4), 0, on, img, score, w, h, fb, threshold, tx,
+              ty, (unsigned)nt, share);
   }
 }
 

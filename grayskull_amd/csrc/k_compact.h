@@ -77,6 +77,7 @@ __global__ __launch_bounds__(256) void k_emit(const unsigned long long *mask,
   if (c >= nchunks) return; /* whole wave */
   const size_t fc = (size_t)blockIdx.y * nchunks + c;
   unsigned r;
+  unsigned long long mine_early = 0;
   if (prefix) {
     if (uniform(count[fc]) == 0) return;
     r = uniform(prefix[fc]);
@@ -90,13 +91,16 @@ __global__ __launch_bounds__(256) void k_emit(const unsigned long long *mask,
       t = wave_sum(t);
       if (lane == 0) total[blockIdx.y] = t < cap ? t : cap;
     }
-    if (uniform(cf[c]) == 0) return;
+    /* the pass is a chain of memory round trips for a handful of hits: the counters before the chunk, its own
+     * counter and its mask words are requested together (the words of an empty chunk are a wasted 256 bytes) */
+    mine_early = lane < kChunkWords ? mask[fc * kChunkWords + lane] : 0ull;
     unsigned before = 0;
     for (unsigned i = lane; i < c; i += 64u) before += cf[i];
+    if (uniform(cf[c]) == 0) return;
     r = wave_sum(before);
   }
   if (r >= cap) return;
-  const unsigned long long mine = lane < kChunkWords ? mask[fc * kChunkWords + lane] : 0ull;
+  const unsigned long long mine = prefix ? (lane < kChunkWords ? mask[fc * kChunkWords + lane] : 0ull) : mine_early;
   const uint32_t mlo = (uint32_t)mine, mhi = (uint32_t)(mine >> 32);
   if constexpr (QUAD) {
     for (unsigned g = 0; g < kChunkWords / 4 && r < cap; g++) { /* wave-uniform */

@@ -258,17 +258,29 @@ __global__ __launch_bounds__(256) void k_fast_score_cq(const uint8_t *img, uint8
  * four scores are stored as ONE zero dword, and only the pixels that pass are queued (LDS, order irrelevant) and
  * scored from the tile's bytes with fast_score -- the same function as every other score kernel, and a pixel the
  * filter rejects has no run of 9, so the stored zero IS its score.  One pass over the 64 x 16 tile per block
- * (256 threads x 4 px) instead of four.  grid / block as k_fast_score_tile. */
+ * (256 threads x 4 px) instead of four.  grid: one block per tile, 1-D (see the tile mapping below); block (64, 4). */
 typedef uint32_t gs_u32_unaligned __attribute__((aligned(1)));
 __global__ __launch_bounds__(256) void k_fast_score_q4(const uint8_t *img, uint8_t *score, unsigned w, unsigned h,
-                                                       size_t frame_bytes, unsigned threshold) {
+                                                       size_t frame_bytes, unsigned threshold, unsigned tiles_x,
+                                                       unsigned tiles_y, unsigned ntiles, unsigned xcd_share) {
   __shared__ uint32_t tile32[(kFastTileRows + 6) * kFastTileDw + 2]; /* + 2: the last thread's third centre dword */
   __shared__ uint16_t queue[64 * kFastTileRows];
   __shared__ unsigned qn;
-  const uint8_t *frame = img + (size_t)blockIdx.z * frame_bytes;
-  uint8_t *out = score + (size_t)blockIdx.z * frame_bytes;
+  /* tile of this block.  Workgroups go to the 8 XCDs round robin and each XCD has its own L2: with neighbouring tiles on
+   * different XCDs every L2 fetches the shared halo rows and the 128-byte lines a 70-byte tile row straddles for itself
+   * (FETCH_SIZE 4.1 x the frame bytes, WRITE_SIZE 1.46 x from the split lines of the score map).  xcd_share != 0: a 1-D
+   * grid of 8 * xcd_share blocks, XCD k walks tiles [k * xcd_share, (k + 1) * xcd_share) in order, so the tiles in flight
+   * on one XCD are a few consecutive tile rows of one frame. */
+  unsigned tile = blockIdx.x;
+  if (xcd_share) {
+    tile = (blockIdx.x & 7u) * xcd_share + (blockIdx.x >> 3);
+    if (tile >= ntiles) return;
+  }
+  const unsigned tcol = tile % tiles_x, trow = (tile / tiles_x) % tiles_y, tframe = tile / (tiles_x * tiles_y);
+  const uint8_t *frame = img + (size_t)tframe * frame_bytes;
+  uint8_t *out = score + (size_t)tframe * frame_bytes;
   const unsigned tid = threadIdx.y * 64u + threadIdx.x;
-  const unsigned x_t = blockIdx.x * 64u, y_t = blockIdx.y * kFastTileRows;
+  const unsigned x_t = tcol * 64u, y_t = trow * kFastTileRows;
   if (tid == 0) qn = 0, tile32[(kFastTileRows + 6) * kFastTileDw] = 0, tile32[(kFastTileRows + 6) * kFastTileDw + 1] = 0;
   for (unsigned i = tid; i < (kFastTileRows + 6) * kFastTileDw; i += 256u) {
     const unsigned r = i / kFastTileDw, c = i - r * kFastTileDw;

@@ -22,8 +22,8 @@ from tests.util import lena
 L = lena(); inputs["lena_tiled"] = np.tile(L, ((H + 127) // 128, (W + 127) // 128))[:H, :W].copy()
 for name, img in inputs.items():
     src = torch.from_numpy(np.stack([img] * F)).cuda(); sm = torch.zeros_like(src)
-    for px in (0, 4, 3, 1, 2):
-        g.tune(7, px)
+    for px in ((0, 4, 3, 1, 2) if not os.environ.get("UB_ONLY") else (int(os.environ["UB_ONLY"]),)):
+        g.tune(7, px); g.tune(18, int(os.environ.get("UB_K18", 0)))
         ms = timeit(lambda: g.fast_batch(src, sm, kps, cnt, 5000, 20))
         ms_score = timeit(lambda: g.probe_fast_score(sm, src, 20))
         print("%-28s %-10s %.4f ms per frame  (%.0f Gpx/s)  score pass alone %.1f us per batch  n0=%d"

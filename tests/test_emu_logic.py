@@ -91,6 +91,11 @@ def test_fast_strip_kernel_equals_per_pixel_kernel(emu, oracle):
                 pc.fast(emu, oracle, img, MEM, threshold=t, caps=(5000,))
             finally:
                 emu.tune(7, 0)
+        emu.tune(18, 1)  # default score kernel with its tiles in launch order instead of the XCD-aware order
+        try:
+            pc.fast(emu, oracle, img, MEM, threshold=t, caps=(5000,))
+        finally:
+            emu.tune(18, 0)
 
 
 @pytest.mark.parametrize("shape", [(96, 80), (64, 40), (1040, 9), (32, 7), (272, 33)])
@@ -469,6 +474,28 @@ def test_fast_batch_split_over_several_launches(emu, oracle):
         assert_same(kps[f, :1].reshape(-1).view(ko.dtype), ko, "frame %d" % f)
         assert_same(sm[f], smo, "scoremap %d" % f)
     assert counts[n - 1] == 0
+
+
+@pytest.mark.parametrize("order", [0, 1])
+def test_fast_batch_tiles_of_several_frames_in_xcd_order(emu, oracle, order):
+    """k_fast_score_q4 numbers its 64 x 16 tiles over the whole batch and hands XCD k the k-th eighth of them (gsh_tune
+    key 18 = 1: launch order): 5 frames of 4 x 3 tiles = 60 tiles, so the 1-D grid has four blocks without a tile"""
+    n, h, w = 5, 40, 200
+    frames = np.stack([Oracle.synth(w, h, 30 + f) for f in range(n)])
+    frames[3, 5:30, 20:150] = np.random.RandomState(3).randint(0, 256, (25, 130))
+    sm = np.zeros_like(frames)
+    kps = np.zeros((n, 300, 12), np.uint32)
+    counts = np.zeros(n, np.uint32)
+    try:
+        emu.tune(18, order)
+        emu.fast_batch(frames, sm, kps, counts, 300, 20)
+    finally:
+        emu.tune(18, 0)
+    for f in range(n):
+        ko, smo = oracle.fast(frames[f], 300, 20)
+        assert counts[f] == len(ko), f
+        assert_same(kps[f, :len(ko)].reshape(-1).view(ko.dtype), ko, "frame %d" % f)
+        assert_same(sm[f], smo, "scoremap %d" % f)
 
 
 def test_device_resident_orb_with_the_reference_nostdlib_trig(emu, reference):
