@@ -2,7 +2,7 @@
 # round 3, full visit: smoke, GPU suite, bench (plain / under RCCL at world 1 / configs[4]), rocprofv3 kernel stats of the
 # full bench command, PMC traffic + feature counters + LBP counters.  Logs -> gpurun_out/
 R=${GRAFT_REPO_ROOT:-/root/repo}
-cd $R; mkdir -p gpurun_out; rm -rf gpurun_out/prof gpurun_out/pmc_* gpurun_out/sqfeat_*; export TMPDIR=/tmp
+cd $R; mkdir -p gpurun_out; rm -rf gpurun_out/prof gpurun_out/pmc_* gpurun_out/sqfeat_* gpurun_out/sqbox_*; export TMPDIR=/tmp
 echo "== smoke"; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee gpurun_out/smoke.log
 echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider --durations=6 2>&1 | tail -14 | tee gpurun_out/pytest_gpu.log
 echo "== bench"; timeout 900 python bench.py 2>gpurun_out/bench.err | tee gpurun_out/bench.json | cut -c1-500
@@ -26,6 +26,8 @@ echo "== PMC: feature kernels"
 PMC_PROBE=scripts/pmc_probe_features.py PMC_FILTER=k_fast,k_hist_partial,k_lbp,k_emit,k_chunk PMC_TAG=sqfeat \
   PMC_SETS="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_WAVES SQ_INSTS_LDS" bash scripts/pmc_fused.sh 2>&1 | grep -v amdgpu.ids | tee gpurun_out/pmc_features.txt
 python scripts/pmc_fast_json.py > gpurun_out/pmc_fast_json.log 2>&1; tail -2 gpurun_out/pmc_fast_json.log | cut -c1-300
+echo "== PMC: sliding box (r = 8) and integral kernels, 64 x 4K"
+PMC_PROBE=scripts/pmc_probe_box.py PMC_FILTER=k_box16,k_integral PMC_TAG=sqbox bash scripts/pmc_fused.sh 2>&1 | grep -v amdgpu.ids | tee gpurun_out/pmc_box.txt
 echo "== PMC: LBP cascade, 8 x 4K noise"
 LBP_PRE=0 PMC_SETS="TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum|TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum|TA_TA_BUSY_sum GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_ACTIVE_INST_VALU" bash scripts/pmc_lbp.sh 2>&1 | grep -v amdgpu.ids | tee gpurun_out/pmc_lbp_quad.txt
 echo "== next rows"; timeout 300 python scripts/ubench_next_rows.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/next_rows.log | tail -12
