@@ -19,7 +19,6 @@
 #include <map>
 #include <vector>
 
-#include "k_box.h"
 #include "k_fast.h"
 #include "k_fast_nms.h"
 #include "k_geom.h"
@@ -57,6 +56,11 @@ void launch_blur_sobel_hist(unsigned radius, dim3 grid, dim3 block, hipStream_t 
                             unsigned *partial);
 void launch_blur_sobel(unsigned radius, dim3 grid, dim3 block, hipStream_t st, uint8_t *dst, const uint8_t *src,
                        unsigned w, unsigned h, unsigned T, size_t frame_bytes);
+/* gs_box.cpp */
+void launch_box(int mode, unsigned ring_radius, dim3 grid, unsigned threads, hipStream_t st, uint8_t *dst, const uint8_t *src, unsigned w,
+                unsigned h, unsigned T, size_t frame_bytes, unsigned r, int c);
+unsigned box_blocks_per_cu(int mode, unsigned ring_radius, unsigned threads);
+unsigned box_ring_max();
 }
 using namespace gs;
 
@@ -444,37 +448,41 @@ void launch_box_generic(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h
      * u16 column sums and LDS halo hold up to r = 127 */
     for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
       const unsigned nn = std::min(kMaxZ, n - f0);
-      /* band height: the launch should be whole rounds of the ~1024 blocks the chip holds (4 per CU), and a band
-       * first loads 2r+1 rows it does not output -- loads and adds only since the vertical-first form, ~0.3 of an
-       * output row each.  Pick the band count with the smallest rounds x (T + 0.3 (2r+1)): 64 4K frames -> 16 bands
-       * of 135 rows (r = 16: 0.50 -> 0.36 ms, r = 40: 1.11 -> 0.63), 8 frames -> 128 bands (r = 40: 1.0 -> 0.16 ms;
-       * profiles/r02l_box_T.log).  Round 1's "at least four window heights per band" dates from a prologue that
-       * cost more than the rows it preceded. */
+      /* r <= 16: the window's raw rows stay in registers (k_box16r: 2 B/px instead of 3-4; 64 x 4K: 0.22 ms for r <= 9,
+       * 0.28 up to 16, against 0.31-0.42 -- profiles/r03r_box_ring.log).  Key 6 = 4: k_box16 always. */
+      const bool ring = g_tune[6] != 4 && r <= box_ring_max() && w >= 32 && h >= 2 * r + 1 && (MODE == 0 || (c > -(1 << 30) && c < (1 << 30)));
+      /* band height: the launch should be whole rounds of the blocks the chip holds (256 CUs x 4 of them, fewer for the
+       * register-heavy ring kernels of r >= 8 / 10), and a band first loads 2r+1 rows it does not output -- loads and
+       * adds only since the vertical-first form, ~0.3 of an output row each.  Pick the band count with the smallest
+       * rounds x (T + 0.3 (2r+1)): 64 4K frames -> 16 bands of 135 rows (r = 16: 0.50 -> 0.36 ms, r = 40: 1.11 -> 0.63),
+       * 8 frames -> 128 bands (r = 40: 1.0 -> 0.16 ms; profiles/r02l_box_T.log).  Round 1's "at least four window
+       * heights per band" dates from a prologue that cost more than the rows it preceded. */
+      const unsigned threads = w <= 1024 ? 64u : w <= 2048 ? 128u : 256u; /* a thread owns 16 px of the row */
+      const unsigned slots = 256u * box_blocks_per_cu(MODE, ring ? r : 0u, threads);
       unsigned T = h;
       if (g_tune[0] > 0) {
         T = (unsigned)g_tune[0];
       } else {
-        /* once the launch is several full rounds, more bands only add prologues (cost ~ nn h / 1024 + nn nbc k / 1024
+        /* once the launch is several full rounds, more bands only add prologues (cost ~ nn h / slots + nn nbc k / slots
          * grows with nbc), so the search stops at 4 rounds' worth of blocks: at most 4096 candidates however tall
-         * the image is; the last answer is kept per (h, nn, r) */
-        static thread_local struct { unsigned h, nn, r, T; } memo = {0, 0, 0, 0};
-        if (memo.h == h && memo.nn == nn && memo.r == r) {
+         * the image is; the last answer is kept per (h, nn, r, slots) */
+        static thread_local struct { unsigned h, nn, r, slots, T; } memo = {0, 0, 0, 0, 0};
+        if (memo.h == h && memo.nn == nn && memo.r == r && memo.slots == slots) {
           T = memo.T;
         } else {
           double best = 1e30;
-          const unsigned nbc_max = std::max(1u, std::min(h / 8u, std::max(1u, 4096u / nn)));
+          const unsigned nbc_max = std::max(1u, std::min(h / 8u, std::max(1u, 4u * slots / nn)));
           for (unsigned nbc = 1; nbc <= nbc_max; nbc++) {
             const unsigned t = (h + nbc - 1) / nbc;
-            const double rounds = (double)(((unsigned long long)nn * ((h + t - 1) / t) + 1023) / 1024);
-            const double cost = rounds * ((double)t + 0.3 * (2.0 * r + 1.0));
+            const double rounds = (double)(((unsigned long long)nn * ((h + t - 1) / t) + slots - 1) / slots);
+            const double cost = rounds * ((double)t + (ring ? 0.12 : 0.3) * (2.0 * r + 1.0)); /* ring: 16 VALU per start-up row */
             if (cost < best - 1e-9) best = cost, T = t;
           }
-          memo = {h, nn, r, T};
+          memo = {h, nn, r, slots, T};
         }
       }
       const unsigned nb = (h + T - 1) / T;
-      GS_LAUNCH(k_box16<MODE>, dim3(1, nb, nn), dim3(256), 0, st, dst + fp * f0, src + fp * f0, w, h, T, fp,
-                r, c);
+      launch_box(MODE, ring ? r : 0u, dim3(1, nb, nn), threads, st, dst + fp * f0, src + fp * f0, w, h, T, fp, r, c);
     }
     return;
   }

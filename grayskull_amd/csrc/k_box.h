@@ -21,7 +21,7 @@
  */
 #ifndef GS_K_BOX_H
 #define GS_K_BOX_H
-#include "prims.h"
+#include "k_strip.h" /* static_for */
 
 namespace gs {
 
@@ -45,7 +45,8 @@ GS_DEV unsigned box_div(unsigned sum, unsigned cx, unsigned cy, float rx, float 
 }
 
 /* MODE 0: dst = mean (gs_blur); MODE 1: dst = src > (int)(mean - (unsigned)c) ? 255 : 0.
- * grid (1, nbands, n frames), block 256; T rows per band; 1 <= r <= 127, w % 16 == 0, w <= 4096. */
+ * grid (1, nbands, n frames), block 64 / 128 / 256 threads >= w / 16 (narrow frames: more blocks per CU instead of idle
+ * waves); T rows per band; 1 <= r <= 127, w % 16 == 0, w <= 4096. */
 template <int MODE>
 __global__ __launch_bounds__(256) void k_box16(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h,
                                                unsigned T, size_t frame_bytes, unsigned r, int c) {
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256) void k_box16(uint8_t *dst, const uint8_t *src,
   if (y0 >= (int)h) return; /* whole block */
   const int nrows = ((int)h - y0) < (int)T ? ((int)h - y0) : (int)T;
   /* zero both row buffers once: the halos and the pad bytes after every 16 entries are never written again */
-  for (unsigned i = tid; i < 2u * kBoxRowBytes / 4u; i += 256u) ((uint32_t *)&rows[0][0])[i] = 0;
+  for (unsigned i = tid; i < 2u * kBoxRowBytes / 4u; i += blockDim.x) ((uint32_t *)&rows[0][0])[i] = 0;
   /* per-pixel column counts and their reciprocals */
   unsigned cx[16];
   float rcx[16];
@@ -168,6 +169,135 @@ __global__ __launch_bounds__(256) void k_box16(uint8_t *dst, const uint8_t *src,
       od[j >> 2] |= o << (8 * (j & 3));
     }
     buf_store16(D, act ? (uint32_t)y * w + x0 : kOOB, U4{od[0], od[1], od[2], od[3]});
+  }
+}
+
+/* ------------------------------------------------------------------ radius known at compile time, r <= 8 */
+/* k_box16 re-reads the row that leaves the window (and, for the adaptive compare, the centre row): it moves 3.1 / 4.2 B/px
+ * where 2 are needed, and since round 2 removed most of its arithmetic that traffic IS its time (64 x 4K, r = 8: 1.66 GB per
+ * launch at the 5.3 TB/s two-buffer rate = 310 of the 339 us measured, VALU issue ~45 % busy; profiles/r03z_pmc_box.txt).
+ * Here the 2 RR + 1 raw rows of the window stay in registers (4 VGPRs each; the row loop is unrolled 2 RR + 1 times so the
+ * ring is indexed statically): every source row is loaded once per band, the leaving and the centre row come from the
+ * ring.  With the radius a constant the LDS offsets of the horizontal pass are immediates, the tap counts are constants
+ * (only the block's first / last thread owns horizontally clipped pixels: w >= 32), the MODE 1 count (cx * cy) is a scalar
+ * product and the MODE 0 quotient is v_mul_hi_u32 by ceil(2^32 / (cx * cy)) from a (RR + 1)^2 table (exact: 255 cnt^2 < 2^32,
+ * see k_box16) -- for every row, clipped or not (h >= 2 RR + 1).  Same results as k_box16 (tests run both).
+ * MODE 1 needs |c| < 2^30 (the launcher sends the wrap-around cases to k_box16). */
+template <int RR> struct BoxMagic {
+  uint32_t m[RR + 1][RR + 1]; /* [cy - (RR + 1)][cx - (RR + 1)] = ceil(2^32 / (cx * cy)) */
+  constexpr BoxMagic() : m() {
+    for (int a = 0; a <= RR; a++)
+      for (int b = 0; b <= RR; b++) m[a][b] = 0xffffffffu / (uint32_t)((RR + 1 + a) * (RR + 1 + b)) + 1u;
+  }
+};
+#ifndef GS_BOXR_ATTR
+#define GS_BOXR_ATTR
+#endif
+template <int MODE, int RR>
+__global__ __launch_bounds__(256) GS_BOXR_ATTR void k_box16r(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned T,
+                                                size_t frame_bytes, int c) {
+  constexpr int N = 2 * RR + 1;
+  static_assert(RR >= 1 && RR <= 16, "horizontally clipped pixels only in the block's first / last thread (w >= 32)");
+  static constexpr BoxMagic<RR> kMagic{};
+  __shared__ __attribute__((aligned(16))) uint8_t rows[2][kBoxRowBytes];
+  const unsigned tid = threadIdx.x, x0 = tid * 16u;
+  const bool act = x0 < w, first = x0 == 0, last = x0 + 16u == w;
+  const BufRsrc S = make_buf(src + (size_t)blockIdx.z * frame_bytes, frame_bytes);
+  const BufRsrc D = make_buf(dst + (size_t)blockIdx.z * frame_bytes, frame_bytes);
+  const int y0 = (int)(blockIdx.y * T);
+  if (y0 >= (int)h) return; /* whole block */
+  const int nrows = ((int)h - y0) < (int)T ? ((int)h - y0) : (int)T;
+  for (unsigned i = tid; i < 2u * kBoxRowBytes / 4u; i += blockDim.x) ((uint32_t *)&rows[0][0])[i] = 0;
+  auto row_load = [&](int yy) {
+    return buf_load16(S, (act && yy >= 0 && yy < (int)h) ? (uint32_t)yy * w + x0 : kOOB);
+  };
+  uint32_t Vc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto vc_add = [&](const U4 &v) {
+    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; q++) Vc[2 * q] += unpack_lo(d[q]), Vc[2 * q + 1] += unpack_hi(d[q]);
+  };
+  auto vc_sub = [&](const U4 &v) {
+    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; q++) Vc[2 * q] -= unpack_lo(d[q]), Vc[2 * q + 1] -= unpack_hi(d[q]);
+  };
+  const unsigned seg = kBoxPad + 36u * tid;
+  auto hsum = [&](unsigned phase, unsigned (&H)[16]) { /* as in k_box16, every offset a constant */
+    const uint8_t *p = &rows[phase][seg];
+    unsigned s = 0;
+    int k = -RR;
+    if (k & 1) s += *(const uint16_t *)(p + box_off(k)), k++;
+#pragma unroll
+    for (; k + 1 <= RR; k += 2) s = udot2_ones(*(const uint32_t *)(p + box_off(k)), s);
+    if (k <= RR) s += *(const uint16_t *)(p + box_off(k));
+    H[0] = s;
+#pragma unroll
+    for (int j = 1; j < 16; j++) {
+      s += *(const uint16_t *)(p + box_off(j + RR));
+      s -= *(const uint16_t *)(p + box_off(j - RR - 1));
+      H[j] = s;
+    }
+  };
+  /* prologue: the window of row y0 into the ring (slot k = row y0 - RR + k) and into the column sums */
+  U4 ring[N];
+  static_for<N>([&](auto K) { ring[decltype(K)::value] = row_load(y0 - RR + decltype(K)::value); });
+  static_for<N>([&](auto K) {
+    constexpr int k = decltype(K)::value;
+    vc_add(ring[k]);
+  });
+  __syncthreads(); /* the zeroing above */
+  U4 nin = row_load(y0 + RR + 1);
+  for (int base = 0; base < nrows; base += N) {
+    static_for<N>([&](auto I_) {
+      constexpr int I = decltype(I_)::value; /* slot of the row that leaves after this step: row y - RR */
+      const int i = base + I;
+      if (i >= nrows) return; /* block-uniform */
+      const int y = y0 + i;
+      const unsigned ph = (unsigned)i & 1u;
+      if (act) {
+        uint32_t *q = (uint32_t *)&rows[ph][seg];
+#pragma unroll
+        for (int k = 0; k < 8; k++) q[k] = Vc[k];
+      }
+      const U4 in = nin;
+      sched_fence();
+      __syncthreads(); /* also orders this phase's writes after the reads of two iterations ago */
+      sched_fence(); /* rows do not mix: the ring stays packed, 4 registers per row */
+      nin = row_load(y + RR + 2);
+      unsigned H[16];
+      hsum(ph, H);
+      const U4 cen = ring[(I + RR) % N]; /* row y */
+      sched_fence(); /* the other rows of the ring stay packed: nothing of theirs is unpacked ahead of time */
+      vc_add(in), vc_sub(ring[I]); /* the window around row y + 1 */
+      sched_fence();
+      ring[I] = U4{opaque(in.x), opaque(in.y), opaque(in.z), opaque(in.w)}; /* 4 registers, not the 8 unpacked ones */
+      const int ya = y - RR < 0 ? 0 : y - RR, yb = y + RR > (int)h - 1 ? (int)h - 1 : y + RR;
+      const unsigned cy = (unsigned)(yb - ya + 1); /* RR + 1 .. N, block-uniform */
+      uint32_t od[4] = {0, 0, 0, 0};
+      const uint32_t cd[4] = {cen.x, cen.y, cen.z, cen.w};
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        /* tap columns of pixel j: N, unless the block's first thread clips it on the left (j < RR: RR + 1 + j columns) or
+         * its last thread on the right (j >= 16 - RR: RR + 16 - j); constants once unrolled */
+        const int el = j < RR ? j : RR, er = j >= 16 - RR ? 15 - j : RR;
+        const bool cl = j < RR && first, cr = j >= 16 - RR && last;
+        unsigned o;
+        if (MODE == 0) {
+          const unsigned a = cy - (unsigned)(RR + 1);
+          /* uniform(): the three multipliers are scalars picked per lane, not a load from a per-lane address */
+          const uint32_t ml = uniform(kMagic.m[a][el]), mr = uniform(kMagic.m[a][er]), mc = uniform(kMagic.m[a][RR]);
+          o = __umulhi(H[j], cl ? ml : cr ? mr : mc) & 0xffu;
+        } else {
+          const unsigned cc = (unsigned)N * cy, ccl = (unsigned)(RR + 1 + el) * cy, ccr = (unsigned)(RR + 1 + er) * cy; /* scalar */
+          const int k = (int)((cd[j >> 2] >> (8 * (j & 3))) & 0xffu) + c;
+          const unsigned kc = (unsigned)(k < 0 ? 0 : k > 256 ? 256 : k);
+          o = kc * (cl ? ccl : cr ? ccr : cc) > H[j] ? 255u : 0u;
+        }
+        od[j >> 2] |= o << (8 * (j & 3));
+      }
+      buf_store16(D, act ? (uint32_t)y * w + x0 : kOOB, U4{od[0], od[1], od[2], od[3]});
+    });
   }
 }
 

@@ -39,7 +39,8 @@ void gsh_sync(void);                      /* hipStreamSynchronize(current stream
  * gsh_edge_pipeline_batch's internal overlap (0 = default 32, negative = never split),
  * 6 comparison switches: 1 = generic two-pass gs_integral, 2 = block-per-band gs_integral,
  * 3 = integral-image route for gs_blur(radius > 3) / gs_adaptive_threshold instead of the sliding
- * box kernel, 7 score kernel of gs_fast: 0 = LDS tile, 4 px per thread through the compass filter, candidates queued (default),
+ * box kernel, 4 = the any-radius box kernel k_box16 also for radii <= 16 (instead of the register-ring form k_box16r),
+ * 7 score kernel of gs_fast: 0 = LDS tile, 4 px per thread through the compass filter, candidates queued (default),
  * 1 = strip kernel (lane = 4 px, image rows in registers), 2 = one global byte load per ring pixel (round 1), 3 = LDS tile, one
  * pixel per lane + candidate queue, 4 = LDS tile, one pixel per lane, whole wave rows scored (round 2),
  * 8 frames per launch (test hook for the batch splitting of every launcher), 9 LBP: stages / survivor
@@ -49,7 +50,7 @@ void gsh_sync(void);                      /* hipStreamSynchronize(current stream
  * 14 stages the optional LBP prefilter k_lbp_dense takes (0 = off, the default; k = k stages; + 100 = full unsigned compares),
  * 15 windows per scale group of gs_lbp_detect (test hook; 0 = default 16 M), 16 = 1: gs_lbp_detect runs its cascade
  * kernels but emits nothing (timing aid; counts / rects are NOT written), 17 = 1: the cascade evaluates re-packed windows
- * one per lane instead of one per quad of lanes, 18 band-to-XCD mapping of the strip kernels (1 = dispatch order, 2 = XCD-aware
+ * one per lane instead of one per quad of lanes, 18 band-to-XCD mapping of the strip kernels and tile-to-XCD mapping of the gs_fast score pass (1 = dispatch order, 2 = XCD-aware
  * always), 19 = 1: pass 2 of gs_fast item by item (k_fast_nms, round 2) instead of the strip form.
  * Results never change (key 16 excepted). */
 void gsh_tune(int key, int value);

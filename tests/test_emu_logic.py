@@ -601,6 +601,44 @@ def test_box_radii_around_the_quotient_switch_and_up_to_127(emu, oracle):
             assert_same(d, oracle.adaptive_threshold(img, r, -3), "gs_adaptive_threshold r=%d %dx%d" % (r, w, h))
 
 
+@pytest.mark.parametrize("shape", [(32, 17), (48, 40), (272, 33), (96, 17), (1040, 19), (64, 70)])
+def test_box_register_ring_kernel_every_radius(emu, oracle, shape):
+    """k_box16r<MODE, r> for r = 1 .. 16 (the window's raw rows in a register ring, constant tap counts, multiply-high
+    quotient from a table for clipped rows too) against the oracle and against k_box16 (gsh_tune key 6 = 4): widths of 2
+    threads up to 65, heights down to 2 r + 1, bright images (largest sums), bands of 1 .. h rows, and compare constants
+    on both sides of every clamp of the product form"""
+    w, h = shape
+    rng = np.random.RandomState(w + h)
+    imgs = [rng.randint(0, 256, (h, w)).astype(np.uint8), np.full((h, w), 255, np.uint8), Oracle.synth(w, h, 7)]
+    imgs[2][:, : w // 2] |= 0xF0
+    try:
+        for r in range(1, 17):
+            if h < 2 * r + 1:
+                continue  # such frames take k_box16 (covered by the any-radius tests)
+            for k, img in enumerate(imgs):
+                for T in ((0,) if k else (0, 1, 5, 2 * r + 1, 2 * r + 2)):
+                    emu.tune(0, T)
+                    d = np.zeros_like(img)
+                    emu.blur(d, img.copy(), r)  # r <= 3 on these widths is k_blur16; the adaptive form below is the ring kernel
+                    assert_same(d, oracle.blur(img, r), "gs_blur r=%d T=%d img %d" % (r, T, k))
+                    for c in ((5, -7, 300, -300, 255, -255, 256, 0) if T == 0 else (5,)):
+                        d = np.zeros_like(img)
+                        emu.adaptive_threshold(d, img.copy(), r, c)
+                        assert_same(d, oracle.adaptive_threshold(img, r, c), "gs_adaptive_threshold r=%d c=%d T=%d img %d" % (r, c, T, k))
+            emu.tune(0, 0)
+            emu.tune(6, 4)  # the any-radius kernel on the same input
+            d = np.zeros_like(imgs[0])
+            emu.blur(d, imgs[0].copy(), r)
+            assert_same(d, oracle.blur(imgs[0], r), "k_box16 gs_blur r=%d" % r)
+            d = np.zeros_like(imgs[0])
+            emu.adaptive_threshold(d, imgs[0].copy(), r, 5)
+            assert_same(d, oracle.adaptive_threshold(imgs[0], r, 5), "k_box16 gs_adaptive_threshold r=%d" % r)
+            emu.tune(6, 0)
+    finally:
+        emu.tune(0, 0)
+        emu.tune(6, 0)
+
+
 def test_box_kernel_any_band_height_and_full_width(emu, oracle):
     """k_box16 with bands of 1 .. 200 rows (gsh_tune key 0; the launcher itself picks 8 .. h) on a batch, and on rows as
     wide as the kernel goes (4096 = 256 threads x 16 px) with radii on both sides of every switch"""

@@ -469,8 +469,8 @@ def test_gsbatch_two_workers_asan_clean(tmp_path):
     csrc = os.path.join(ROOT, "grayskull_amd", "csrc")
     lib = str(tmp_path / "libgs_kernel_emu.so")
     san = ["-fsanitize=address", "-fno-omit-frame-pointer", "-g", "-O1"]
-    subprocess.check_call(["g++", "-DGS_EMU", *san, "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-w",
-                           "-I" + emu_dir, "-I" + csrc, os.path.join(csrc, "gs_api.cpp"), os.path.join(csrc, "gs_fused.cpp"),
+    subprocess.check_call(["g++", "-DGS_EMU", "-DGS_BOXR_MAX=3", *san, "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-w",
+                           "-I" + emu_dir, "-I" + csrc, os.path.join(csrc, "gs_api.cpp"), os.path.join(csrc, "gs_fused.cpp"), os.path.join(csrc, "gs_box.cpp"),
                            os.path.join(emu_dir, "hip_emu.cpp"), "-o", lib])
     exe = str(tmp_path / "gsbatch_asan")
     subprocess.check_call(["gcc", "-std=c99", *san, "-I" + os.path.join(ROOT, "include"), SRC, "-o", exe,
