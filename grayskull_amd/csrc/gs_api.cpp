@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "k_fast.h"
+#include "k_fast_fused.h"
 #include "k_fast_nms.h"
 #include "k_geom.h"
 #include "k_integral.h"
@@ -673,6 +674,35 @@ void launch_fast(const uint8_t *img, uint8_t *score, unsigned w, unsigned h, uns
     return;
   }
   const size_t fb = (size_t)w * h;
+  /* key 7 = 6: both passes in one walk (k_fast_fused.h).  Measured and NOT the default: 32 x 720p block noise 127 us against
+   * 63 + 23 for the two passes below -- the walk executes 50 M VALU + 21 M SALU wave-instructions where the two passes
+   * execute 40 M + 18 M (ownership / interior masks, the border handling of the score tile, three barriers per step) at
+   * 4 waves per SIMD instead of 8 (profiles/r03t_fast_fused_not_kept.log, r03u_pmc_fast_fused.txt). */
+  if (g_tune[7] == 6 && g_tune[19] != 1 && threshold <= 0xffffff00u && !(clip_w && n == 1 && (clip_w < w || clip_h < h)) &&
+      (unsigned long long)((w + 63) / 64) * 64 * h < (1ull << 32)) {
+    const unsigned wpr = (w + 63) / 64, nwords = wpr * h, nchunks = (nwords + kChunkWords - 1) / kChunkWords;
+    unsigned long long *mask = (unsigned long long *)ctx().scratch(SL_MASK, (size_t)n * nchunks * kChunkWords * 8);
+    unsigned *cnt = (unsigned *)ctx().scratch(SL_CNT, (size_t)n * nchunks * 4);
+    unsigned *pfx = (unsigned *)ctx().scratch(SL_PFX, (size_t)n * nchunks * 4);
+    GS_HIP(hipMemsetAsync(mask, 0, (size_t)n * nchunks * kChunkWords * 8, st));
+    GS_HIP(hipMemsetAsync(cnt, 0, (size_t)n * nchunks * 4, st));
+    /* bands of 16 m - 2 rows: ~4 rounds of the 2048 blocks the chip holds, at least 30 rows (2 of every 16 m score rows
+     * are computed twice), at most 254 */
+    const unsigned strips = (w - 6 + kFfCols - 1) / kFfCols, rows = h - 6;
+    const unsigned long long cols = (unsigned long long)strips * n;
+    const unsigned want = (unsigned)std::max<unsigned long long>(1, 8192 / cols);
+    unsigned m = g_tune[0] > 0 ? (unsigned)g_tune[0] : (rows / want + 2 + 15) / 16;
+    m = std::max(2u, std::min(16u, m));
+    const unsigned bands = (rows + 16 * m - 3) / (16 * m - 2);
+    const unsigned long long nt = cols * bands;
+    GS_ASSERT(nt <= 0x7ffffff0ull);
+    const unsigned share = g_tune[18] == 1 ? 0u : (unsigned)((nt + 7) / 8);
+    FastFusedArgs fa{img, score, w, h, fb, threshold, strips, bands, m, (unsigned)nt, share, mask, cnt, wpr, nchunks};
+    GS_LAUNCH(k_fast_fused, dim3(share ? share * 8u : (unsigned)nt), dim3(64, 4), 0, st, fa);
+    run_compaction(mask, cnt, nchunks, n, nkps, counts,
+                   FastEmitPadded{score, w, wpr * 64u, fb, kps, nkps, ((uintptr_t)kps & 15) == 0}, st, pfx);
+    return;
+  }
   launch_fast_score(st, img, score, w, h, n, threshold);
   /* pass 2 in strip form (k_fast_nms.h) when the score map qualifies for the strip machinery: items numbered over
    * rows padded to whole mask words.  Key 19 = 1: the item-by-item kernel k_fast_nms (round 2). */

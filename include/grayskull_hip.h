@@ -42,7 +42,8 @@ void gsh_sync(void);                      /* hipStreamSynchronize(current stream
  * box kernel, 4 = the any-radius box kernel k_box16 also for radii <= 16 (instead of the register-ring form k_box16r),
  * 7 score kernel of gs_fast: 0 = LDS tile, 4 px per thread through the compass filter, candidates queued (default),
  * 1 = strip kernel (lane = 4 px, image rows in registers), 2 = one global byte load per ring pixel (round 1), 3 = LDS tile, one
- * pixel per lane + candidate queue, 4 = LDS tile, one pixel per lane, whole wave rows scored (round 2),
+ * pixel per lane + candidate queue, 4 = LDS tile, one pixel per lane, whole wave rows scored (round 2), 6 = score, NMS and
+ * mask words in one walk down column strips (k_fast_fused; key 0 = steps per band; measured, not the default),
  * 8 frames per launch (test hook for the batch splitting of every launcher), 9 LBP: stages / survivor
  * share at which a block first re-packs (max stages + 16 * tenths [+ later points]; key 4 >= 1000 = custom fixed split),
  * 10 trips per block gs_histogram aims at, 11 its blocks per frame, 12 bytes per histogram piece (test

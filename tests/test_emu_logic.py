@@ -61,7 +61,7 @@ def test_next_rows(emu, oracle, shape):
                                    (64, 40), (48, 7), (32, 16), (1040, 9), (2064, 8)])
 def test_fast(emu, oracle, shape):
     w, h = shape
-    for strip in ((0, 1, 2, 3, 4) if w % 4 == 0 else (0, 2, 3, 4)):  # gsh_tune key 7: 0 LDS tile, 4 px per thread + candidate queue (default), 1 strip kernel, 2 one global byte load per ring pixel, 3 LDS tile + candidate queue, 4 LDS tile (round 2)
+    for strip in ((0, 6, 1, 2, 3, 4) if w % 4 == 0 else (0, 6, 2, 3, 4)):  # gsh_tune key 7: 0 LDS tile, 4 px per thread + candidate queue (default), 6 both passes in one walk (k_fast_fused), 1 strip kernel, 2 one global byte load per ring pixel, 3 LDS tile + candidate queue, 4 LDS tile (round 2)
         emu.tune(7, strip)
         try:
             pc.fast(emu, oracle, Oracle.synth(w, h, 5), MEM)
@@ -73,6 +73,45 @@ def test_fast(emu, oracle, shape):
                 pc.fast(emu, oracle, img, MEM, threshold=t, caps=(5000,))  # incl. thresholds where p + t wraps
         finally:
             emu.tune(7, 0)
+
+
+@pytest.mark.parametrize("shape,m", [((70, 200), 2), ((70, 200), 3), ((40, 300), 16), ((130, 64), 2), ((200, 37), 0), ((64, 36), 2),
+                                     ((65, 35), 2), ((68, 38), 2), ((69, 39), 0)])
+def test_fast_fused_walk_bands_steps_and_strip_borders(emu, oracle, shape, m):
+    """k_fast_fused (gsh_tune key 7 = 6; measured, not the default): strips of 62 owned columns (widths that end a strip at its first / last column), bands of 16 m - 2 rows
+    (gsh_tune key 0 = m; heights that end a band on its first / last row and inside a step), several steps per band with
+    the shared image rows copied LDS to LDS and the score rows carried over, keypoints and plateaus on strip / band
+    borders (the same pixel is scored by two blocks and owned by one), a caller's score map with non-zero frame
+    content next to peaks, dense (random) and sparse tiles, several frames per call"""
+    w, h = shape
+    rng = np.random.RandomState(w * 7 + h + m)
+    imgs = [Oracle.synth(w, h, 40 + m), rng.randint(0, 256, (h, w)).astype(np.uint8), np.full((h, w), 90, np.uint8)]
+    # isolated corners and 2 x 2 plateaus exactly on the strip borders (x = 64, 65, 126, 127) and band borders (y = 3 + k (16 m - 2))
+    tb = 16 * (m or 2) - 2
+    for xx in (3, 4, 63, 64, 65, 66, 126, 127, w - 5, w - 4):
+        for yy in (3, 4, 2 + tb, 3 + tb, 4 + tb, 3 + 2 * tb, 17, 18, 19, h - 5, h - 4):
+            if 3 <= xx < w - 4 and 3 <= yy < h - 4:
+                imgs[2][yy:yy + 2, xx:xx + 2] = 200 if (xx + yy) % 3 else 10
+    try:
+        emu.tune(0, m)
+        emu.tune(7, 6)
+        for img in imgs:
+            for t in (20, 5):
+                pc.fast(emu, oracle, img, MEM, threshold=t, caps=(20000,))
+        frames = np.stack(imgs)
+        sm0 = rng.randint(0, 256, frames.shape).astype(np.uint8)
+        sm = sm0.copy()
+        kps = np.zeros((3, 3000, 12), np.uint32)
+        counts = np.zeros(3, np.uint32)
+        emu.fast_batch(frames, sm, kps, counts, 3000, 20)
+        for f in range(3):
+            ko, smo = oracle.fast(frames[f], 3000, 20, sm0[f])
+            assert counts[f] == len(ko), f
+            assert_same(kps[f, :len(ko)].reshape(-1).view(ko.dtype), ko, "frame %d" % f)
+            assert_same(sm[f], smo, "scoremap %d" % f)
+    finally:
+        emu.tune(0, 0)
+        emu.tune(7, 0)
 
 
 def test_fast_strip_kernel_equals_per_pixel_kernel(emu, oracle):
