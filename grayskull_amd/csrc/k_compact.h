@@ -8,8 +8,8 @@
  *      word i/64) and adds popcount(word) to the counter of its chunk (kChunkWords words);
  *   2. k_chunk_scan: exclusive prefix sum of the chunk counters (one block per frame) -- or, for frames of at
  *      most kEmitSelfScan chunks, no pass at all: each k_emit wave adds up the counters before its own chunk;
- *   3. k_emit<F>: one wave per non-empty chunk walks its words in order and writes the hits
- *      of a word in parallel, hit number r (< cap) through the functor F(frame, item, r).
+ *   3. k_emit<F>: one wave per non-empty chunk; a lane owns 32 consecutive items, ranks its hits behind those of the
+ *      lanes before it and writes hit number r (< cap) through the functor F(frame, item, r).
  */
 #ifndef GS_K_COMPACT_H
 #define GS_K_COMPACT_H
@@ -60,9 +60,7 @@ __global__ __launch_bounds__(1024) void k_chunk_scan(const unsigned *count, unsi
 }
 
 /* One WAVE per chunk (grid (ceil(nchunks/4), n frames), block 256): lane k < 32 fetches word k of
- * the chunk once; the wave then visits the words in order, broadcasting word k (v_readlane) and
- * letting lane b take bit b: its rank is the hits before the word + popcount of the lower bits,
- * so the up to 64 hits of a word are written in parallel and in scan order.  (One thread per
+ * the chunk once, then every lane takes one 32-item half of a word (see the loop at the end).  (One thread per
  * chunk walked up to 2048 items serially: 100 us for a chunk full of FAST corners.) */
 /* QUAD: the producer's lanes own 4 consecutive items each (k_fast_nms), so a group of 256 items is
  * 4 words in SLOT-major form -- word s of the group, bit l = item 256 g + 4 l + s -- i.e. the four
@@ -120,13 +118,22 @@ __global__ __launch_bounds__(256) void k_emit(const unsigned long long *mask,
     }
     return;
   }
-  for (unsigned k = 0; k < kChunkWords && r < cap; k++) { /* wave-uniform */
-    const uint64_t m = ((uint64_t)readlane_at(mhi, k) << 32) | readlane_at(mlo, k);
-    if (!m) continue;
-    const uint64_t below = m & ((1ull << lane) - 1ull);
-    const unsigned rank = r + (unsigned)__popcll(below);
-    if (((m >> lane) & 1ull) && rank < cap) emit(blockIdx.y, (size_t)c * kChunkItems + k * 64u + lane, rank);
-    r += (unsigned)__popcll(m);
+  /* Lane l takes half l & 1 of word l >> 1: its hits rank after all hits of the lower halves (one wave scan of the 64
+   * popcounts) and are written one per trip, every lane at once -- max popcount(half) trips for the chunk.  (Visiting
+   * the words one after the other, 64 lanes per word, took one memory round trip per NON-EMPTY word -- the functor
+   * loads before it stores -- i.e. up to 32 in a row for a chunk full of corners: the launch's tail.) */
+  const uint32_t hlo = shfl(mlo, (int)(lane >> 1)), hhi = shfl(mhi, (int)(lane >> 1));
+  uint32_t half = (lane & 1u) ? hhi : hlo;
+  const unsigned pc = (unsigned)__popc(half);
+  unsigned rank = r + wave_incl_scan(pc) - pc;
+  const size_t item0 = (size_t)c * kChunkItems + lane * 32u;
+  while (ballot(half != 0u && rank < cap) != 0) { /* wave-uniform */
+    if (half != 0u) {
+      const unsigned b = (unsigned)__ffs((int)half) - 1u;
+      half &= half - 1u;
+      if (rank < cap) emit(blockIdx.y, item0 + b, rank);
+      rank++;
+    }
   }
 }
 

@@ -139,6 +139,7 @@ template <class T> inline T atomicMin(T *p, T v) { T o = *p; if (v < o) *p = v; 
 template <class T> inline T atomicMax(T *p, T v) { T o = *p; if (v > o) *p = v; return o; }
 
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
+inline int __ffs(int v) { return __builtin_ffs(v); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((uint64_t)a * b) >> 32); }
 
