@@ -624,8 +624,9 @@ void run_compaction(unsigned long long *mask, unsigned *cnt, unsigned nchunks, u
  * large p < t regions (the block-noise frames of configs[3]: there every pixel is a candidate under the reference's
  * unsigned wrap, and a 256-px span almost always touches one).  Key 7 = 2: one global byte load per ring pixel
  * (the round-1 form: texture-addresser bound, 4.9 vs 4.2 us per frame). */
-void launch_fast_score(hipStream_t on, const uint8_t *img, uint8_t *score, unsigned w, unsigned h, unsigned n,
-                       unsigned threshold) {
+/* zero_words / zero_n: words the default kernel clears on the side (pass 2's chunk counters); returns whether it did */
+bool launch_fast_score(hipStream_t on, const uint8_t *img, uint8_t *score, unsigned w, unsigned h, unsigned n,
+                       unsigned threshold, unsigned *zero_words = nullptr, unsigned zero_n = 0) {
   const size_t fb = (size_t)w * h;
   if (g_tune[7] == 1 && w % 4 == 0 && fb < 0x7fffffffull && ((uintptr_t)img & 3) == 0 && ((uintptr_t)score & 3) == 0 &&
       threshold <= 0xffffff00u) {
@@ -652,8 +653,10 @@ void launch_fast_score(hipStream_t on, const uint8_t *img, uint8_t *score, unsig
     GS_ASSERT(nt <= 0x7ffffff0ull); /* 2^31 tiles = 2^41 pixels in one call */
     const unsigned share = g_tune[18] == 1 ? 0u : (unsigned)((nt + 7) / 8); /* key 18 = 1: tiles in launch order */
     GS_LAUNCH(k_fast_score_q4, dim3(share ? share * 8u : (unsigned)nt), dim3(64, 4), 0, on, img, score, w, h, fb, threshold, tx,
-              ty, (unsigned)nt, share);
+              ty, (unsigned)nt, share, zero_words, zero_n);
+    return true;
   }
+  return false;
 }
 
 /* clip_w / clip_h (single frame only): the caller's score map is smaller than the image; positions
@@ -703,7 +706,6 @@ void launch_fast(const uint8_t *img, uint8_t *score, unsigned w, unsigned h, uns
                    FastEmitPadded{score, w, wpr * 64u, fb, kps, nkps, ((uintptr_t)kps & 15) == 0}, st, pfx);
     return;
   }
-  launch_fast_score(st, img, score, w, h, n, threshold);
   /* pass 2 in strip form (k_fast_nms.h) when the score map qualifies for the strip machinery: items numbered over
    * rows padded to whole mask words.  Key 19 = 1: the item-by-item kernel k_fast_nms (round 2). */
   if (g_tune[19] != 1 && strip_ok(w, h, score, score) && w >= 32 && (unsigned long long)((w + 63) / 64) * 64 * h < (1ull << 32)) {
@@ -711,9 +713,12 @@ void launch_fast(const uint8_t *img, uint8_t *score, unsigned w, unsigned h, uns
     unsigned long long *mask = (unsigned long long *)ctx().scratch(SL_MASK, (size_t)n * nchunks * kChunkWords * 8);
     unsigned *cnt = (unsigned *)ctx().scratch(SL_CNT, (size_t)n * nchunks * 4);
     unsigned *pfx = (unsigned *)ctx().scratch(SL_PFX, (size_t)n * nchunks * 4);
+    /* the default score kernel zeroes the chunk counters on the side (a fill launch costs 5 us of a 100-us call) */
+    GS_ASSERT((unsigned long long)n * nchunks < (1ull << 32)); /* n <= 65535 frames of < 2^32 padded items */
+    const bool zeroed = launch_fast_score(st, img, score, w, h, n, threshold, cnt, n * nchunks);
     if (clip_w && n == 1 && (clip_w < w || clip_h < h))
       GS_LAUNCH(k_fast_clip, grid2d(w, h, 1), dim3(64, 4), 0, st, score, w, h, clip_w, clip_h);
-    GS_HIP(hipMemsetAsync(cnt, 0, (size_t)n * nchunks * 4, st));
+    if (!zeroed) GS_HIP(hipMemsetAsync(cnt, 0, (size_t)n * nchunks * 4, st));
     for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
       const unsigned nn = std::min(kMaxZ, n - f0);
       const StripCfg c = strip_cfg(w, h - 6, nn);
@@ -727,6 +732,7 @@ void launch_fast(const uint8_t *img, uint8_t *score, unsigned w, unsigned h, uns
                    FastEmitPadded{score, w, wpr * 64u, fb, kps, nkps, ((uintptr_t)kps & 15) == 0}, st, pfx);
     return;
   }
+  launch_fast_score(st, img, score, w, h, n, threshold);
   const unsigned nitems = (w - 6) * (h - 6);
   const unsigned nchunks = (nitems + kChunkItems - 1) / kChunkItems;
   unsigned long long *mask =

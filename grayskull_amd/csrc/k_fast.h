@@ -262,7 +262,8 @@ __global__ __launch_bounds__(256) void k_fast_score_cq(const uint8_t *img, uint8
 typedef uint32_t gs_u32_unaligned __attribute__((aligned(1)));
 __global__ __launch_bounds__(256) void k_fast_score_q4(const uint8_t *img, uint8_t *score, unsigned w, unsigned h,
                                                        size_t frame_bytes, unsigned threshold, unsigned tiles_x,
-                                                       unsigned tiles_y, unsigned ntiles, unsigned xcd_share) {
+                                                       unsigned tiles_y, unsigned ntiles, unsigned xcd_share,
+                                                       unsigned *zero_words, unsigned zero_n) {
   __shared__ uint32_t tile32[(kFastTileRows + 6) * kFastTileDw + 2]; /* + 2: the last thread's third centre dword */
   __shared__ uint16_t queue[64 * kFastTileRows];
   __shared__ unsigned qn;
@@ -271,6 +272,8 @@ __global__ __launch_bounds__(256) void k_fast_score_q4(const uint8_t *img, uint8
    * (FETCH_SIZE 4.1 x the frame bytes, WRITE_SIZE 1.46 x from the split lines of the score map).  xcd_share != 0: a 1-D
    * grid of 8 * xcd_share blocks, XCD k walks tiles [k * xcd_share, (k + 1) * xcd_share) in order, so the tiles in flight
    * on one XCD are a few consecutive tile rows of one frame. */
+  /* the chunk counters of pass 2 are zeroed here (zero_n words, spread over the grid) instead of by a 5-us fill launch */
+  for (unsigned i = blockIdx.x * 256u + threadIdx.y * 64u + threadIdx.x; i < zero_n; i += gridDim.x * 256u) zero_words[i] = 0;
   unsigned tile = blockIdx.x;
   if (xcd_share) {
     tile = (blockIdx.x & 7u) * xcd_share + (blockIdx.x >> 3);
