@@ -29,6 +29,7 @@
 #include "k_orb.h"
 #include "k_pointwise.h"
 #include "k_stencil.h"
+#include "k_tmatch.h"
 
 #include "../../include/grayskull_hip.h"
 
@@ -275,7 +276,7 @@ dim3 grid2d(unsigned w, unsigned h, unsigned n) { return dim3((w + 63) / 64, (h 
 inline bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 /* ---- launch tuning (gsh_tune): 0 rows per band (0 = auto), 1 block shape, 2 prefetch depth */
-int g_tune[20] = {0, 3, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+int g_tune[24] = {0, 3, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 /* gsh_lbp_count_evaluated: device counter that receives the windows the cascade really evaluated */
 thread_local unsigned long long *g_lbp_evaluated = nullptr;
 
@@ -1262,7 +1263,7 @@ unsigned gsh_profile_read(double *total_ms) {
   return n;
 }
 void gsh_tune(int key, int value) {
-  if (key >= 0 && key < 20) g_tune[key] = value;
+  if (key >= 0 && key < 24) g_tune[key] = value;
 }
 void gsh_probe_strip_copy(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned n) {
   GS_ASSERT(dst && src && w % 16 == 0 && al16(dst) && al16(src));
@@ -2001,7 +2002,39 @@ void gs_match_template(struct gs_image img, struct gs_image tmpl, struct gs_imag
   const bool dhost = !is_dev(result.data);
   uint8_t *d = dhost ? (uint8_t *)ctx().scratch(SL_OUT, rb) : result.data;
   const dim3 g((result.w + 63) / 64, (result.h + 3) / 4);
-  if (tmpl.w <= kTmplTile - 3) {
+  /* templates of 512 .. 32768 taps, 16 .. 257 wide, whose block fits the LDS: the cross term on the matrix cores (k_tmatch.h;
+   * smaller ones are as fast on the dot-product kernels: 1280x720, 16 x 16: 39 vs 47 us).
+   * gsh_tune key 20 = 1: the VALU dot-product kernels below; 2 / 3: always 64 x 128 tiles / always 32 x 64 tiles with split rows. */
+  /* few 64 x 128 tiles (video-sized images): 32 x 64 tiles, the template rows split over the block's four waves */
+  const bool tm_split = g_tune[20] == 3 || (g_tune[20] != 2 && (unsigned long long)((result.w + 127) / 128) * ((result.h + 63) / 64) < 512);
+  const unsigned nkc = (tmpl.w + 31 + 31) / 32, istride = (tm_split ? 32 : 96) + 32 * nkc + 16, tstride = 32 * nkc + 48;
+  const size_t tm_lds = std::max<size_t>((size_t)((tm_split ? 31 : 63) + tmpl.h) * istride + (size_t)tmpl.h * tstride + 16,
+                                         tm_split ? 32768 : 0);
+  if (g_tune[20] != 1 && tmpl.w >= 16 && nkc <= 9 && tmpl.h >= 4 && (tb >= 512 || g_tune[20] >= 2) && tb <= 32768 && tm_lds <= 150 * 1024 &&
+      ib < 0x7fffffffull) {
+    hipStream_t st = ctx().s();
+    unsigned *rowp = (unsigned *)ctx().scratch(SL_II, (size_t)img.h * (img.w + 1) * 4);
+    unsigned *s2 = (unsigned *)ctx().scratch(SL_PAD, rb * 4);
+    uint8_t *tpad = (uint8_t *)ctx().scratch(SL_PRE, (size_t)tmpl.h * tstride + 16);
+    unsigned *tsqp = (unsigned *)(tpad + (((size_t)tmpl.h * tstride + 3) & ~(size_t)3)); /* tstride is a multiple of 16 */
+    GS_LAUNCH(k_tm_prep, dim3(1), dim3(1024), 0, st, t, tmpl.w, tmpl.h, tstride, tpad, tsqp);
+    GS_LAUNCH(k_tm_rowprefix, dim3((img.h + 3) / 4), dim3(64, 4), 0, st, s, img.w, img.h, rowp);
+    GS_LAUNCH(k_tm_colsq, dim3((result.w + 63) / 64, (result.h + kTmRun - 1) / kTmRun), dim3(64), 0, st, (const unsigned *)rowp,
+              img.w, tmpl.w, tmpl.h, result.w, result.h, s2);
+#ifndef GS_EMU
+    static thread_local bool lds_raised = false;
+    if (!lds_raised) { /* more than the default 64 KB of dynamic LDS */
+      GS_HIP(hipFuncSetAttribute((const void *)k_match_template_mfma<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      GS_HIP(hipFuncSetAttribute((const void *)k_match_template_mfma<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      lds_raised = true;
+    }
+#endif
+    TmArgs ta{s, img.w, img.h, (const uint8_t *)tpad, (const unsigned *)tsqp, tmpl.w, tmpl.h, s2, d, result.w, result.h, nkc, istride, tstride};
+    if (tm_split)
+      GS_LAUNCH(k_match_template_mfma<4>, dim3((result.w + 63) / 64, (result.h + 31) / 32), dim3(256), tm_lds, st, ta);
+    else
+      GS_LAUNCH(k_match_template_mfma<1>, dim3((result.w + 127) / 128, (result.h + 63) / 64), dim3(256), tm_lds, st, ta);
+  } else if (tmpl.w <= kTmplTile - 3) {
     unsigned long long *tsq = (unsigned long long *)ctx().scratch(SL_PFX, 8);
     GS_LAUNCH(k_sum_squares, dim3(1), dim3(256), 0, ctx().s(), t, (unsigned long long)tb, tsq);
     const size_t twp = ((size_t)tmpl.w + 3) & ~(size_t)3;

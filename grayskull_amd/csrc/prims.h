@@ -163,6 +163,28 @@ GS_DEV uint32_t pk_sar_i16(uint32_t a, unsigned s) {
   int al = (int16_t)(a & 0xffff), ah = (int16_t)(a >> 16);
   return GS_PK2((uint32_t)(al >> s), (uint32_t)(ah >> s));
 }
+/* v_mfma_i32_32x32x32_i8: D = A (32 x 32, signed bytes) . B (32 x 32) + C for the whole wave.  Operand slots: lane l
+ * holds, in its 16 bytes, A[i = l & 31][slot (l >> 5, byte)] resp. B[slot (l >> 5, byte)][j = l & 31]; the hardware
+ * pairs slot s of A with slot s of B (which k a slot stands for never matters to a caller that fills both operands
+ * by the same rule).  C / D: register r of lane l is row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31. */
+GS_DEV void mfma_i32_32x32x32_i8(const U4 &a, const U4 &b, int32_t (&c)[16]) {
+  const unsigned l = lane_id();
+  uint64_t A[64][2], B[64][2];
+  const uint64_t av[2] = {a.x | ((uint64_t)a.y << 32), a.z | ((uint64_t)a.w << 32)};
+  const uint64_t bv[2] = {b.x | ((uint64_t)b.y << 32), b.z | ((uint64_t)b.w << 32)};
+  for (int h = 0; h < 2; h++) {
+    emu::wave_exchange(av[h], [&](const uint64_t *s, const bool *v) { for (int i = 0; i < 64; i++) A[i][h] = v[i] ? s[i] : 0; return 0; });
+    emu::wave_exchange(bv[h], [&](const uint64_t *s, const bool *v) { for (int i = 0; i < 64; i++) B[i][h] = v[i] ? s[i] : 0; return 0; });
+  }
+  auto byte_of = [](const uint64_t (&q)[2], int k) { return (int)(int8_t)((q[k >> 3] >> (8 * (k & 7))) & 0xff); };
+  for (int r = 0; r < 16; r++) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (int)(l >> 5), col = (int)(l & 31);
+    int32_t acc = c[r];
+    for (int g = 0; g < 2; g++)
+      for (int k = 0; k < 16; k++) acc += byte_of(A[row + 32 * g], k) * byte_of(B[col + 32 * g], k);
+    c[r] = acc;
+  }
+}
 #else
 /* ------------------------------------------------------------------ gfx950 */
 GS_DEV unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
@@ -327,6 +349,18 @@ GS_DEV uint32_t pk_shl7_sat_u16(uint32_t a) {
 GS_DEV uint32_t pk_abs_i16(uint32_t a) { return GS_R(__builtin_elementwise_abs(GS_I2(a))); }           /* v_pk_sub_i16 + v_pk_max_i16 */
 GS_DEV uint32_t pk_max_i16(uint32_t a, uint32_t b) { return GS_R(__builtin_elementwise_max(GS_I2(a), GS_I2(b))); } /* v_pk_max_i16 */
 GS_DEV uint32_t pk_sar_i16(uint32_t a, unsigned s) { return GS_R((gs_i16x2)(GS_I2(a) >> (short)s)); }            /* v_pk_ashrrev_i16 */
+/* v_mfma_i32_32x32x32_i8 (see the emulation above for the operand slots) */
+GS_DEV void mfma_i32_32x32x32_i8(const U4 &a, const U4 &b, int32_t (&c)[16]) {
+  typedef int gs_i32x4 __attribute__((ext_vector_type(4)));
+  typedef int gs_i32x16 __attribute__((ext_vector_type(16)));
+  gs_i32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; r++) acc[r] = c[r];
+  acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(gs_i32x4{(int)a.x, (int)a.y, (int)a.z, (int)a.w},
+                                              gs_i32x4{(int)b.x, (int)b.y, (int)b.z, (int)b.w}, acc, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 16; r++) c[r] = acc[r];
+}
 #endif
 
 /* ------------------------------------------------------------------ common */

@@ -53,6 +53,8 @@ void gsh_sync(void);                      /* hipStreamSynchronize(current stream
  * kernels but emits nothing (timing aid; counts / rects are NOT written), 17 = 1: the cascade evaluates re-packed windows
  * one per lane instead of one per quad of lanes, 18 band-to-XCD mapping of the strip kernels and tile-to-XCD mapping of the gs_fast score pass (1 = dispatch order, 2 = XCD-aware
  * always), 19 = 1: pass 2 of gs_fast item by item (k_fast_nms, round 2) instead of the strip form.
+ * 20 = 1: gs_match_template on the VALU dot-product kernels instead of the matrix cores (2 / 3: the matrix-core kernel with
+ * 64 x 128 tiles / with 32 x 64 tiles and the template rows split over four waves, whatever the image size).
  * Results never change (key 16 excepted). */
 void gsh_tune(int key, int value);
 /* measurement aid for bench.py: while on, gsh_edge_pipeline_batch brackets every launch of its

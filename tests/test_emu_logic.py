@@ -181,6 +181,40 @@ def test_geometry_and_template_matching(emu, oracle, shape):
     pc.geometry(emu, oracle, np.random.RandomState(w).randint(0, 256, (h, w)).astype(np.uint8), MEM, seed=9)
 
 
+@pytest.mark.parametrize("case", [(100, 80, 16, 4), (131, 70, 17, 5), (200, 150, 31, 8), (97, 90, 32, 32), (260, 140, 64, 64),
+                                  (300, 200, 128, 128), (290, 66, 160, 3 + 1), (64, 64, 64, 64), (129, 65, 33, 33), (400, 40, 256, 8)])
+def test_match_template_on_the_matrix_cores(emu, oracle, case):
+    """k_match_template_mfma (templates of 16 x 4 .. 32768 taps): the cross term as Toeplitz matrix products in the i8 MFMA
+    accumulator, sum I'^2 from the two sliding-sum kernels -- against the oracle and against the dot-product kernels
+    (gsh_tune key 20 = 1): result sizes below, at and above the 128 x 64 block tile, widths that leave 1 .. 31 columns in
+    the last K step, a template as large as the image, all-0 / all-255 images against all-255 / all-0 templates (the
+    largest sums), and an exact sub-image (score 255 at its place)"""
+    iw, ih, tw, th = case
+    rs = np.random.RandomState(iw + tw)
+    img = rs.randint(0, 256, (ih, iw)).astype(np.uint8)
+    tmpls = [rs.randint(0, 256, (th, tw)).astype(np.uint8), img[ih - th:, iw - tw:].copy(), np.full((th, tw), 255, np.uint8)]
+    imgs = [img, img, np.zeros_like(img)]
+    if tw * th <= 4096:
+        tmpls.append(np.zeros((th, tw), np.uint8)); imgs.append(np.full_like(img, 255))
+    try:
+        for im, t in zip(imgs, tmpls):
+            ro = oracle.match_template(im, t)
+            for tiles in (2, 3):  # 64 x 128 tiles / 32 x 64 tiles with the template rows split over the block's waves
+                emu.tune(20, tiles)
+                r = np.zeros((ih - th + 1, iw - tw + 1), np.uint8)
+                emu.match_template(im, t, r)
+                assert_same(r, ro, "gs_match_template (mfma, key 20 = %d) %dx%d on %dx%d" % (tiles, tw, th, iw, ih))
+    finally:
+        emu.tune(20, 0)
+    try:
+        emu.tune(20, 1)
+        r = np.zeros((ih - th + 1, iw - tw + 1), np.uint8)
+        emu.match_template(img, tmpls[0], r)
+        assert_same(r, oracle.match_template(img, tmpls[0]), "gs_match_template (dot4) %dx%d" % (tw, th))
+    finally:
+        emu.tune(20, 0)
+
+
 def test_template_wider_than_the_lds_tile(emu, oracle):
     """templates wider than 16381 px take the per-tap kernel; 16380 is the widest dot4 / LDS-row case"""
     rs = np.random.RandomState(2)
