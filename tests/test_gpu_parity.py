@@ -450,6 +450,37 @@ def test_template_matching_large(hip, oracle):
     assert_same(rn[180:180 + rows.shape[0]], rows, "template rows 180..")
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(300, 200, 128, 128), (400, 260, 64, 64), (517, 131, 33, 17), (1280, 720, 181, 181),
+                                  (640, 96, 257, 32), (200, 180, 16, 32), (3840, 400, 256, 64)])
+def test_match_template_matrix_core_kernel_on_the_gpu(hip, oracle, case):
+    """k_match_template_mfma on real matrix cores (the emulator only models v_mfma_i32_32x32x32_i8): both tilings
+    (gsh_tune key 20 = 2 / 3) and the launcher's own choice against the dot-product kernels (key 20 = 1) byte for byte,
+    and a slab of rows against the oracle; random, all-255-on-all-0 (largest sums) and cut-out templates"""
+    import torch
+    iw, ih, tw, th = case
+    rs = np.random.RandomState(iw + tw)
+    img = rs.randint(0, 256, (ih, iw)).astype(np.uint8)
+    pairs = [(img, rs.randint(0, 256, (th, tw)).astype(np.uint8)), (img, img[ih - th:, iw - tw:].copy()),
+             (np.zeros_like(img), np.full((th, tw), 255, np.uint8))]
+    try:
+        for k, (im, t) in enumerate(pairs):
+            d_im, d_t = torch.from_numpy(im).cuda(), torch.from_numpy(t).cuda()
+            outs = {}
+            for key in (1, 0, 2, 3):
+                hip.tune(20, key)
+                r = torch.zeros((ih - th + 1, iw - tw + 1), dtype=torch.uint8, device="cuda")
+                hip.match_template(d_im, d_t, r)
+                outs[key] = r.cpu().numpy()
+            for key in (0, 2, 3):
+                assert_same(outs[key], outs[1], "mfma (key 20 = %d) vs dot4, pair %d, %dx%d on %dx%d" % (key, k, tw, th, iw, ih))
+            rows = min(6, ih - th + 1)
+            slab = oracle.match_template(im[: th + rows - 1], t)
+            assert_same(outs[0][:rows], slab, "mfma vs oracle, first rows, pair %d" % k)
+    finally:
+        hip.tune(20, 0)
+
+
 def test_orb_extract_batch(hip, oracle):
     frames = np.stack([Oracle.synth(1280, 720, 4 + i) for i in range(5)])
     frames[2] = 0  # a frame without corners

@@ -294,14 +294,14 @@ def test_gpu_resize_any_shape(hip, oracle, w, h, dw, dh, seed, nn):
 
 
 @_cfg(20)
-@given(w=st.integers(1, 60), h=st.integers(1, 40), seed=st.integers(0, 2 ** 16), data=st.data())
+@given(w=st.one_of(st.integers(1, 60), st.integers(61, 160)), h=st.one_of(st.integers(1, 40), st.integers(41, 70)), seed=st.integers(0, 2 ** 16), data=st.data())
 def test_template_any_shape(emu, oracle, w, h, seed, data):
     _body_template_any_shape(emu, oracle, w=w, h=h, seed=seed, data=data)
 
 
 @pytest.mark.gpu
 @_cfg(20)
-@given(w=st.integers(1, 60), h=st.integers(1, 40), seed=st.integers(0, 2 ** 16), data=st.data())
+@given(w=st.one_of(st.integers(1, 60), st.integers(61, 160)), h=st.one_of(st.integers(1, 40), st.integers(41, 70)), seed=st.integers(0, 2 ** 16), data=st.data())
 def test_gpu_template_any_shape(hip, oracle, w, h, seed, data):
     _body_template_any_shape(hip, oracle, w=w, h=h, seed=seed, data=data)
 
