@@ -405,6 +405,9 @@ def main():
         "gs_histogram+otsu": (lambda: g.otsu_batch(dst, hist, thr), 1.0 * npx, 1.0 * npx),
         "gs_threshold k_threshold": (lambda: g.threshold_batch(dst, thr), 2.0 * npx, 2.0 * npx),
         "gs_erode k_morph16": (lambda: g.erode_batch(dst, src), 2.0 * npx, 2.0 * npx),
+        # radii <= 16 keep the window's rows in a register ring (k_box16r)
+        "gs_blur(r=5) k_box16r": (lambda: g.blur_batch(tmp, src, 5), 2.0 * npx, 2.0 * npx),
+        "gs_adaptive_threshold(r=15, c=5) k_box16r": (lambda: g.adaptive_threshold_batch(tmp, src, 15, 5), 2.0 * npx, 2.0 * npx),
     }
     # gs_integral on 64 frames (u32 table: 2.1 GB): bytes moved from the PMC passes when they cover this shape
     n_ii = min(64, F)
