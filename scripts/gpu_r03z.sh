@@ -31,3 +31,4 @@ PMC_PROBE=scripts/pmc_probe_box.py PMC_FILTER=k_box16,k_integral PMC_TAG=sqbox b
 echo "== PMC: LBP cascade, 8 x 4K noise"
 LBP_PRE=0 PMC_SETS="TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum|TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum|TA_TA_BUSY_sum GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_ACTIVE_INST_VALU" bash scripts/pmc_lbp.sh 2>&1 | grep -v amdgpu.ids | tee gpurun_out/pmc_lbp_quad.txt
 echo "== next rows"; timeout 300 python scripts/ubench_next_rows.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/next_rows.log | tail -12
+echo "== gs_match_template: matrix cores vs dot-product kernels"; timeout 600 python scripts/ubench_tmatch.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/tmatch_mfma.log | tail -12
