@@ -5,6 +5,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, grayskull_amd as gs
 g = gs.lib(); g.use_torch_stream()
+if os.environ.get("BOX_ANY_RADIUS"): g.tune(6, 4)  # the any-radius kernel k_box16 instead of the ring kernels
 F, H, W = 64, 2160, 3840
 src = torch.empty((F, H, W), dtype=torch.uint8, device="cuda"); g.synth_batch(src, 1000)
 dst = torch.zeros_like(src)
