@@ -276,7 +276,7 @@ dim3 grid2d(unsigned w, unsigned h, unsigned n) { return dim3((w + 63) / 64, (h 
 inline bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 /* ---- launch tuning (gsh_tune): 0 rows per band (0 = auto), 1 block shape, 2 prefetch depth */
-int g_tune[24] = {0, 3, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+int g_tune[32] = {0, 3, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 /* gsh_lbp_count_evaluated: device counter that receives the windows the cascade really evaluated */
 thread_local unsigned long long *g_lbp_evaluated = nullptr;
 
@@ -300,7 +300,7 @@ struct StripCfg {
 StripCfg strip_cfg(unsigned w, unsigned rows, unsigned n, unsigned waves_per_simd = 5, unsigned halo_rows = 2,
                    unsigned short_T = 8) {
   StripCfg c;
-  const unsigned strips = (w + 15) / 16;
+  const unsigned strips = (w + 15) / 16 + strip_ragged_shift(w); /* ragged rows may idle lane 0 (k_strip.h) */
   const unsigned long long waves_x = (strips + 63) / 64;
   unsigned long long t;
   if (g_tune[0] > 0) {
@@ -356,7 +356,17 @@ StripCfg strip_cfg(unsigned w, unsigned rows, unsigned n, unsigned waves_per_sim
   }
   return c;
 }
+/* The strip kernels take any width >= 32 and any byte alignment of the frames (round 4): rows of a frame whose width
+ * is not a multiple of 16 start at every 16-byte phase anyway (the API has no stride, ref grayskull.h:14-17), the
+ * hardware serves 16-byte accesses at any address, and the ragged last strip of a row is anchored at w - 16 (k_strip.h,
+ * RAGGED).  Key 21 = 1 restores the round-3 rule (multiples of 16, 16-byte aligned frames; everything else per pixel). */
 inline bool strip_ok(unsigned w, unsigned h, const void *a, const void *b) {
+  if (g_tune[21] == 1) return w % 16 == 0 && (unsigned long long)w * h < 0x7fffffffull && al16(a) && al16(b);
+  return w >= 32 && (unsigned long long)w * h < 0x7fffffffull;
+}
+inline bool ragged(unsigned w) { return (w & 15u) != 0u; }
+/* kernels that still need whole 16-px strips at 16-byte aligned addresses */
+inline bool strip_ok16(unsigned w, unsigned h, const void *a, const void *b) {
   return w % 16 == 0 && (unsigned long long)w * h < 0x7fffffffull && al16(a) && al16(b);
 }
 /* frames per launch (grid.y / grid.z limit 65535); gsh_tune key 8 lowers it so that the splitting
@@ -371,6 +381,7 @@ inline unsigned max_frames_per_launch() { return g_tune[8] > 0 ? (unsigned)g_tun
 void launch_sobel(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned n,
                   bool keep_cols = true) {
   if (w < 3 || h < 3 || n == 0) return;
+  if (g_tune[22] == 1) keep_cols = false; /* probe: without the dst column reads (columns 0 / w-1 then receive junk) */
   hipStream_t st = ctx().s();
   const size_t fb = (size_t)w * h;
   for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
@@ -379,7 +390,10 @@ void launch_sobel(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsi
     const uint8_t *s = src + fb * f0;
     if (strip_ok(w, h, d, s) && w >= 32) {
       const StripCfg c = strip_cfg(w, h - 2, nn, 5, 2, 6);
-      if (keep_cols) GS_LAUNCH(k_sobel16<true>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
+      if (ragged(w)) {
+        if (keep_cols) GS_LAUNCH((k_sobel16<true, true>), c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
+        else GS_LAUNCH((k_sobel16<false, true>), c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
+      } else if (keep_cols) GS_LAUNCH(k_sobel16<true>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
       else GS_LAUNCH(k_sobel16<false>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
     } else {
       GS_LAUNCH(k_sobel_px, grid2d(w, h, nn), dim3(64, 4), 0, st, d, s, w, h, fb);
@@ -398,7 +412,8 @@ void launch_morph(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsi
     const uint8_t *s = src + fb * f0;
     if (strip_ok(w, h, d, s)) {
       const StripCfg c = strip_cfg(w, h, nn, 5, 2, 4);
-      GS_LAUNCH(k_morph16<DILATE>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
+      if (ragged(w)) GS_LAUNCH((k_morph16<DILATE, true>), c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
+      else GS_LAUNCH(k_morph16<DILATE>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
     } else {
       GS_LAUNCH(k_morph_px<DILATE>, grid2d(w, h, nn), dim3(64, 4), 0, st, d, s, w, h, fb);
     }
@@ -444,7 +459,7 @@ void launch_box_generic(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h
   hipStream_t st = ctx().s();
   const size_t fp = (size_t)w * h;
   const unsigned r = std::min(radius, std::max(w, h)); /* larger windows clip identically */
-  if (g_tune[6] != 3 && r >= 1 && r <= 127 && w <= 4096 && strip_ok(w, h, dst, src)) {
+  if (g_tune[6] != 3 && r >= 1 && r <= 127 && w <= 4096 && strip_ok16(w, h, dst, src)) {
     /* sliding box sums straight from the source rows (k_box.h): 3-4 B/px instead of the ~16 of the integral-image
      * route below (64 4K frames: 2.8 ms whatever the radius; this one: r = 16 0.36 ms, r = 40 0.63 ms); the kernel's
      * u16 column sums and LDS halo hold up to r = 127 */
@@ -509,7 +524,11 @@ void launch_blur(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsig
       const StripCfg c = strip_cfg(w, h, nn, 5, radius, radius == 1 ? 4 : radius == 2 ? 6 : 12);
       uint8_t *d = dst + fb * f0;
       const uint8_t *s = src + fb * f0;
-      if (radius == 1) GS_LAUNCH(k_blur16<1>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
+      if (ragged(w)) {
+        if (radius == 1) GS_LAUNCH((k_blur16<1, true>), c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
+        else if (radius == 2) GS_LAUNCH((k_blur16<2, true>), c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
+        else GS_LAUNCH((k_blur16<3, true>), c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
+      } else if (radius == 1) GS_LAUNCH(k_blur16<1>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
       else if (radius == 2) GS_LAUNCH(k_blur16<2>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
       else GS_LAUNCH(k_blur16<3>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
       /* the 2*radius vertically clipped rows of each frame get their true divisors */
@@ -1263,12 +1282,14 @@ unsigned gsh_profile_read(double *total_ms) {
   return n;
 }
 void gsh_tune(int key, int value) {
-  if (key >= 0 && key < 24) g_tune[key] = value;
+  if (key >= 0 && key < 32) g_tune[key] = value;
 }
 void gsh_probe_strip_copy(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned n) {
-  GS_ASSERT(dst && src && w % 16 == 0 && al16(dst) && al16(src));
-  const StripCfg c = strip_cfg(w, h, n);
-  GS_LAUNCH(k_strip_copy, c.grid, c.block, 0, ctx().s(), dst, src, w, h, c.T, (size_t)w * h | c.xcd_flag);
+  GS_ASSERT(dst && src && w >= 32);
+  const StripCfg c = strip_cfg(w, h, n, 5, 2, g_tune[0] > 0 ? (unsigned)g_tune[0] : 8u);
+  if (g_tune[23] == 1) GS_LAUNCH((k_strip_copy<false, true>), c.grid, c.block, 0, ctx().s(), dst, src, w, h, c.T, (size_t)w * h | c.xcd_flag);
+  else if (ragged(w)) GS_LAUNCH(k_strip_copy<true>, c.grid, c.block, 0, ctx().s(), dst, src, w, h, c.T, (size_t)w * h | c.xcd_flag);
+  else GS_LAUNCH(k_strip_copy<false>, c.grid, c.block, 0, ctx().s(), dst, src, w, h, c.T, (size_t)w * h | c.xcd_flag);
 }
 void gsh_probe_fast_score(uint8_t *score, const uint8_t *img, unsigned w, unsigned h, unsigned n, unsigned threshold) {
   GS_ASSERT(score && img && w >= 7 && h >= 7 && n >= 1 && n <= kMaxZ);
@@ -1352,7 +1373,7 @@ void gsh_blur_sobel_batch(uint8_t *dst, const uint8_t *src, unsigned w, unsigned
   if (n == 0) return;
   const size_t fb = (size_t)w * h;
   hipStream_t st = ctx().s();
-  if (g_tune[3] == 0 && radius >= 1 && radius <= 3 && strip_ok(w, h, dst, src) && w >= 32 && h >= 3 &&
+  if (g_tune[3] == 0 && radius >= 1 && radius <= 3 && strip_ok16(w, h, dst, src) && w >= 32 && h >= 3 &&
       h > 2 * radius) {
     for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
       const unsigned nn = std::min(kMaxZ, n - f0);
@@ -1378,7 +1399,7 @@ void gsh_edge_pipeline_batch(uint8_t *dst, uint8_t *tmp, const uint8_t *src, uns
       GS_LAUNCH(k_zero_frame, dim3((2 * w + 2 * h + 255) / 256, std::min(kMaxZ, n - f0)), dim3(256), 0,
                 st, dst + fb * f0, w, h, fb);
   };
-  if (!tmp && g_tune[3] == 0 && radius >= 1 && radius <= 3 && strip_ok(w, h, dst, src) && w >= 32 &&
+  if (!tmp && g_tune[3] == 0 && radius >= 1 && radius <= 3 && strip_ok16(w, h, dst, src) && w >= 32 &&
       h >= 3 && h > 2 * radius) { /* every window is clipped on at most one side per axis */
     /* fused: the blurred image only ever exists in registers (1 R + 1 W per pixel).
      * The fused kernel is VALU-bound (~40 % of HBM peak) and the passes after it HBM-bound with
@@ -1794,7 +1815,8 @@ void gsh_filter_batch(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, 
     for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
       const unsigned nn = std::min(kMaxZ, n - f0);
       const StripCfg c = strip_cfg(w, h, nn, 6);
-      GS_LAUNCH(k_filter16, c.grid, c.block, 0, st, dst + fb * f0, src + fb * f0, w, h, c.T, fb | c.xcd_flag, fk);
+      if (ragged(w)) GS_LAUNCH(k_filter16<true>, c.grid, c.block, 0, st, dst + fb * f0, src + fb * f0, w, h, c.T, fb | c.xcd_flag, fk);
+      else GS_LAUNCH(k_filter16<false>, c.grid, c.block, 0, st, dst + fb * f0, src + fb * f0, w, h, c.T, fb | c.xcd_flag, fk);
     }
     return;
   }

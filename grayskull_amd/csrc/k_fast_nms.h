@@ -34,10 +34,14 @@ __global__ __launch_bounds__(256) void k_fast_nms16(const uint8_t *score, unsign
   const int y0 = 3 + (int)(S.band * T);
   if (y0 >= (int)h - 3) return; /* whole wave */
   const int nrows = ((int)h - 3 - y0) < (int)T ? ((int)h - 3 - y0) : (int)T;
-  /* interior columns 3 .. w-4 of this lane's 16 */
-  unsigned colmask = S.x0 < w ? 0xffffu : 0u;
-  if (S.x0 == 0) colmask &= 0xfff8u;
-  if (S.x0 + 16 == w) colmask &= 0x1fffu;
+  /* interior columns 3 .. w-4 of this lane's 16.  Any width: the strips stay on the 16-px grid (no stores of pixels here),
+   * the last lane of a ragged row reads on into the next row -- still inside the frame, the rows below y + 2 <= h - 2
+   * included -- and those columns never reach a flag. */
+  unsigned colmask = 0u;
+  if (S.x0 < w) {
+    const int lo = S.x0 >= 3u ? 0 : 3 - (int)S.x0, hi = (int)w - 4 - (int)S.x0 > 15 ? 15 : (int)w - 4 - (int)S.x0;
+    if (hi >= lo) colmask = ((2u << hi) - 1u) & ~((1u << lo) - 1u);
+  }
   auto hpass = [](const uint32_t(&U)[12], uint32_t(&H)[8]) { /* max of px x-1, x, x+1 for the own pairs */
 #pragma unroll
     for (int k = 0; k < 8; k++) {
@@ -48,9 +52,9 @@ __global__ __launch_bounds__(256) void k_fast_nms16(const uint8_t *score, unsign
   uint32_t ring[3][8], C[2][8]; /* horizontal maxima of rows y-1, y, y+1; own pairs of the last two rows loaded */
   {
     uint32_t U[12];
-    strip_unpack(S.load(y0 - 1), U);
+    S.unpack(S.load(y0 - 1), U);
     hpass(U, ring[0]);
-    strip_unpack(S.load(y0), U);
+    S.unpack(S.load(y0), U);
     hpass(U, ring[1]);
 #pragma unroll
     for (int k = 0; k < 8; k++) C[1][k] = U[k + 2];
@@ -77,7 +81,7 @@ __global__ __launch_bounds__(256) void k_fast_nms16(const uint8_t *score, unsign
       if (i >= nrows) return; /* wave-uniform */
       const int y = y0 + i;
       uint32_t U[12];
-      strip_unpack(raw, U);
+      S.unpack(raw, U);
       raw = S.load(y + 2);
       hpass(U, ring[ic]);
 #pragma unroll

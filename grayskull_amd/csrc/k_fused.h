@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) GS_FUSED_VGPR_ATTR void k_blur_sobel_hist16(ui
     static_for<N>([&](auto K) {
       constexpr int kk = decltype(K)::value;
       uint32_t U[12];
-      strip_unpack(S.load(y0 - 1 - R + kk), U);
+      S.unpack(S.load(y0 - 1 - R + kk), U);
       blur_hsum10<R>(U, ring[kk + P0]);
 #pragma unroll
       for (int k = 0; k < 10; k++) V[k] = add2(V[k], ring[kk + P0][k]);
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) GS_FUSED_VGPR_ATTR void k_blur_sobel_hist16(ui
     blurred(y0 - 1, UB0);
     {
       uint32_t U[12], Hn[10];
-      strip_unpack(S.load(y0 + R), U);
+      S.unpack(S.load(y0 + R), U);
       blur_hsum10<R>(U, Hn); /* enters slot 0 (SPARE: the free slot); the oldest row (slot P0) leaves */
 #pragma unroll
       for (int k = 0; k < 10; k++) V[k] = sub2(add2(V[k], Hn[k]), ring[P0][k]), ring[0][k] = Hn[k];

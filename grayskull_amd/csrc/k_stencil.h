@@ -27,10 +27,10 @@
 namespace gs {
 
 /* ------------------------------------------------------------------ sobel, strips (helpers: k_strip.h) */
-template <bool KEEP_COLS>
+template <bool KEEP_COLS, bool RAGGED = false>
 __global__ __launch_bounds__(256) void k_sobel16(uint8_t *dst, const uint8_t *src, unsigned w,
                                                  unsigned h, unsigned T, size_t frame_bytes) {
-  const Strip<> S(src, dst, w, h, frame_bytes);
+  const Strip<false, RAGGED> S(src, dst, w, h, frame_bytes);
   if (S.wave_outside()) return; /* block wider than the frame */
   const int y0 = 1 + (int)(S.band * T);
   if (y0 >= (int)h - 1) return; /* whole wave */
@@ -38,8 +38,8 @@ __global__ __launch_bounds__(256) void k_sobel16(uint8_t *dst, const uint8_t *sr
   SobelState st;
   {
     uint32_t U0[12], U1[12];
-    strip_unpack(S.load(y0 - 1), U0);
-    strip_unpack(S.load(y0), U1);
+    S.unpack(S.load(y0 - 1), U0);
+    S.unpack(S.load(y0), U1);
     st.init(U0, U1);
   }
   auto body = [&](auto I, int, const uint32_t(&U)[12]) { return st.template step<decltype(I)::value>(U); };
@@ -61,11 +61,20 @@ __global__ __launch_bounds__(256) void k_put_cols(uint8_t *img, const uint8_t *c
 }
 
 /* ------------------------------------------------------------------ box blur, strips (helpers: k_strip.h) */
-template <int R>
+/* ceil(2^24 / (N * cols)) for a run-time column count R+1 .. N (RAGGED: the lane left of the tail lane may own
+ * pixels less than R from the right edge too; evaluated once per lane, before the row loop) */
+template <int R> GS_DEV uint32_t blur_mul_cols(unsigned cols) {
+  constexpr unsigned N = 2 * R + 1;
+  uint32_t m = BlurMagic<R>::mul;
+#pragma unroll
+  for (unsigned c = R + 1; c < N; c++) m = cols == c ? (0x1000000u + N * c - 1u) / (N * c) : m;
+  return m;
+}
+template <int R, bool RAGGED = false>
 __global__ __launch_bounds__(256) void k_blur16(uint8_t *dst, const uint8_t *src, unsigned w,
                                                 unsigned h, unsigned T, size_t frame_bytes) {
   constexpr int N = 2 * R + 1;
-  const Strip<> S(src, dst, w, h, frame_bytes);
+  const Strip<false, RAGGED> S(src, dst, w, h, frame_bytes);
   if (S.wave_outside()) return; /* block wider than the frame */
   const bool first = S.x0 == 0, last = S.x0 + 16 == w;
   const int y0 = (int)(S.band * T);
@@ -77,10 +86,19 @@ __global__ __launch_bounds__(256) void k_blur16(uint8_t *dst, const uint8_t *src
 #pragma unroll
   for (int r = 0; r < N - 1; r++) { /* image rows y0-R .. y0+R-1 */
     uint32_t U[12];
-    strip_unpack(S.load(y0 - R + r), U);
+    S.unpack(S.load(y0 - R + r), U);
     blur_hsum<R>(U, ring[r]);
 #pragma unroll
     for (int k = 0; k < 8; k++) V[k] = add2(V[k], ring[r][k]);
+  }
+  /* RAGGED: columns in the image for the lane's R rightmost pixels, from the distance to the right edge */
+  uint32_t mRr[R];
+  if constexpr (RAGGED) {
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+      const int d = (int)w - 1 - (int)(S.x0 + 16 - R + q); /* >= 0 for every lane inside the image */
+      mRr[q] = blur_mul_cols<R>((unsigned)(R + 1 + (d < R ? d : R)));
+    }
   }
   strip_rows<N, false, !GS_BLUR_NOEXIT>(S, y0, nrows, R, S.load(y0 + R), [&](auto I, int, const uint32_t(&U)[12]) {
     constexpr int slot = (decltype(I)::value + N - 1) % N; /* row i-1 leaves, row i+2R enters */
@@ -95,6 +113,7 @@ __global__ __launch_bounds__(256) void k_blur16(uint8_t *dst, const uint8_t *src
     for (int q = 0; q < R; q++) {
       mL[q] = first ? (0x1000000u + N * (R + 1 + q) - 1u) / (N * (R + 1 + q)) : mC;
       mR[q] = last ? (0x1000000u + N * (2 * R - q) - 1u) / (N * (2 * R - q)) : mC;
+      if constexpr (RAGGED) mR[q] = mRr[q];
     }
     uint32_t od[4];
 #pragma unroll
@@ -140,10 +159,10 @@ __global__ __launch_bounds__(256) void k_blur_edge_rows(uint8_t *dst, const uint
 /* ------------------------------------------------------------------ 3x3 erode / dilate, strips */
 /* ref grayskull.h:285-304: max over in-image taps == max with 0 fill; erode runs as
  * ~dilate(~x) (Strip<INVERT>), i.e. min with 255 fill. */
-template <bool DILATE>
+template <bool DILATE, bool RAGGED = false>
 __global__ __launch_bounds__(256) void k_morph16(uint8_t *dst, const uint8_t *src, unsigned w,
                                                  unsigned h, unsigned T, size_t frame_bytes) {
-  const Strip<!DILATE> S(src, dst, w, h, frame_bytes);
+  const Strip<!DILATE, RAGGED> S(src, dst, w, h, frame_bytes);
   if (S.wave_outside()) return; /* block wider than the frame */
   const int y0 = (int)(S.band * T);
   if (y0 >= (int)h) return;
@@ -158,9 +177,9 @@ __global__ __launch_bounds__(256) void k_morph16(uint8_t *dst, const uint8_t *sr
   uint32_t ring[3][8];
   {
     uint32_t U[12];
-    strip_unpack(S.load(y0 - 1), U);
+    S.unpack(S.load(y0 - 1), U);
     hpass(U, ring[0]);
-    strip_unpack(S.load(y0), U);
+    S.unpack(S.load(y0), U);
     hpass(U, ring[1]);
   }
   strip_rows<3, !DILATE>(S, y0, nrows, 1, S.load(y0 + 1), [&](auto I, int, const uint32_t(&U)[12]) {
@@ -175,9 +194,10 @@ __global__ __launch_bounds__(256) void k_morph16(uint8_t *dst, const uint8_t *sr
 }
 
 /* diagnostic: same traffic pattern as the strip kernels, no arithmetic (access-pattern ceiling) */
+template <bool RAGGED = false, bool HALO = false> /* HALO: keep the halo dword load of the stencils alive (probe) */
 __global__ __launch_bounds__(256) void k_strip_copy(uint8_t *dst, const uint8_t *src, unsigned w,
                                                     unsigned h, unsigned T, size_t frame_bytes) {
-  const Strip<> S(src, dst, w, h, frame_bytes);
+  const Strip<false, RAGGED> S(src, dst, w, h, frame_bytes);
   if (S.wave_outside()) return; /* block wider than the frame */
   const int y0 = (int)(S.band * T);
   if (y0 >= (int)h) return;
@@ -185,6 +205,7 @@ __global__ __launch_bounds__(256) void k_strip_copy(uint8_t *dst, const uint8_t 
   RawRow raw = S.load(y0);
   for (int i = 0; i < nrows; i++) {
     const U4 cur = raw.v;
+    if constexpr (HALO) (void)opaque(raw.hh);
     raw = S.load(y0 + i + 1);
     S.store(y0 + i, true, cur);
   }
@@ -210,9 +231,10 @@ GS_DEV void filter_hrow(const uint32_t (&U)[12], const uint32_t (&kr)[3], uint32
   }
 }
 
+template <bool RAGGED = false>
 __global__ __launch_bounds__(256) void k_filter16(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h,
                                                   unsigned T, size_t frame_bytes, FilterK fk) {
-  const Strip<> S(src, dst, w, h, frame_bytes);
+  const Strip<false, RAGGED> S(src, dst, w, h, frame_bytes);
   if (S.wave_outside()) return; /* block wider than the frame */
   const int y0 = (int)(S.band * T);
   if (y0 >= (int)h) return;
@@ -220,9 +242,9 @@ __global__ __launch_bounds__(256) void k_filter16(uint8_t *dst, const uint8_t *s
   uint32_t P0[8], P1[8]; /* P1 = H0(y-1) + H1(y) waits for H2(y+1); P0 = H0(y) waits for H1(y+1) */
   {
     uint32_t U[12], Ha[8], Hb[8];
-    strip_unpack(S.load(y0 - 1), U);
+    S.unpack(S.load(y0 - 1), U);
     filter_hrow(U, fk.k[0], Ha); /* H0(y0-1) */
-    strip_unpack(S.load(y0), U);
+    S.unpack(S.load(y0), U);
     filter_hrow(U, fk.k[1], Hb); /* H1(y0) */
 #pragma unroll
     for (int p = 0; p < 8; p++) P1[p] = pk_add_u16(Ha[p], Hb[p]);

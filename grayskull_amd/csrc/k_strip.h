@@ -16,6 +16,9 @@
 #ifndef GS_BLUR_NOEXIT
 #define GS_BLUR_NOEXIT 0
 #endif
+#ifndef GS_STRIP_PF
+#define GS_STRIP_PF 1 /* input rows requested ahead of the arithmetic (experiment hook: 2) */
+#endif
 #ifndef GS_SOBEL_NOEXIT
 #define GS_SOBEL_NOEXIT 1 /* 1: k_sobel16 runs whole unroll groups (one basic block, no phi copies) */
 #endif
@@ -48,24 +51,65 @@ constexpr uint32_t kRowOOB = 0x7fffffffu;
  * Mapped, XCD k walks the k-th eighth of every frame top to bottom, so a band's halo rows are the rows its
  * own L2 fetched for the previous band. */
 constexpr size_t kStripXcdFlag = (size_t)1 << 63;
-template <bool INVERT = false> struct Strip {
+/* RAGGED (w % 16 != 0, w >= 32; the API has no stride field, ref grayskull.h:14-17, so rows of such a frame start at
+ * every 16-byte phase): strips 0 .. t-1 (t = (w-1)/16) lie on the 16-px grid as usual and the LAST strip is anchored at
+ * x0 = w - 16 -- it overlaps its left neighbour by 16 - w % 16 pixels, which both lanes compute (same inputs, same
+ * bytes) and both store.  So every load and store is a whole 16 bytes inside the row: no partial store, no
+ * read-modify-write of the next row's head, nothing read past the frame.  The two lanes at the seam cannot take their
+ * horizontal neighbours from the adjacent lane (the tail lane's registers are shifted): the tail lane's left dword
+ * (px w-20 .. w-17) and its neighbour's right dword (px 16t .. 16t+3) ride in the per-lane halo load that lane 0 /
+ * lane 63 of every wave use anyway, selected behind the DPP move with one v_cndmask each (unpack).  A right-halo dword
+ * that would cross the row end is fetched early and shifted down: pixels >= w read 0 like everything outside the image.
+ * One lane has one halo slot: were the seam's left lane also lane 0 of a wave that needs its own left halo (t % 64 == 1),
+ * the whole row is moved up by one lane (`shift`; lane 0 of the first wave idles).  Rows are w bytes apart whatever
+ * w is, and so are these accesses: gfx950 serves buffer_load/store_dwordx4 at any byte address. */
+__host__ __device__ inline unsigned strip_ragged_shift(unsigned w) { /* also the launcher's: one more strip to place */
+  const unsigned t = (w - 1u) >> 4;
+  return ((w & 15u) != 0u && (t & 63u) == 1u && t > 1u) ? 1u : 0u;
+}
+template <bool INVERT = false, bool RAGGED = false> struct Strip {
   BufRsrc src, dst;
-  unsigned w, h, x0, lane, band;
+  unsigned w, h, x0, lane, band, gid;
   uint32_t col_off, halo_off; /* this lane's 16 B / its halo dword inside a row (kOOB: none) */
+  bool sel_l = false, sel_r = false; /* RAGGED: left / right neighbour dword comes from the halo load, not from the next lane */
+  uint32_t halo_shift = 0;           /* RAGGED: bits the right-halo dword was fetched early by */
+  uint32_t keep_r = 0xffffffffu;     /* RAGGED: 0 in the tail lane -- nothing lies right of it (as lane 63 its DPP fill is its LEFT halo) */
   GS_DEV Strip(const uint8_t *s, uint8_t *d, unsigned w_, unsigned h_, size_t frame_bytes)
       : src(make_buf(s + (size_t)blockIdx.z * (frame_bytes & ~kStripXcdFlag), frame_bytes & ~kStripXcdFlag)),
         dst(make_buf(d + (size_t)blockIdx.z * (frame_bytes & ~kStripXcdFlag), frame_bytes & ~kStripXcdFlag)), w(w_), h(h_) {
     lane = threadIdx.x & 63u;
-    x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 16u;
+    gid = blockIdx.x * blockDim.x + threadIdx.x;
     band = uniform(blockIdx.y * blockDim.y + threadIdx.y); /* same for the wave's 64 lanes: SGPR */
     if (frame_bytes & kStripXcdFlag) band = (blockIdx.y & 7u) * (gridDim.y >> 3) + (blockIdx.y >> 3);
-    col_off = x0 < w ? x0 : kOOB;
-    halo_off = kOOB;
-    if (lane == 0 && x0 > 0 && x0 < w) halo_off = x0 - 4;
-    if (lane == 63 && x0 + 16 < w) halo_off = x0 + 16;
+    if constexpr (!RAGGED) {
+      x0 = gid * 16u;
+      col_off = x0 < w ? x0 : kOOB;
+      halo_off = kOOB;
+      if (lane == 0 && x0 > 0 && x0 < w) halo_off = x0 - 4;
+      if (lane == 63 && x0 + 16 < w) halo_off = x0 + 16;
+    } else {
+      const unsigned t = (w - 1u) >> 4;
+      gid -= strip_ragged_shift(w); /* the idle lane wraps to 2^32 - 1: outside like everything right of the image */
+      const bool tail = gid == t, in = gid <= t;
+      x0 = tail ? w - 16u : gid * 16u;
+      keep_r = tail ? 0u : 0xffffffffu;
+      col_off = in ? x0 : kOOB;
+      halo_off = kOOB;
+      uint32_t right = kOOB; /* start of the dword right of this lane's 16 px, where the lane has to fetch it itself */
+      if (in && x0 > 0 && (lane == 0 || tail)) halo_off = x0 - 4, sel_l = lane != 0;
+      if (gid < t && (lane == 63 || gid + 1u == t)) right = x0 + 16, sel_r = lane != 63;
+      if (right != kOOB) { /* in the row from `right` on (right <= 16 t < w); the dword may cross the row end */
+        const uint32_t at = right + 4u > w ? w - 4u : right;
+        halo_off = at, halo_shift = 8u * (right - at);
+      }
+    }
   }
   /* the whole wave lies right of the image (its block is wider than the frame): nothing to load, compute or store */
-  GS_DEV bool wave_outside() const { return uniform(x0 - lane * 16u) >= w; }
+  GS_DEV bool wave_outside() const {
+    if constexpr (RAGGED) return (int)uniform(gid - lane) > (int)((w - 1u) >> 4);
+    else return uniform(x0 - lane * 16u) >= w;
+  }
+  GS_DEV bool in_image() const { return col_off != kOOB; }
   GS_DEV uint32_t row_off(int y, bool ok = true) const { /* y, ok wave-uniform */
     return (ok && (unsigned)y < h) ? (uint32_t)y * w : kRowOOB;
   }
@@ -77,11 +121,12 @@ template <bool INVERT = false> struct Strip {
     r.v = buf_load16(src, row + col_off);
     r.hh = buf_load4(src, row + halo_off);
     if (INVERT) { /* complement in-image bytes only: out-of-range stays 0 in the inverted domain */
-      const bool ok = (unsigned)y < h && x0 < w;
+      const bool ok = (unsigned)y < h && in_image();
       const uint32_t m = ok ? 0xffffffffu : 0u, hm = (ok && halo_off != kOOB) ? 0xffffffffu : 0u;
       r.v = U4{r.v.x ^ m, r.v.y ^ m, r.v.z ^ m, r.v.w ^ m};
       r.hh ^= hm;
     }
+    if constexpr (RAGGED) r.hh >>= halo_shift; /* the pixels past the row end: 0 (inverted domain included) */
     return r;
   }
   /* whole 16 B of row y (dropped when !ok or the lane is outside the image) */
@@ -89,19 +134,19 @@ template <bool INVERT = false> struct Strip {
     if (INVERT) o = U4{~o.x, ~o.y, ~o.z, ~o.w};
     buf_store16(dst, row_off(y, ok) + col_off, o);
   }
+  /* 24 bytes = cols x0-4 .. x0+19 as 12 dwords of u16 pairs: U[j] = (px 2j-4, px 2j-3). */
+  GS_DEV void unpack(const RawRow &r, uint32_t (&U)[12]) const {
+    uint32_t L = wave_shr1(r.v.w, r.hh); /* left neighbour's last dword (lane 0: halo)   */
+    uint32_t R = wave_shl1(r.v.x, r.hh); /* right neighbour's first dword (lane 63: halo) */
+    if constexpr (RAGGED) L = sel_l ? r.hh : L, R = (sel_r ? r.hh : R) & keep_r;
+    U[0] = unpack_lo(L), U[1] = unpack_hi(L);
+    U[2] = unpack_lo(r.v.x), U[3] = unpack_hi(r.v.x);
+    U[4] = unpack_lo(r.v.y), U[5] = unpack_hi(r.v.y);
+    U[6] = unpack_lo(r.v.z), U[7] = unpack_hi(r.v.z);
+    U[8] = unpack_lo(r.v.w), U[9] = unpack_hi(r.v.w);
+    U[10] = unpack_lo(R), U[11] = unpack_hi(R);
+  }
 };
-
-/* 24 bytes = cols x0-4 .. x0+19 as 12 dwords of u16 pairs: U[j] = (px 2j-4, px 2j-3). */
-GS_DEV void strip_unpack(const RawRow &r, uint32_t (&U)[12]) {
-  const uint32_t L = wave_shr1(r.v.w, r.hh); /* left neighbour's last dword (lane 0: halo)   */
-  const uint32_t R = wave_shl1(r.v.x, r.hh); /* right neighbour's first dword (lane 63: halo) */
-  U[0] = unpack_lo(L), U[1] = unpack_hi(L);
-  U[2] = unpack_lo(r.v.x), U[3] = unpack_hi(r.v.x);
-  U[4] = unpack_lo(r.v.y), U[5] = unpack_hi(r.v.y);
-  U[6] = unpack_lo(r.v.z), U[7] = unpack_hi(r.v.z);
-  U[8] = unpack_lo(r.v.w), U[9] = unpack_hi(r.v.w);
-  U[10] = unpack_lo(R), U[11] = unpack_hi(R);
-}
 
 /* Row loop shared by the strip kernels.  Per output row i of the band:
  *     wait for row i's raw data -> unpack (raw registers die) -> store row i-1's result ->
@@ -119,10 +164,13 @@ struct NoFin {
  * computed and dropped (stores predicated off; their loads are in-frame rows of the next band or
  * out-of-range zero fill).  false costs registers; it pays for the VALU-heavy fused kernel only.
  * The input is requested one row ahead (two measured no better and costs 5 registers). */
-template <int RING, bool INVERT, bool EXITS = true, class Body, class Fin = NoFin>
-GS_DEV void strip_rows(const Strip<INVERT> &S, int y0, int nrows, int lead, RawRow first, Body &&body,
+template <int RING, bool INVERT, bool EXITS = true, bool RAGGED = false, class Body, class Fin = NoFin>
+GS_DEV void strip_rows(const Strip<INVERT, RAGGED> &S, int y0, int nrows, int lead, RawRow first, Body &&body,
                        Fin fin = Fin()) {
   RawRow raw = first; /* = load(y0 + lead): the newest input row output row 0 needs */
+#if GS_STRIP_PF == 2
+  RawRow raw2 = S.load(y0 + lead + 1);
+#endif
   U4 o_prev{0, 0, 0, 0};
   fin.prefetch(y0);
   int base = 0;
@@ -134,9 +182,13 @@ GS_DEV void strip_rows(const Strip<INVERT> &S, int y0, int nrows, int lead, RawR
       }
       if constexpr (!EXITS) sched_fence(); /* the next row's unpack (= its vmcnt wait) stays down here */
       uint32_t U[12];
-      strip_unpack(raw, U);
+      S.unpack(raw, U);
       S.store(y0 + i - 1, i > 0 && i <= nrows, fin(o_prev, y0 + i - 1));
+#if GS_STRIP_PF == 2
+      raw = raw2, raw2 = S.load(y0 + i + lead + 2);
+#else
       raw = S.load(y0 + i + lead + 1);
+#endif
       fin.prefetch(y0 + i);
       if constexpr (!EXITS) sched_fence(); /* one big block: keep the loads ahead of the arithmetic */
       o_prev = body(I, i, U);
@@ -172,8 +224,8 @@ struct SobelKeepCols { /* Fin functor of strip_rows */
   bool first, last;
   uint32_t keep_off;
   uint32_t e = 0; /* dst dword holding the protected byte of the row that is stored next */
-  GS_DEV SobelKeepCols(const Strip<> &S) : dst(S.dst), w(S.w), x0(S.x0) {
-    first = x0 == 0, last = x0 + 16 == w; /* launcher guarantees w >= 32: never both */
+  template <bool RAGGED> GS_DEV SobelKeepCols(const Strip<false, RAGGED> &S) : dst(S.dst), w(S.w), x0(S.x0) {
+    first = x0 == 0, last = x0 + 16 == w; /* launcher guarantees w >= 32: never both; RAGGED: the tail lane ends at w */
     keep_off = first ? x0 : last ? x0 + 12 : kOOB;
   }
   /* strip_rows calls prefetch(y) in the iteration that COMPUTES row y and operator() in the next

@@ -1,0 +1,143 @@
+"""Ragged widths (w % 16 != 0) and frames at any byte address on the strip kernels (round 4).
+
+The API has no stride (ref grayskull.h:14-17), so rows of such frames start at every 16-byte phase; since round 4 the
+strip kernels take them (k_strip.h RAGGED / REALIGN) instead of the per-pixel kernels.  Every op is compared bit for
+bit with the compiled reference (the pinned restatement where oracle/_ref is absent) inside sentinel-guarded buffers:
+a byte written outside the frame, or a wrong byte inside it, fails.
+
+CPU: the kernel sources through the host-fiber emulator (batch entry points take the buffers as "device" memory, so
+odd base addresses are real).  GPU (-m gpu): the same cases on the MI355X.
+"""
+import numpy as np
+import pytest
+
+from util import assert_same
+
+GUARD = 192
+K3 = np.array([[1, -2, 1], [2, 4, -2], [1, 2, 1]], np.int8)
+
+
+class Bufs:
+    """sentinel-guarded frame batches for one backend"""
+
+    def __init__(self, kind):
+        self.kind = kind
+        if kind == "gpu":
+            import torch
+            self.torch = torch
+
+    def make(self, n, h, w, off, fill):
+        nb = n * h * w
+        if self.kind == "gpu":
+            buf = self.torch.full((GUARD + off + nb + GUARD,), 0xAB, dtype=self.torch.uint8, device="cuda")
+            v = buf[GUARD + off:GUARD + off + nb].view(n, h, w)
+            v.copy_(self.torch.from_numpy(np.ascontiguousarray(fill)))
+        else:
+            buf = np.full(GUARD + off + nb + GUARD, 0xAB, np.uint8)
+            v = buf[GUARD + off:GUARD + off + nb].reshape(n, h, w)
+            v[...] = fill
+        return buf, v
+
+    def host(self, t):
+        return t.cpu().numpy() if self.kind == "gpu" else np.array(t)
+
+    def guards_ok(self, buf, off, nb):
+        a = self.host(buf)
+        return bool((a[:GUARD + off] == 0xAB).all() and (a[GUARD + off + nb:] == 0xAB).all())
+
+
+def _ops(g, o):
+    return {
+        "sobel": (lambda d, s: g.sobel_batch(d, s), lambda img, d0: o.sobel(img, d0)),
+        "blur1": (lambda d, s: g.blur_batch(d, s, 1), lambda img, d0: o.blur(img, 1)),
+        "blur2": (lambda d, s: g.blur_batch(d, s, 2), lambda img, d0: o.blur(img, 2)),
+        "blur3": (lambda d, s: g.blur_batch(d, s, 3), lambda img, d0: o.blur(img, 3)),
+        "erode": (lambda d, s: g.erode_batch(d, s), lambda img, d0: o.erode(img)),
+        "dilate": (lambda d, s: g.dilate_batch(d, s), lambda img, d0: o.dilate(img)),
+        "filter": (lambda d, s: g.filter_batch(d, s, K3, 8), lambda img, d0: o.filter(img, K3, 8)),
+    }
+
+
+def check_width(g, o, bufs, w, h, off, rs, n=2, which=None):
+    img = rs.randint(0, 256, (n, h, w)).astype(np.uint8)
+    d0 = rs.randint(0, 256, (n, h, w)).astype(np.uint8)
+    _, s = bufs.make(n, h, w, off, img)
+    for name, (run, ref) in _ops(g, o).items():
+        if which and name not in which:
+            continue
+        db, d = bufs.make(n, h, w, off, d0)
+        run(d, s)
+        if bufs.kind == "gpu":
+            bufs.torch.cuda.synchronize()
+        exp = np.stack([ref(img[i], d0[i]) for i in range(n)])
+        assert_same(bufs.host(d), exp, "%s %dx%d at base+%d" % (name, w, h, off))
+        assert bufs.guards_ok(db, off, n * h * w), "%s %dx%d at base+%d wrote outside the frames" % (name, w, h, off)
+
+
+def _oracle(request):
+    from oracle import pyoracle
+    return request.getfixturevalue("reference" if pyoracle.have_reference() else "oracle")
+
+
+def test_emu_all_widths_32_to_1100(emu, request):
+    """every width from 32 to 1100: the seam between the grid strips and the anchored tail strip, the idle-lane shift
+    (tail in lane 1 of the second wave: w = 1041 .. 1055) and the per-lane edge divisors of gs_blur"""
+    o, bufs, rs = _oracle(request), Bufs("emu"), np.random.RandomState(11)
+    for w in range(32, 1101):
+        check_width(emu, o, bufs, w, 7, 0, rs, n=1)
+
+
+@pytest.mark.parametrize("off", [1, 2, 3, 4, 8, 15])
+def test_emu_frames_at_odd_addresses(emu, request, off):
+    o, bufs, rs = _oracle(request), Bufs("emu"), np.random.RandomState(12 + off)
+    for w in (32, 48, 61, 64, 100, 612, 1024, 1037, 1041, 1080, 2064, 2071):
+        check_width(emu, o, bufs, w, 9, off, rs)
+
+
+def test_emu_ragged_tall_and_batched(emu, request):
+    """bands: several per frame, frames of a batch back to back at every phase"""
+    o, bufs, rs = _oracle(request), Bufs("emu"), np.random.RandomState(13)
+    emu.tune(0, 5)
+    try:
+        for w, h in ((37, 41), (612, 33), (1029, 23), (1366, 19)):
+            check_width(emu, o, bufs, w, h, 3, rs, n=3)
+    finally:
+        emu.tune(0, 0)
+
+
+def test_emu_fast_any_width(emu, request):
+    """gs_fast pass 2 on the strip machinery for any width (the strips stay on the grid, flags are masked)"""
+    o, rs = _oracle(request), np.random.RandomState(14)
+    for w in list(range(32, 70)) + [100, 127, 129, 612, 1000, 1023, 1025, 1041, 1080]:
+        for h in (9, 20):
+            img = (rs.randint(0, 256, (h, w)) * (rs.rand(h, w) < 0.7)).astype(np.uint8)
+            sm0 = rs.randint(0, 256, (h, w)).astype(np.uint8)
+            sm = sm0.copy()
+            k = emu.fast(img, sm, 5000, 20)
+            ko, smo = o.fast(img, 5000, 20, sm0)
+            assert_same(k, ko, "fast %dx%d" % (w, h))
+            assert_same(sm, smo, "fast scoremap %dx%d" % (w, h))
+
+
+@pytest.mark.gpu
+def test_gpu_all_widths_32_to_1100(hip, request):
+    o, bufs, rs = _oracle(request), Bufs("gpu"), np.random.RandomState(21)
+    for w in range(32, 1101):
+        check_width(hip, o, bufs, w, 7, 0, rs, n=1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("off", [1, 2, 3, 4, 8, 15])
+def test_gpu_frames_at_odd_addresses(hip, request, off):
+    o, bufs, rs = _oracle(request), Bufs("gpu"), np.random.RandomState(22 + off)
+    for w in (32, 48, 61, 64, 100, 612, 1024, 1037, 1041, 1080, 2064, 2071, 3838, 3840):
+        check_width(hip, o, bufs, w, 23, off, rs, n=3)
+
+
+@pytest.mark.gpu
+def test_gpu_ragged_video_sizes(hip, request):
+    """the reference's own fixture size (testdata/receipt.pgm, 612 x 816), portrait 1080p, 1366 x 768, a cropped 4K"""
+    o, bufs, rs = _oracle(request), Bufs("gpu"), np.random.RandomState(23)
+    for w, h in ((612, 816), (1080, 1920), (1366, 768), (3838, 2160)):
+        check_width(hip, o, bufs, w, h, 0, rs, n=2)
+        check_width(hip, o, bufs, w, h, 1, rs, n=1, which=("sobel", "blur2"))
