@@ -424,26 +424,34 @@ void launch_integral(const uint8_t *src, unsigned w, unsigned h, unsigned n, uns
   if (n == 0) return;
   hipStream_t st = ctx().s();
   const size_t fp = (size_t)w * h;
-  const bool banded = g_tune[6] != 1 && w % 16 == 0 && w <= 4096 && fp * 4 < 0x7fffffffull && al16(src) && al16(ii);
+  /* the banded form takes any width >= 32 at any alignment (round 4: ragged rows, frames wider than 4096 px in column
+   * chunks); key 6 = 1 or key 21 = 1: the rows + columns form */
+  const bool banded = g_tune[6] != 1 && fp * 4 < 0x7fffffffull &&
+                      (g_tune[21] == 1 ? (w % 16 == 0 && w <= 4096 && al16(src) && al16(ii)) : w >= 32);
   for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
     const unsigned nn = std::min(kMaxZ, n - f0);
     if (banded) {
+      const bool wide = w > 4096;
       unsigned nb = std::max(1u, 2048u / nn);               /* ~2K blocks in flight */
       nb = std::min(nb, std::max(1u, h / 8));
+      if (wide) nb = std::max(nb, (h + kIntegralWideRows - 1) / kIntegralWideRows); /* a row's carry waits in LDS */
       const unsigned BH = (h + nb - 1) / nb;
       nb = (h + BH - 1) / BH;
       unsigned *cs = (unsigned *)ctx().scratch(SL_HISTP, (size_t)nn * nb * w * 4);
-      GS_LAUNCH(k_integral_colsum, dim3(1, nb, nn), dim3(256), 0, st, src + fp * f0, w, h, BH, nb, cs);
+      const uint8_t *s = src + fp * f0;
+      unsigned *o = ii + fp * f0;
+      GS_LAUNCH(k_integral_colsum, dim3((w + 4095) / 4096, nb, nn), dim3(256), 0, st, s, w, h, BH, nb, cs);
       GS_LAUNCH(k_integral_colbase, dim3((w + 63) / 64, nn), dim3(64, 16), 0, st, cs, w, nb);
-      if (g_tune[6] == 2) /* the block-per-band form (one barrier per row), kept for comparison */
-        GS_LAUNCH(k_integral_band, dim3(1, nb, nn), dim3(256), 0, st, src + fp * f0, w, h, BH, nb,
-                  (const unsigned *)cs, ii + fp * f0);
-      else if (w <= 2048)
-        GS_LAUNCH(k_integral_wave<8>, dim3(1, (nb + 3) / 4, nn), dim3(256), 0, st, src + fp * f0, w, h, BH,
-                  nb, (const unsigned *)cs, ii + fp * f0);
-      else
-        GS_LAUNCH(k_integral_wave<16>, dim3(1, (nb + 3) / 4, nn), dim3(256), 0, st, src + fp * f0, w, h, BH,
-                  nb, (const unsigned *)cs, ii + fp * f0);
+      const dim3 gw(1, (nb + 3) / 4, nn);
+      const bool rg = (w & 3u) != 0u;
+      if (g_tune[6] == 2 && !rg && !wide && w % 16 == 0) /* the block-per-band form (one barrier per row), kept for comparison */
+        GS_LAUNCH(k_integral_band, dim3(1, nb, nn), dim3(256), 0, st, s, w, h, BH, nb, (const unsigned *)cs, o);
+      else if (wide && rg) GS_LAUNCH((k_integral_wave<16, true, true>), gw, dim3(256), 0, st, s, w, h, BH, nb, (const unsigned *)cs, o);
+      else if (wide) GS_LAUNCH((k_integral_wave<16, false, true>), gw, dim3(256), 0, st, s, w, h, BH, nb, (const unsigned *)cs, o);
+      else if (w <= 2048 && rg) GS_LAUNCH((k_integral_wave<8, true>), gw, dim3(256), 0, st, s, w, h, BH, nb, (const unsigned *)cs, o);
+      else if (w <= 2048) GS_LAUNCH(k_integral_wave<8>, gw, dim3(256), 0, st, s, w, h, BH, nb, (const unsigned *)cs, o);
+      else if (rg) GS_LAUNCH((k_integral_wave<16, true>), gw, dim3(256), 0, st, s, w, h, BH, nb, (const unsigned *)cs, o);
+      else GS_LAUNCH(k_integral_wave<16>, gw, dim3(256), 0, st, s, w, h, BH, nb, (const unsigned *)cs, o);
     } else {
       GS_LAUNCH(k_integral_rows, dim3(h, nn), dim3(256), 0, st, src + fp * f0, w, h, ii + fp * f0);
       GS_LAUNCH(k_integral_cols, dim3((w + 255) / 256, nn), dim3(256), 0, st, ii + fp * f0, w, h);
@@ -459,7 +467,7 @@ void launch_box_generic(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h
   hipStream_t st = ctx().s();
   const size_t fp = (size_t)w * h;
   const unsigned r = std::min(radius, std::max(w, h)); /* larger windows clip identically */
-  if (g_tune[6] != 3 && r >= 1 && r <= 127 && w <= 4096 && strip_ok16(w, h, dst, src)) {
+  if (g_tune[6] != 3 && r >= 1 && r <= 127 && w <= 4096 && strip_ok(w, h, dst, src)) {
     /* sliding box sums straight from the source rows (k_box.h): 3-4 B/px instead of the ~16 of the integral-image
      * route below (64 4K frames: 2.8 ms whatever the radius; this one: r = 16 0.36 ms, r = 40 0.63 ms); the kernel's
      * u16 column sums and LDS halo hold up to r = 127 */
@@ -467,7 +475,7 @@ void launch_box_generic(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h
       const unsigned nn = std::min(kMaxZ, n - f0);
       /* r <= 16: the window's raw rows stay in registers (k_box16r: 2 B/px instead of 3-4; 64 x 4K: 0.22 ms for r <= 9,
        * 0.28 up to 16, against 0.31-0.42 -- profiles/r03r_box_ring.log).  Key 6 = 4: k_box16 always. */
-      const bool ring = g_tune[6] != 4 && r <= box_ring_max() && w >= 32 && h >= 2 * r + 1 && (MODE == 0 || (c > -(1 << 30) && c < (1 << 30)));
+      const bool ring = g_tune[6] != 4 && !ragged(w) && r <= box_ring_max() && w >= 32 && h >= 2 * r + 1 && (MODE == 0 || (c > -(1 << 30) && c < (1 << 30)));
       /* band height: the launch should be whole rounds of the blocks the chip holds (256 CUs x 4 of them, fewer for the
        * register-heavy ring kernels of r >= 8 / 10), and a band first loads 2r+1 rows it does not output -- loads and
        * adds only since the vertical-first form, ~0.3 of an output row each.  Pick the band count with the smallest
@@ -1373,7 +1381,7 @@ void gsh_blur_sobel_batch(uint8_t *dst, const uint8_t *src, unsigned w, unsigned
   if (n == 0) return;
   const size_t fb = (size_t)w * h;
   hipStream_t st = ctx().s();
-  if (g_tune[3] == 0 && radius >= 1 && radius <= 3 && strip_ok16(w, h, dst, src) && w >= 32 && h >= 3 &&
+  if (g_tune[3] == 0 && radius >= 1 && radius <= 3 && strip_ok(w, h, dst, src) && w >= 32 && h >= 3 &&
       h > 2 * radius) {
     for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
       const unsigned nn = std::min(kMaxZ, n - f0);
@@ -1487,6 +1495,15 @@ void gsh_edge_pipeline_batch(uint8_t *dst, uint8_t *tmp, const uint8_t *src, uns
       f0 += nn;
     }
 #endif
+    return;
+  }
+  if (!tmp && g_tune[3] == 0 && radius >= 1 && radius <= 3 && strip_ok(w, h, dst, src) && w >= 32 && h >= 3 &&
+      h > 2 * radius) {
+    /* ragged rows or frames at odd addresses: blur + sobel still in one pass (the fused kernel without its histogram
+     * half), the histogram as a pass of its own: 5 B/px moved instead of 4, against 9 for the separate calls */
+    gsh_blur_sobel_batch(dst, src, w, h, n, radius);
+    launch_otsu(dst, w, h, n, hist_scratch, thr);
+    launch_threshold(dst, fb, n, thr, 0);
     return;
   }
   uint8_t *t = tmp ? tmp : (uint8_t *)ctx().scratch(SL_AUX, fb * n);
@@ -1832,8 +1849,8 @@ void gsh_downsample_batch(uint8_t *dst, const uint8_t *src, unsigned sw, unsigne
   const size_t sfb = (size_t)sw * sh, dfb = (size_t)(sw / 2) * (sh / 2);
   for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
     const unsigned nn = std::min(kMaxZ, n - f0);
-    if (sw % 16 == 0 && al16(src) && al16(dst) && sfb % 16 == 0 && dfb % 8 == 0)
-      GS_LAUNCH(k_downsample8, dim3((sw / 16 + 63) / 64, (sh / 2 + 3) / 4, nn), dim3(64, 4), 0, st,
+    if (g_tune[21] == 1 ? (sw % 16 == 0 && al16(src) && al16(dst) && sfb % 16 == 0 && dfb % 8 == 0) : sw >= 16)
+      GS_LAUNCH(k_downsample8, dim3(((sw / 2 + 7) / 8 + 63) / 64, (sh / 2 + 3) / 4, nn), dim3(64, 4), 0, st,
                 dst + dfb * f0, src + sfb * f0, sw, sh);
     else
       GS_LAUNCH(k_downsample_px, grid2d(sw / 2, sh / 2, nn), dim3(64, 4), 0, st, dst + dfb * f0,

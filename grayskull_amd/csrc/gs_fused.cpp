@@ -22,6 +22,12 @@ void launch_blur_sobel_hist(unsigned radius, dim3 grid, dim3 block, hipStream_t 
 void launch_blur_sobel(unsigned radius, dim3 grid, dim3 block, hipStream_t st, uint8_t *dst, const uint8_t *src,
                        unsigned w, unsigned h, unsigned T, size_t frame_bytes) {
   unsigned *none = nullptr;
+  if (w % 16 != 0) { /* ragged rows: the tail strip anchored at w - 16 (k_strip.h) */
+    if (radius == 1) GS_LAUNCH((k_blur_sobel_hist16<1, false, true>), grid, block, 0, st, dst, src, w, h, T, frame_bytes, none);
+    else if (radius == 2) GS_LAUNCH((k_blur_sobel_hist16<2, false, true>), grid, block, 0, st, dst, src, w, h, T, frame_bytes, none);
+    else GS_LAUNCH((k_blur_sobel_hist16<3, false, true>), grid, block, 0, st, dst, src, w, h, T, frame_bytes, none);
+    return;
+  }
   if (radius == 1) GS_LAUNCH((k_blur_sobel_hist16<1, false>), grid, block, 0, st, dst, src, w, h, T, frame_bytes, none);
   else if (radius == 2) GS_LAUNCH((k_blur_sobel_hist16<2, false>), grid, block, 0, st, dst, src, w, h, T, frame_bytes, none);
   else GS_LAUNCH((k_blur_sobel_hist16<3, false>), grid, block, 0, st, dst, src, w, h, T, frame_bytes, none);

@@ -45,14 +45,22 @@ GS_DEV unsigned box_div(unsigned sum, unsigned cx, unsigned cy, float rx, float 
 }
 
 /* MODE 0: dst = mean (gs_blur); MODE 1: dst = src > (int)(mean - (unsigned)c) ? 255 : 0.
- * grid (1, nbands, n frames), block 64 / 128 / 256 threads >= w / 16 (narrow frames: more blocks per CU instead of idle
- * waves); T rows per band; 1 <= r <= 127, w % 16 == 0, w <= 4096. */
+ * grid (1, nbands, n frames), block 64 / 128 / 256 threads >= ceil(w / 16) (narrow frames: more blocks per CU instead of
+ * idle waves); T rows per band; 1 <= r <= 127, 32 <= w <= 4096, any alignment.
+ * Ragged rows (m = w % 16 != 0, round 4): the strips stay on the 16-px grid, the column sums of the last strip's
+ * 16 - m columns past the row end are 0 like everything outside the image.  Its loads must not cross the row end
+ * (behind the last row lies another frame, or nothing): it loads the row's last 16 bytes and shifts them down into
+ * grid position, zeros entering; its m result bytes go out as 8 + 4 + 2 + 1-byte stores (no byte of the next row is
+ * touched). */
 template <int MODE>
 __global__ __launch_bounds__(256) void k_box16(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h,
                                                unsigned T, size_t frame_bytes, unsigned r, int c) {
   __shared__ __attribute__((aligned(16))) uint8_t rows[2][kBoxRowBytes]; /* [phase]: the block's column sums as u16 */
   const unsigned tid = threadIdx.x, x0 = tid * 16u;
   const bool act = x0 < w;
+  const unsigned m = w & 15u;                   /* block-uniform: bytes of the last strip inside the row */
+  const bool tail = act && x0 + 16u > w;        /* m != 0 and this thread owns that strip */
+  const uint32_t ld_off = !act ? kOOB : tail ? w - 16u : x0, st_off = (act && !tail) ? x0 : kOOB;
   const BufRsrc S = make_buf(src + (size_t)blockIdx.z * frame_bytes, frame_bytes);
   const BufRsrc D = make_buf(dst + (size_t)blockIdx.z * frame_bytes, frame_bytes);
   const int y0 = (int)(blockIdx.y * T);
@@ -67,7 +75,7 @@ __global__ __launch_bounds__(256) void k_box16(uint8_t *dst, const uint8_t *src,
   for (int j = 0; j < 16; j++) {
     const int x = (int)x0 + j;
     const int xa = x - (int)r < 0 ? 0 : x - (int)r, xb = x + (int)r > (int)w - 1 ? (int)w - 1 : x + (int)r;
-    cx[j] = act ? (unsigned)(xb - xa + 1) : 1u;
+    cx[j] = (act && x < (int)w) ? (unsigned)(xb - xa + 1) : 1u;
     rcx[j] = 1.0f / (float)cx[j];
   }
   /* MODE 0, rows whose window is not clipped vertically (cy = 2r + 1), r <= 31: the quotient is ONE v_mul_hi_u32 with
@@ -79,7 +87,13 @@ __global__ __launch_bounds__(256) void k_box16(uint8_t *dst, const uint8_t *src,
 #pragma unroll
   for (int j = 0; j < 16; j++) Mi[j] = MODE == 0 ? 0xffffffffu / (cx[j] * (2u * r + 1u)) + 1u : 0u; /* cnt >= 4 */
   auto row_load = [&](int yy) { /* this thread's 16 B of row yy, zeros outside the image */
-    return buf_load16(S, (act && yy >= 0 && yy < (int)h) ? (uint32_t)yy * w + x0 : kOOB);
+    const U4 v = buf_load16(S, (yy >= 0 && yy < (int)h) ? (uint32_t)yy * w + ld_off : kOOB);
+    uint32_t a = v.x, b = v.y, c = v.z, d = v.w; /* scalars: hipcc selects / merges whole structs through scratch memory */
+    if (m) { /* block-uniform */
+      const U4 sh = shift_down_bytes(v, 16u - m);
+      a = tail ? sh.x : a, b = tail ? sh.y : b, c = tail ? sh.z : c, d = tail ? sh.w : d;
+    }
+    return U4{a, b, c, d};
   };
   /* column sums += / -= one row (bytes -> u16 pairs; fields cannot carry or borrow: 0 <= Vc <= 255 * 255) */
   uint32_t Vc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -168,7 +182,8 @@ __global__ __launch_bounds__(256) void k_box16(uint8_t *dst, const uint8_t *src,
       }
       od[j >> 2] |= o << (8 * (j & 3));
     }
-    buf_store16(D, act ? (uint32_t)y * w + x0 : kOOB, U4{od[0], od[1], od[2], od[3]});
+    buf_store16(D, (uint32_t)y * w + st_off, U4{od[0], od[1], od[2], od[3]}); /* st_off = kOOB: dropped */
+    if (m) buf_store_first(D, tail ? (uint32_t)y * w + x0 : kOOB, od[0], od[1], od[2], od[3], m);
   }
 }
 

@@ -57,10 +57,14 @@ GS_DEV void blur_hsum10(const uint32_t (&U)[12], uint32_t (&H)[10]) { /* pairs =
 #ifndef GS_FUSED_VGPR_ATTR
 #define GS_FUSED_VGPR_ATTR /* experiment hook: -DGS_FUSED_VGPR_ATTR='__attribute__((amdgpu_num_vgpr(144)))' */
 #endif
-template <int R, bool HIST = true>
+/* RAGGED (w % 16 != 0, without the histogram half): the strips of k_strip.h with the tail strip anchored at w - 16.  The lane
+ * left of the tail lane may own pixels -- its own last R and the two it blurs for its right neighbour's sobel taps -- that are
+ * less than R columns from the right edge, so the right-hand divisors are chosen per lane from the distance to the edge. */
+template <int R, bool HIST = true, bool RAGGED = false>
 __global__ __launch_bounds__(256) GS_FUSED_VGPR_ATTR void k_blur_sobel_hist16(uint8_t *dst, const uint8_t *src,
                                                            unsigned w, unsigned h, unsigned T,
                                                            size_t frame_bytes, unsigned *partial) {
+  static_assert(!(HIST && RAGGED), "ragged rows take the histogram as a separate pass");
   constexpr int N = 2 * R + 1;
   __shared__ unsigned lh[HIST ? 256 * 32 : 1];
   const unsigned tid = threadIdx.y * blockDim.x + threadIdx.x, copy = tid & 31u;
@@ -68,11 +72,20 @@ __global__ __launch_bounds__(256) GS_FUSED_VGPR_ATTR void k_blur_sobel_hist16(ui
     for (unsigned i = tid; i < 256 * 32; i += 256) lh[i] = 0;
     __syncthreads();
   }
-  const Strip<> S(src, dst, w, h, frame_bytes);
+  const Strip<false, RAGGED> S(src, dst, w, h, frame_bytes);
   const int y0 = 1 + (int)(S.band * T);
   if (y0 < (int)h - 1 && !S.wave_outside()) { /* wave-uniform; no early return: every wave reaches the barrier */
     const int nrows = ((int)h - 1 - y0) < (int)T ? ((int)h - 1 - y0) : (int)T;
-    const bool first = S.x0 == 0, last = S.x0 + 16 == w, inimg = S.x0 < w;
+    const bool first = S.x0 == 0, last = S.x0 + 16 == w, inimg = S.in_image();
+    /* RAGGED: is own pixel 16 - R + q (q = 0 .. R + 1) exactly R + 1 + i columns' worth from the right edge? (lane constants) */
+    bool edge[R + 2][R];
+    if constexpr (RAGGED) {
+      static_for<R + 2>([&](auto Q) {
+        constexpr int q = decltype(Q)::value;
+        const int d = (int)w - 1 - (int)(S.x0 + 16 - R + q); /* columns between the pixel and the last one */
+        static_for<R>([&](auto I) { edge[q][decltype(I)::value] = inimg && d == decltype(I)::value; });
+      });
+    }
     /* N+1 ring slots: the new row lands in the free slot and the unroll period N+1 is even, so
      * the sobel history alternates (step<parity>) without register moves */
     constexpr bool SPARE = R <= 2; /* R = 3: the 8th slot would cost the third wave per SIMD */
@@ -84,12 +97,21 @@ __global__ __launch_bounds__(256) GS_FUSED_VGPR_ATTR void k_blur_sobel_hist16(ui
       const int ya = b - R < 0 ? 0 : b - R, yb = b + R > (int)h - 1 ? (int)h - 1 : b + R;
       const unsigned cy = (unsigned)(yb - ya + 1);
       const uint32_t mC = blur_mul_for_rows<R, N>(cy);
-      uint32_t mL[R], mR[R];
+      uint32_t mL[R], mR[R + 2];
       static_for<R>([&](auto Q) {
         constexpr int q = decltype(Q)::value;
         mL[q] = first ? blur_mul_for_rows<R, R + 1 + q>(cy) : mC;
         mR[q] = last ? blur_mul_for_rows<R, 2 * R - q>(cy) : mC;
       });
+      mR[R] = mR[R + 1] = mC;
+      if constexpr (RAGGED) {
+        static_for<R + 2>([&](auto Q) {
+          constexpr int q = decltype(Q)::value;
+          uint32_t m = mC;
+          static_for<R>([&](auto I) { m = edge[q][decltype(I)::value] ? blur_mul_for_rows<R, R + 1 + decltype(I)::value>(cy) : m; });
+          mR[q] = m;
+        });
+      }
       UB[0] = 0, UB[11] = 0;
 #pragma unroll
       for (int k = 0; k < 10; k++) { /* pair k = own pixels (2k-2, 2k-1) */
@@ -98,8 +120,9 @@ __global__ __launch_bounds__(256) GS_FUSED_VGPR_ATTR void k_blur_sobel_hist16(ui
         for (int hlf = 0; hlf < 2; hlf++) {
           const int q = 2 * k - 2 + hlf; /* own pixel index -2..17 */
           const uint32_t sv = hlf ? (V[k] >> 16) : (V[k] & 0xffffu);
+          constexpr int qr = RAGGED ? 18 : 16; /* RAGGED: pixels 16, 17 (a neighbour's) may lie at the edge as well */
           const uint32_t m = (q >= 0 && q < R) ? mL[(q >= 0 && q < R) ? q : 0]
-                             : (q >= 16 - R && q < 16) ? mR[(q >= 16 - R && q < 16) ? q - (16 - R) : 0]
+                             : (q >= 16 - R && q < qr) ? mR[(q >= 16 - R && q < qr) ? q - (16 - R) : 0]
                                                        : mC;
           pr[hlf] = sv * m; /* quotient = byte 3 */
         }

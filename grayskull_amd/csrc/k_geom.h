@@ -134,7 +134,6 @@ __global__ __launch_bounds__(256) void k_match_template(const uint8_t *img, unsi
  * and the frame is 4-byte aligned), coalesced across lanes.  The four shifted windows come from
  * v_alignbyte_b32; per step: 1 load, 3 alignbyte, 8 dot4 for 16 tap-results (the one-result kernel
  * needs 4 overlapping unaligned loads for the same work).  grid (ceil(rw/4/64), ceil(rh/4)). */
-GS_DEV uint32_t alignbyte(uint32_t hi, uint32_t lo, unsigned bytes) { return alignbit(hi, lo, 8u * bytes); }
 
 __global__ __launch_bounds__(256) void k_match_template4(const uint8_t *img, unsigned iw, unsigned ih,
                                                          const uint8_t *tmpl, unsigned tw, unsigned th,

@@ -95,29 +95,33 @@ __global__ __launch_bounds__(256) void k_integral_cols(unsigned *ii, unsigned w,
  * row's inclusive prefix: in-lane scan, wave scan, one LDS hand-off between the 4 waves
  * (double-buffered: one barrier per row), then writes 4 B/px once. */
 
-/* grid (ceil(w/4096) = 1, nbands, n frames), block 256 */
+/* grid (ceil(w/4096), nbands, n frames), block 256.  Any w >= 16 and any alignment: the strip that would cross the row
+ * end is anchored at w - 16 instead (it overlaps its neighbour; both store the same sums), so every load lies inside
+ * the row. */
 __global__ __launch_bounds__(256) void k_integral_colsum(const uint8_t *src, unsigned w, unsigned h,
                                                          unsigned BH, unsigned nbands,
                                                          unsigned *colsum) {
-  const unsigned x0 = threadIdx.x * 16u;
+  const unsigned xg = (blockIdx.x * 256u + threadIdx.x) * 16u;
+  const bool act = xg < w;
+  const unsigned x0 = xg + 16u > w ? w - 16u : xg;
   const size_t fb = (size_t)w * h;
   const BufRsrc S = make_buf(src + (size_t)blockIdx.z * fb, fb);
   const unsigned y0 = blockIdx.y * BH, y1 = y0 + BH < h ? y0 + BH : h;
   unsigned V[16];
 #pragma unroll
   for (int k = 0; k < 16; k++) V[k] = 0;
-  U4 nxt = buf_load16(S, x0 < w ? y0 * w + x0 : kOOB);
+  U4 nxt = buf_load16(S, act ? y0 * w + x0 : kOOB);
   for (unsigned y = y0; y < y1; y++) {
     const U4 cur = nxt;
-    nxt = buf_load16(S, (x0 < w && y + 1 < y1) ? (y + 1) * w + x0 : kOOB);
+    nxt = buf_load16(S, (act && y + 1 < y1) ? (y + 1) * w + x0 : kOOB);
     const uint32_t d[4] = {cur.x, cur.y, cur.z, cur.w};
 #pragma unroll
     for (int k = 0; k < 16; k++) V[k] += (d[k >> 2] >> (8 * (k & 3))) & 0xffu;
   }
-  if (x0 < w) {
+  if (act) {
     unsigned *o = colsum + ((size_t)blockIdx.z * nbands + blockIdx.y) * w + x0;
 #pragma unroll
-    for (int q = 0; q < 4; q++) *(U4 *)(o + 4 * q) = U4{V[4 * q], V[4 * q + 1], V[4 * q + 2], V[4 * q + 3]};
+    for (int q = 0; q < 4; q++) store_u32x4_any(o + 4 * q, U4{V[4 * q], V[4 * q + 1], V[4 * q + 2], V[4 * q + 3]});
   }
 }
 
@@ -218,47 +222,81 @@ __global__ __launch_bounds__(256) void k_integral_band(const uint8_t *src, unsig
  * column sums V[TILES][4] live in registers; per row: in-lane prefix of 4, one DPP wave scan per
  * tile, and the tile totals chain through a scalar carry (v_readlane).  No LDS, no barrier, the
  * next row's TILES dwords are in flight during the arithmetic.
- * grid (1, ceil(nbands/4), n frames), block 256 = 4 waves = 4 bands.  w <= TILES*256, w % 4 == 0. */
-template <int TILES>
+ * grid (1, ceil(nbands/4), n frames), block 256 = 4 waves = 4 bands.
+ * RAGGED (w % 4 != 0): the one lane whose 4 px would cross the row end is anchored at w - 4; it overlaps its left
+ * neighbour by ov = 1..3 px, so it enters the scan with the sum of its LAST 4 - ov px only -- the prefix at its
+ * pixels is still (inclusive scan - own four) + in-lane prefix -- and both lanes store the same values where they
+ * overlap: whole dwordx4 stores, nothing past the row end, no read-modify-write of the next row's head.
+ * WIDE (w > TILES * 256): the wave walks the row's column chunks of TILES * 256 px one after the other, rows top to
+ * bottom inside each; what a row hands from chunk to chunk -- its prefix at the chunk's left edge -- waits in a
+ * register of lane (row - y0): v_readlane / one masked move per row, no LDS (BH <= kIntegralWideRows = 64). */
+constexpr unsigned kIntegralWideRows = 64;
+template <int TILES, bool RAGGED = false, bool WIDE = false>
 __global__ __launch_bounds__(256) void k_integral_wave(const uint8_t *src, unsigned w, unsigned h,
                                                        unsigned BH, unsigned nbands,
                                                        const unsigned *colbase, unsigned *ii) {
   const unsigned lane = threadIdx.x & 63u;
   const unsigned band = uniform(blockIdx.y * 4u + (threadIdx.x >> 6));
+  unsigned rowcarry = 0; /* WIDE: lane i keeps row y0 + i's prefix at the left edge of the next chunk */
   if (band >= nbands) return; /* whole wave */
   const size_t fb = (size_t)w * h;
   const BufRsrc S = make_buf(src + (size_t)blockIdx.z * fb, fb);
   const BufRsrc D = make_buf(ii + (size_t)blockIdx.z * fb, fb * 4);
   const BufRsrc C = make_buf(colbase + ((size_t)blockIdx.z * nbands + band) * w, (size_t)w * 4);
   const unsigned y0 = band * BH, y1 = y0 + BH < h ? y0 + BH : h;
-  unsigned V[TILES][4];
-  uint32_t xo[TILES], nxt[TILES]; /* per-tile byte offset of the lane's 4 px inside a row, or OOB */
-#pragma unroll
-  for (int t = 0; t < TILES; t++) {
-    const unsigned x = (unsigned)t * 256u + lane * 4u;
-    xo[t] = x < w ? x : kOOB;
-    const U4 b = buf_load16(C, x < w ? x * 4u : kOOB); /* zero beyond w */
-    V[t][0] = b.x, V[t][1] = b.y, V[t][2] = b.z, V[t][3] = b.w;
-    nxt[t] = buf_load4(S, x < w ? y0 * w + x : kOOB);
-  }
-  for (unsigned y = y0; y < y1; y++) { /* wave-uniform trip count */
-    uint32_t cur[TILES];
-    const bool more = y + 1 < y1;
+  const unsigned nchunk = WIDE ? (w + TILES * 256u - 1u) / (TILES * 256u) : 1u;
+  for (unsigned ch = 0; ch < nchunk; ch++) { /* wave-uniform */
+    const unsigned cx = ch * (unsigned)TILES * 256u;
+    unsigned V[TILES][4];
+    uint32_t xo[TILES], nxt[TILES]; /* per-tile byte offset of the lane's 4 px inside a row, or OOB */
+    /* RAGGED: tile and lane-constant masks of the anchored lane (ov px shared with its left neighbour) */
+    unsigned k0 = 0, k1 = 0, k2 = 0;
+    int tail_tile = -1;
 #pragma unroll
     for (int t = 0; t < TILES; t++) {
-      cur[t] = nxt[t];
-      nxt[t] = buf_load4(S, (more && xo[t] != kOOB) ? (y + 1) * w + xo[t] : kOOB);
+      unsigned x = cx + (unsigned)t * 256u + lane * 4u;
+      const bool in = x < w;
+      if constexpr (RAGGED) {
+        if (cx + (unsigned)t * 256u < w && w < cx + (unsigned)(t + 1) * 256u) tail_tile = t; /* wave-uniform */
+        if (in && x + 4u > w) {
+          const unsigned ov = x + 4u - w;
+          x = w - 4u, k0 = 0xffffffffu, k1 = ov >= 2u ? 0xffffffffu : 0u, k2 = ov >= 3u ? 0xffffffffu : 0u;
+        }
+      }
+      xo[t] = in ? x : kOOB;
+      const U4 b = buf_load16(C, in ? x * 4u : kOOB); /* zero beyond w */
+      V[t][0] = b.x, V[t][1] = b.y, V[t][2] = b.z, V[t][3] = b.w;
+      nxt[t] = buf_load4(S, in ? y0 * w + x : kOOB);
     }
-    unsigned carry = 0; /* sum of the tiles to the left, wave-uniform */
+    for (unsigned y = y0; y < y1; y++) { /* wave-uniform trip count */
+      uint32_t cur[TILES];
+      const bool more = y + 1 < y1;
 #pragma unroll
-    for (int t = 0; t < TILES; t++) {
-      const uint32_t d = cur[t];
-      V[t][0] += d & 0xffu, V[t][1] += (d >> 8) & 0xffu, V[t][2] += (d >> 16) & 0xffu, V[t][3] += d >> 24;
-      const unsigned p0 = V[t][0], p1 = p0 + V[t][1], p2 = p1 + V[t][2], p3 = p2 + V[t][3];
-      const unsigned inc = wave_incl_scan(p3);
-      const unsigned off = carry + inc - p3;
-      buf_store16_wb(D, xo[t] != kOOB ? (y * w + xo[t]) * 4u : kOOB, U4{off + p0, off + p1, off + p2, off + p3});
-      carry += readlane_last(inc);
+      for (int t = 0; t < TILES; t++) {
+        cur[t] = nxt[t];
+        nxt[t] = buf_load4(S, (more && xo[t] != kOOB) ? (y + 1) * w + xo[t] : kOOB);
+      }
+      unsigned carry = 0; /* sum of the tiles to the left, wave-uniform */
+      if constexpr (WIDE) {
+        carry = readlane_at(rowcarry, y - y0); /* 0 in the first chunk */
+      }
+#pragma unroll
+      for (int t = 0; t < TILES; t++) {
+        const uint32_t d = cur[t];
+        V[t][0] += d & 0xffu, V[t][1] += (d >> 8) & 0xffu, V[t][2] += (d >> 16) & 0xffu, V[t][3] += d >> 24;
+        const unsigned p0 = V[t][0], p1 = p0 + V[t][1], p2 = p1 + V[t][2], p3 = p2 + V[t][3];
+        unsigned mine = p3; /* what this lane adds to the row's running sum */
+        if constexpr (RAGGED) {
+          if (t == tail_tile) mine = p3 - ((V[t][0] & k0) + (V[t][1] & k1) + (V[t][2] & k2));
+        }
+        const unsigned inc = wave_incl_scan(mine);
+        const unsigned off = carry + inc - p3;
+        buf_store16_wb(D, xo[t] != kOOB ? (y * w + xo[t]) * 4u : kOOB, U4{off + p0, off + p1, off + p2, off + p3});
+        carry += readlane_last(inc);
+      }
+      if constexpr (WIDE) {
+        rowcarry = lane == y - y0 ? carry : rowcarry;
+      }
     }
   }
 }

@@ -361,15 +361,17 @@ __global__ __launch_bounds__(256) void k_downsample_px(uint8_t *dst, const uint8
 }
 
 /* same, 8 output px per thread: two 16-byte loads (rows 2y and 2y+1), one 8-byte store.  The 2x2
- * sums are formed two at a time on u16 pairs.  Needs sw % 16 == 0 and 16-byte aligned frames.
- * grid (ceil(dw/8/64), ceil(dh/4), n), block (64,4) */
+ * sums are formed two at a time on u16 pairs.  Any sw >= 16 at any alignment (round 4): the group that would cross the
+ * end of the output row is anchored at dw - 8 (it overlaps its neighbour, same bytes), so loads and stores stay whole
+ * and inside their rows.  grid (ceil(ceil(dw/8)/64), ceil(dh/4), n), block (64,4) */
 __global__ __launch_bounds__(256) void k_downsample8(uint8_t *dst, const uint8_t *src, unsigned sw,
                                                      unsigned sh) {
   const unsigned dw = sw / 2, dh = sh / 2;
   const unsigned gx = blockIdx.x * 64u + threadIdx.x, y = blockIdx.y * 4u + threadIdx.y;
   if (gx * 8u >= dw || y >= dh) return;
-  const uint8_t *f = src + (size_t)blockIdx.z * ((size_t)sw * sh) + (size_t)(2 * y) * sw + 16u * gx;
-  const U4 a = *(const U4 *)f, b = *(const U4 *)(f + sw);
+  const unsigned ox = gx * 8u + 8u > dw ? dw - 8u : gx * 8u;
+  const uint8_t *f = src + (size_t)blockIdx.z * ((size_t)sw * sh) + (size_t)(2 * y) * sw + 2u * ox;
+  const U4 a = load_u32x4_any(f), b = load_u32x4_any(f + sw);
   const uint32_t ra[4] = {a.x, a.y, a.z, a.w}, rb[4] = {b.x, b.y, b.z, b.w};
   uint32_t o[2];
 #pragma unroll
@@ -385,8 +387,7 @@ __global__ __launch_bounds__(256) void k_downsample8(uint8_t *dst, const uint8_t
     }
     o[q] = out;
   }
-  uint32_t *d = (uint32_t *)(dst + (size_t)blockIdx.z * ((size_t)dw * dh) + (size_t)y * dw + 8u * gx);
-  d[0] = o[0], d[1] = o[1];
+  store_u32x2_any(dst + (size_t)blockIdx.z * ((size_t)dw * dh) + (size_t)y * dw + ox, o[0], o[1]);
 }
 
 }  // namespace gs

@@ -99,11 +99,25 @@ GS_DEV uint32_t buf_load4(const BufRsrc &b, uint32_t off) {
   return v;
 }
 GS_DEV void store_u32x4(void *p, const U4 &v) { memcpy(p, &v, 16); }
+GS_DEV void store_u32x4_any(void *p, const U4 &v) { memcpy(p, &v, 16); }
+GS_DEV U4 load_u32x4_any(const void *p) { U4 v; memcpy(&v, p, 16); return v; }
+GS_DEV void store_u32x2_any(void *p, uint32_t lo, uint32_t hi) { memcpy(p, &lo, 4), memcpy((char *)p + 4, &hi, 4); }
 GS_DEV void buf_store16(const BufRsrc &b, uint32_t off, const U4 &v) {
   emu_buf_check(b, off, 16);
   if (off < b.n) memcpy(b.base + off, &v, 16);
 }
 GS_DEV void buf_store16_wb(const BufRsrc &b, uint32_t off, const U4 &v) { buf_store16(b, off, v); }
+GS_DEV void buf_store_n(const BufRsrc &b, uint32_t off, uint64_t v, uint32_t n) { /* the low n bytes of v */
+  emu_buf_check(b, off, n);
+  if (off < b.n) memcpy(b.base + off, &v, n);
+}
+GS_DEV void buf_store8(const BufRsrc &b, uint32_t off, uint32_t lo, uint32_t hi) { buf_store_n(b, off, lo | ((uint64_t)hi << 32), 8); }
+GS_DEV void buf_store4(const BufRsrc &b, uint32_t off, uint32_t v) { buf_store_n(b, off, v, 4); }
+GS_DEV void buf_store2(const BufRsrc &b, uint32_t off, uint32_t v) { buf_store_n(b, off, v, 2); }
+GS_DEV void buf_store1(const BufRsrc &b, uint32_t off, uint32_t v) { buf_store_n(b, off, v, 1); }
+GS_DEV uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) { /* v_alignbyte_b32 */
+  return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * (sh & 3)));
+}
 /* dword gather: per-lane byte offset + wave-uniform byte offset (SGPR soffset on the GPU) */
 GS_DEV uint32_t buf_gather4(const BufRsrc &b, uint32_t voff, uint32_t soff) { return buf_load4(b, voff + soff); }
 GS_DEV uint32_t uniform(uint32_t x) { return x; } /* v_readfirstlane_b32 on the GPU */
@@ -233,6 +247,17 @@ GS_DEV uint32_t buf_gather4(const BufRsrc &b, uint32_t voff, uint32_t soff) {
 GS_DEV uint32_t uniform(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 /* one global_store_dwordx4 at a 16-byte aligned address */
 GS_DEV void store_u32x4(void *p, const U4 &v) { *(gs_u32x4 *)p = gs_u32x4{v.x, v.y, v.z, v.w}; }
+/* the same at any address (global memory takes a dwordx4 / dwordx2 at any byte address) */
+typedef gs_u32x4 gs_u32x4_a1 __attribute__((aligned(1)));
+GS_DEV void store_u32x4_any(void *p, const U4 &v) { *(gs_u32x4_a1 *)p = gs_u32x4{v.x, v.y, v.z, v.w}; }
+GS_DEV U4 load_u32x4_any(const void *p) {
+  const gs_u32x4 v = *(const gs_u32x4_a1 *)p;
+  return U4{v.x, v.y, v.z, v.w};
+}
+GS_DEV void store_u32x2_any(void *p, uint32_t lo, uint32_t hi) {
+  typedef unsigned int u32x2_a1 __attribute__((ext_vector_type(2), aligned(1)));
+  *(u32x2_a1 *)p = u32x2_a1{lo, hi};
+}
 GS_DEV void buf_store16(const BufRsrc &b, uint32_t off, const U4 &v) { /* buffer_store_dwordx4 offen */
   __builtin_amdgcn_raw_buffer_store_b128(gs_u32x4{v.x, v.y, v.z, v.w}, b.r, (int)off, 0, GS_STORE_AUX);
 }
@@ -242,6 +267,15 @@ GS_DEV void buf_store16(const BufRsrc &b, uint32_t off, const U4 &v) { /* buffer
 GS_DEV void buf_store16_wb(const BufRsrc &b, uint32_t off, const U4 &v) {
   __builtin_amdgcn_raw_buffer_store_b128(gs_u32x4{v.x, v.y, v.z, v.w}, b.r, (int)off, 0, 0);
 }
+/* narrower stores (default policy: they complete lines other lanes fill) for the ragged end of a row */
+typedef unsigned int gs_u32x2 __attribute__((ext_vector_type(2)));
+GS_DEV void buf_store8(const BufRsrc &b, uint32_t off, uint32_t lo, uint32_t hi) { /* buffer_store_dwordx2 offen */
+  __builtin_amdgcn_raw_buffer_store_b64(gs_u32x2{lo, hi}, b.r, (int)off, 0, 0);
+}
+GS_DEV void buf_store4(const BufRsrc &b, uint32_t off, uint32_t v) { __builtin_amdgcn_raw_buffer_store_b32(v, b.r, (int)off, 0, 0); }
+GS_DEV void buf_store2(const BufRsrc &b, uint32_t off, uint32_t v) { __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v, b.r, (int)off, 0, 0); }
+GS_DEV void buf_store1(const BufRsrc &b, uint32_t off, uint32_t v) { __builtin_amdgcn_raw_buffer_store_b8((unsigned char)v, b.r, (int)off, 0, 0); }
+GS_DEV uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); } /* v_alignbyte_b32 */
 typedef unsigned short gs_u16x2 __attribute__((ext_vector_type(2)));
 typedef short gs_i16x2 __attribute__((ext_vector_type(2)));
 #define GS_U2(x) __builtin_bit_cast(gs_u16x2, (uint32_t)(x))
@@ -450,6 +484,30 @@ GS_DEV uint32_t wave_sum(uint32_t v) {
   return v;
 }
 GS_DEV int wave_sum_i(int v) { return (int)wave_sum((uint32_t)v); }
+
+/* 16 bytes shifted down by nb = 1..15 bytes, zeros entering at the top (nb wave-uniform: the dword part of the shift
+ * is a scalar choice, the byte part one v_alignbyte_b32 per dword) */
+GS_DEV U4 shift_down_bytes(U4 v, unsigned nb) {
+  /* as two 64-bit halves (chains of selects on nb / 4 end up as a table in scratch memory with hipcc) */
+  const uint64_t lo = v.x | ((uint64_t)v.y << 32), hi = v.z | ((uint64_t)v.w << 32);
+  const unsigned sh = 8u * nb; /* 8 .. 120 */
+  uint64_t olo, ohi;
+  if (sh < 64u) olo = (lo >> sh) | (hi << (64u - sh)), ohi = hi >> sh;
+  else olo = hi >> (sh - 64u), ohi = 0;
+  return U4{(uint32_t)olo, (uint32_t)(olo >> 32), (uint32_t)ohi, (uint32_t)(ohi >> 32)};
+}
+/* the first m = 1..15 bytes of o to buffer offset off (m wave-uniform): 8 + 4 + 2 + 1 byte stores as m's bits say.
+ * Lanes that must not store pass off = kOOB. */
+GS_DEV void buf_store_first(const BufRsrc &b, uint32_t off, uint32_t ox, uint32_t oy, uint32_t oz, uint32_t ow, unsigned m) {
+  /* scalars by value: with a struct behind a reference hipcc turns "the low or the high half" into an indexed load from a
+   * scratch copy */
+  const bool on = off != kOOB;
+  uint64_t rest = ox | ((uint64_t)oy << 32);
+  if (m & 8u) buf_store8(b, off, ox, oy), rest = oz | ((uint64_t)ow << 32);
+  if (m & 4u) buf_store4(b, on ? off + (m & 8u) : kOOB, (uint32_t)rest), rest >>= 32;
+  if (m & 2u) buf_store2(b, on ? off + (m & 12u) : kOOB, (uint32_t)rest), rest >>= 16;
+  if (m & 1u) buf_store1(b, on ? off + (m & 14u) : kOOB, (uint32_t)rest);
+}
 
 /* bytes {b0,b1,b2,b3} of a dword -> two dwords of u16 pairs: lo=(b0,b1) hi=(b2,b3) */
 GS_DEV uint32_t unpack_lo(uint32_t d) { return perm_b32(0, d, 0x0c010c00u); }

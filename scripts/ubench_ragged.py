@@ -83,3 +83,22 @@ for (w, h, off) in shapes:
             g.tune(21, 1); old = "%.4f" % timeit(lambda: fn(d, s), 3); g.tune(21, 0)
         gbs = 2.0 * n * w * h / ms / 1e6
         print("%-7s %5d %5d %3d %3d %9.4f %8.1f %6.3f   %s" % (name, w, h, off, n, ms, gbs, gbs / 8000, old), flush=True)
+
+# ---- round 4, second part: gs_integral (banded form), the sliding box, gs_downsample on the same shapes
+print("%-14s %5s %5s %3s %3s %9s %8s %6s   %s" % ("op", "w", "h", "off", "F", "ms", "GB/s(alg)", "frac", "old-rule ms"))
+for (w, h, off, n) in [(3840, 2160, 0, 64), (3838, 2160, 0, 64), (612, 816, 0, 64), (612, 816, 0, 256), (1080, 1920, 0, 64), (1920, 1080, 0, 64), (7680, 4320, 0, 8)]:
+    sb, s = guarded(n, h, w, off, None); s.copy_(torch.randint(0, 256, (n, h, w), dtype=torch.uint8, device="cuda"))
+    db, d = guarded(n, h, w, off, None)
+    ii = torch.empty((n, h, w), dtype=torch.int32, device="cuda")
+    half = torch.empty((n, h // 2, w // 2), dtype=torch.uint8, device="cuda")
+    more = {"integral": (lambda: g.integral_batch(s, ii), 5.0), "blur r=5": (lambda: g.blur_batch(d, s, 5), 2.0), "blur r=16": (lambda: g.blur_batch(d, s, 16), 2.0),
+            "adaptive r=15": (lambda: g.adaptive_threshold_batch(d, s, 15, 5), 2.0), "downsample": (lambda: g.downsample_batch(half, s), 1.25)}
+    for name, (fn, bpp) in more.items():
+        if w > 4096 and name != "integral" and name != "downsample": continue
+        ms = timeit(fn)
+        old = ""
+        if (w % 16 or off or w > 4096):
+            g.tune(21, 1); old = "%.4f" % timeit(fn, 3); g.tune(21, 0)
+        gbs = bpp * n * w * h / ms / 1e6
+        print("%-14s %5d %5d %3d %3d %9.4f %8.1f %6.3f   %s" % (name, w, h, off, n, ms, gbs, gbs / 8000, old), flush=True)
+    del ii, half, sb, db

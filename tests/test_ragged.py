@@ -74,6 +74,71 @@ def check_width(g, o, bufs, w, h, off, rs, n=2, which=None):
         assert bufs.guards_ok(db, off, n * h * w), "%s %dx%d at base+%d wrote outside the frames" % (name, w, h, off)
 
 
+def check_more(g, o, bufs, w, h, off, rs, n=2, radii=(4, 16, 17)):
+    """the other strip-class ops on the same kind of frames: gs_blur r > 3 / gs_adaptive_threshold (sliding box),
+    gs_integral (banded form), gs_downsample"""
+    img = rs.randint(0, 256, (n, h, w)).astype(np.uint8)
+    d0 = rs.randint(0, 256, (n, h, w)).astype(np.uint8)
+    _, s = bufs.make(n, h, w, off, img)
+    sync = bufs.torch.cuda.synchronize if bufs.kind == "gpu" else (lambda: None)
+    for r in radii:
+        db, d = bufs.make(n, h, w, off, d0)
+        g.blur_batch(d, s, r), sync()
+        assert_same(bufs.host(d), np.stack([o.blur(img[i], r) for i in range(n)]), "blur r=%d %dx%d at base+%d" % (r, w, h, off))
+        assert bufs.guards_ok(db, off, n * h * w), "blur r=%d %dx%d wrote outside the frames" % (r, w, h)
+        db, d = bufs.make(n, h, w, off, d0)
+        g.adaptive_threshold_batch(d, s, r, 3), sync()
+        assert_same(bufs.host(d), np.stack([o.adaptive_threshold(img[i], r, 3) for i in range(n)]),
+                    "adaptive r=%d %dx%d at base+%d" % (r, w, h, off))
+        assert bufs.guards_ok(db, off, n * h * w), "adaptive r=%d %dx%d wrote outside the frames" % (r, w, h)
+    # integral: u32 table behind the same kind of guards (4-byte aligned by the C type)
+    ib, iv = bufs.make(n, h, 4 * w, 4 * (off // 4) if off >= 4 else 0, np.zeros((n, h, 4 * w), np.uint8))
+    ioff = 4 * (off // 4) if off >= 4 else 0
+    if bufs.kind == "gpu":
+        g.integral_batch(s, iv.view(bufs.torch.int32)), sync()
+        got = bufs.host(iv).view(np.uint32)
+    else:
+        g.integral_batch(s, iv.view(np.uint32))
+        got = np.array(iv).view(np.uint32)
+    assert_same(got, np.stack([o.integral(img[i]) for i in range(n)]), "integral %dx%d at base+%d" % (w, h, off))
+    assert bufs.guards_ok(ib, ioff, n * h * w * 4), "integral %dx%d wrote outside the table" % (w, h)
+    if h >= 2:
+        hw, hh = w // 2, h // 2
+        hb, hv = bufs.make(n, hh, hw, off, np.full((n, hh, hw), 0xCD, np.uint8))
+        g.downsample_batch(hv, s), sync()
+        assert_same(bufs.host(hv), np.stack([o.downsample(img[i]) for i in range(n)]), "downsample %dx%d at base+%d" % (w, h, off))
+        assert bufs.guards_ok(hb, off, n * hh * hw), "downsample %dx%d wrote outside the frames" % (w, h)
+
+
+def check_fused(g, o, bufs, w, h, off, rs, n=2, radii=(1, 2, 3)):
+    """gs_blur -> gs_sobel into a zeroed image in one pass, and the whole config-2 chain behind gsh_edge_pipeline_batch"""
+    img = rs.randint(0, 256, (n, h, w)).astype(np.uint8)
+    d0 = rs.randint(0, 256, (n, h, w)).astype(np.uint8)
+    _, s = bufs.make(n, h, w, off, img)
+    sync = bufs.torch.cuda.synchronize if bufs.kind == "gpu" else (lambda: None)
+    for r in radii:
+        if h <= 2 * r:
+            continue
+        exp = np.stack([o.sobel(o.blur(img[i], r), np.zeros((h, w), np.uint8)) for i in range(n)])
+        db, d = bufs.make(n, h, w, off, d0)
+        g.blur_sobel_batch(d, s, r), sync()
+        assert_same(bufs.host(d), exp, "blur+sobel r=%d %dx%d at base+%d" % (r, w, h, off))
+        assert bufs.guards_ok(db, off, n * h * w), "blur+sobel r=%d %dx%d wrote outside the frames" % (r, w, h)
+        db, d = bufs.make(n, h, w, off, d0)
+        if bufs.kind == "gpu":
+            hist = bufs.torch.zeros((n, 256), dtype=bufs.torch.int32, device="cuda")
+            thr = bufs.torch.zeros(n, dtype=bufs.torch.uint8, device="cuda")
+        else:
+            hist, thr = np.zeros((n, 256), np.uint32), np.zeros(n, np.uint8)
+        g.edge_pipeline_batch(d, None, s, r, hist, thr), sync()
+        got, t = bufs.host(d), bufs.host(thr)
+        for i in range(n):
+            te = o.otsu_threshold(exp[i])
+            assert int(t[i]) == te, "otsu %d vs %d (%dx%d r=%d at base+%d)" % (t[i], te, w, h, r, off)
+            assert_same(got[i], o.threshold(exp[i], te), "pipeline r=%d %dx%d at base+%d" % (r, w, h, off))
+        assert bufs.guards_ok(db, off, n * h * w), "pipeline r=%d %dx%d wrote outside the frames" % (r, w, h)
+
+
 def _oracle(request):
     from oracle import pyoracle
     return request.getfixturevalue("reference" if pyoracle.have_reference() else "oracle")
@@ -105,6 +170,32 @@ def test_emu_ragged_tall_and_batched(emu, request):
         emu.tune(0, 0)
 
 
+def test_emu_box_integral_downsample_any_width(emu, request):
+    o, bufs, rs = _oracle(request), Bufs("emu"), np.random.RandomState(15)
+    for w in list(range(32, 66)) + [100, 255, 257, 612, 1021, 1023, 1025, 1039, 2047, 2049, 4094]:
+        check_more(emu, o, bufs, w, 11, 0, rs, n=1)
+    for w, off in ((37, 1), (64, 3), (612, 5), (1029, 8), (1366, 15)):
+        check_more(emu, o, bufs, w, 23, off, rs, n=2)
+
+
+def test_emu_integral_wider_than_4096(emu, request):
+    """column chunks of 4096 px: a row's prefix at the chunk edge waits in a lane register (k_integral_wave WIDE)"""
+    o, rs = _oracle(request), np.random.RandomState(16)
+    for w, h in ((4097, 9), (5000, 70), (8192, 33), (8193, 5), (9001, 130)):
+        img = rs.randint(0, 256, (2, h, w)).astype(np.uint8)
+        ii = np.full((2, h, w), 0xABABABAB, np.uint32)
+        emu.integral_batch(img, ii)
+        assert_same(ii, np.stack([o.integral(img[i]) for i in range(2)]), "integral %dx%d" % (w, h))
+
+
+def test_emu_fused_blur_sobel_any_width(emu, request):
+    o, bufs, rs = _oracle(request), Bufs("emu"), np.random.RandomState(17)
+    for w in list(range(32, 70)) + [100, 255, 257, 612, 1009, 1023, 1025, 1039, 1041, 1055, 2047, 2065]:
+        check_fused(emu, o, bufs, w, 9, 0, rs, n=1)
+    for w, off in ((37, 1), (64, 3), (612, 5), (1029, 8), (1366, 15)):
+        check_fused(emu, o, bufs, w, 40, off, rs, n=2)
+
+
 def test_emu_fast_any_width(emu, request):
     """gs_fast pass 2 on the strip machinery for any width (the strips stay on the grid, flags are masked)"""
     o, rs = _oracle(request), np.random.RandomState(14)
@@ -132,6 +223,36 @@ def test_gpu_frames_at_odd_addresses(hip, request, off):
     o, bufs, rs = _oracle(request), Bufs("gpu"), np.random.RandomState(22 + off)
     for w in (32, 48, 61, 64, 100, 612, 1024, 1037, 1041, 1080, 2064, 2071, 3838, 3840):
         check_width(hip, o, bufs, w, 23, off, rs, n=3)
+
+
+@pytest.mark.gpu
+def test_gpu_box_integral_downsample_any_width(hip, request):
+    o, bufs, rs = _oracle(request), Bufs("gpu"), np.random.RandomState(24)
+    for w in list(range(32, 66)) + [100, 255, 257, 612, 1021, 1023, 1025, 1039, 2047, 2049, 4094]:
+        check_more(hip, o, bufs, w, 11, 0, rs, n=1)
+    for w, h, off in ((37, 23, 1), (64, 23, 3), (612, 816, 5), (1029, 40, 8), (1366, 768, 15), (1080, 1920, 0), (3838, 300, 2)):
+        check_more(hip, o, bufs, w, h, off, rs, n=2)
+
+
+@pytest.mark.gpu
+def test_gpu_fused_blur_sobel_any_width(hip, request):
+    o, bufs, rs = _oracle(request), Bufs("gpu"), np.random.RandomState(26)
+    for w in list(range(32, 70)) + [100, 255, 257, 612, 1009, 1023, 1025, 1039, 1041, 1055, 2047, 2065]:
+        check_fused(hip, o, bufs, w, 9, 0, rs, n=1)
+    for w, h, off in ((37, 40, 1), (64, 40, 3), (612, 816, 5), (1080, 1920, 0), (1366, 768, 15), (3838, 2160, 0), (3840, 2160, 1)):
+        check_fused(hip, o, bufs, w, h, off, rs, n=2, radii=(2,) if w * h > 10**6 else (1, 2, 3))
+
+
+@pytest.mark.gpu
+def test_gpu_integral_wider_than_4096(hip, request):
+    import torch
+    o, rs = _oracle(request), np.random.RandomState(25)
+    for w, h in ((4097, 9), (5000, 70), (8192, 33), (7680, 4320), (9001, 130)):
+        n = 1 if w * h > 10**7 else 2
+        img = rs.randint(0, 256, (n, h, w)).astype(np.uint8)
+        ii = torch.full((n, h, w), -1, dtype=torch.int32, device="cuda")
+        hip.integral_batch(torch.from_numpy(img).cuda(), ii)
+        assert_same(ii.cpu().numpy().view(np.uint32), np.stack([o.integral(img[i]) for i in range(n)]), "integral %dx%d" % (w, h))
 
 
 @pytest.mark.gpu
