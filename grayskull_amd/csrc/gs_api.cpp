@@ -75,7 +75,7 @@ enum Slot { SL_IN = 0, SL_OUT, SL_AUX, SL_AUX2, SL_II, SL_PAD, SL_MASK, SL_CNT, 
 
 /* gsh_edge_pipeline_batch: frames per chunk (measured best for 64..512-frame batches of 4K frames:
  * profiles/r01g_chunk_overlap.log) and the most chunks per call */
-constexpr unsigned kChunkFrames = 32, kMaxChunks = 64;
+constexpr unsigned kChunkFrames = 32, kMaxChunks = 256; /* 8192 frames per call keep the chunk overlap */
 /* per-(thread, cascade) scan geometry of the last gs_lbp_detect call: the scale list and the
  * per-(scale, classifier) corner offsets on the device.  Lives in the calling thread's context, not
  * in the cascade handle, so threads sharing one handle never touch each other's tables. */
@@ -118,9 +118,18 @@ inline unsigned sync_event_flags() { return GS_EVENT_FLAGS; } /* timing-only eve
 #endif
 inline unsigned order_event_flags() { return hipEventDisableTiming | GS_ORDER_EVENT_FLAGS; }
 #endif
+/* What the launch heuristics need to know about the device, read once per context from the runtime instead of MI355X
+ * literals (round 4): a CPX-partitioned or smaller part reports fewer CUs / one XCD, and then the band counts scale
+ * with it and the XCD-aware block mappings (which assume the dispatcher's round robin over EIGHT dies) stay off. */
+struct Topo {
+  unsigned cus = 256, xcds = 8;
+  unsigned simds() const { return cus * 4u; } /* CDNA: four SIMDs per CU */
+  bool eight_xcds() const { return xcds == 8u; }
+};
 struct Ctx {
   int device = 0;
   bool device_set = false;
+  Topo topo;
   hipStream_t stream = nullptr;
   bool own_stream = false, user_stream = false, async = false;
   struct Buf { void *p = nullptr; size_t cap = 0; } slot[SL_COUNT];
@@ -188,6 +197,12 @@ struct Ctx {
 #endif
     GS_HIP(hipSetDevice(device));
     device_set = true;
+#ifndef GS_EMU
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) topo.cus = (unsigned)v;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeNumberOfXccs, device) == hipSuccess && v > 0) topo.xcds = (unsigned)v;
+    else (void)hipGetLastError();
+#endif
   }
   hipStream_t s() {
     ensure_device();
@@ -275,8 +290,23 @@ void finish(bool any_host_output) {
 dim3 grid2d(unsigned w, unsigned h, unsigned n) { return dim3((w + 63) / 64, (h + 3) / 4, n); }
 inline bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
-/* ---- launch tuning (gsh_tune): 0 rows per band (0 = auto), 1 block shape, 2 prefetch depth */
-int g_tune[32] = {0, 3, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+/* ---- launch tuning (gsh_tune): 0 rows per band (0 = auto), 1 block shape, ...  Experiment / test hooks with PROCESS-WIDE
+ * scope by design (a measurement script flips a key and every thread's next launch sees it); each entry is an atomic,
+ * so concurrent host threads (gsbatch --gpus N workers) read whole values.  Nothing in a product path writes them. */
+struct TuneTable {
+  std::atomic<int> v[32];
+  TuneTable() {
+    for (auto &e : v) e.store(0, std::memory_order_relaxed);
+    v[1].store(3, std::memory_order_relaxed), v[2].store(1, std::memory_order_relaxed);
+  }
+  int operator[](int k) const { return v[k].load(std::memory_order_relaxed); }
+  void set(int k, int x) { v[k].store(x, std::memory_order_relaxed); }
+};
+TuneTable g_tune;
+inline const Topo &topo() {
+  ctx().ensure_device();
+  return ctx().topo;
+}
 /* gsh_lbp_count_evaluated: device counter that receives the windows the cascade really evaluated */
 thread_local unsigned long long *g_lbp_evaluated = nullptr;
 
@@ -318,7 +348,7 @@ StripCfg strip_cfg(unsigned w, unsigned rows, unsigned n, unsigned waves_per_sim
      * chip idle for the whole launch and two bands would run a 1.33rd round at a third occupancy, so
      * take the band count whose last round is fullest (here 3: exactly two rounds; gsh_blur_sobel_batch
      * 512 frames 1.96 -> 1.89 ms, 200 frames 0.90 -> 0.74 ms, profiles/r02f_band_count_512.log). */
-    const unsigned long long cap = 1024ull * waves_per_simd, wn = waves_x * n;
+    const unsigned long long cap = (unsigned long long)topo().simds() * waves_per_simd, wn = waves_x * n;
     const unsigned long long nb_max = rows / 8 ? rows / 8 : 1; /* bands of >= 8 rows */
     unsigned long long nb = cap / wn;
     if (nb < 1) nb = 1;
@@ -349,7 +379,7 @@ StripCfg strip_cfg(unsigned w, unsigned rows, unsigned n, unsigned waves_per_sim
    * count padded to a multiple of 8 (blocks past the last band return at once).  Key 18: 1 = off, 2 = always. */
   /* measured (profiles/r03g_strip_xcd_bands.log): 512 x 4K gs_blur(2) +3.1 %, gs_erode +2.6 %, gs_sobel +2.0 %,
    * 64 x 4096^2 copy +2 %, sobel -1 % (noise); gs_filter (waves_per_simd 6) -3.5 %: not for that one */
-  const bool want = g_tune[18] == 2 || (g_tune[18] == 0 && waves_per_simd == 5 && nb >= 64);
+  const bool want = g_tune[18] == 2 || (g_tune[18] == 0 && waves_per_simd == 5 && nb >= 64 && topo().eight_xcds());
   if (want && c.grid.x == 1 && by == 1) {
     c.grid.y = (nb + 7u) & ~7u;
     c.xcd_flag = kStripXcdFlag;
@@ -432,7 +462,7 @@ void launch_integral(const uint8_t *src, unsigned w, unsigned h, unsigned n, uns
     const unsigned nn = std::min(kMaxZ, n - f0);
     if (banded) {
       const bool wide = w > 4096;
-      unsigned nb = std::max(1u, 2048u / nn);               /* ~2K blocks in flight */
+      unsigned nb = std::max(1u, 8u * topo().cus / nn);      /* ~8 blocks per CU in flight */
       nb = std::min(nb, std::max(1u, h / 8));
       if (wide) nb = std::max(nb, (h + kIntegralWideRows - 1) / kIntegralWideRows); /* a row's carry waits in LDS */
       const unsigned BH = (h + nb - 1) / nb;
@@ -483,7 +513,7 @@ void launch_box_generic(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h
        * 8 frames -> 128 bands (r = 40: 1.0 -> 0.16 ms; profiles/r02l_box_T.log).  Round 1's "at least four window
        * heights per band" dates from a prologue that cost more than the rows it preceded. */
       const unsigned threads = w <= 1024 ? 64u : w <= 2048 ? 128u : 256u; /* a thread owns 16 px of the row */
-      const unsigned slots = 256u * box_blocks_per_cu(MODE, ring ? r : 0u, threads);
+      const unsigned slots = topo().cus * box_blocks_per_cu(MODE, ring ? r : 0u, threads);
       unsigned T = h;
       if (g_tune[0] > 0) {
         T = (unsigned)g_tune[0];
@@ -564,7 +594,7 @@ unsigned hist_bpf(size_t frame_bytes, unsigned n) {
   const size_t bt = hist_threads();
   const size_t chunks = frame_bytes / 16 + 1, trips = g_tune[10] % 1000 > 0 ? (size_t)(g_tune[10] % 1000) : 64 * 256 / bt;
   const size_t by_size = (chunks + bt * trips - 1) / (bt * trips);
-  const size_t by_fill = std::min<size_t>(std::min<size_t>((1280 + n - 1) / n, chunks / (bt * 16)), 256);
+  const size_t by_fill = std::min<size_t>(std::min<size_t>((5u * topo().cus + n - 1) / n, chunks / (bt * 16)), 256); /* 5 resident blocks per CU */
   return (unsigned)std::max<size_t>(1, std::min<size_t>(std::max(by_size, by_fill), 2048));
 }
 void launch_hist_partial(dim3 grid, hipStream_t st, const uint8_t *img, size_t frame_bytes, unsigned *partial) {
@@ -679,7 +709,7 @@ bool launch_fast_score(hipStream_t on, const uint8_t *img, uint8_t *score, unsig
     const unsigned tx = (w - 6 + 63) / 64, ty = (h - 6 + kFastTileRows - 1) / kFastTileRows;
     const unsigned long long nt = (unsigned long long)tx * ty * n;
     GS_ASSERT(nt <= 0x7ffffff0ull); /* 2^31 tiles = 2^41 pixels in one call */
-    const unsigned share = g_tune[18] == 1 ? 0u : (unsigned)((nt + 7) / 8); /* key 18 = 1: tiles in launch order */
+    const unsigned share = (g_tune[18] == 1 || !topo().eight_xcds()) ? 0u : (unsigned)((nt + 7) / 8); /* key 18 = 1: tiles in launch order */
     GS_LAUNCH(k_fast_score_q4, dim3(share ? share * 8u : (unsigned)nt), dim3(64, 4), 0, on, img, score, w, h, fb, threshold, tx,
               ty, (unsigned)nt, share, zero_words, zero_n);
     return true;
@@ -727,7 +757,7 @@ void launch_fast(const uint8_t *img, uint8_t *score, unsigned w, unsigned h, uns
     const unsigned bands = (rows + 16 * m - 3) / (16 * m - 2);
     const unsigned long long nt = cols * bands;
     GS_ASSERT(nt <= 0x7ffffff0ull);
-    const unsigned share = g_tune[18] == 1 ? 0u : (unsigned)((nt + 7) / 8);
+    const unsigned share = (g_tune[18] == 1 || !topo().eight_xcds()) ? 0u : (unsigned)((nt + 7) / 8);
     FastFusedArgs fa{img, score, w, h, fb, threshold, strips, bands, m, (unsigned)nt, share, mask, cnt, wpr, nchunks};
     GS_LAUNCH(k_fast_fused, dim3(share ? share * 8u : (unsigned)nt), dim3(64, 4), 0, st, fa);
     run_compaction(mask, cnt, nchunks, n, nkps, counts,
@@ -953,7 +983,7 @@ void launch_lbp_padded(const gsh_cascade *dc, const LbpGeomCache &gc, const unsi
   /* XCD-aware chunk mapping (k_lbp.h) once the integral image no longer fits one XCD's 4 MB L2: 1080p -3 %, 4K block
    * noise -4 %, 4K edge maps -12 % (5.76 -> 5.08 ms per frame); 720p (3.7 MB) is 1-4 % better off in dispatch order
    * (profiles/r02l_lbp_xcd.log).  Key 13: 1 = never, 2 = always. */
-  a.xcd_swizzle = g_tune[13] == 1 ? 0u : g_tune[13] == 2 ? 1u : (a.frame_stride * 4 >= (size_t)6 << 20 ? 1u : 0u);
+  a.xcd_swizzle = g_tune[13] == 1 ? 0u : g_tune[13] == 2 ? 1u : ((a.frame_stride * 4 >= (size_t)6 << 20 && topo().eight_xcds()) ? 1u : 0u);
   const size_t lds = (size_t)dc->nstages * sizeof(LbpStage) +
                      (size_t)dc->nweaks * (sizeof(LbpWeak) + sizeof(LbpGeom)) + (size_t)dc->nsub * 4;
   GS_ASSERT(lds <= 60 * 1024 && "cascade tables must fit the block's LDS");
@@ -1290,7 +1320,7 @@ unsigned gsh_profile_read(double *total_ms) {
   return n;
 }
 void gsh_tune(int key, int value) {
-  if (key >= 0 && key < 32) g_tune[key] = value;
+  if (key >= 0 && key < 32) g_tune.set(key, value);
 }
 void gsh_probe_strip_copy(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned n) {
   GS_ASSERT(dst && src && w >= 32);
@@ -2061,11 +2091,14 @@ void gs_match_template(struct gs_image img, struct gs_image tmpl, struct gs_imag
     GS_LAUNCH(k_tm_colsq, dim3((result.w + 63) / 64, (result.h + kTmRun - 1) / kTmRun), dim3(64), 0, st, (const unsigned *)rowp,
               img.w, tmpl.w, tmpl.h, result.w, result.h, s2);
 #ifndef GS_EMU
-    static thread_local bool lds_raised = false;
-    if (!lds_raised) { /* more than the default 64 KB of dynamic LDS */
+    /* more than the default 64 KB of dynamic LDS: a per-DEVICE attribute of the function (a thread that moved to
+     * another device with gsh_set_device kept a thread-local "done" flag and the launch failed there) */
+    static std::atomic<unsigned long long> lds_raised{0};
+    const unsigned long long dev_bit = 1ull << ((unsigned)ctx().device & 63u);
+    if (ctx().device >= 64 || !(lds_raised.load(std::memory_order_acquire) & dev_bit)) {
       GS_HIP(hipFuncSetAttribute((const void *)k_match_template_mfma<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       GS_HIP(hipFuncSetAttribute((const void *)k_match_template_mfma<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      lds_raised = true;
+      lds_raised.fetch_or(dev_bit, std::memory_order_release);
     }
 #endif
     TmArgs ta{s, img.w, img.h, (const uint8_t *)tpad, (const unsigned *)tsqp, tmpl.w, tmpl.h, s2, d, result.w, result.h, nkc, istride, tstride};

@@ -118,6 +118,8 @@ class Sharder:
         import torch
         n = torch.tensor([len(data) if self.rank == root else 0], dtype=torch.int64, device=self._dev())
         self.dist.broadcast(n, src=root)
+        if int(n.item()) == 0:  # nothing to send (torch.frombuffer refuses an empty buffer)
+            return b""
         buf = torch.empty(int(n.item()), dtype=torch.uint8, device=self._dev())
         if self.rank == root:
             buf.copy_(torch.frombuffer(bytearray(data), dtype=torch.uint8))
@@ -134,7 +136,10 @@ class Sharder:
         import torch
         nloc = counts.numel()
         c = counts.to(torch.int64)
-        rec = records if records.dim() == 3 else records.reshape(nloc, -1, records.shape[-1])
+        if nloc == 0:  # a rank that owns no frame (world > total): an empty [0, 1, k] list still takes part in the collectives
+            rec = records.new_zeros((0, 1, records.shape[-1]))
+        else:
+            rec = records if records.dim() == 3 else records.reshape(nloc, -1, records.shape[-1])
         cap, k = rec.shape[1], rec.shape[2]
         keep = torch.arange(cap, device=rec.device)[None, :] < c.to(rec.device)[:, None]
         packed = rec[keep]                                     # [sum(counts), k], frame order kept

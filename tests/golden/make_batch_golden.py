@@ -10,7 +10,7 @@ into a zeroed dst;  t = gs_otsu_threshold(e);  gs_threshold(e, t).  Stored: t an
 wsum(e) = sum_i (i + 1) * (byte_i + 1) mod 2^64 (what gsh_checksum_batch computes on the device).
 
 configs[4], a sample of frames (the first and last frame of every rank's shard at N = 1, 2, 4, 8 with 512
-frames per GPU, plus frames 1..3):  e as above before thresholding;  ii = gs_integral(e);
+frames per GPU, frames 1..3, and 72 frames drawn over the whole batch with a fixed seed):  e as above before thresholding;  ii = gs_integral(e);
 gs_lbp_detect(frontalface, ii, 4096 rects, 1.1, 1.0, 4.0, step 1).  Stored: the count and wsum over the
 count * 16 bytes of gs_rect records.
 
@@ -32,7 +32,10 @@ sys.path.insert(0, ROOT)
 
 W, H, RADIUS, SEED0, FRAMES = 3840, 2160, 2, 1000, 4096
 LBP = {"max_rects": 4096, "scale_factor": 1.1, "min_scale": 1.0, "max_scale": 4.0, "step": 1}
-CFG4_FRAMES = sorted({0, 1, 2, 3} | {k * 512 for k in range(8)} | {k * 512 + 511 for k in range(8)})
+CFG4_BOUNDARY = sorted({0, 1, 2, 3} | {k * 512 for k in range(8)} | {k * 512 + 511 for k in range(8)})
+# round 4: + 72 frames drawn once over the whole batch (fixed seed), so that every rank's shard at any N has frames to check
+CFG4_RANDOM = sorted(int(x) for x in np.random.RandomState(4096).choice(4096, 72, replace=False))
+CFG4_FRAMES = sorted(set(CFG4_BOUNDARY) | set(CFG4_RANDOM))
 OUT = os.path.join(HERE, "batch_checksums.json")
 
 
@@ -87,6 +90,7 @@ def generate(jobs, frames1=None, frames4=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--write", action="store_true")
+    ap.add_argument("--add-cfg4", action="store_true", help="generate the configs[4] frames of CFG4_FRAMES the file lacks and merge them in")
     ap.add_argument("--jobs", type=int, default=os.cpu_count() or 1)
     ap.add_argument("--sample", type=int, default=32, help="verify mode: configs[1] frames to re-derive (0 = all)")
     ap.add_argument("--sample4", type=int, default=1, help="verify mode: configs[4] frames to re-derive")
@@ -105,9 +109,21 @@ def main():
         print("wrote", OUT, os.path.getsize(OUT), "bytes")
         return 0
     gold = json.load(open(OUT))
+    if args.add_cfg4:
+        missing = [f for f in CFG4_FRAMES if str(f) not in gold["cfg4"]["frames"]]
+        _, r4 = generate(args.jobs, [], missing)
+        for f, n, s in r4:
+            gold["cfg4"]["frames"][str(f)] = {"n": n, "wsum": "%016x" % s}
+        gold["cfg4"]["frames"] = {k: gold["cfg4"]["frames"][k] for k in sorted(gold["cfg4"]["frames"], key=int)}
+        with open(OUT, "w") as fh:
+            json.dump(gold, fh, separators=(",", ":"))
+            fh.write("\n")
+        print("added %d configs[4] frames: %s" % (len(r4), [f for f, _, _ in r4]))
+        return 0
     rng = np.random.default_rng(int.from_bytes(os.urandom(4), "little"))
     f1 = list(range(FRAMES)) if args.sample == 0 else sorted(int(x) for x in rng.choice(FRAMES, args.sample, replace=False))
-    f4 = [int(x) for x in rng.choice(CFG4_FRAMES, min(args.sample4, len(CFG4_FRAMES)), replace=False)]
+    have4 = [f for f in CFG4_FRAMES if str(f) in gold["cfg4"]["frames"]]
+    f4 = [int(x) for x in rng.choice(have4, min(args.sample4, len(have4)), replace=False)]
     r1, r4 = generate(args.jobs, f1, f4)
     bad = [f for f, t, s in r1 if gold["cfg1"]["otsu"][f] != t or gold["cfg1"]["wsum"][f] != "%016x" % s]
     bad += [("cfg4", f) for f, n, s in r4 if gold["cfg4"]["frames"][str(f)] != {"n": n, "wsum": "%016x" % s}]
