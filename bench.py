@@ -113,10 +113,26 @@ def physical_cores():
     return max(1, len(seen))
 
 
+def cpu_quota():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited: the GPU boxes
+    show 256 hardware threads to a process that is allowed ~8 of them, and threads beyond the quota only take turns"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline_pthreads(w, h, radius):
     """The unmodified reference behind a pthread loop over frames (oracle/ref_bench.c -> oracle/_ref/libgs_ref_bench.so):
-    one run per thread count in {1, physical cores, usable hardware threads}, ~1 s each, buffers preallocated and
-    touched, threads released together.  The best aggregate is `value`, its thread count `cores`."""
+    one run per thread count 1, 2, 4, ... while the aggregate keeps growing, buffers preallocated and touched, threads
+    released together.  The best aggregate is `value`, its thread count `cores`."""
     import ctypes as C
     import numpy as np
     from oracle import pyoracle
@@ -135,20 +151,28 @@ def cpu_baseline_pthreads(w, h, radius):
     dt1 = lib.ref_chain_frames(1, 2, w, h, radius, frames.ctypes.data, nsrc, C.byref(chk))
     one = 2 * px / dt1 / 1e6
     runs.append({"threads": 1, "frames": 2, "seconds": round(dt1, 3), "Mpix/s": round(one, 2)})
-    per_frame_s = dt1 / 2
-    for nt in sorted({physical_cores(), usable_cores()} - {1}):
-        per = max(2, int(round(0.8 / per_frame_s)))  # ~0.8 s of work per thread if the cores scale perfectly
-        dt = lib.ref_chain_frames(nt, per, w, h, radius, frames.ctypes.data, nsrc, C.byref(chk))
+    # thread counts double until a run takes 2.5 x as long as one frame on one thread: a container that shows 256 hardware
+    # threads but is allowed ~8 CPUs' worth of time stops at 32 after sub-second runs instead of time-slicing 256 threads
+    # for half a minute (one frame per thread: the threads start together, so one frame each is a fair sample)
+    quota = cpu_quota()
+    cap = usable_cores() if not quota else min(usable_cores(), 2 * max(1, int(round(quota))))
+    nt, per_frame_s = 2, dt1 / 2
+    while nt <= cap:
+        dt = lib.ref_chain_frames(nt, 1, w, h, radius, frames.ctypes.data, nsrc, C.byref(chk))
         if dt <= 0:
-            continue
-        v = nt * per * px / dt / 1e6
-        runs.append({"threads": nt, "frames": nt * per, "seconds": round(dt, 3), "Mpix/s": round(v, 2),
+            break
+        v = nt * px / dt / 1e6
+        runs.append({"threads": nt, "frames": nt, "seconds": round(dt, 3), "Mpix/s": round(v, 2),
                      "parallel_efficiency": round(v / (nt * one), 3)})
+        if dt > 2.5 * per_frame_s:
+            break
+        nt = min(2 * nt, cap) if nt < cap else cap + 1
     best = max(runs, key=lambda r: r["Mpix/s"])
     return {"value": best["Mpix/s"], "unit": "Mpix/s", "cores": best["threads"], "kind": "reference",
             "seconds": round(time.time() - t_all, 2), "runs": runs,
             "single_thread": {"value": round(one, 2), "unit": "Mpix/s", "cores": 1, "frames": 2, "seconds": round(dt1, 3)},
             "cpu_model": cpu_model(), "nproc": os.cpu_count(), "usable_cores": usable_cores(), "physical_cores": physical_cores(),
+            "cgroup_cpu_quota": quota,
             "sample": "%d frames %dx%d on %d threads (best of the thread counts in `runs`), blur(r=%d)->sobel->otsu->threshold, "
                       "unmodified reference C (oracle/_ref/libgs_ref_bench.so: grayskull.h as it lies, gcc -std=c99 -O2, pthread "
                       "loop over frames in the harness, buffers preallocated)" % (best["frames"], w, h, best["threads"], radius)}

@@ -57,7 +57,7 @@ void launch_blur_sobel_hist(unsigned radius, dim3 grid, dim3 block, hipStream_t 
                             const uint8_t *src, unsigned w, unsigned h, unsigned T, size_t frame_bytes,
                             unsigned *partial);
 void launch_blur_sobel(unsigned radius, dim3 grid, dim3 block, hipStream_t st, uint8_t *dst, const uint8_t *src,
-                       unsigned w, unsigned h, unsigned T, size_t frame_bytes);
+                       unsigned w, unsigned h, unsigned T, size_t frame_bytes, int rg);
 /* gs_box.cpp */
 void launch_box(int mode, unsigned ring_radius, dim3 grid, unsigned threads, hipStream_t st, uint8_t *dst, const uint8_t *src, unsigned w,
                 unsigned h, unsigned T, size_t frame_bytes, unsigned r, int c);
@@ -328,9 +328,11 @@ struct StripCfg {
  * The VALU-heavy fused kernels (waves_per_simd 3) keep long bands: each band first recomputes
  * 2R+2 rows of horizontal sums (8-row bands: 0.25 -> 0.38 ms per 64 frames). */
 StripCfg strip_cfg(unsigned w, unsigned rows, unsigned n, unsigned waves_per_simd = 5, unsigned halo_rows = 2,
-                   unsigned short_T = 8) {
+                   unsigned short_T = 8, int rg = -1) {
   StripCfg c;
-  const unsigned strips = (w + 15) / 16 + strip_ragged_shift(w); /* ragged rows may idle lane 0 (k_strip.h) */
+  /* lanes to place (k_strip.h): ragged rows may idle lane 0, the realigning flavour uses the lane behind the last one.
+   * rg = -1: the caller's kernel has no flavours (or ignores the extra lane) */
+  const unsigned strips = (w + 15) / 16 + (rg == 2 ? strip_realign_shift(w) + strip_realign_helper(w) : rg == 1 ? strip_ragged_shift(w) : (w & 15u) ? 1u : 0u);
   const unsigned long long waves_x = (strips + 63) / 64;
   unsigned long long t;
   if (g_tune[0] > 0) {
@@ -392,9 +394,25 @@ StripCfg strip_cfg(unsigned w, unsigned rows, unsigned n, unsigned waves_per_sim
  * RAGGED).  Key 21 = 1 restores the round-3 rule (multiples of 16, 16-byte aligned frames; everything else per pixel). */
 inline bool strip_ok(unsigned w, unsigned h, const void *a, const void *b) {
   if (g_tune[21] == 1) return w % 16 == 0 && (unsigned long long)w * h < 0x7fffffffull && al16(a) && al16(b);
-  return w >= 32 && (unsigned long long)w * h < 0x7fffffffull;
+  return w >= 32 && (unsigned long long)w * h < 0x7fff0000ull; /* a row offset + base phase + column must not wrap 2^32 */
 }
 inline bool ragged(unsigned w) { return (w & 15u) != 0u; }
+/* which Strip flavour (k_strip.h): 0 = whole 16-px strips, rows at dword-aligned addresses; 1 = ragged width, rows still at
+ * dword-aligned addresses (w % 4 == 0 and the frame at such an address): direct 16-byte loads at any 16-byte phase cost
+ * nothing; 2 = any other byte phase: dword-aligned loads, realigned in registers (a 16-byte load at an address that is not
+ * a multiple of 4 costs the stencils 30-45 %, profiles/r04b_byte_phase_cost.log).  Key 24 = 1: never 2 (A/B). */
+inline int strip_mode(unsigned w, const void *src) {
+  const int direct = ragged(w) ? 1 : 0;
+  if ((w & 3u) == 0u && ((uintptr_t)src & 3u) == 0u) return direct;
+  if (g_tune[24] == 1) return direct;
+  /* the realigning flavour places up to two more lanes per row (k_strip.h); where that opens another wave of 64 -- widths
+   * just below a multiple of 1024 -- the wave costs more than the misaligned loads do (4094 x 4096: 0.39 against 0.64 of
+   * the HBM peak, profiles/r04g_ragged_realign.log) */
+  const unsigned strips = (w + 15) / 16;
+  const unsigned lanes2 = strips + strip_realign_shift(w) + strip_realign_helper(w), lanes1 = strips + (direct ? strip_ragged_shift(w) : 0u);
+  if (g_tune[24] != 2 && (lanes2 + 63) / 64 > (lanes1 + 63) / 64) return direct;
+  return 2;
+}
 /* kernels that still need whole 16-px strips at 16-byte aligned addresses */
 inline bool strip_ok16(unsigned w, unsigned h, const void *a, const void *b) {
   return w % 16 == 0 && (unsigned long long)w * h < 0x7fffffffull && al16(a) && al16(b);
@@ -419,10 +437,14 @@ void launch_sobel(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsi
     uint8_t *d = dst + fb * f0;
     const uint8_t *s = src + fb * f0;
     if (strip_ok(w, h, d, s) && w >= 32) {
-      const StripCfg c = strip_cfg(w, h - 2, nn, 5, 2, 6);
-      if (ragged(w)) {
-        if (keep_cols) GS_LAUNCH((k_sobel16<true, true>), c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
-        else GS_LAUNCH((k_sobel16<false, true>), c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
+      const int rg = strip_mode(w, s);
+      const StripCfg c = strip_cfg(w, h - 2, nn, 5, 2, 6, rg);
+      if (rg == 1) {
+        if (keep_cols) GS_LAUNCH((k_sobel16<true, 1>), c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
+        else GS_LAUNCH((k_sobel16<false, 1>), c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
+      } else if (rg == 2) {
+        if (keep_cols) GS_LAUNCH((k_sobel16<true, 2>), c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
+        else GS_LAUNCH((k_sobel16<false, 2>), c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
       } else if (keep_cols) GS_LAUNCH(k_sobel16<true>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
       else GS_LAUNCH(k_sobel16<false>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
     } else {
@@ -441,8 +463,10 @@ void launch_morph(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsi
     uint8_t *d = dst + fb * f0;
     const uint8_t *s = src + fb * f0;
     if (strip_ok(w, h, d, s)) {
-      const StripCfg c = strip_cfg(w, h, nn, 5, 2, 4);
-      if (ragged(w)) GS_LAUNCH((k_morph16<DILATE, true>), c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
+      const int rg = strip_mode(w, s);
+      const StripCfg c = strip_cfg(w, h, nn, 5, 2, 4, rg);
+      if (rg == 1) GS_LAUNCH((k_morph16<DILATE, 1>), c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
+      else if (rg == 2) GS_LAUNCH((k_morph16<DILATE, 2>), c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
       else GS_LAUNCH(k_morph16<DILATE>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
     } else {
       GS_LAUNCH(k_morph_px<DILATE>, grid2d(w, h, nn), dim3(64, 4), 0, st, d, s, w, h, fb);
@@ -559,13 +583,18 @@ void launch_blur(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsig
   if (radius >= 1 && radius <= 3 && strip_ok(w, h, dst, src) && h > 2 * radius && w > 2 * radius) {
     for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
       const unsigned nn = std::min(kMaxZ, n - f0);
-      const StripCfg c = strip_cfg(w, h, nn, 5, radius, radius == 1 ? 4 : radius == 2 ? 6 : 12);
       uint8_t *d = dst + fb * f0;
       const uint8_t *s = src + fb * f0;
-      if (ragged(w)) {
-        if (radius == 1) GS_LAUNCH((k_blur16<1, true>), c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
-        else if (radius == 2) GS_LAUNCH((k_blur16<2, true>), c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
-        else GS_LAUNCH((k_blur16<3, true>), c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
+      const int rg = strip_mode(w, s);
+      const StripCfg c = strip_cfg(w, h, nn, 5, radius, radius == 1 ? 4 : radius == 2 ? 6 : 12, rg);
+      if (rg == 1) {
+        if (radius == 1) GS_LAUNCH((k_blur16<1, 1>), c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
+        else if (radius == 2) GS_LAUNCH((k_blur16<2, 1>), c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
+        else GS_LAUNCH((k_blur16<3, 1>), c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
+      } else if (rg == 2) {
+        if (radius == 1) GS_LAUNCH((k_blur16<1, 2>), c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
+        else if (radius == 2) GS_LAUNCH((k_blur16<2, 2>), c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
+        else GS_LAUNCH((k_blur16<3, 2>), c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
       } else if (radius == 1) GS_LAUNCH(k_blur16<1>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
       else if (radius == 2) GS_LAUNCH(k_blur16<2>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
       else GS_LAUNCH(k_blur16<3>, c.grid, c.block, 0, st, d, s, w, h, c.T, fb | c.xcd_flag);
@@ -1324,10 +1353,10 @@ void gsh_tune(int key, int value) {
 }
 void gsh_probe_strip_copy(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned n) {
   GS_ASSERT(dst && src && w >= 32);
-  const StripCfg c = strip_cfg(w, h, n, 5, 2, g_tune[0] > 0 ? (unsigned)g_tune[0] : 8u);
-  if (g_tune[23] == 1) GS_LAUNCH((k_strip_copy<false, true>), c.grid, c.block, 0, ctx().s(), dst, src, w, h, c.T, (size_t)w * h | c.xcd_flag);
-  else if (ragged(w)) GS_LAUNCH(k_strip_copy<true>, c.grid, c.block, 0, ctx().s(), dst, src, w, h, c.T, (size_t)w * h | c.xcd_flag);
-  else GS_LAUNCH(k_strip_copy<false>, c.grid, c.block, 0, ctx().s(), dst, src, w, h, c.T, (size_t)w * h | c.xcd_flag);
+  const StripCfg c = strip_cfg(w, h, n, 5, 2, g_tune[0] > 0 ? (unsigned)g_tune[0] : 8u, ragged(w) ? 1 : 0);
+  if (g_tune[23] == 1) GS_LAUNCH((k_strip_copy<0, true>), c.grid, c.block, 0, ctx().s(), dst, src, w, h, c.T, (size_t)w * h | c.xcd_flag);
+  else if (ragged(w)) GS_LAUNCH(k_strip_copy<1>, c.grid, c.block, 0, ctx().s(), dst, src, w, h, c.T, (size_t)w * h | c.xcd_flag);
+  else GS_LAUNCH(k_strip_copy<0>, c.grid, c.block, 0, ctx().s(), dst, src, w, h, c.T, (size_t)w * h | c.xcd_flag);
 }
 void gsh_probe_fast_score(uint8_t *score, const uint8_t *img, unsigned w, unsigned h, unsigned n, unsigned threshold) {
   GS_ASSERT(score && img && w >= 7 && h >= 7 && n >= 1 && n <= kMaxZ);
@@ -1415,9 +1444,10 @@ void gsh_blur_sobel_batch(uint8_t *dst, const uint8_t *src, unsigned w, unsigned
       h > 2 * radius) {
     for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
       const unsigned nn = std::min(kMaxZ, n - f0);
-      const StripCfg c = strip_cfg(w, h - 2, nn, 3);
+      const int rg = strip_mode(w, src + fb * f0);
+      const StripCfg c = strip_cfg(w, h - 2, nn, 3, 2, 8, rg);
       launch_blur_sobel(radius, dim3(c.grid.x, c.grid.y, nn), c.block, st, dst + fb * f0, src + fb * f0, w, h,
-                        c.T, fb);
+                        c.T, fb, rg);
       GS_LAUNCH(k_zero_frame, dim3((2 * w + 2 * h + 255) / 256, nn), dim3(256), 0, st, dst + fb * f0, w, h, fb);
     }
     return;
@@ -1861,9 +1891,11 @@ void gsh_filter_batch(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, 
     fk.neg_is_255 = norm > 1 ? 0xffffffffu : 0u;
     for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
       const unsigned nn = std::min(kMaxZ, n - f0);
-      const StripCfg c = strip_cfg(w, h, nn, 6);
-      if (ragged(w)) GS_LAUNCH(k_filter16<true>, c.grid, c.block, 0, st, dst + fb * f0, src + fb * f0, w, h, c.T, fb | c.xcd_flag, fk);
-      else GS_LAUNCH(k_filter16<false>, c.grid, c.block, 0, st, dst + fb * f0, src + fb * f0, w, h, c.T, fb | c.xcd_flag, fk);
+      const int rg = strip_mode(w, src + fb * f0);
+      const StripCfg c = strip_cfg(w, h, nn, 6, 2, 8, rg);
+      if (rg == 1) GS_LAUNCH(k_filter16<1>, c.grid, c.block, 0, st, dst + fb * f0, src + fb * f0, w, h, c.T, fb | c.xcd_flag, fk);
+      else if (rg == 2) GS_LAUNCH(k_filter16<2>, c.grid, c.block, 0, st, dst + fb * f0, src + fb * f0, w, h, c.T, fb | c.xcd_flag, fk);
+      else GS_LAUNCH(k_filter16<0>, c.grid, c.block, 0, st, dst + fb * f0, src + fb * f0, w, h, c.T, fb | c.xcd_flag, fk);
     }
     return;
   }

@@ -8,6 +8,10 @@
  */
 #include "k_fused.h"
 
+#ifndef GS_FUSED_MINW
+#define GS_FUSED_MINW 1
+#endif
+
 namespace gs {
 
 void launch_blur_sobel_hist(unsigned radius, dim3 grid, dim3 block, hipStream_t st, uint8_t *dst,
@@ -20,16 +24,22 @@ void launch_blur_sobel_hist(unsigned radius, dim3 grid, dim3 block, hipStream_t 
 
 /* the same kernel without the histogram half (gsh_blur_sobel_batch) */
 void launch_blur_sobel(unsigned radius, dim3 grid, dim3 block, hipStream_t st, uint8_t *dst, const uint8_t *src,
-                       unsigned w, unsigned h, unsigned T, size_t frame_bytes) {
+                       unsigned w, unsigned h, unsigned T, size_t frame_bytes, int rg) {
   unsigned *none = nullptr;
-  if (w % 16 != 0) { /* ragged rows: the tail strip anchored at w - 16 (k_strip.h) */
-    if (radius == 1) GS_LAUNCH((k_blur_sobel_hist16<1, false, true>), grid, block, 0, st, dst, src, w, h, T, frame_bytes, none);
-    else if (radius == 2) GS_LAUNCH((k_blur_sobel_hist16<2, false, true>), grid, block, 0, st, dst, src, w, h, T, frame_bytes, none);
-    else GS_LAUNCH((k_blur_sobel_hist16<3, false, true>), grid, block, 0, st, dst, src, w, h, T, frame_bytes, none);
+  if (rg == 1) { /* ragged rows: the tail strip anchored at w - 16 (k_strip.h) */
+    if (radius == 1) GS_LAUNCH((k_blur_sobel_hist16<1, false, 1>), grid, block, 0, st, dst, src, w, h, T, frame_bytes, none);
+    else if (radius == 2) GS_LAUNCH((k_blur_sobel_hist16<2, false, 1>), grid, block, 0, st, dst, src, w, h, T, frame_bytes, none);
+    else GS_LAUNCH((k_blur_sobel_hist16<3, false, 1>), grid, block, 0, st, dst, src, w, h, T, frame_bytes, none);
+    return;
+  }
+  if (rg == 2) { /* any byte phase: dword-aligned loads, realigned in registers */
+    if (radius == 1) GS_LAUNCH((k_blur_sobel_hist16<1, false, 2>), grid, block, 0, st, dst, src, w, h, T, frame_bytes, none);
+    else if (radius == 2) GS_LAUNCH((k_blur_sobel_hist16<2, false, 2>), grid, block, 0, st, dst, src, w, h, T, frame_bytes, none);
+    else GS_LAUNCH((k_blur_sobel_hist16<3, false, 2>), grid, block, 0, st, dst, src, w, h, T, frame_bytes, none);
     return;
   }
   if (radius == 1) GS_LAUNCH((k_blur_sobel_hist16<1, false>), grid, block, 0, st, dst, src, w, h, T, frame_bytes, none);
-  else if (radius == 2) GS_LAUNCH((k_blur_sobel_hist16<2, false>), grid, block, 0, st, dst, src, w, h, T, frame_bytes, none);
+  else if (radius == 2) GS_LAUNCH((k_blur_sobel_hist16<2, false, 0, GS_FUSED_MINW>), grid, block, 0, st, dst, src, w, h, T, frame_bytes, none);
   else GS_LAUNCH((k_blur_sobel_hist16<3, false>), grid, block, 0, st, dst, src, w, h, T, frame_bytes, none);
 }
 

@@ -54,16 +54,23 @@ GS_DEV void blur_hsum10(const uint32_t (&U)[12], uint32_t (&H)[10]) { /* pairs =
 
 /* grid like the strip kernels; partial: [frame][blockIdx.y * gridDim.x + blockIdx.x][256] */
 /* HIST = false: gs_blur + gs_sobel only (gsh_blur_sobel_batch): no LDS, no histogram, `partial` unused */
+/* the spare ring slot (see the kernel).  Without it the kernel needs MORE registers, not fewer (R = 2 without the histogram
+ * half: 145 against 138; the odd unroll period keeps the shifted sobel history alive): experiment hook only */
+#ifndef GS_FUSED_SPARE
+#define GS_FUSED_SPARE(hist) true
+#endif
 #ifndef GS_FUSED_VGPR_ATTR
 #define GS_FUSED_VGPR_ATTR /* experiment hook: -DGS_FUSED_VGPR_ATTR='__attribute__((amdgpu_num_vgpr(144)))' */
 #endif
 /* RAGGED (w % 16 != 0, without the histogram half): the strips of k_strip.h with the tail strip anchored at w - 16.  The lane
  * left of the tail lane may own pixels -- its own last R and the two it blurs for its right neighbour's sobel taps -- that are
  * less than R columns from the right edge, so the right-hand divisors are chosen per lane from the distance to the edge. */
-template <int R, bool HIST = true, bool RAGGED = false>
-__global__ __launch_bounds__(256) GS_FUSED_VGPR_ATTR void k_blur_sobel_hist16(uint8_t *dst, const uint8_t *src,
+/* MINW: waves per SIMD the register allocation has to leave room for (__launch_bounds__' second argument) */
+template <int R, bool HIST = true, int RG = 0, int MINW = 1>
+__global__ __launch_bounds__(256, MINW) GS_FUSED_VGPR_ATTR void k_blur_sobel_hist16(uint8_t *dst, const uint8_t *src,
                                                            unsigned w, unsigned h, unsigned T,
                                                            size_t frame_bytes, unsigned *partial) {
+  constexpr bool RAGGED = RG != 0;
   static_assert(!(HIST && RAGGED), "ragged rows take the histogram as a separate pass");
   constexpr int N = 2 * R + 1;
   __shared__ unsigned lh[HIST ? 256 * 32 : 1];
@@ -72,7 +79,7 @@ __global__ __launch_bounds__(256) GS_FUSED_VGPR_ATTR void k_blur_sobel_hist16(ui
     for (unsigned i = tid; i < 256 * 32; i += 256) lh[i] = 0;
     __syncthreads();
   }
-  const Strip<false, RAGGED> S(src, dst, w, h, frame_bytes);
+  const Strip<false, RG> S(src, dst, w, h, frame_bytes);
   const int y0 = 1 + (int)(S.band * T);
   if (y0 < (int)h - 1 && !S.wave_outside()) { /* wave-uniform; no early return: every wave reaches the barrier */
     const int nrows = ((int)h - 1 - y0) < (int)T ? ((int)h - 1 - y0) : (int)T;
@@ -88,7 +95,7 @@ __global__ __launch_bounds__(256) GS_FUSED_VGPR_ATTR void k_blur_sobel_hist16(ui
     }
     /* N+1 ring slots: the new row lands in the free slot and the unroll period N+1 is even, so
      * the sobel history alternates (step<parity>) without register moves */
-    constexpr bool SPARE = R <= 2; /* R = 3: the 8th slot would cost the third wave per SIMD */
+    constexpr bool SPARE = R <= 2 && GS_FUSED_SPARE(HIST); /* R = 3: the 8th slot would cost the third wave per SIMD */
     constexpr int NS = SPARE ? N + 1 : N, P0 = SPARE ? 1 : 0; /* P0: slot of the first prologue row */
     uint32_t ring[NS][10], V[10];
     SobelState st;

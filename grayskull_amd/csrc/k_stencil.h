@@ -27,10 +27,10 @@
 namespace gs {
 
 /* ------------------------------------------------------------------ sobel, strips (helpers: k_strip.h) */
-template <bool KEEP_COLS, bool RAGGED = false>
+template <bool KEEP_COLS, int RG = 0>
 __global__ __launch_bounds__(256) void k_sobel16(uint8_t *dst, const uint8_t *src, unsigned w,
                                                  unsigned h, unsigned T, size_t frame_bytes) {
-  const Strip<false, RAGGED> S(src, dst, w, h, frame_bytes);
+  const Strip<false, RG> S(src, dst, w, h, frame_bytes);
   if (S.wave_outside()) return; /* block wider than the frame */
   const int y0 = 1 + (int)(S.band * T);
   if (y0 >= (int)h - 1) return; /* whole wave */
@@ -70,11 +70,11 @@ template <int R> GS_DEV uint32_t blur_mul_cols(unsigned cols) {
   for (unsigned c = R + 1; c < N; c++) m = cols == c ? (0x1000000u + N * c - 1u) / (N * c) : m;
   return m;
 }
-template <int R, bool RAGGED = false>
+template <int R, int RG = 0>
 __global__ __launch_bounds__(256) void k_blur16(uint8_t *dst, const uint8_t *src, unsigned w,
                                                 unsigned h, unsigned T, size_t frame_bytes) {
   constexpr int N = 2 * R + 1;
-  const Strip<false, RAGGED> S(src, dst, w, h, frame_bytes);
+  const Strip<false, RG> S(src, dst, w, h, frame_bytes);
   if (S.wave_outside()) return; /* block wider than the frame */
   const bool first = S.x0 == 0, last = S.x0 + 16 == w;
   const int y0 = (int)(S.band * T);
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void k_blur16(uint8_t *dst, const uint8_t *src
   }
   /* RAGGED: columns in the image for the lane's R rightmost pixels, from the distance to the right edge */
   uint32_t mRr[R];
-  if constexpr (RAGGED) {
+  if constexpr (RG != 0) {
 #pragma unroll
     for (int q = 0; q < R; q++) {
       const int d = (int)w - 1 - (int)(S.x0 + 16 - R + q); /* >= 0 for every lane inside the image */
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void k_blur16(uint8_t *dst, const uint8_t *src
     for (int q = 0; q < R; q++) {
       mL[q] = first ? (0x1000000u + N * (R + 1 + q) - 1u) / (N * (R + 1 + q)) : mC;
       mR[q] = last ? (0x1000000u + N * (2 * R - q) - 1u) / (N * (2 * R - q)) : mC;
-      if constexpr (RAGGED) mR[q] = mRr[q];
+      if constexpr (RG != 0) mR[q] = mRr[q];
     }
     uint32_t od[4];
 #pragma unroll
@@ -159,10 +159,10 @@ __global__ __launch_bounds__(256) void k_blur_edge_rows(uint8_t *dst, const uint
 /* ------------------------------------------------------------------ 3x3 erode / dilate, strips */
 /* ref grayskull.h:285-304: max over in-image taps == max with 0 fill; erode runs as
  * ~dilate(~x) (Strip<INVERT>), i.e. min with 255 fill. */
-template <bool DILATE, bool RAGGED = false>
+template <bool DILATE, int RG = 0>
 __global__ __launch_bounds__(256) void k_morph16(uint8_t *dst, const uint8_t *src, unsigned w,
                                                  unsigned h, unsigned T, size_t frame_bytes) {
-  const Strip<!DILATE, RAGGED> S(src, dst, w, h, frame_bytes);
+  const Strip<!DILATE, RG> S(src, dst, w, h, frame_bytes);
   if (S.wave_outside()) return; /* block wider than the frame */
   const int y0 = (int)(S.band * T);
   if (y0 >= (int)h) return;
@@ -194,10 +194,10 @@ __global__ __launch_bounds__(256) void k_morph16(uint8_t *dst, const uint8_t *sr
 }
 
 /* diagnostic: same traffic pattern as the strip kernels, no arithmetic (access-pattern ceiling) */
-template <bool RAGGED = false, bool HALO = false> /* HALO: keep the halo dword load of the stencils alive (probe) */
+template <int RG = 0, bool HALO = false> /* HALO: keep the halo dword load of the stencils alive (probe) */
 __global__ __launch_bounds__(256) void k_strip_copy(uint8_t *dst, const uint8_t *src, unsigned w,
                                                     unsigned h, unsigned T, size_t frame_bytes) {
-  const Strip<false, RAGGED> S(src, dst, w, h, frame_bytes);
+  const Strip<false, RG> S(src, dst, w, h, frame_bytes);
   if (S.wave_outside()) return; /* block wider than the frame */
   const int y0 = (int)(S.band * T);
   if (y0 >= (int)h) return;
@@ -231,10 +231,10 @@ GS_DEV void filter_hrow(const uint32_t (&U)[12], const uint32_t (&kr)[3], uint32
   }
 }
 
-template <bool RAGGED = false>
+template <int RG = 0>
 __global__ __launch_bounds__(256) void k_filter16(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h,
                                                   unsigned T, size_t frame_bytes, FilterK fk) {
-  const Strip<false, RAGGED> S(src, dst, w, h, frame_bytes);
+  const Strip<false, RG> S(src, dst, w, h, frame_bytes);
   if (S.wave_outside()) return; /* block wider than the frame */
   const int y0 = (int)(S.band * T);
   if (y0 >= (int)h) return;

@@ -33,7 +33,6 @@ template <int N, class F> GS_DEV void static_for(F &&f) {
 }
 
 /* ------------------------------------------------------------------ strip helpers */
-struct RawRow { U4 v; uint32_t hh; };
 
 /* One lane's view of a frame pair.  The block shape is free: blockDim.x is a multiple of 64 (a
  * wave's lanes are 64 consecutive strips of one band), blockDim.y stacks further bands.
@@ -67,13 +66,35 @@ __host__ __device__ inline unsigned strip_ragged_shift(unsigned w) { /* also the
   const unsigned t = (w - 1u) >> 4;
   return ((w & 15u) != 0u && (t & 63u) == 1u && t > 1u) ? 1u : 0u;
 }
-template <bool INVERT = false, bool RAGGED = false> struct Strip {
+/* REALIGN (RG = 2; rows whose byte phase is not a multiple of 4: w % 4 != 0 or a frame at such an address).  Measured
+ * on MI355X (profiles/r04b_byte_phase_cost.log): 16-byte loads at a dword-aligned address cost the stencils 3 % whatever
+ * the 16-byte phase, at any other address 30-45 % (the plain copy loses nothing, a second row in flight changes nothing,
+ * stores lose 5 %).  So this mode loads every lane's 16 bytes from the dword-aligned address BELOW its pixels and moves
+ * the bytes into place in registers: the lane's 24-byte neighbourhood starts p = address & 3 bytes into the seven
+ * dwords [left, own x 4, right, right'], one v_alignbyte_b32 per output dword.  The halo load is two dwords (lane 63
+ * needs both right-hand ones).  The tail strip stays anchored at w - 16 as in RG = 1 -- its own phase, its left dword
+ * from its halo slot -- and the lane behind it loads the 16 bytes that follow, so that the tail lane finds its
+ * right-hand dwords (the one with the row's last p pixels) where every lane does; the last lane of a row of whole strips
+ * fetches them itself, its halo slot is free.  Pixels left of column 0 / right of column w - 1 that come along are
+ * masked.  Stores go out at the byte address as they are. */
+__host__ __device__ inline unsigned strip_realign_shift(unsigned w) {
+  const unsigned t = (w - 1u) >> 4, l = t & 63u;
+  return ((w & 15u) != 0u && (l == 1u || l == 63u) && t > 1u) ? 1u : 0u; /* tail not in lane 63 (helper lane), its left neighbour not in lane 0 */
+}
+__host__ __device__ inline unsigned strip_realign_helper(unsigned w) { /* one more lane loads the 16 bytes behind the row's last strip */
+  return ((w & 15u) != 0u || (((w - 1u) >> 4) & 63u) == 0u) ? 1u : 0u;
+}
+struct RawRow { U4 v; uint32_t hh; uint32_t hh2 = 0, p = 0; }; /* hh2, p: RG = 2 only */
+
+template <bool INVERT = false, int RG = 0> struct Strip {
+  static constexpr bool RAGGED = RG != 0;
   BufRsrc src, dst;
   unsigned w, h, x0, lane, band, gid;
-  uint32_t col_off, halo_off; /* this lane's 16 B / its halo dword inside a row (kOOB: none) */
+  uint32_t col_off, halo_off; /* this lane's 16 B / its halo dword(s) inside a row (kOOB: none) */
   bool sel_l = false, sel_r = false; /* RAGGED: left / right neighbour dword comes from the halo load, not from the next lane */
-  uint32_t halo_shift = 0;           /* RAGGED: bits the right-halo dword was fetched early by */
-  uint32_t keep_r = 0xffffffffu;     /* RAGGED: 0 in the tail lane -- nothing lies right of it (as lane 63 its DPP fill is its LEFT halo) */
+  uint32_t halo_shift = 0;           /* RG 1: bits the right-halo dword was fetched early by */
+  uint32_t keep_r = 0xffffffffu;     /* RG 1: 0 in the tail lane -- nothing lies right of it (as lane 63 its DPP fill is its LEFT halo) */
+  uint32_t src_off = kOOB, bp = 0, mask_l = 0xffffffffu, mask_r = 0xffffffffu; /* RG 2: load column, base phase, in-image bytes of the outer dwords */
   GS_DEV Strip(const uint8_t *s, uint8_t *d, unsigned w_, unsigned h_, size_t frame_bytes)
       : src(make_buf(s + (size_t)blockIdx.z * (frame_bytes & ~kStripXcdFlag), frame_bytes & ~kStripXcdFlag)),
         dst(make_buf(d + (size_t)blockIdx.z * (frame_bytes & ~kStripXcdFlag), frame_bytes & ~kStripXcdFlag)), w(w_), h(h_) {
@@ -81,32 +102,47 @@ template <bool INVERT = false, bool RAGGED = false> struct Strip {
     gid = blockIdx.x * blockDim.x + threadIdx.x;
     band = uniform(blockIdx.y * blockDim.y + threadIdx.y); /* same for the wave's 64 lanes: SGPR */
     if (frame_bytes & kStripXcdFlag) band = (blockIdx.y & 7u) * (gridDim.y >> 3) + (blockIdx.y >> 3);
-    if constexpr (!RAGGED) {
+    if constexpr (RG == 0) {
       x0 = gid * 16u;
       col_off = x0 < w ? x0 : kOOB;
       halo_off = kOOB;
       if (lane == 0 && x0 > 0 && x0 < w) halo_off = x0 - 4;
       if (lane == 63 && x0 + 16 < w) halo_off = x0 + 16;
     } else {
-      const unsigned t = (w - 1u) >> 4;
-      gid -= strip_ragged_shift(w); /* the idle lane wraps to 2^32 - 1: outside like everything right of the image */
-      const bool tail = gid == t, in = gid <= t;
+      const unsigned t = (w - 1u) >> 4, m = w & 15u;
+      gid -= RG == 2 ? strip_realign_shift(w) : strip_ragged_shift(w); /* the idle lane wraps to 2^32 - 1: outside like everything right of the image */
+      const bool tail = m != 0u && gid == t, in = gid <= t;
       x0 = tail ? w - 16u : gid * 16u;
       keep_r = tail ? 0u : 0xffffffffu;
       col_off = in ? x0 : kOOB;
       halo_off = kOOB;
       uint32_t right = kOOB; /* start of the dword right of this lane's 16 px, where the lane has to fetch it itself */
       if (in && x0 > 0 && (lane == 0 || tail)) halo_off = x0 - 4, sel_l = lane != 0;
-      if (gid < t && (lane == 63 || gid + 1u == t)) right = x0 + 16, sel_r = lane != 63;
-      if (right != kOOB) { /* in the row from `right` on (right <= 16 t < w); the dword may cross the row end */
-        const uint32_t at = right + 4u > w ? w - 4u : right;
-        halo_off = at, halo_shift = 8u * (right - at);
+      if (gid < t && (lane == 63 || (m != 0u && gid + 1u == t))) right = x0 + 16, sel_r = lane != 63;
+      /* RG 2, whole strips: the row's last p pixels lie behind the last lane's 16 bytes; its halo slot is free unless it is lane 0 */
+      if (RG == 2 && m == 0u && gid == t && lane != 0u) right = x0 + 16, sel_r = lane != 63;
+      if constexpr (RG == 1) {
+        if (right != kOOB) { /* in the row from `right` on (right <= 16 t < w); the dword may cross the row end */
+          const uint32_t at = right + 4u > w ? w - 4u : right;
+          halo_off = at, halo_shift = 8u * (right - at);
+        }
+      } else {
+        if (right != kOOB) halo_off = right;
+        const size_t fb = frame_bytes & ~kStripXcdFlag;
+        const uint8_t *base = s + (size_t)blockIdx.z * fb;
+        bp = (uint32_t)((uintptr_t)base & 3u);
+        /* the dwords that hold the frame's first and last byte lie in the pages those bytes lie in; what is beyond reads 0 */
+        src = make_buf(base - bp, (fb + bp + 3u) & ~(size_t)3u);
+        src_off = in ? x0 : (strip_realign_helper(w) && gid == t + 1u) ? w : kOOB; /* the lane behind the tail lane: the 16 bytes that follow */
+        mask_l = (in && x0 == 0u) ? 0u : 0xffffffffu;
+        const int nv = (int)w - (int)(x0 + 16u); /* pixels x0 + 16 .. x0 + 19 inside the row */
+        mask_r = !in || nv <= 0 ? 0u : nv >= 4 ? 0xffffffffu : (1u << (8 * nv)) - 1u;
       }
     }
   }
   /* the whole wave lies right of the image (its block is wider than the frame): nothing to load, compute or store */
   GS_DEV bool wave_outside() const {
-    if constexpr (RAGGED) return (int)uniform(gid - lane) > (int)((w - 1u) >> 4);
+    if constexpr (RAGGED) return (int)uniform(gid - lane) > (int)((w - 1u) >> 4) + (RG == 2 ? 1 : 0);
     else return uniform(x0 - lane * 16u) >= w;
   }
   GS_DEV bool in_image() const { return col_off != kOOB; }
@@ -118,6 +154,18 @@ template <bool INVERT = false, bool RAGGED = false> struct Strip {
   GS_DEV RawRow load(int y) const {
     const uint32_t row = row_off(y);
     RawRow r;
+    if constexpr (RG == 2) {
+      const uint32_t a = row + bp + src_off; /* byte offset of the lane's first pixel from the dword-aligned base */
+      r.v = buf_load16(src, a & ~3u);
+      const U2 hx = buf_load8(src, (row + bp + halo_off) & ~3u); /* same phase: halo_off = x0 - 4 or x0 + 16 */
+      r.hh = hx.x, r.hh2 = hx.y, r.p = a & 3u;
+      if (INVERT) { /* every byte of an in-image row; what lies outside the row is masked in unpack() (stays 0 in the inverted domain) */
+        const uint32_t m = (unsigned)y < h ? 0xffffffffu : 0u;
+        r.v = U4{r.v.x ^ m, r.v.y ^ m, r.v.z ^ m, r.v.w ^ m};
+        r.hh ^= m, r.hh2 ^= m;
+      }
+      return r;
+    }
     r.v = buf_load16(src, row + col_off);
     r.hh = buf_load4(src, row + halo_off);
     if (INVERT) { /* complement in-image bytes only: out-of-range stays 0 in the inverted domain */
@@ -126,7 +174,7 @@ template <bool INVERT = false, bool RAGGED = false> struct Strip {
       r.v = U4{r.v.x ^ m, r.v.y ^ m, r.v.z ^ m, r.v.w ^ m};
       r.hh ^= hm;
     }
-    if constexpr (RAGGED) r.hh >>= halo_shift; /* the pixels past the row end: 0 (inverted domain included) */
+    if constexpr (RG == 1) r.hh >>= halo_shift; /* the pixels past the row end: 0 (inverted domain included) */
     return r;
   }
   /* whole 16 B of row y (dropped when !ok or the lane is outside the image) */
@@ -138,7 +186,20 @@ template <bool INVERT = false, bool RAGGED = false> struct Strip {
   GS_DEV void unpack(const RawRow &r, uint32_t (&U)[12]) const {
     uint32_t L = wave_shr1(r.v.w, r.hh); /* left neighbour's last dword (lane 0: halo)   */
     uint32_t R = wave_shl1(r.v.x, r.hh); /* right neighbour's first dword (lane 63: halo) */
-    if constexpr (RAGGED) L = sel_l ? r.hh : L, R = (sel_r ? r.hh : R) & keep_r;
+    if constexpr (RG == 2) {
+      uint32_t R2 = wave_shl1(r.v.y, r.hh2);
+      L = sel_l ? r.hh : L, R = sel_r ? r.hh : R, R2 = sel_r ? r.hh2 : R2;
+      const uint32_t d0 = alignbyte(r.v.x, L, r.p) & mask_l, d1 = alignbyte(r.v.y, r.v.x, r.p), d2 = alignbyte(r.v.z, r.v.y, r.p),
+                     d3 = alignbyte(r.v.w, r.v.z, r.p), d4 = alignbyte(R, r.v.w, r.p), d5 = alignbyte(R2, R, r.p) & mask_r;
+      U[0] = unpack_lo(d0), U[1] = unpack_hi(d0);
+      U[2] = unpack_lo(d1), U[3] = unpack_hi(d1);
+      U[4] = unpack_lo(d2), U[5] = unpack_hi(d2);
+      U[6] = unpack_lo(d3), U[7] = unpack_hi(d3);
+      U[8] = unpack_lo(d4), U[9] = unpack_hi(d4);
+      U[10] = unpack_lo(d5), U[11] = unpack_hi(d5);
+      return;
+    }
+    if constexpr (RG == 1) L = sel_l ? r.hh : L, R = (sel_r ? r.hh : R) & keep_r;
     U[0] = unpack_lo(L), U[1] = unpack_hi(L);
     U[2] = unpack_lo(r.v.x), U[3] = unpack_hi(r.v.x);
     U[4] = unpack_lo(r.v.y), U[5] = unpack_hi(r.v.y);
@@ -164,8 +225,8 @@ struct NoFin {
  * computed and dropped (stores predicated off; their loads are in-frame rows of the next band or
  * out-of-range zero fill).  false costs registers; it pays for the VALU-heavy fused kernel only.
  * The input is requested one row ahead (two measured no better and costs 5 registers). */
-template <int RING, bool INVERT, bool EXITS = true, bool RAGGED = false, class Body, class Fin = NoFin>
-GS_DEV void strip_rows(const Strip<INVERT, RAGGED> &S, int y0, int nrows, int lead, RawRow first, Body &&body,
+template <int RING, bool INVERT, bool EXITS = true, int RG = 0, class Body, class Fin = NoFin>
+GS_DEV void strip_rows(const Strip<INVERT, RG> &S, int y0, int nrows, int lead, RawRow first, Body &&body,
                        Fin fin = Fin()) {
   RawRow raw = first; /* = load(y0 + lead): the newest input row output row 0 needs */
 #if GS_STRIP_PF == 2
@@ -224,18 +285,21 @@ struct SobelKeepCols { /* Fin functor of strip_rows */
   bool first, last;
   uint32_t keep_off;
   uint32_t e = 0; /* dst dword holding the protected byte of the row that is stored next */
-  template <bool RAGGED> GS_DEV SobelKeepCols(const Strip<false, RAGGED> &S) : dst(S.dst), w(S.w), x0(S.x0) {
-    first = x0 == 0, last = x0 + 16 == w; /* launcher guarantees w >= 32: never both; RAGGED: the tail lane ends at w */
-    keep_off = first ? x0 : last ? x0 + 12 : kOOB;
+  bool bytes = false; /* RG 2: one byte at its own address (a dword there would be a misaligned load) */
+  template <int RG> GS_DEV SobelKeepCols(const Strip<false, RG> &S) : dst(S.dst), w(S.w), x0(S.x0) {
+    first = S.in_image() && x0 == 0, last = S.in_image() && x0 + 16 == w; /* launcher guarantees w >= 32: never both; RAGGED: the tail lane ends at w */
+    bytes = RG == 2;
+    keep_off = first ? x0 : last ? x0 + (RG == 2 ? 15u : 12u) : kOOB;
   }
   /* strip_rows calls prefetch(y) in the iteration that COMPUTES row y and operator() in the next
    * one, right before row y is stored (and before the next prefetch): one iteration of latency */
   GS_DEV void prefetch(int y) {
-    e = buf_load4(dst, (uint32_t)y * w + keep_off); /* rows handed in are inside the frame */
+    if (bytes) e = buf_load1(dst, (uint32_t)y * w + keep_off); /* compile-time choice: bytes = (RG == 2) */
+    else e = buf_load4(dst, (uint32_t)y * w + keep_off); /* rows handed in are inside the frame */
   }
   GS_DEV U4 operator()(U4 o, int) const {
     o.x = first ? perm_b32(o.x, e, 0x07060500u) : o.x; /* byte 0 <- dst */
-    o.w = last ? perm_b32(o.w, e, 0x03060504u) : o.w;  /* byte 3 <- dst */
+    o.w = last ? perm_b32(o.w, e, bytes ? 0x00060504u : 0x03060504u) : o.w;  /* byte 3 <- dst */
     return o;
   }
 };

@@ -86,12 +86,30 @@ GS_DEV BufRsrc make_buf(const void *base, size_t bytes) {
 GS_DEV void emu_buf_check(const BufRsrc &b, uint32_t off, uint32_t sz) {
   if (off < b.n && off + sz > b.n) { fprintf(stderr, "emu: partially out-of-range buffer access\n"); abort(); }
 }
+/* multi-dword loads are range-checked per component (dword) like the hardware does: a component that lies wholly
+ * behind the end reads 0, one that straddles the end is an error of the kernel */
 GS_DEV U4 buf_load16(const BufRsrc &b, uint32_t off) {
-  U4 v{0, 0, 0, 0};
-  emu_buf_check(b, off, 16);
-  if (off < b.n) memcpy(&v, b.base + off, 16);
-  return v;
+  uint32_t d[4] = {0, 0, 0, 0};
+  for (uint32_t k = 0; k < 4; k++) {
+    const uint64_t o = (uint64_t)off + 4u * k;
+    if (o >= b.n) continue;
+    emu_buf_check(b, (uint32_t)o, 4);
+    memcpy(&d[k], b.base + o, 4);
+  }
+  return U4{d[0], d[1], d[2], d[3]};
 }
+struct U2 { uint32_t x, y; };
+GS_DEV U2 buf_load8(const BufRsrc &b, uint32_t off) {
+  uint32_t d[2] = {0, 0};
+  for (uint32_t k = 0; k < 2; k++) {
+    const uint64_t o = (uint64_t)off + 4u * k;
+    if (o >= b.n) continue;
+    emu_buf_check(b, (uint32_t)o, 4);
+    memcpy(&d[k], b.base + o, 4);
+  }
+  return U2{d[0], d[1]};
+}
+GS_DEV uint32_t buf_load1(const BufRsrc &b, uint32_t off) { return off < b.n ? b.base[off] : 0u; }
 GS_DEV uint32_t buf_load4(const BufRsrc &b, uint32_t off) {
   uint32_t v = 0;
   emu_buf_check(b, off, 4);
@@ -237,6 +255,15 @@ GS_DEV U4 buf_load16(const BufRsrc &b, uint32_t off) { /* buffer_load_dwordx4 of
 }
 GS_DEV uint32_t buf_load4(const BufRsrc &b, uint32_t off) { /* buffer_load_dword offen */
   return __builtin_amdgcn_raw_buffer_load_b32(b.r, (int)off, 0, GS_LOAD_AUX);
+}
+struct U2 { uint32_t x, y; };
+GS_DEV U2 buf_load8(const BufRsrc &b, uint32_t off) { /* buffer_load_dwordx2 offen */
+  typedef unsigned int gs_u32x2_ __attribute__((ext_vector_type(2)));
+  const gs_u32x2_ v = __builtin_amdgcn_raw_buffer_load_b64(b.r, (int)off, 0, GS_LOAD_AUX);
+  return U2{v.x, v.y};
+}
+GS_DEV uint32_t buf_load1(const BufRsrc &b, uint32_t off) { /* buffer_load_ubyte offen */
+  return (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(b.r, (int)off, 0, GS_LOAD_AUX);
 }
 /* buffer_load_dword v, voff, s[rsrc], soff offen: the wave-uniform part of the address rides in
  * an SGPR, so a gather whose lanes differ only by a fixed per-lane origin needs NO vector ALU

@@ -84,6 +84,7 @@ for (w, h, off) in shapes:
         gbs = 2.0 * n * w * h / ms / 1e6
         print("%-7s %5d %5d %3d %3d %9.4f %8.1f %6.3f   %s" % (name, w, h, off, n, ms, gbs, gbs / 8000, old), flush=True)
 
+if os.environ.get("RG_PART") == "1": sys.exit(0)
 # ---- round 4, second part: gs_integral (banded form), the sliding box, gs_downsample on the same shapes
 print("%-14s %5s %5s %3s %3s %9s %8s %6s   %s" % ("op", "w", "h", "off", "F", "ms", "GB/s(alg)", "frac", "old-rule ms"))
 for (w, h, off, n) in [(3840, 2160, 0, 64), (3838, 2160, 0, 64), (612, 816, 0, 64), (612, 816, 0, 256), (1080, 1920, 0, 64), (1920, 1080, 0, 64), (7680, 4320, 0, 8)]:
