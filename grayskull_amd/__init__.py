@@ -140,6 +140,16 @@ _SIGS = {
     "gsh_downsample_batch": (None, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint]),
     "gsh_synth_batch": (None, [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_uint32]),
     "gsh_checksum_batch": (None, [C.c_void_p, C.c_size_t, C.c_uint, C.c_void_p]),
+    # multi-GPU control plane of one-process host programs (csrc/gs_comm.cpp; RCCL looked up at run time)
+    "gsh_comm_init_all": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int)]),
+    "gsh_comm_destroy_all": (None, [C.POINTER(C.c_void_p), C.c_int]),
+    "gsh_comm_rank": (C.c_int, [C.c_void_p]),
+    "gsh_comm_world": (C.c_int, [C.c_void_p]),
+    "gsh_comm_backend": (C.c_char_p, [C.c_void_p]),
+    "gsh_comm_broadcast": (None, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
+    "gsh_comm_all_gather": (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "gsh_comm_all_reduce_u64": (None, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
+    "gsh_comm_all_reduce_f64": (None, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
 }
 EXPORTED_SYMBOLS = tuple(sorted(_SIGS))
 

@@ -1,0 +1,1137 @@
+/*
+ * gs_detect.cpp -- launchers and C ABI of the detectors of libgrayskull_hip.so: the ordered, capped compaction, gs_fast,
+ * the LBP cascade (gs_lbp_detect / gs_lbp_window), gs_orb_extract and its halves, gs_match_orb.  The only arithmetic done
+ * on the host is what the reference itself delegates to libm (atan2f / sinf, grayskull.h:100-101), the float32 scale
+ * progression of gs_lbp_detect (ref :819-821, :799-804) and the stable sort of <= 5000 candidates (ref :639).
+ */
+#include "gs_internal.h"
+
+#include "k_fast.h"
+#include "k_fast_fused.h"
+#include "k_fast_nms.h"
+#include "k_lbp.h"
+#include "k_lbp_dense.h"
+#include "k_orb.h"
+
+namespace gsi {
+thread_local unsigned long long *g_lbp_evaluated = nullptr;
+}
+
+namespace {
+
+/* ------------------------------------------------------------------ ordered compaction driver */
+template <bool QUAD = false, class F>
+void run_compaction(unsigned long long *mask, unsigned *cnt, unsigned nchunks, unsigned n,
+                    unsigned cap, unsigned *totals_dev, F emit, hipStream_t on = nullptr, unsigned *pfx_in = nullptr) {
+  hipStream_t st = on ? on : ctx().s();
+  if (nchunks <= kEmitSelfScan) { /* FAST on video frames, match: one launch less on a latency-bound tail */
+    GS_LAUNCH((k_emit<F, QUAD>), dim3((nchunks + 3) / 4, n), dim3(256), 0, st,
+              (const unsigned long long *)mask, (const unsigned *)cnt, (const unsigned *)nullptr, nchunks,
+              cap, emit, totals_dev);
+    return;
+  }
+  unsigned *pfx = pfx_in ? pfx_in : (unsigned *)ctx().scratch(SL_PFX, (size_t)n * nchunks * 4);
+  GS_LAUNCH(k_chunk_scan, dim3(n), dim3(1024), 0, st, (const unsigned *)cnt, nchunks, pfx,
+            totals_dev, cap);
+  GS_LAUNCH((k_emit<F, QUAD>), dim3((nchunks + 3) / 4, n), dim3(256), 0, st,
+            (const unsigned long long *)mask, (const unsigned *)cnt, (const unsigned *)pfx, nchunks,
+            cap, emit, (unsigned *)nullptr);
+}
+
+/* ------------------------------------------------------------------ FAST */
+/* gs_fast pass 1 (w, h >= 7, n <= kMaxZ): the LDS-tile kernel by default.  The strip kernel (gsh_tune key 7 = 1)
+ * decides per 256-px row span instead of per 64 px: on 32 x 720p (profiles/r02i_fast_tile.log) it is 1.25x faster on
+ * flat frames (1.6 vs 2.0 us per frame), equal on bright frames and 1.1-1.4x SLOWER on texture and on frames with
+ * large p < t regions (the block-noise frames of configs[3]: there every pixel is a candidate under the reference's
+ * unsigned wrap, and a 256-px span almost always touches one).  Key 7 = 2: one global byte load per ring pixel
+ * (the round-1 form: texture-addresser bound, 4.9 vs 4.2 us per frame). */
+/* zero_words / zero_n: words the default kernel clears on the side (pass 2's chunk counters); returns whether it did */
+bool launch_fast_score(hipStream_t on, const uint8_t *img, uint8_t *score, unsigned w, unsigned h, unsigned n,
+                       unsigned threshold, unsigned *zero_words = nullptr, unsigned zero_n = 0) {
+  const size_t fb = (size_t)w * h;
+  if (g_tune[7] == 1 && w % 4 == 0 && fb < 0x7fffffffull && ((uintptr_t)img & 3) == 0 && ((uintptr_t)score & 3) == 0 &&
+      threshold <= 0xffffff00u) {
+    /* strip kernel: ~6 waves per SIMD when the batch allows, bands of >= 8 rows */
+    const unsigned cw = (w + 255) / 256, rows = h - 6;
+    unsigned long long T = ((unsigned long long)rows * cw * n + 6143) / 6144;
+    T = T < 8 ? 8 : T > 64 ? 64 : T;
+    const unsigned nb = (rows + (unsigned)T - 1) / (unsigned)T;
+    GS_LAUNCH(k_fast_score4, dim3(cw, (nb + 3) / 4, n), dim3(64, 4), 0, on, img, score, w, h, (unsigned)T, fb, threshold);
+  } else if (g_tune[7] == 2) {
+    GS_LAUNCH(k_fast_score_px, grid2d(w - 6, h - 6, n), dim3(64, 4), 0, on, img, score, w, h, fb, threshold);
+  } else if (g_tune[7] == 3) {
+    /* LDS tile + block-local candidate queue: measured and NOT the default (profiles/r03i_fast_candidate_queue.log, 32 x 720p
+     * score pass): block noise 72.7 -> 69.9 us, tiled lena 109 -> 92, but +8 % on bright noise, flat and random frames --
+     * half of the pass is the tile load, the compass filter and the byte stores, which the queue does not touch */
+    GS_LAUNCH(k_fast_score_cq, dim3((w - 6 + 63) / 64, (h - 6 + kFastTileRows - 1) / kFastTileRows, n), dim3(64, 4), 0, on,
+              img, score, w, h, fb, threshold);
+  } else if (g_tune[7] == 4 || threshold > 0xffffff00u) { /* round-2 default: one pixel per lane, whole wave rows scored */
+    GS_LAUNCH(k_fast_score_tile, dim3((w - 6 + 63) / 64, (h - 6 + kFastTileRows - 1) / kFastTileRows, n), dim3(64, 4), 0, on,
+              img, score, w, h, fb, threshold);
+  } else { /* LDS tile, 4 px per thread through the compass filter, candidates queued (k_fast.h) */
+    const unsigned tx = (w - 6 + 63) / 64, ty = (h - 6 + kFastTileRows - 1) / kFastTileRows;
+    const unsigned long long nt = (unsigned long long)tx * ty * n;
+    GS_ASSERT(nt <= 0x7ffffff0ull); /* 2^31 tiles = 2^41 pixels in one call */
+    const unsigned share = (g_tune[18] == 1 || !topo().eight_xcds()) ? 0u : (unsigned)((nt + 7) / 8); /* key 18 = 1: tiles in launch order */
+    GS_LAUNCH(k_fast_score_q4, dim3(share ? share * 8u : (unsigned)nt), dim3(64, 4), 0, on, img, score, w, h, fb, threshold, tx,
+              ty, (unsigned)nt, share, zero_words, zero_n);
+    return true;
+  }
+  return false;
+}
+
+/* clip_w / clip_h (single frame only): the caller's score map is smaller than the image; positions
+ * outside it read 0 in the NMS pass like gs_get does (ref :524) */
+void launch_fast(const uint8_t *img, uint8_t *score, unsigned w, unsigned h, unsigned n,
+                 unsigned *kps, unsigned *counts, unsigned nkps, unsigned threshold, unsigned clip_w = 0,
+                 unsigned clip_h = 0) {
+  hipStream_t st = ctx().s();
+  if (n == 0) return;
+  if (n > kMaxZ) { /* grid.y / grid.z carry the frame index: split like every other launcher */
+    for (unsigned f0 = 0; f0 < n; f0 += kMaxZ)
+      launch_fast(img + (size_t)w * h * f0, score + (size_t)w * h * f0, w, h, std::min(kMaxZ, n - f0),
+                  kps + (size_t)f0 * nkps * 12, counts + f0, nkps, threshold);
+    return;
+  }
+  if (w < 7 || h < 7) { /* reference loops are empty for 3 <= dim < 7 */
+    GS_HIP(hipMemsetAsync(counts, 0, (size_t)n * 4, st));
+    return;
+  }
+  const size_t fb = (size_t)w * h;
+  /* key 7 = 6: both passes in one walk (k_fast_fused.h).  Measured and NOT the default: 32 x 720p block noise 127 us against
+   * 63 + 23 for the two passes below -- the walk executes 50 M VALU + 21 M SALU wave-instructions where the two passes
+   * execute 40 M + 18 M (ownership / interior masks, the border handling of the score tile, three barriers per step) at
+   * 4 waves per SIMD instead of 8 (profiles/r03t_fast_fused_not_kept.log, r03u_pmc_fast_fused.txt). */
+  if (g_tune[7] == 6 && g_tune[19] != 1 && threshold <= 0xffffff00u && !(clip_w && n == 1 && (clip_w < w || clip_h < h)) &&
+      (unsigned long long)((w + 63) / 64) * 64 * h < (1ull << 32)) {
+    const unsigned wpr = (w + 63) / 64, nwords = wpr * h, nchunks = (nwords + kChunkWords - 1) / kChunkWords;
+    unsigned long long *mask = (unsigned long long *)ctx().scratch(SL_MASK, (size_t)n * nchunks * kChunkWords * 8);
+    unsigned *cnt = (unsigned *)ctx().scratch(SL_CNT, (size_t)n * nchunks * 4);
+    unsigned *pfx = (unsigned *)ctx().scratch(SL_PFX, (size_t)n * nchunks * 4);
+    GS_HIP(hipMemsetAsync(mask, 0, (size_t)n * nchunks * kChunkWords * 8, st));
+    GS_HIP(hipMemsetAsync(cnt, 0, (size_t)n * nchunks * 4, st));
+    /* bands of 16 m - 2 rows: ~4 rounds of the 2048 blocks the chip holds, at least 30 rows (2 of every 16 m score rows
+     * are computed twice), at most 254 */
+    const unsigned strips = (w - 6 + kFfCols - 1) / kFfCols, rows = h - 6;
+    const unsigned long long cols = (unsigned long long)strips * n;
+    const unsigned want = (unsigned)std::max<unsigned long long>(1, 8192 / cols);
+    unsigned m = g_tune[0] > 0 ? (unsigned)g_tune[0] : (rows / want + 2 + 15) / 16;
+    m = std::max(2u, std::min(16u, m));
+    const unsigned bands = (rows + 16 * m - 3) / (16 * m - 2);
+    const unsigned long long nt = cols * bands;
+    GS_ASSERT(nt <= 0x7ffffff0ull);
+    const unsigned share = (g_tune[18] == 1 || !topo().eight_xcds()) ? 0u : (unsigned)((nt + 7) / 8);
+    FastFusedArgs fa{img, score, w, h, fb, threshold, strips, bands, m, (unsigned)nt, share, mask, cnt, wpr, nchunks};
+    GS_LAUNCH(k_fast_fused, dim3(share ? share * 8u : (unsigned)nt), dim3(64, 4), 0, st, fa);
+    run_compaction(mask, cnt, nchunks, n, nkps, counts,
+                   FastEmitPadded{score, w, wpr * 64u, fb, kps, nkps, ((uintptr_t)kps & 15) == 0}, st, pfx);
+    return;
+  }
+  /* pass 2 in strip form (k_fast_nms.h) when the score map qualifies for the strip machinery: items numbered over
+   * rows padded to whole mask words.  Key 19 = 1: the item-by-item kernel k_fast_nms (round 2). */
+  if (g_tune[19] != 1 && strip_ok(w, h, score, score) && w >= 32 && (unsigned long long)((w + 63) / 64) * 64 * h < (1ull << 32)) {
+    const unsigned wpr = (w + 63) / 64, nwords = wpr * h, nchunks = (nwords + kChunkWords - 1) / kChunkWords;
+    unsigned long long *mask = (unsigned long long *)ctx().scratch(SL_MASK, (size_t)n * nchunks * kChunkWords * 8);
+    unsigned *cnt = (unsigned *)ctx().scratch(SL_CNT, (size_t)n * nchunks * 4);
+    unsigned *pfx = (unsigned *)ctx().scratch(SL_PFX, (size_t)n * nchunks * 4);
+    /* the default score kernel zeroes the chunk counters on the side (a fill launch costs 5 us of a 100-us call) */
+    GS_ASSERT((unsigned long long)n * nchunks < (1ull << 32)); /* n <= 65535 frames of < 2^32 padded items */
+    const bool zeroed = launch_fast_score(st, img, score, w, h, n, threshold, cnt, n * nchunks);
+    if (clip_w && n == 1 && (clip_w < w || clip_h < h))
+      GS_LAUNCH(k_fast_clip, grid2d(w, h, 1), dim3(64, 4), 0, st, score, w, h, clip_w, clip_h);
+    if (!zeroed) GS_HIP(hipMemsetAsync(cnt, 0, (size_t)n * nchunks * 4, st));
+    for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
+      const unsigned nn = std::min(kMaxZ, n - f0);
+      const StripCfg c = strip_cfg(w, h - 6, nn);
+      GS_LAUNCH(k_fast_nms16, c.grid, c.block, 0, st, (const uint8_t *)score + fb * f0, w, h, c.T, fb | c.xcd_flag,
+                mask + (size_t)f0 * nchunks * kChunkWords, cnt + (size_t)f0 * nchunks, wpr, nchunks);
+    }
+    /* (Tried and not kept: eight chunks per emit wave -- fewer waves, loads batched -- 19 -> 33 us per 32 x 720p: the pass is
+     * one wave's latency chain, and 14,464 small waves hide it better than 1,808 long ones.  Bands of 16 rows for the NMS
+     * kernel: 23.6 -> 25 us.  profiles/r03m_fast_emit_not_kept.log) */
+    run_compaction(mask, cnt, nchunks, n, nkps, counts,
+                   FastEmitPadded{score, w, wpr * 64u, fb, kps, nkps, ((uintptr_t)kps & 15) == 0}, st, pfx);
+    return;
+  }
+  launch_fast_score(st, img, score, w, h, n, threshold);
+  const unsigned nitems = (w - 6) * (h - 6);
+  const unsigned nchunks = (nitems + kChunkItems - 1) / kChunkItems;
+  unsigned long long *mask =
+      (unsigned long long *)ctx().scratch(SL_MASK, (size_t)n * nchunks * kChunkWords * 8);
+  unsigned *cnt = (unsigned *)ctx().scratch(SL_CNT, (size_t)n * nchunks * 4);
+  unsigned *pfx = (unsigned *)ctx().scratch(SL_PFX, (size_t)n * nchunks * 4);
+  /* row = item / (w-6) by multiplication where the magic fits (see div_by) */
+  const unsigned iw = w - 6;
+  const unsigned magic = (iw > 256 && iw <= 8192 && (unsigned long long)iw * (h - 6) <= (1ull << 26))
+                             ? (unsigned)(((1ull << 40) + iw - 1) / iw) : 0u;
+  /* NMS flags, chunk scan, ordered emit of frames [f0, f0 + nn) on stream `on` */
+  auto rest = [&](hipStream_t on, unsigned f0, unsigned nn) {
+    if (clip_w && n == 1 && (clip_w < w || clip_h < h))
+      GS_LAUNCH(k_fast_clip, grid2d(w, h, 1), dim3(64, 4), 0, on, score, w, h, clip_w, clip_h);
+    unsigned *c = cnt + (size_t)f0 * nchunks; /* k_fast_nms stores every chunk's count: no zeroing */
+    GS_LAUNCH(k_fast_nms, dim3(nchunks, nn), dim3(256), 0, on, (const uint8_t *)score + fb * f0, w, h, fb,
+              mask + (size_t)f0 * nchunks * kChunkWords, c, nchunks, magic);
+    run_compaction</*QUAD=*/true>(mask + (size_t)f0 * nchunks * kChunkWords, c, nchunks, nn, nkps, counts + f0, /* k_fast_nms: 4 items per lane */
+                                  FastEmit{score + fb * f0, w, fb, kps + (size_t)f0 * nkps * 12, nkps, ((uintptr_t)kps & 15) == 0}, on,
+                                  pfx + (size_t)f0 * nchunks);
+  };
+  /* Tried and not kept: cutting a batch into 2-8 groups of frames and running group i's NMS / scan / emit on the side
+   * stream under group i+1's score pass.  The cross-stream event hops cost more than the ~60 us of small passes
+   * they could hide: 32 x 720p 4.2 us per frame in one piece, 5.1 in two, 6.8 in four (profiles/r02i_fast_groups_not_kept.log). */
+  rest(st, 0, n);
+}
+
+/* ------------------------------------------------------------------ LBP cascade */
+}  // namespace
+
+struct gsh_cascade {
+  unsigned window_w, window_h, nfeatures, nweaks, nstages, nsub = 0;
+  std::vector<int8_t> features;
+  std::vector<uint16_t> weak_feature_idx;
+  LbpWeak *d_weak = nullptr;
+  LbpStage *d_stage = nullptr;
+  int32_t *d_subsets = nullptr;
+  unsigned *d_pass_lut = nullptr; /* per stage: truth table of the stage decision over its match bits (k_lbp_dense.h) */
+  unsigned pre_max = 0;           /* leading stages with <= kPreMaxWeaks weak classifiers */
+  unsigned long long id = 0; /* unique per handle: key of the calling threads' geometry caches */
+};
+
+namespace gsi {
+/* the device tables of a handle, without touching any context (used while a context is being released) */
+void gsh_cascade_tables_deleter::operator()(gsh_cascade *dc) const {
+  (void)hipFree(dc->d_weak), (void)hipFree(dc->d_stage), (void)hipFree(dc->d_subsets), (void)hipFree(dc->d_pass_lut);
+  delete dc;
+}
+}  // namespace gsi
+
+namespace {
+
+/* The reference's scale loop and per-feature truncation (ref :819-821, :799-804), float32. */
+void build_scales(const gsh_cascade &c, unsigned iw, unsigned ih, float scale_factor,
+                  float min_scale, float max_scale, int step, std::vector<LbpScale> &scales,
+                  std::vector<LbpGeom> &geom, bool &guard, unsigned long long &nwin,
+                  unsigned long long *max_cell_px = nullptr) {
+  scales.clear();
+  geom.clear();
+  guard = false;
+  nwin = 0;
+  unsigned chunk_base = 0;
+  const unsigned S = iw + 1;
+  for (float scale = min_scale; scale <= max_scale; scale *= scale_factor) {
+    const int win_w = (int)((int)c.window_w * scale), win_h = (int)((int)c.window_h * scale);
+    if (win_w > (int)iw || win_h > (int)ih) break;
+    LbpScale sc;
+    sc.win_w = win_w, sc.win_h = win_h;
+    sc.nx = ((unsigned)((int)iw - win_w)) / (unsigned)step + 1;
+    sc.ny = ((unsigned)((int)ih - win_h)) / (unsigned)step + 1;
+    sc.chunk_base = chunk_base;
+    sc.nchunks = (sc.nx * sc.ny + kChunkItems - 1) / kChunkItems;
+    chunk_base += sc.nchunks;
+    nwin += (unsigned long long)sc.nx * sc.ny;
+    for (unsigned wi = 0; wi < c.nweaks; wi++) {
+      const int fi = c.weak_feature_idx[wi];
+      int fx = (int)((int)c.features[fi * 4 + 0] * scale);
+      int fy = (int)((int)c.features[fi * 4 + 1] * scale);
+      int fw = (int)((int)c.features[fi * 4 + 2] * scale);
+      int fh = (int)((int)c.features[fi * 4 + 3] * scale);
+      if (fw < 1) fw = 1;
+      if (fh < 1) fh = 1;
+      if (fx < 0 || fy < 0 || fx + 3 * fw > win_w || fy + 3 * fh > win_h) guard = true;
+      geom.push_back(LbpGeom{(fy * (int)S + fx) * 4, fw * 4, fh * (int)S * 4, fh});
+      if (max_cell_px) *max_cell_px = std::max(*max_cell_px, (unsigned long long)fw * (unsigned long long)fh);
+    }
+    scales.push_back(sc);
+    if (scales.size() >= 4096 || !(scale_factor > 1.0f)) break; /* the reference would not terminate */
+  }
+}
+
+LbpGeomCache &cascade_prepare(const gsh_cascade *dc, unsigned iw, unsigned ih, float sf, float mn, float mx,
+                              int step) {
+  Ctx &cx = ctx();
+  if (cx.geom_cache.size() > 16 && !cx.geom_cache.count(dc->id)) { /* handles come and go: bound the cache */
+    cx.sync();
+    cx.drop_geom();
+  }
+  LbpGeomCache &gc = cx.geom_cache[dc->id];
+  if (gc.iw == iw && gc.ih == ih && gc.sf == sf && gc.mn == mn && gc.mx == mx && gc.step == step && gc.d_scales)
+    return gc;
+  std::vector<LbpGeom> geom;
+  gc.max_cell_px = 0;
+  build_scales(*dc, iw, ih, sf, mn, mx, step, gc.scales, geom, gc.guard, gc.nwindows, &gc.max_cell_px);
+  cx.sync(); /* tables may be in use by an earlier launch of this thread */
+  const size_t sb = std::max<size_t>(1, gc.scales.size()) * sizeof(LbpScale);
+  const size_t gb = std::max<size_t>(1, geom.size()) * sizeof(LbpGeom);
+  if (gc.d_scales_cap < sb) {
+    if (gc.d_scales) GS_HIP(hipFree(gc.d_scales));
+    GS_HIP(hipMalloc((void **)&gc.d_scales, sb));
+    gc.d_scales_cap = sb;
+  }
+  if (gc.d_geom_cap < gb) {
+    if (gc.d_geom) GS_HIP(hipFree(gc.d_geom));
+    GS_HIP(hipMalloc((void **)&gc.d_geom, gb));
+    gc.d_geom_cap = gb;
+  }
+  if (!gc.scales.empty()) {
+    GS_HIP(hipMemcpy(gc.d_scales, gc.scales.data(), gc.scales.size() * sizeof(LbpScale), hipMemcpyHostToDevice));
+    GS_HIP(hipMemcpy(gc.d_geom, geom.data(), geom.size() * sizeof(LbpGeom), hipMemcpyHostToDevice));
+  }
+  gc.total_chunks = 0, gc.max_chunks = 0;
+  for (auto &sc : gc.scales) {
+    gc.total_chunks += sc.nchunks;
+    gc.max_chunks = std::max(gc.max_chunks, sc.nchunks);
+  }
+  /* prefilter layout: one bit per window, window rows padded to whole u64 words; 64 x 64-window tiles */
+  gc.pre_words = 0, gc.max_tiles = 0;
+  if (step == 1 && !gc.scales.empty()) {
+    std::vector<LbpPreScale> pre;
+    for (auto &sc : gc.scales) {
+      LbpPreScale ps;
+      ps.word_base = gc.pre_words, ps.wpr = (sc.nx + 63u) / 64u, ps.tiles_x = ps.wpr;
+      ps.ntiles = ps.tiles_x * ((sc.ny + kPreTile - 1u) / kPreTile), ps.pad = 0;
+      gc.pre_words += (unsigned long long)ps.wpr * sc.ny;
+      gc.max_tiles = std::max(gc.max_tiles, ps.ntiles);
+      pre.push_back(ps);
+    }
+    const size_t pb = pre.size() * sizeof(LbpPreScale);
+    if (gc.d_pre_cap < pb) {
+      if (gc.d_pre) GS_HIP(hipFree(gc.d_pre));
+      GS_HIP(hipMalloc((void **)&gc.d_pre, pb));
+      gc.d_pre_cap = pb;
+    }
+    GS_HIP(hipMemcpy(gc.d_pre, pre.data(), pb, hipMemcpyHostToDevice));
+  }
+  gc.iw = iw, gc.ih = ih, gc.sf = sf, gc.mn = mn, gc.mx = mx, gc.step = step;
+  return gc;
+}
+
+/* padded: n frames of (iw+1)*(ih+1) u32 on device */
+void launch_lbp_padded(const gsh_cascade *dc, const LbpGeomCache &gc, const unsigned *padded, unsigned iw,
+                       unsigned ih, unsigned n, unsigned *rects, unsigned *counts, unsigned max_rects,
+                       int step, const unsigned *not_integral) {
+  hipStream_t st = ctx().s();
+  if (gc.scales.empty() || max_rects == 0) {
+    GS_HIP(hipMemsetAsync(counts, 0, (size_t)n * 4, st));
+    return;
+  }
+  const unsigned nch = gc.total_chunks;
+  unsigned long long *mask =
+      (unsigned long long *)ctx().scratch(SL_MASK, (size_t)n * nch * kChunkWords * 8);
+  const unsigned nsc0 = (unsigned)gc.scales.size();
+  /* chunk counters, then the early-exit counters: one per group of 32 chunks, one per 1024 */
+  const unsigned ngroups = (nch >> kLbpGroupShift) + 1, nsupers = (nch >> kLbpSuperShift) + 1;
+  const size_t ncnt = (size_t)n * nch + (size_t)n * ngroups + (size_t)n * nsupers + n;
+  unsigned *cnt = (unsigned *)ctx().scratch(SL_CNT, ncnt * 4);
+  GS_HIP(hipMemsetAsync(cnt, 0, ncnt * 4, st));
+  GS_HIP(hipMemsetAsync(mask, 0, (size_t)n * nch * kChunkWords * 8, st));
+  LbpArgs a;
+  a.hits_group = cnt + (size_t)n * nch;
+  a.hits_super = a.hits_group + (size_t)n * ngroups;
+  a.hits_total = a.hits_super + (size_t)n * nsupers;
+  a.scale0 = 0;
+  a.ngroups = ngroups, a.nsupers = nsupers;
+  a.evaluated = g_lbp_evaluated;
+  a.nscales = nsc0, a.cap = max_rects;
+  a.nwindows_cap = (unsigned)std::min<unsigned long long>(gc.nwindows, 0xffffffffull);
+  a.padded = padded;
+  a.frame_stride = (size_t)(iw + 1) * (ih + 1);
+  a.S = iw + 1;
+  a.limit_bytes = (unsigned)((a.frame_stride - 1) * 4);
+  a.step = step;
+  a.nweaks = dc->nweaks, a.nstages = dc->nstages, a.nsub = dc->nsub;
+  a.scales = gc.d_scales, a.geom = gc.d_geom, a.weak = dc->d_weak, a.stage = dc->d_stage;
+  a.subsets = dc->d_subsets;
+  a.mask = mask, a.chunk_count = cnt, a.total_chunks = nch;
+  a.pre_bitmap = nullptr, a.pre_scales = gc.d_pre, a.pre_words = gc.pre_words, a.pre_stages = 0;
+  const unsigned nsc = (unsigned)gc.scales.size();
+  /* XCD-aware chunk mapping (k_lbp.h) once the integral image no longer fits one XCD's 4 MB L2: 1080p -3 %, 4K block
+   * noise -4 %, 4K edge maps -12 % (5.76 -> 5.08 ms per frame); 720p (3.7 MB) is 1-4 % better off in dispatch order
+   * (profiles/r02l_lbp_xcd.log).  Key 13: 1 = never, 2 = always. */
+  a.xcd_swizzle = g_tune[13] == 1 ? 0u : g_tune[13] == 2 ? 1u : ((a.frame_stride * 4 >= (size_t)6 << 20 && topo().eight_xcds()) ? 1u : 0u);
+  const size_t lds = (size_t)dc->nstages * sizeof(LbpStage) +
+                     (size_t)dc->nweaks * (sizeof(LbpWeak) + sizeof(LbpGeom)) + (size_t)dc->nsub * 4;
+  GS_ASSERT(lds <= 60 * 1024 && "cascade tables must fit the block's LDS");
+  /* phases of the block-local survivor re-packing: g_tune[4] selects a preset */
+  LbpPhases ph;
+  {
+    static const unsigned presets[8][kLbpMaxPhases] = {
+        {2, 4, 7, 99, 99, 99, 99, 99},    /* 0 default (measured best on MI355X, frontalface) */
+        {99, 99, 99, 99, 99, 99, 99, 99}, /* 1: single dense phase (no re-packing) */
+        {1, 2, 4, 6, 9, 13, 99, 99},
+        {1, 2, 3, 4, 6, 8, 12, 99},
+        {1, 2, 5, 99, 99, 99, 99, 99},
+        {2, 5, 99, 99, 99, 99, 99, 99},
+        {2, 6, 99, 99, 99, 99, 99, 99},
+        {3, 7, 99, 99, 99, 99, 99, 99}};
+    unsigned custom[kLbpMaxPhases];
+    const unsigned *pr = presets[(g_tune[4] >= 0 && g_tune[4] < 8) ? g_tune[4] : 0];
+    if (g_tune[4] >= 1000) { /* experiments: 1000 + e0 + 32 e1 + 1024 e2 + 32768 e3 (0 = no further split) */
+      unsigned v = (unsigned)g_tune[4] - 1000u;
+      for (unsigned i = 0; i < kLbpMaxPhases; i++, v >>= 5) custom[i] = (v & 31u) ? (v & 31u) : 99u;
+      pr = custom;
+    }
+    ph.n = 0;
+    unsigned prev = 0;
+    for (unsigned i = 0; i < kLbpMaxPhases && prev < dc->nstages; i++) {
+      const unsigned e = (i + 1 == kLbpMaxPhases) ? dc->nstages : std::min(pr[i], dc->nstages);
+      if (e <= prev) continue;
+      ph.end[ph.n++] = e, prev = e;
+    }
+    if (ph.n == 0) ph.n = 1, ph.end[0] = dc->nstages;
+    ph.end[ph.n - 1] = dc->nstages;
+    /* preset 0 (default): first re-packing point chosen per block between stages 2 and 8 (k_lbp.h) */
+    ph.adaptive_max = (g_tune[4] == 0 && dc->nstages > 2) ? 8u : 0u; /* 6 .. 15 within 1.5 % (profiles/r02l_lbp_adaptive_xcd.log) */
+    ph.adaptive_tenths = 2u;
+    ph.quad = g_tune[17] == 1 ? 0u : 1u; /* key 17 = 1: one lane per re-packed window (the round-2 form) */
+    /* with quad-lane survivors (profiles/r03f_lbp_adaptive_quad.log, r03k_lbp_adaptive_next.log): +1 +2 +4 is best on
+     * block noise (8 x 1080p 0.76 vs 0.80 ms for +1 +3 +6, 4K 3.15 vs 3.17) and within 0.5 % of the best on edge maps */
+    ph.adaptive_next[0] = 1u, ph.adaptive_next[1] = 2u, ph.adaptive_next[2] = 4u;
+    if (ph.adaptive_max && g_tune[9] > 0) { /* experiments: key 9 = max + 16 * tenths (+ 256 d1 + 4096 d2 + 65536 d3: later points) */
+      const unsigned v = (unsigned)g_tune[9];
+      ph.adaptive_max = v & 15u, ph.adaptive_tenths = (v >> 4) & 15u;
+      if (v >> 8) ph.adaptive_next[0] = (v >> 8) & 15u, ph.adaptive_next[1] = (v >> 12) & 15u, ph.adaptive_next[2] = (v >> 16) & 15u;
+    }
+  }
+  const size_t lds_all = ((lds + 15) & ~(size_t)15) + 2 * kChunkItems * 2 + 64 * 4 + 16;
+  /* Prefilter (k_lbp_dense.h, OPTIONAL, key 14 = k > 0: that many stages; default off): stages [0, pre) for every
+   * window with the table rows shared down the columns of 64 x 64-window tiles; the cascade kernel then starts from
+   * the surviving set.  Needs unit step, in-window geometry, the adaptive preset and stages of <= 5 weak classifiers.
+   * Measured (profiles/r03a_lbp_prefilter_first.log, r03d_pmc_lbp.txt): 2.8x fewer gather instructions per weak
+   * classifier, but 0.22 ms per classifier and 4K frame against 0.18 for the dense phase of k_lbp_cascade -- ~1000
+   * tiles per XCD walk 64-row bands of the table at once, half their L2 requests miss (the cascade kernel's chunks
+   * stay inside a 3 MB band: 1 % misses) and the texture path stalls on pending misses half the time.
+   * The prefilter cannot see detections of its own launch, so the scales are issued in GROUPS (prefilter, then
+   * cascade, group after group on the stream): a group's tiles skip once the groups before it hold max_rects
+   * detections -- the reference stops scanning there (ref :819-823) -- while the chunk-granular exit inside the
+   * cascade kernel stays as it was.  A group is at least ~16 M windows (key 15 overrides, a test hook), so a
+   * launch always fills the chip: 8 x 4K = one scale per group, one 1080p frame = two groups. */
+  const int k14 = g_tune[14] >= 100 ? g_tune[14] - 100 : g_tune[14];
+  unsigned pre = k14 > 0 ? (unsigned)k14 : 0u; /* off by default: measured slower than the dense phase it replaces (see above) */
+  pre = std::min(pre, std::min(dc->pre_max, dc->nstages > 0 ? dc->nstages - 1u : 0u));
+  if (step != 1 || gc.guard || !ph.adaptive_max || !gc.d_pre || !dc->d_pass_lut || a.frame_stride * 4 >= (1ull << 31)) pre = 0;
+  LbpPreArgs pa;
+  pa.pass_lut = dc->d_pass_lut, pa.bitmap = nullptr, pa.xcd_swizzle = a.xcd_swizzle;
+  pa.not_integral = not_integral;
+  /* sign-bit compares (k_lbp_dense.h: lbp_code8) need every cell sum < 2^31: cells of the prefiltered classifiers
+   * cover at most max_cell_px pixels of <= 255 each.  Key 14 + 100 forces the general compare (A/B, tests). */
+  pa.small_cells = (not_integral && gc.max_cell_px < (1ull << 31) / 255ull && g_tune[14] < 100) ? 1u : 0u;
+  if (pre) {
+    pa.bitmap = (unsigned long long *)ctx().scratch(SL_PRE, (size_t)n * gc.pre_words * 8);
+    a.pre_bitmap = pa.bitmap, a.pre_stages = pre;
+  }
+  const unsigned long long group_windows = g_tune[15] > 0 ? (unsigned long long)g_tune[15] : 16ull << 20;
+  for (unsigned s0 = 0; s0 < nsc;) {
+    unsigned s1 = s0;
+    unsigned long long wsum = 0;
+    unsigned mc = 0, mt = 0;
+    do {
+      wsum += (unsigned long long)n * gc.scales[s1].nx * gc.scales[s1].ny;
+      mc = std::max(mc, gc.scales[s1].nchunks);
+      mt = std::max(mt, (gc.scales[s1].nx + 63u) / 64u * ((gc.scales[s1].ny + kPreTile - 1u) / kPreTile));
+      s1++;
+    } while (pre && s1 < nsc && wsum < group_windows);
+    if (!pre) /* no prefilter: one launch over all scales, as before */
+      for (; s1 < nsc; s1++) mc = std::max(mc, gc.scales[s1].nchunks);
+    a.scale0 = s0;
+    if (pre) {
+      const unsigned nblk = (mt + 3u) / 4u;
+      const dim3 gd(pa.xcd_swizzle ? (nblk + 7u) & ~7u : nblk, s1 - s0, n);
+      if (a.evaluated) GS_LAUNCH(k_lbp_dense<true>, gd, dim3(256), lds + 16, st, a, pa);
+      else GS_LAUNCH(k_lbp_dense<false>, gd, dim3(256), lds + 16, st, a, pa);
+    }
+    const dim3 g(a.xcd_swizzle ? (mc + 7u) & ~7u : mc, s1 - s0, n);
+    if (a.evaluated) { /* counting build: the same kernel + one register that counts classifier evaluations */
+      if (gc.guard) GS_LAUNCH((k_lbp_cascade<true, true>), g, dim3(256), lds_all, st, a, ph);
+      else GS_LAUNCH((k_lbp_cascade<false, true>), g, dim3(256), lds_all, st, a, ph);
+    } else if (gc.guard) GS_LAUNCH(k_lbp_cascade<true>, g, dim3(256), lds_all, st, a, ph);
+    else GS_LAUNCH(k_lbp_cascade<false>, g, dim3(256), lds_all, st, a, ph);
+    s0 = s1;
+  }
+  if (g_tune[16] == 1) return; /* timing aid (scripts/bench_lbp_stages.py): the cascade kernels alone, no rect emission */
+  run_compaction(mask, cnt, nch, n, max_rects, counts,
+                 LbpEmit{gc.d_scales, (unsigned)gc.scales.size(), step, rects, max_rects});
+}
+
+constexpr unsigned kLbpGroup = 8; /* frames per cascade launch (bounds mask/padded scratch) */
+
+void launch_lbp_unpadded(const gsh_cascade *dc, const unsigned *ii, unsigned iw, unsigned ih, unsigned n,
+                         unsigned *rects, unsigned *counts, unsigned max_rects, float sf, float mn,
+                         float mx, int step) {
+  GS_ASSERT(step > 0);
+  const LbpGeomCache &gc = cascade_prepare(dc, iw, ih, sf, mn, mx, step);
+  hipStream_t st = ctx().s();
+  const size_t fp = (size_t)iw * ih, pp = (size_t)(iw + 1) * (ih + 1);
+  for (unsigned f0 = 0; f0 < n; f0 += kLbpGroup) {
+    const unsigned nn = std::min(kLbpGroup, n - f0);
+    unsigned *padded = (unsigned *)ctx().scratch(SL_PAD, pp * 4 * nn);
+    /* "is this table an integral image of bytes" is only asked by the optional stage prefilter (key 14 > 0): without it
+     * the padding pass skips the three extra table loads per element and the flag buffer is never touched */
+    unsigned *notii = nullptr;
+    if (g_tune[14] > 0) {
+      notii = (unsigned *)ctx().scratch(SL_NOTII, (size_t)nn * 4);
+      GS_HIP(hipMemsetAsync(notii, 0, (size_t)nn * 4, st));
+    }
+    launch_integral_pad(dim3((iw + 64) / 64, (ih + 4) / 4, nn), st, ii + fp * f0, iw, ih, padded, notii);
+    launch_lbp_padded(dc, gc, padded, iw, ih, nn, rects + (size_t)f0 * max_rects * 4, counts + f0,
+                      max_rects, step, notii);
+  }
+}
+
+/* one window on a (win_w+1) x (win_h+1) table: grid 1, block 64, lane 0 decides */
+__global__ void k_lbp_single(LbpArgs a, const LbpGeom *geom, unsigned *out) {
+#ifndef GS_EMU
+#pragma clang fp contract(off)
+#endif
+  GS_DYN_LDS(smem);
+  const LbpLds t = lbp_stage_tables(smem, a, geom, threadIdx.x, 64u);
+  __syncthreads();
+  if (threadIdx.x == 0)
+    out[0] = lbp_window_stages<true>(t, a.padded, 0u, a.limit_bytes, 0u, a.nstages) ? 1u : 0u;
+}
+
+/* ------------------------------------------------------------------ ORB host logic */
+
+/* gs_orb_extract (ref :651-669) for up to 4 independent images (pyramid levels) with TWO host round
+ * trips in total: (1) FAST + NMS + ordered emit + disc moments of every candidate slot, per level,
+ * then one copy-back of counts + records + moments; host: stable sort (desc response, ref :639),
+ * 15-px border filter, atan2f / sinf from libm (ref :100-101); (2) BRIEF for the kept keypoints of
+ * all levels, one copy-back of the descriptors. */
+struct OrbLevel {
+  const uint8_t *img;
+  unsigned w, h;
+  uint8_t *score;
+  gs_keypoint *out; /* host */
+  unsigned nkps;    /* wanted */
+  unsigned got;
+};
+
+void orb_extract_levels(OrbLevel *L, unsigned nl, unsigned threshold) {
+  hipStream_t st = ctx().s();
+  unsigned cap[4], coff[4], ctot = 0;
+  for (unsigned l = 0; l < nl; l++) {
+    cap[l] = (L[l].nkps && L[l].w >= 7 && L[l].h >= 7) ? std::min(L[l].nkps * 4u, 5000u) : 0u;
+    coff[l] = ctot, ctot += cap[l], L[l].got = 0;
+  }
+  if (!ctot) return;
+  unsigned *kps = (unsigned *)ctx().scratch(SL_KPS, (size_t)ctot * 48 + 16);
+  unsigned *cnt = (unsigned *)ctx().scratch(SL_TOT, 16);
+  int *mom = (int *)ctx().scratch(SL_MOM, (size_t)ctot * 8);
+  for (unsigned l = 0; l < nl; l++) {
+    if (!cap[l]) continue;
+    launch_fast(L[l].img, L[l].score, L[l].w, L[l].h, 1, kps + (size_t)coff[l] * 12, cnt + l, cap[l], threshold);
+    /* moments of every candidate slot (blocks beyond the device-side count exit) */
+    GS_LAUNCH(k_orient_moments, dim3(cap[l]), dim3(64), 0, st, L[l].img, L[l].w, L[l].h,
+              (const unsigned *)(kps + (size_t)coff[l] * 12), 12u, 15u, mom + (size_t)coff[l] * 2,
+              (const unsigned *)(cnt + l));
+  }
+  std::vector<unsigned> hk((size_t)ctot * 12);
+  std::vector<int> hm((size_t)ctot * 2);
+  unsigned hn[4] = {0, 0, 0, 0};
+  GS_HIP(hipMemcpyAsync(hn, cnt, 16, hipMemcpyDeviceToHost, st));
+  GS_HIP(hipMemcpyAsync(hk.data(), kps, (size_t)ctot * 48, hipMemcpyDeviceToHost, st));
+  GS_HIP(hipMemcpyAsync(hm.data(), mom, (size_t)ctot * 8, hipMemcpyDeviceToHost, st));
+  ctx().sync();
+  /* host half of ref :657-667 */
+  struct Cand { unsigned x, y, response; int m01, m10; };
+  std::vector<KpIn> kin;
+  unsigned koff[4], ktot = 0;
+  const unsigned r = 15;
+  for (unsigned l = 0; l < nl; l++) {
+    koff[l] = ktot;
+    if (!cap[l]) continue;
+    const unsigned n = std::min(hn[l], cap[l]);
+    std::vector<Cand> cand(n);
+    for (unsigned i = 0; i < n; i++) {
+      const size_t q = (size_t)coff[l] + i;
+      cand[i] = Cand{hk[q * 12], hk[q * 12 + 1], hk[q * 12 + 2], hm[2 * q], hm[2 * q + 1]};
+    }
+    std::stable_sort(cand.begin(), cand.end(),
+                     [](const Cand &a, const Cand &b) { return a.response > b.response; });
+    unsigned kept = 0;
+    for (size_t i = 0; i < cand.size() && kept < L[l].nkps; i++) {
+      const Cand &c = cand[i];
+      if (c.x >= r && c.y >= r && c.x < L[l].w - r && c.y < L[l].h - r) {
+        gs_keypoint &k = L[l].out[kept];
+        k.pt.x = c.x, k.pt.y = c.y, k.response = c.response;
+        k.angle = atan2f((float)c.m01, (float)c.m10); /* ref :620, :100 */
+        const float angle = k.angle;
+        kin.push_back(KpIn{c.x, c.y, sinf(angle), sinf((float)(angle + 1.57079f))}); /* ref :626 */
+        kept++;
+      }
+    }
+    L[l].got = kept, ktot += kept;
+  }
+  if (!ktot) return;
+  KpIn *dk = (KpIn *)ctx().scratch(SL_KIN, (size_t)ktot * sizeof(KpIn));
+  uint32_t *dd = (uint32_t *)ctx().scratch(SL_DESC, (size_t)ktot * 32);
+  GS_HIP(hipMemcpyAsync(dk, kin.data(), (size_t)ktot * sizeof(KpIn), hipMemcpyHostToDevice, st));
+  for (unsigned l = 0; l < nl; l++)
+    if (L[l].got)
+      GS_LAUNCH(k_brief, dim3(L[l].got), dim3(256), 0, st, L[l].img, L[l].w, L[l].h,
+                (const KpIn *)(dk + koff[l]), dd + (size_t)koff[l] * 8);
+  std::vector<uint32_t> hd((size_t)ktot * 8);
+  GS_HIP(hipMemcpyAsync(hd.data(), dd, (size_t)ktot * 32, hipMemcpyDeviceToHost, st));
+  ctx().sync();
+  for (unsigned l = 0; l < nl; l++)
+    for (unsigned i = 0; i < L[l].got; i++)
+      memcpy(L[l].out[i].descriptor, &hd[((size_t)koff[l] + i) * 8], 32);
+}
+
+void launch_match(const uint32_t *k1, unsigned n1, const uint32_t *k2, unsigned n2,
+                  unsigned *matches, unsigned *count, unsigned max_matches, float max_distance) {
+  hipStream_t st = ctx().s();
+  if (n1 == 0 || max_matches == 0) {
+    GS_HIP(hipMemsetAsync(count, 0, 4, st));
+    return;
+  }
+  const unsigned blocks = (n1 + 3) / 4, words = (n1 + 63) / 64;
+  const unsigned nchunks = (words + kChunkWords - 1) / kChunkWords;
+  unsigned long long *mask =
+      (unsigned long long *)ctx().scratch(SL_MASK, (size_t)nchunks * kChunkWords * 8);
+  unsigned *cnt = (unsigned *)ctx().scratch(SL_CNT, (size_t)nchunks * 4);
+  unsigned *best = (unsigned *)ctx().scratch(SL_BEST, (size_t)n1 * 8);
+  GS_HIP(hipMemsetAsync(mask, 0, (size_t)nchunks * kChunkWords * 8, st));
+  GS_HIP(hipMemsetAsync(cnt, 0, (size_t)nchunks * 4, st));
+  GS_LAUNCH(k_match, dim3(blocks), dim3(256), 0, st, k1, n1, k2, n2, max_distance, best, best + n1,
+            mask, cnt);
+  run_compaction(mask, cnt, nchunks, 1, max_matches, count,
+                 MatchEmit{best, best + n1, matches});
+}
+
+}  // namespace
+
+extern "C" {
+
+void gsh_probe_fast_score(uint8_t *score, const uint8_t *img, unsigned w, unsigned h, unsigned n, unsigned threshold) {
+  GS_ASSERT(score && img && w >= 7 && h >= 7 && n >= 1 && n <= kMaxZ);
+  launch_fast_score(ctx().s(), img, score, w, h, n, threshold);
+}
+gsh_cascade *gsh_cascade_create(const struct gs_lbp_cascade *c) {
+  GS_ASSERT(c && c->features && c->weak_feature_idx && c->subsets);
+  ctx().ensure_device();
+  gsh_cascade *dc = new gsh_cascade();
+  static std::atomic<unsigned long long> next_id{1};
+  dc->id = next_id.fetch_add(1);
+  dc->window_w = c->window_w, dc->window_h = c->window_h;
+  dc->nfeatures = c->nfeatures, dc->nweaks = c->nweaks, dc->nstages = c->nstages;
+  dc->features.assign(c->features, c->features + (size_t)c->nfeatures * 4);
+  dc->weak_feature_idx.assign(c->weak_feature_idx, c->weak_feature_idx + c->nweaks);
+  /* device tables in EVALUATION order: stage by stage, so a stage range is one contiguous run of
+   * weak classifiers (the reference indexes through stage_weak_start, ref :795-798) */
+  std::vector<LbpWeak> wk;
+  std::vector<LbpStage> stg(c->nstages);
+  dc->weak_feature_idx.clear();
+  unsigned nsub = 0;
+  for (unsigned si = 0; si < c->nstages; si++) {
+    stg[si] = LbpStage{(unsigned)wk.size(), c->stage_nweaks[si], c->stage_threshold[si], 0.0f};
+    for (unsigned k = 0; k < c->stage_nweaks[si]; k++) {
+      const unsigned i = (unsigned)c->stage_weak_start[si] + k;
+      wk.push_back(LbpWeak{c->weak_left_val[i], c->weak_right_val[i], c->weak_subset_offset[i],
+                           c->weak_num_subsets[i]});
+      dc->weak_feature_idx.push_back(c->weak_feature_idx[i]);
+      nsub = std::max(nsub, (unsigned)c->weak_subset_offset[i] + c->weak_num_subsets[i]);
+    }
+  }
+  dc->nweaks = (unsigned)wk.size(); /* classifiers actually reachable through the stages */
+  dc->nsub = nsub;
+  GS_HIP(hipMalloc((void **)&dc->d_weak, std::max<size_t>(1, wk.size()) * sizeof(LbpWeak)));
+  GS_HIP(hipMalloc((void **)&dc->d_stage, std::max<size_t>(1, stg.size()) * sizeof(LbpStage)));
+  GS_HIP(hipMalloc((void **)&dc->d_subsets, std::max<size_t>(1, nsub) * 4));
+  GS_HIP(hipMemcpy(dc->d_weak, wk.data(), wk.size() * sizeof(LbpWeak), hipMemcpyHostToDevice));
+  GS_HIP(hipMemcpy(dc->d_stage, stg.data(), stg.size() * sizeof(LbpStage), hipMemcpyHostToDevice));
+  GS_HIP(hipMemcpy(dc->d_subsets, c->subsets, (size_t)nsub * 4, hipMemcpyHostToDevice));
+  /* Truth tables of the stage decisions (k_lbp_dense.h): for every combination b of a stage's match bits the
+   * reference's own sequence -- sum = 0.0f; sum += match ? left : right in weak order; pass unless
+   * sum < threshold (ref :796-810) -- evaluated here in float32 (this file is built -ffp-contract=off). */
+  std::vector<unsigned> lut(std::max<size_t>(1, stg.size()), 0u);
+  dc->pre_max = 0;
+  bool leading = true;
+  for (unsigned si = 0; si < c->nstages; si++) {
+    if (stg[si].count > kPreMaxWeaks) {
+      leading = false;
+      continue;
+    }
+    for (unsigned b = 0; b < (1u << stg[si].count); b++) {
+      volatile float sum = 0.0f;
+      for (unsigned k = 0; k < stg[si].count; k++) {
+        const LbpWeak &w = wk[stg[si].first + k];
+        sum = sum + (((b >> k) & 1u) ? w.left : w.right);
+      }
+      if (!(sum < stg[si].threshold)) lut[si] |= 1u << b;
+    }
+    if (leading) dc->pre_max = si + 1;
+  }
+  GS_HIP(hipMalloc((void **)&dc->d_pass_lut, lut.size() * 4));
+  GS_HIP(hipMemcpy(dc->d_pass_lut, lut.data(), lut.size() * 4, hipMemcpyHostToDevice));
+  return dc;
+}
+void gsh_cascade_destroy(gsh_cascade *dc) {
+  if (!dc) return;
+  ctx().sync();
+  /* geometry tables of this handle in the calling thread's cache go with it; other threads' entries
+   * are keyed by the (never reused) id and are dropped when their context is released */
+  auto it = ctx().geom_cache.find(dc->id);
+  if (it != ctx().geom_cache.end()) {
+    if (it->second.d_scales) (void)hipFree(it->second.d_scales);
+    if (it->second.d_geom) (void)hipFree(it->second.d_geom);
+    if (it->second.d_pre) (void)hipFree(it->second.d_pre);
+    ctx().geom_cache.erase(it);
+  }
+  gsh_cascade_tables_deleter()(dc);
+}
+void gsh_lbp_detect_batch(const gsh_cascade *dc, const unsigned *ii, unsigned iw, unsigned ih,
+                          unsigned n, struct gs_rect *rects, unsigned *counts, unsigned max_rects,
+                          float scale_factor, float min_scale, float max_scale, int step) {
+  GS_ASSERT(dc && ii && rects && counts && iw > 0 && ih > 0);
+  launch_lbp_unpadded(dc, ii, iw, ih, n, (unsigned *)rects, counts,
+                      max_rects, scale_factor, min_scale, max_scale, step);
+}
+void gsh_lbp_count_evaluated(unsigned long long *counter_dev) { g_lbp_evaluated = counter_dev; }
+uint64_t gsh_lbp_window_count(const struct gs_lbp_cascade *c, unsigned iw, unsigned ih,
+                              float scale_factor, float min_scale, float max_scale, int step) {
+  gsh_cascade tmp;
+  tmp.window_w = c->window_w, tmp.window_h = c->window_h, tmp.nweaks = 0;
+  std::vector<LbpScale> sc;
+  std::vector<LbpGeom> ge;
+  bool guard;
+  unsigned long long nwin;
+  build_scales(tmp, iw, ih, scale_factor, min_scale, max_scale, step, sc, ge, guard, nwin);
+  return nwin;
+}
+
+/* ---------------------------------------------------------------- batch: FAST / ORB / match */
+void gsh_fast_batch(const uint8_t *img, uint8_t *scoremap, unsigned w, unsigned h, unsigned n,
+                    struct gs_keypoint *kps, unsigned *counts, unsigned nkps, unsigned threshold) {
+  GS_ASSERT(img && scoremap && kps && counts && nkps > 0 && w > 0 && h > 0);
+  launch_fast(img, scoremap, w, h, n, (unsigned *)kps, counts, nkps, threshold);
+}
+unsigned gsh_orb_extract(const uint8_t *img_dev, unsigned w, unsigned h, uint8_t *scoremap_dev,
+                         struct gs_keypoint *kps_host, unsigned nkps, unsigned threshold) {
+  GS_ASSERT(img_dev && scoremap_dev && kps_host && nkps > 0 && w > 0 && h > 0);
+  OrbLevel L{img_dev, w, h, scoremap_dev, kps_host, nkps, 0};
+  orb_extract_levels(&L, 1, threshold);
+  return L.got;
+}
+/* gs_orb_extract (ref :651-669) for n frames of one size with two host round trips in total:
+ * FAST + NMS + emit and the disc moments run as batch launches over all frames. */
+void gsh_orb_extract_batch(const uint8_t *img_dev, unsigned w, unsigned h, unsigned n,
+                           uint8_t *scoremap_dev, struct gs_keypoint *kps_host, unsigned *counts_host,
+                           unsigned nkps, unsigned threshold) {
+  GS_ASSERT(img_dev && scoremap_dev && kps_host && counts_host && nkps > 0 && w > 0 && h > 0);
+  constexpr unsigned kOrbGroup = 4096; /* frames per pass: bounds the host-side candidate buffers and grid.y */
+  if (n > kOrbGroup) {
+    for (unsigned f0 = 0; f0 < n; f0 += kOrbGroup)
+      gsh_orb_extract_batch(img_dev + (size_t)w * h * f0, w, h, std::min(kOrbGroup, n - f0),
+                            scoremap_dev + (size_t)w * h * f0, kps_host + (size_t)f0 * nkps, counts_host + f0, nkps,
+                            threshold);
+    return;
+  }
+  for (unsigned f = 0; f < n; f++) counts_host[f] = 0;
+  if (n == 0 || w < 7 || h < 7) return;
+  hipStream_t st = ctx().s();
+  const size_t fb = (size_t)w * h;
+  const unsigned cap = std::min(nkps * 4u, 5000u), r = 15;
+  unsigned *kps = (unsigned *)ctx().scratch(SL_KPS, (size_t)n * cap * 48 + 16);
+  unsigned *cnt = (unsigned *)ctx().scratch(SL_TOT, (size_t)n * 4 + 16);
+  int *mom = (int *)ctx().scratch(SL_MOM, (size_t)n * cap * 8);
+  launch_fast(img_dev, scoremap_dev, w, h, n, kps, cnt, cap, threshold);
+  GS_LAUNCH(k_orient_moments, dim3(cap, n), dim3(64), 0, st, img_dev, w, h, (const unsigned *)kps, 12u, r, mom,
+            (const unsigned *)cnt, fb);
+  std::vector<unsigned> hk((size_t)n * cap * 12), hn(n);
+  std::vector<int> hm((size_t)n * cap * 2);
+  GS_HIP(hipMemcpyAsync(hn.data(), cnt, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+  GS_HIP(hipMemcpyAsync(hk.data(), kps, hk.size() * 4, hipMemcpyDeviceToHost, st));
+  GS_HIP(hipMemcpyAsync(hm.data(), mom, hm.size() * 4, hipMemcpyDeviceToHost, st));
+  ctx().sync();
+  struct Cand { unsigned x, y, response; int m01, m10; };
+  std::vector<KpIn> kin;
+  std::vector<unsigned> koff(n);
+  std::vector<Cand> cand;
+  for (unsigned f = 0; f < n; f++) { /* host half of ref :657-667, frame by frame */
+    koff[f] = (unsigned)kin.size();
+    const unsigned m = std::min(hn[f], cap);
+    cand.resize(m);
+    for (unsigned i = 0; i < m; i++) {
+      const size_t q = (size_t)f * cap + i;
+      cand[i] = Cand{hk[q * 12], hk[q * 12 + 1], hk[q * 12 + 2], hm[2 * q], hm[2 * q + 1]};
+    }
+    std::stable_sort(cand.begin(), cand.end(),
+                     [](const Cand &a, const Cand &b) { return a.response > b.response; });
+    unsigned kept = 0;
+    gs_keypoint *out = kps_host + (size_t)f * nkps;
+    for (size_t i = 0; i < cand.size() && kept < nkps; i++) {
+      const Cand &c = cand[i];
+      if (c.x >= r && c.y >= r && c.x < w - r && c.y < h - r) {
+        gs_keypoint &k = out[kept];
+        k.pt.x = c.x, k.pt.y = c.y, k.response = c.response;
+        k.angle = atan2f((float)c.m01, (float)c.m10); /* ref :620, :100 */
+        const float angle = k.angle;
+        kin.push_back(KpIn{c.x, c.y, sinf(angle), sinf((float)(angle + 1.57079f))}); /* ref :626 */
+        kept++;
+      }
+    }
+    counts_host[f] = kept;
+  }
+  if (kin.empty()) return;
+  KpIn *dk = (KpIn *)ctx().scratch(SL_KIN, kin.size() * sizeof(KpIn));
+  uint32_t *dd = (uint32_t *)ctx().scratch(SL_DESC, kin.size() * 32);
+  GS_HIP(hipMemcpyAsync(dk, kin.data(), kin.size() * sizeof(KpIn), hipMemcpyHostToDevice, st));
+  for (unsigned f = 0; f < n; f++)
+    if (counts_host[f])
+      GS_LAUNCH(k_brief, dim3(counts_host[f]), dim3(256), 0, st, img_dev + fb * f, w, h,
+                (const KpIn *)(dk + koff[f]), dd + (size_t)koff[f] * 8);
+  std::vector<uint32_t> hd(kin.size() * 8);
+  GS_HIP(hipMemcpyAsync(hd.data(), dd, hd.size() * 4, hipMemcpyDeviceToHost, st));
+  ctx().sync();
+  for (unsigned f = 0; f < n; f++)
+    for (unsigned i = 0; i < counts_host[f]; i++)
+      memcpy(kps_host[(size_t)f * nkps + i].descriptor, &hd[((size_t)koff[f] + i) * 8], 32);
+}
+
+/* gs_orb_extract (ref :651-669) for n frames, everything on the device, no host round trip: FAST ->
+ * selection (stable descending sort + 15-px border filter + cap, k_orb_select) -> orientation + BRIEF
+ * (k_orb_describe) with the reference's GS_NO_STDLIB trig (ref :70-88).  Results are those of the
+ * reference header compiled with -DGS_NO_STDLIB; the libm flavour (glibc atan2f / sinf bits) stays
+ * with gsh_orb_extract_batch, whose trig runs on the host. */
+void gsh_orb_extract_batch_nostdlib(const uint8_t *img_dev, unsigned w, unsigned h, unsigned n,
+                                    uint8_t *scoremap_dev, struct gs_keypoint *kps_dev, unsigned *counts_dev,
+                                    unsigned nkps, unsigned threshold) {
+  GS_ASSERT(img_dev && scoremap_dev && kps_dev && counts_dev && nkps > 0 && w > 0 && h > 0);
+  if (n == 0) return;
+  hipStream_t st = ctx().s();
+  if (w < 7 || h < 7) {
+    GS_HIP(hipMemsetAsync(counts_dev, 0, (size_t)n * 4, st));
+    return;
+  }
+  const size_t fb = (size_t)w * h;
+  const unsigned cap = std::min(nkps * 4u, 5000u);
+  for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
+    const unsigned nn = std::min(kMaxZ, n - f0);
+    unsigned *cand = (unsigned *)ctx().scratch(SL_KPS, (size_t)nn * cap * 48 + 16);
+    unsigned *cnt = (unsigned *)ctx().scratch(SL_TOT, (size_t)nn * 4 + 16);
+    launch_fast(img_dev + fb * f0, scoremap_dev + fb * f0, w, h, nn, cand, cnt, cap, threshold);
+    unsigned *out = (unsigned *)kps_dev + (size_t)f0 * nkps * 12;
+    GS_LAUNCH(k_orb_select, dim3(nn), dim3(64), 0, st, (const unsigned *)cand, (const unsigned *)cnt, cap, w, h, nkps,
+              out, counts_dev + f0);
+    GS_LAUNCH(k_orb_describe, dim3(nkps, nn), dim3(256), 0, st, img_dev + fb * f0, w, h, fb, out,
+              (const unsigned *)(counts_dev + f0), nkps);
+  }
+}
+
+size_t gsh_orb_pyramid_buffer_bytes(unsigned w, unsigned h, unsigned n_levels) {
+  if (n_levels > 4) n_levels = 4;
+  size_t levels = 0, maps = (size_t)w * h;
+  for (unsigned l = 1; l < n_levels; l++) {
+    w /= 2, h /= 2;
+    if (w < 32 || h < 32) break;
+    levels += (size_t)w * h, maps += (size_t)w * h;
+  }
+  return levels + maps;
+}
+/* ref examples/nanomagick/nanomagick.c:245-290 with every level resident on the device */
+unsigned gsh_orb_extract_pyramid(const uint8_t *img_dev, unsigned w, unsigned h, uint8_t *buffer_dev,
+                                 struct gs_keypoint *kps_host, unsigned nkps, unsigned threshold,
+                                 unsigned n_levels) {
+  GS_ASSERT(img_dev && buffer_dev && kps_host && w > 0 && h > 0);
+  if (n_levels > 4) n_levels = 4;
+  if (n_levels == 0 || nkps == 0) return 0; /* the reference driver's level loop is empty (nanomagick.c:262) */
+  const uint8_t *lev[4];
+  unsigned lw[4], lh[4], total = 0;
+  size_t off = 0;
+  lev[0] = img_dev, lw[0] = w, lh[0] = h;
+  for (unsigned l = 1; l < n_levels; l++) {
+    const unsigned nw = lw[l - 1] / 2, nh = lh[l - 1] / 2;
+    if (nw < 32 || nh < 32) {
+      n_levels = l;
+      break;
+    }
+    uint8_t *d = buffer_dev + off;
+    off += (size_t)nw * nh;
+    gsh_downsample_batch(d, lev[l - 1], lw[l - 1], lh[l - 1], 1);
+    lev[l] = d, lw[l] = nw, lh[l] = nh;
+  }
+  /* per-level quotas depend on how many keypoints the earlier levels produced only for the last
+   * level ("the remainder", nanomagick.c:275): run the first n_levels-1 levels as one batch, then
+   * the last one */
+  OrbLevel L[4];
+  uint8_t *sm[4];
+  for (unsigned l = 0; l < n_levels; l++) {
+    sm[l] = buffer_dev + off;
+    off += (size_t)lw[l] * lh[l];
+  }
+  const unsigned per = nkps / n_levels;
+  for (unsigned l = 0; l + 1 < n_levels; l++) L[l] = OrbLevel{lev[l], lw[l], lh[l], sm[l], kps_host + (size_t)l * per, per, 0};
+  if (n_levels > 1) orb_extract_levels(L, n_levels - 1, threshold);
+  for (unsigned l = 0; l + 1 < n_levels; l++) {
+    /* levels write at l*per; the reference packs them back to back (total_kps) */
+    if (L[l].got && total != l * per) memmove(kps_host + total, kps_host + (size_t)l * per, (size_t)L[l].got * sizeof(gs_keypoint));
+    for (unsigned i = total; i < total + L[l].got; i++) kps_host[i].pt.x <<= l, kps_host[i].pt.y <<= l;
+    total += L[l].got;
+  }
+  {
+    const unsigned l = n_levels - 1, want = nkps - total;
+    if (want) {
+      L[l] = OrbLevel{lev[l], lw[l], lh[l], sm[l], kps_host + total, want, 0};
+      orb_extract_levels(&L[l], 1, threshold);
+      for (unsigned i = total; i < total + L[l].got; i++) kps_host[i].pt.x <<= l, kps_host[i].pt.y <<= l;
+      total += L[l].got;
+    }
+  }
+  return total;
+}
+void gsh_match_orb_dev(const struct gs_keypoint *k1, unsigned n1, const struct gs_keypoint *k2,
+                       unsigned n2, struct gs_match *matches, unsigned *count,
+                       unsigned max_matches, float max_distance) {
+  GS_ASSERT(k1 && k2 && matches && count);
+  launch_match((const uint32_t *)k1, n1, (const uint32_t *)k2, n2, (unsigned *)matches, count,
+               max_matches, max_distance);
+}
+
+/* The reference re-reads the caller's tables on every call (ref :790-835), so a cascade edited in
+ * place, or freed and rebuilt at the same addresses, must take effect.  The flattened device copy
+ * is therefore cached per calling thread keyed by a hash of the table CONTENTS (FNV-1a 64 over
+ * ~7 KB: microseconds next to the launch), never by the struct's pointer values. */
+static uint64_t cascade_content_hash(const struct gs_lbp_cascade *c) {
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&](const void *p, size_t n) {
+    const uint8_t *b = (const uint8_t *)p;
+    for (size_t i = 0; i < n; i++) h = (h ^ b[i]) * 1099511628211ull;
+  };
+  const uint16_t dims[5] = {c->window_w, c->window_h, c->nfeatures, c->nweaks, c->nstages};
+  mix(dims, sizeof dims);
+  mix(c->features, (size_t)c->nfeatures * 4);
+  mix(c->weak_feature_idx, (size_t)c->nweaks * 2);
+  mix(c->weak_left_val, (size_t)c->nweaks * 4);
+  mix(c->weak_right_val, (size_t)c->nweaks * 4);
+  mix(c->weak_subset_offset, (size_t)c->nweaks * 2);
+  mix(c->weak_num_subsets, (size_t)c->nweaks * 2);
+  unsigned nsub = 0;
+  for (unsigned i = 0; i < c->nweaks; i++)
+    nsub = std::max(nsub, (unsigned)c->weak_subset_offset[i] + c->weak_num_subsets[i]);
+  mix(c->subsets, (size_t)nsub * 4);
+  mix(c->stage_weak_start, (size_t)c->nstages * 2);
+  mix(c->stage_nweaks, (size_t)c->nstages * 2);
+  mix(c->stage_threshold, (size_t)c->nstages * 4);
+  return h;
+}
+static gsh_cascade *cached_cascade(const struct gs_lbp_cascade *c) {
+  Ctx &cx = ctx();
+  const uint64_t h = cascade_content_hash(c);
+  if (cx.dropin_cascade && cx.dropin_cascade_hash == h) return cx.dropin_cascade;
+  if (cx.dropin_cascade) gsh_cascade_destroy(cx.dropin_cascade);
+  cx.dropin_cascade = gsh_cascade_create(c);
+  cx.dropin_cascade_hash = h;
+  return cx.dropin_cascade;
+}
+
+unsigned gs_lbp_detect(const struct gs_lbp_cascade *c, const unsigned *ii, unsigned iw,
+                       unsigned ih, struct gs_rect *rects, unsigned max_rects, float scale_factor,
+                       float min_scale, float max_scale, int step) { /* ref :815 */
+  GS_ASSERT(c && ii && iw > 0 && ih > 0 && (rects || max_rects == 0));
+  if (max_rects == 0) return 0;
+  gsh_cascade *dc = cached_cascade(c);
+  const size_t np = (size_t)iw * ih;
+  const unsigned *dii = (const unsigned *)stage_in(ii, np * 4, SL_II);
+  const bool rhost = !is_dev(rects);
+  unsigned *dr = rhost ? (unsigned *)ctx().scratch(SL_OUT, (size_t)max_rects * 16) : (unsigned *)rects;
+  unsigned *dcnt = (unsigned *)ctx().scratch(SL_TOT, 16);
+  launch_lbp_unpadded(dc, dii, iw, ih, 1, dr, dcnt, max_rects, scale_factor, min_scale, max_scale,
+                      step);
+  unsigned n = 0;
+  GS_HIP(hipMemcpyAsync(&n, dcnt, 4, hipMemcpyDeviceToHost, ctx().s()));
+  ctx().sync();
+  if (rhost && n) GS_HIP(hipMemcpy(rects, dr, (size_t)n * 16, hipMemcpyDeviceToHost));
+  return n;
+}
+
+unsigned gs_lbp_window(const struct gs_lbp_cascade *c, const unsigned *ii, unsigned iw, unsigned ih,
+                       int x, int y, float scale) { /* ref :790 */
+  GS_ASSERT(c && ii);
+  const int win_w = (int)((int)c->window_w * scale), win_h = (int)((int)c->window_h * scale);
+  if (x + win_w > (int)iw || y + win_h > (int)ih) return 0; /* ref :793 */
+  if (x < 0 || y < 0 || win_w <= 0 || win_h <= 0) return 0;
+  gsh_cascade *dc = cached_cascade(c);
+  hipStream_t st = ctx().s();
+  /* (win_w+1) x (win_h+1) zero-bordered sub-table around the window: the cascade only ever
+   * forms D + A - B - C differences, so absolute table values carry over unchanged */
+  const unsigned S = (unsigned)win_w + 1, R = (unsigned)win_h + 1;
+  unsigned *tab = (unsigned *)ctx().scratch(SL_PAD, (size_t)S * R * 4 + 64);
+  GS_HIP(hipMemsetAsync(tab, 0, (size_t)S * R * 4, st));
+  const unsigned cx = x > 0 ? 1 : 0, cy = y > 0 ? 1 : 0;
+  const unsigned *src0 = ii + (size_t)(y - (int)cy) * iw + (x - (int)cx);
+  GS_HIP(hipMemcpy2DAsync(tab + (size_t)(1 - cy) * S + (1 - cx), (size_t)S * 4, src0, (size_t)iw * 4,
+                          (size_t)(win_w + cx) * 4, (size_t)(win_h + cy),
+                          is_dev(ii) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+  std::vector<LbpGeom> geom(dc->nweaks);
+  for (unsigned wi = 0; wi < dc->nweaks; wi++) {
+    const int fi = dc->weak_feature_idx[wi];
+    int fx = (int)((int)dc->features[fi * 4 + 0] * scale), fy = (int)((int)dc->features[fi * 4 + 1] * scale);
+    int fw = (int)((int)dc->features[fi * 4 + 2] * scale), fh = (int)((int)dc->features[fi * 4 + 3] * scale);
+    if (fw < 1) fw = 1;
+    if (fh < 1) fh = 1;
+    geom[wi] = LbpGeom{(fy * (int)S + fx) * 4, fw * 4, fh * (int)S * 4, 0};
+  }
+  LbpGeom *dg = (LbpGeom *)ctx().scratch(SL_TAB, std::max<size_t>(1, geom.size()) * sizeof(LbpGeom));
+  GS_HIP(hipMemcpyAsync(dg, geom.data(), geom.size() * sizeof(LbpGeom), hipMemcpyHostToDevice, st));
+  unsigned *dout = (unsigned *)ctx().scratch(SL_TOT, 16);
+  LbpArgs a;
+  memset(&a, 0, sizeof a);
+  a.padded = tab, a.frame_stride = (size_t)S * R, a.S = S, a.limit_bytes = (unsigned)(((size_t)S * R - 1) * 4), a.step = 1;
+  a.nweaks = dc->nweaks, a.nstages = dc->nstages, a.nsub = dc->nsub;
+  a.weak = dc->d_weak, a.stage = dc->d_stage, a.subsets = dc->d_subsets;
+  const size_t lds = (size_t)dc->nstages * sizeof(LbpStage) +
+                     (size_t)dc->nweaks * (sizeof(LbpWeak) + sizeof(LbpGeom)) + (size_t)dc->nsub * 4;
+  GS_LAUNCH(k_lbp_single, dim3(1), dim3(64), lds, st, a, (const LbpGeom *)dg, dout);
+  unsigned r = 0;
+  GS_HIP(hipMemcpyAsync(&r, dout, 4, hipMemcpyDeviceToHost, st));
+  ctx().sync();
+  return r;
+}
+
+unsigned gs_fast(struct gs_image img, struct gs_image scoremap, struct gs_keypoint *kps,
+                 unsigned nkps, unsigned threshold) { /* ref :482 */
+  GS_ASSERT(GS_VALID(img) && kps && nkps > 0);
+  const unsigned w = img.w, h = img.h;
+  if (w < 7 || h < 7) return 0;
+  /* The reference writes the map through gs_set and reads it through gs_get (ref :512, :518-524), so a
+   * map of another size -- or no map at all -- is legal: positions outside it are never written and
+   * read 0.  Same here: the kernels run on an image-sized device map M that starts as the caller's
+   * map where the two overlap (0 elsewhere); positions outside the caller's map are zeroed again
+   * between the two passes; the overlap is copied back. */
+  if (!GS_VALID(scoremap)) return 0; /* every gs_get(scoremap) is 0: the NMS pass skips every pixel */
+  const size_t nb = (size_t)w * h;
+  const uint8_t *s = (const uint8_t *)stage_in(img.data, nb, SL_IN);
+  const bool same = scoremap.w == w && scoremap.h == h;
+  const bool mhost = !is_dev(scoremap.data);
+  const unsigned ow = std::min(w, scoremap.w), oh = std::min(h, scoremap.h); /* overlap */
+  uint8_t *dm = (mhost || !same) ? (uint8_t *)ctx().scratch(SL_AUX, nb) : scoremap.data;
+  /* NMS reads the caller's 3-px frame (ref :524): ship the whole map in */
+  if (same) {
+    if (mhost) GS_HIP(hipMemcpyAsync(dm, scoremap.data, nb, hipMemcpyHostToDevice, ctx().s()));
+  } else {
+    GS_HIP(hipMemsetAsync(dm, 0, nb, ctx().s()));
+    GS_HIP(hipMemcpy2DAsync(dm, w, scoremap.data, scoremap.w, ow, oh,
+                            mhost ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, ctx().s()));
+  }
+  const bool khost = !is_dev(kps);
+  unsigned *dk = khost ? (unsigned *)ctx().scratch(SL_KPS, (size_t)nkps * 48) : (unsigned *)kps;
+  unsigned *dcnt = (unsigned *)ctx().scratch(SL_TOT, 16);
+  launch_fast(s, dm, w, h, 1, dk, dcnt, nkps, threshold, same ? 0u : scoremap.w, same ? 0u : scoremap.h);
+  unsigned n = 0;
+  GS_HIP(hipMemcpyAsync(&n, dcnt, 4, hipMemcpyDeviceToHost, ctx().s()));
+  if (same) {
+    if (mhost) GS_HIP(hipMemcpyAsync(scoremap.data, dm, nb, hipMemcpyDeviceToHost, ctx().s()));
+  } else {
+    GS_HIP(hipMemcpy2DAsync(scoremap.data, scoremap.w, dm, w, ow, oh,
+                            mhost ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, ctx().s()));
+  }
+  ctx().sync();
+  if (khost && n) GS_HIP(hipMemcpy(kps, dk, (size_t)n * 48, hipMemcpyDeviceToHost));
+  return n;
+}
+
+/* image patch [x-r, x+r] x [y-r, y+r] zero-filled outside the image, on the device */
+static const uint8_t *stage_patch(struct gs_image img, int x, int y, int r, int slot) {
+  const int side = 2 * r + 1;
+  uint8_t *d = (uint8_t *)ctx().scratch(slot, (size_t)side * side);
+  hipStream_t st = ctx().s();
+  GS_HIP(hipMemsetAsync(d, 0, (size_t)side * side, st));
+  const int xa = std::max(0, x - r), xb = std::min((int)img.w - 1, x + r);
+  const int ya = std::max(0, y - r), yb = std::min((int)img.h - 1, y + r);
+  if (xa <= xb && ya <= yb)
+    GS_HIP(hipMemcpy2DAsync(d + (size_t)(ya - (y - r)) * side + (xa - (x - r)), side,
+                            img.data + (size_t)ya * img.w + xa, img.w, (size_t)(xb - xa + 1),
+                            (size_t)(yb - ya + 1),
+                            is_dev(img.data) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+  return d;
+}
+
+float gs_compute_orientation(struct gs_image img, unsigned x, unsigned y, unsigned r) { /* ref :608 */
+  GS_ASSERT(GS_VALID(img) && x >= r && y >= r && x < img.w - r && y < img.h - r);
+  hipStream_t st = ctx().s();
+  const uint8_t *patch = stage_patch(img, (int)x, (int)y, (int)r, SL_AUX2);
+  if (r > kOrientExactR) { /* partial sums can pass 2^24: the reference's float32 order, one thread */
+    float *df = (float *)ctx().scratch(SL_MOM, 16);
+    GS_LAUNCH(k_orient_moments_seq, dim3(1), dim3(1), 0, st, patch, 2 * r + 1, 2 * r + 1, r, r, r, df);
+    float mf[2];
+    GS_HIP(hipMemcpyAsync(mf, df, 8, hipMemcpyDeviceToHost, st));
+    ctx().sync();
+    return atan2f(mf[0], mf[1]);
+  }
+  unsigned pt[2] = {r, r};
+  unsigned *dp = (unsigned *)ctx().scratch(SL_KIN, 16);
+  int *dm = (int *)ctx().scratch(SL_MOM, 16);
+  GS_HIP(hipMemcpyAsync(dp, pt, 8, hipMemcpyHostToDevice, st));
+  GS_LAUNCH(k_orient_moments, dim3(1), dim3(64), 0, st, patch, 2 * r + 1, 2 * r + 1,
+            (const unsigned *)dp, 2u, r, dm, (const unsigned *)nullptr);
+  int m[2];
+  GS_HIP(hipMemcpyAsync(m, dm, 8, hipMemcpyDeviceToHost, st));
+  ctx().sync();
+  return atan2f((float)m[0], (float)m[1]); /* ref :620 -> libm, as the reference (ref :100) */
+}
+
+void gs_brief_descriptor(struct gs_image img, struct gs_keypoint *kp) { /* ref :623 */
+  GS_ASSERT(GS_VALID(img) && kp);
+  hipStream_t st = ctx().s();
+  const int R = 22; /* |pattern| <= 15 rotated reaches <= 21 px */
+  gs_keypoint k;
+  if (is_dev(kp)) gsh_download(&k, kp, sizeof k);
+  else k = *kp;
+  const uint8_t *patch = stage_patch(img, (int)k.pt.x, (int)k.pt.y, R, SL_AUX2);
+  const float angle = k.angle;
+  KpIn in{(unsigned)R, (unsigned)R, sinf(angle), sinf((float)(angle + 1.57079f))};
+  KpIn *dk = (KpIn *)ctx().scratch(SL_KIN, sizeof in);
+  uint32_t *dd = (uint32_t *)ctx().scratch(SL_DESC, 32);
+  GS_HIP(hipMemcpyAsync(dk, &in, sizeof in, hipMemcpyHostToDevice, st));
+  GS_LAUNCH(k_brief, dim3(1), dim3(256), 0, st, patch, 2u * R + 1, 2u * R + 1, (const KpIn *)dk, dd);
+  GS_HIP(hipMemcpyAsync(k.descriptor, dd, 32, hipMemcpyDeviceToHost, st));
+  ctx().sync();
+  if (is_dev(kp)) gsh_upload(kp, &k, sizeof k);
+  else memcpy(kp->descriptor, k.descriptor, 32);
+}
+
+unsigned gs_orb_extract(struct gs_image img, struct gs_keypoint *kps, unsigned nkps,
+                        unsigned threshold, uint8_t *scoremap_buffer) { /* ref :651 */
+  GS_ASSERT(GS_VALID(img) && kps && nkps > 0 && scoremap_buffer);
+  const unsigned w = img.w, h = img.h;
+  if (w < 7 || h < 7) return 0;
+  const size_t nb = (size_t)w * h;
+  const uint8_t *s = (const uint8_t *)stage_in(img.data, nb, SL_IN);
+  const bool mhost = !is_dev(scoremap_buffer);
+  uint8_t *dm = mhost ? (uint8_t *)ctx().scratch(SL_AUX, nb) : scoremap_buffer;
+  if (mhost) GS_HIP(hipMemcpyAsync(dm, scoremap_buffer, nb, hipMemcpyHostToDevice, ctx().s()));
+  const bool khost = !is_dev(kps);
+  std::vector<gs_keypoint> tmp;
+  gs_keypoint *out = kps;
+  if (!khost) {
+    tmp.resize(nkps);
+    out = tmp.data();
+  }
+  OrbLevel L{s, w, h, dm, out, nkps, 0};
+  orb_extract_levels(&L, 1, threshold);
+  const unsigned n = L.got;
+  if (mhost) GS_HIP(hipMemcpyAsync(scoremap_buffer, dm, nb, hipMemcpyDeviceToHost, ctx().s()));
+  ctx().sync();
+  if (!khost && n) gsh_upload(kps, out, (size_t)n * sizeof(gs_keypoint));
+  return n;
+}
+
+unsigned gs_match_orb(const struct gs_keypoint *kps1, unsigned n1, const struct gs_keypoint *kps2,
+                      unsigned n2, struct gs_match *matches, unsigned max_matches,
+                      float max_distance) { /* ref :680 */
+  GS_ASSERT(kps1 && kps2 && matches);
+  if (n1 == 0 || max_matches == 0) return 0;
+  const uint32_t *d1 = (const uint32_t *)stage_in(kps1, (size_t)n1 * 48, SL_IN);
+  const uint32_t *d2 = n2 ? (const uint32_t *)stage_in(kps2, (size_t)n2 * 48, SL_AUX)
+                          : (const uint32_t *)ctx().scratch(SL_AUX, 48);
+  const bool mhost = !is_dev(matches);
+  unsigned *dm = mhost ? (unsigned *)ctx().scratch(SL_OUT, (size_t)max_matches * 12) : (unsigned *)matches;
+  unsigned *dcnt = (unsigned *)ctx().scratch(SL_TOT, 16);
+  launch_match(d1, n1, d2, n2, dm, dcnt, max_matches, max_distance);
+  unsigned n = 0;
+  GS_HIP(hipMemcpyAsync(&n, dcnt, 4, hipMemcpyDeviceToHost, ctx().s()));
+  ctx().sync();
+  if (mhost && n) GS_HIP(hipMemcpy(matches, dm, (size_t)n * 12, hipMemcpyDeviceToHost));
+  return n;
+}
+
+}  /* extern "C" */

@@ -17,19 +17,10 @@
 #ifndef GS_K_LBP_H
 #define GS_K_LBP_H
 #include "k_compact.h"
+#include "lbp_types.h"
 
 namespace gs {
 
-struct LbpScale {          /* one entry per visited scale (host-computed, float32 like ref :819-821) */
-  int win_w, win_h;
-  unsigned nx, ny;         /* window positions per row / column (step applied) */
-  unsigned chunk_base;     /* first chunk of this scale in the frame's chunk array */
-  unsigned nchunks;
-};
-struct LbpGeom { int off0, fw, fh_stride, pad; };      /* per (scale, weak): BYTE offsets in the padded table; pad = fh in rows */
-/* per scale: where its windows' "alive after the prefiltered stages" bits live (k_lbp_dense.h): window
- * (xi, yi) is bit xi % 64 of word word_base + yi * wpr + xi / 64; tiles of 64 x 64 windows, row-major */
-struct LbpPreScale { unsigned long long word_base; unsigned wpr, tiles_x, ntiles, pad; };
 struct LbpWeak { float left, right; unsigned sub_off, nsub; };
 struct LbpStage { unsigned first, count; float threshold, pad; };
 

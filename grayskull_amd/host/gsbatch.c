@@ -30,8 +30,12 @@
  *                       and is not imposed here.)
  * --gpus N shards the files of every size group over N GPUs (contiguous, balanced blocks of the
  * group's files: the frame_range rule of grayskull_amd/shard.py), one host thread per device
- * (gsh_set_device); frames never leave their GPU and no collective is needed -- the per-file results
- * land in the process's own memory.
+ * (gsh_set_device); frames never leave their GPU.  What crosses GPUs is SURVEY.md 8(e)'s control traffic, over RCCL
+ * (gsh_comm_*, one communicator per worker from ncclCommInitAll; librccl is looked up at run time and one GPU works
+ * without it): the cascade blob is read by worker 0 and BROADCAST, every worker's per-file counts and output checksums
+ * are ALL-GATHERED, the job's wall time is the ALL-REDUCE(max) of the workers'.  -v prints the checksum of checksums
+ * over the files in command-line order -- for the same frames and chain the digest bench.py reports as
+ * output_checksum_of_checksums.
  * PGM reading / writing follows the reference's gs_read_pgm / gs_write_pgm (grayskull.h:111-136):
  * binary P5, maxval 255, header "P5\n%u %u\n255\n".
  *
@@ -360,6 +364,7 @@ static const char *base_name(const char *path) {
 struct cascade_file {
   struct gs_lbp_cascade c;
   uint8_t *raw;
+  size_t raw_bytes;
 };
 static int cascade_tables_ok(const struct gs_lbp_cascade *c, uint32_t nsub) {
   /* every index array must stay inside the table it points into: gsh_cascade_create and the kernels trust them */
@@ -374,23 +379,15 @@ static int cascade_tables_ok(const struct gs_lbp_cascade *c, uint32_t nsub) {
   return 1;
 }
 
-static int load_cascade(const char *path, struct cascade_file *cf) {
-  FILE *fp = fopen(path, "rb");
-  long sz;
+/* the blob as bytes (read from a file by rank 0, received over RCCL by the others); takes ownership of raw */
+static int parse_cascade(uint8_t *raw, size_t sz, struct cascade_file *cf) {
   uint16_t hdr[6];
   uint32_t nsub;
   size_t off = 20, cnt[10], esz[10] = {1, 2, 4, 4, 2, 2, 4, 2, 2, 4};
   const void *arr[10];
   int i;
-  cf->raw = NULL;
-  if (!fp) return -1;
-  if (fseek(fp, 0, SEEK_END) != 0 || (sz = ftell(fp)) < 20 || fseek(fp, 0, SEEK_SET) != 0) return fclose(fp), -1;
-  cf->raw = (uint8_t *)malloc((size_t)sz);
-  if (!cf->raw || fread(cf->raw, 1, (size_t)sz, fp) != (size_t)sz) {
-    fclose(fp);
-    goto bad;
-  }
-  fclose(fp);
+  cf->raw = raw, cf->raw_bytes = sz;
+  if (!raw || sz < 20) goto bad;
   if (memcmp(cf->raw, "LBPC", 4) != 0) goto bad;
   memcpy(hdr, cf->raw + 4, sizeof hdr); /* window_w, window_h, nfeatures, nweaks, nstages, pad */
   memcpy(&nsub, cf->raw + 16, 4);
@@ -398,9 +395,9 @@ static int load_cascade(const char *path, struct cascade_file *cf) {
   cnt[7] = cnt[8] = cnt[9] = hdr[4];
   for (i = 0; i < 10; i++) {
     arr[i] = cf->raw + off;
-    if (cnt[i] > ((size_t)sz - off) / esz[i]) goto bad; /* also keeps `off` from wrapping on a hostile nsub */
+    if (cnt[i] > (sz - off) / esz[i]) goto bad; /* also keeps `off` from wrapping on a hostile nsub */
     off += (cnt[i] * esz[i] + 3) & ~(size_t)3;
-    if (off > (size_t)sz && i < 9) goto bad;
+    if (off > sz && i < 9) goto bad;
   }
   cf->c.window_w = hdr[0], cf->c.window_h = hdr[1], cf->c.nfeatures = hdr[2], cf->c.nweaks = hdr[3], cf->c.nstages = hdr[4];
   cf->c.features = (const int8_t *)arr[0], cf->c.weak_feature_idx = (const uint16_t *)arr[1];
@@ -412,8 +409,25 @@ static int load_cascade(const char *path, struct cascade_file *cf) {
   return 0;
 bad:
   free(cf->raw);
-  cf->raw = NULL;
+  cf->raw = NULL, cf->raw_bytes = 0;
   return -1;
+}
+
+static int load_cascade(const char *path, struct cascade_file *cf) {
+  FILE *fp = fopen(path, "rb");
+  long sz;
+  uint8_t *raw;
+  cf->raw = NULL, cf->raw_bytes = 0;
+  if (!fp) return -1;
+  if (fseek(fp, 0, SEEK_END) != 0 || (sz = ftell(fp)) < 20 || fseek(fp, 0, SEEK_SET) != 0) return fclose(fp), -1;
+  raw = (uint8_t *)malloc((size_t)sz);
+  if (!raw || fread(raw, 1, (size_t)sz, fp) != (size_t)sz) {
+    fclose(fp);
+    free(raw);
+    return -1;
+  }
+  fclose(fp);
+  return parse_cascade(raw, (size_t)sz, cf);
 }
 
 /* nanomagick.c:172-184, restated: Bresenham with clipping */
@@ -447,9 +461,14 @@ struct job {
   struct frame *fr;
   int nf, ngroups;
   const char *outdir;
-  const struct gs_lbp_cascade *cascade;
+  const struct cascade_file *cascade; /* rank 0's copy (it read the file); the other ranks receive the bytes over RCCL */
   int rc;
   double t_alloc, t_read, t_up, t_run, t_down, t_write;
+  /* multi-GPU control plane: one RCCL communicator per worker, created together by main() */
+  gsh_comm *comm;
+  uint64_t *file_sum, *file_cnt; /* nf entries each: checksum of the final plane / terminal-verb count of the files THIS worker owns */
+  uint64_t *all_sum, *all_cnt;   /* nf entries each, filled on every worker by the all-gather: every file of the job */
+  double t_wall, t_wall_max;     /* this worker's wall time; the job's (all-reduce max) */
 };
 
 /* contiguous, balanced share of `total` items for worker `rank` of `world` (grayskull_amd/shard.py frame_range) */
@@ -467,9 +486,33 @@ static void *worker(void *arg) {
   const struct stage *term = (ns > 0 && IS_TERMINAL(st[ns - 1].v)) ? &st[ns - 1] : NULL;
   gsh_cascade *dc = NULL;
   int g, i;
+  struct cascade_file mine; /* this worker's cascade, parsed from the bytes the broadcast delivered */
+  const double t_start = now_ms();
+  memset(&mine, 0, sizeof mine);
   gsh_set_device(jb->device);
   gsh_set_async(1); /* per-frame gs_resize / gs_crop on device pointers stay stream-ordered */
-  if (term && term->v == V_FACES) dc = gsh_cascade_create(jb->cascade);
+  if (term && term->v == V_FACES) {
+    /* SURVEY 8(e) collective (1): rank 0 read the blob; its length travels as an all-reduce(max), its bytes as one
+     * broadcast; every rank -- rank 0 included -- builds its device tables from the bytes it received */
+    unsigned long long *len_dev = (unsigned long long *)gsh_malloc(8), len = jb->device == 0 ? jb->cascade->raw_bytes : 0;
+    uint8_t *blob_dev, *blob;
+    gsh_upload(len_dev, &len, 8);
+    gsh_comm_all_reduce_u64(jb->comm, len_dev, 1, 1);
+    gsh_download(&len, len_dev, 8);
+    blob_dev = (uint8_t *)gsh_malloc((size_t)len);
+    if (jb->device == 0) gsh_upload(blob_dev, jb->cascade->raw, (size_t)len);
+    else gsh_memset(blob_dev, 0, (size_t)len);
+    gsh_comm_broadcast(jb->comm, blob_dev, (size_t)len, 0);
+    blob = (uint8_t *)malloc((size_t)len);
+    if (!blob) return jb->rc = 1, (void *)0;
+    gsh_download(blob, blob_dev, (size_t)len);
+    gsh_free(blob_dev), gsh_free(len_dev);
+    if (parse_cascade(blob, (size_t)len, &mine) != 0) {
+      fprintf(stderr, "Error: gpu %d received a cascade blob it cannot parse (%llu bytes)\n", jb->device, len);
+      abort();
+    }
+    dc = gsh_cascade_create(&mine.c);
+  }
   /* orb <template.pgm>: the template is read once and lives on the device */
   struct frame tmpl;
   uint8_t *tmpl_host = NULL, *tmpl_dev = NULL;
@@ -505,6 +548,7 @@ static void *worker(void *arg) {
     uint8_t *orb_buf = NULL;
     size_t orb_buf_bytes = 0;
     uint8_t *score = NULL;
+    uint64_t *sums_dev = NULL, *sums_host = NULL;
     struct gs_keypoint *kps_dev = NULL, *kps_host = NULL;
     unsigned *ii = NULL, *cnt_dev = NULL, *cnt_host = NULL;
     struct gs_rect *rects_dev = NULL, *rects_host = NULL;
@@ -549,6 +593,9 @@ static void *worker(void *arg) {
     p.thr_host = (uint8_t *)malloc(cap);
     failed = (int *)malloc(cap * sizeof *failed);
     stage = (uint8_t *)gsh_host_alloc(max_fb * cap); /* page-locked: one DMA each way per slice */
+    sums_dev = (uint64_t *)gsh_malloc((size_t)cap * 8);
+    sums_host = (uint64_t *)malloc((size_t)cap * 8);
+    if (!sums_host) return jb->rc = 1, (void *)0;
     if (term && term->v == V_ORB) {
       /* one scratch buffer for both pyramids, like nanomagick's (there: a static 1 MiB array, which a
        * frame beyond ~700x500 overruns; here: as large as the bigger pyramid needs) */
@@ -601,11 +648,13 @@ static void *worker(void *arg) {
         gsh_integral_batch(p.cur, ow, oh, nb, ii);
         gsh_lbp_detect_batch(dc, ii, ow, oh, nb, rects_dev, cnt_dev, kFaceCap, 1.2f, 1.0f, 4.0f, term->a[0]);
       }
+      gsh_checksum_batch(p.cur, (size_t)ow * oh, nb, sums_dev); /* of the final plane, on the device (what bench.py checks) */
       gsh_sync();
       jb->t_run += now_ms() - t0;
 
       t0 = now_ms();
       gsh_download(stage, p.cur, (size_t)ow * oh * nb);
+      gsh_download(sums_host, sums_dev, (size_t)nb * 8);
       if (term && term->v != V_ORB) {
         gsh_download(cnt_host, cnt_dev, (size_t)nb * sizeof(unsigned));
         if (term->v == V_KEYPOINTS) gsh_download(kps_host, kps_dev, (size_t)nb * kFastCap * sizeof *kps_host);
@@ -623,6 +672,8 @@ static void *worker(void *arg) {
           fi->failed = 1, jb->rc = 1;
           continue;
         }
+        jb->file_sum[idx[lo + b0 + f]] = sums_host[f];
+        jb->file_cnt[idx[lo + b0 + f]] = (term && term->v != V_ORB) ? cnt_host[f] : 0;
         if (term && term->v == V_ORB) { /* nanomagick.c:292-345, frame by frame like one process per file */
           unsigned nt, nsc, nm, k, x, y;
           FILE *rec;
@@ -733,6 +784,8 @@ static void *worker(void *arg) {
     gsh_free(ii);
     gsh_free(rects_dev);
     gsh_free(cnt_dev);
+    gsh_free(sums_dev);
+    free(sums_host);
     free(kps_host);
     free(rects_host);
     free(cnt_host);
@@ -741,11 +794,38 @@ static void *worker(void *arg) {
     free(idx);
   }
   if (dc) gsh_cascade_destroy(dc);
+  free(mine.raw);
   gsh_free(tmpl_dev);
   free(tmpl_host);
   free(tkps);
   free(skps);
   free(matches);
+  { /* SURVEY 8(e) collectives (2) and (4): every worker learns every file's count + checksum (all-gather of the nf-long
+     * arrays, zero where a worker owns nothing: a file has one owner, so the column sums are the owners' values), and the
+     * job's wall time is the all-reduce(max) of the workers' */
+    const int world = gsh_comm_world(jb->comm);
+    const size_t per = (size_t)2 * (size_t)nf * 8;
+    uint64_t *send_host = (uint64_t *)malloc(per), *recv_host = (uint64_t *)malloc(per * (size_t)world);
+    uint64_t *send_dev = (uint64_t *)gsh_malloc(per), *recv_dev = (uint64_t *)gsh_malloc(per * (size_t)world);
+    double *t_dev = (double *)gsh_malloc(8);
+    int r;
+    if (!send_host || !recv_host) return jb->rc = 1, (void *)0;
+    memcpy(send_host, jb->file_sum, (size_t)nf * 8), memcpy(send_host + nf, jb->file_cnt, (size_t)nf * 8);
+    gsh_upload(send_dev, send_host, per);
+    gsh_comm_all_gather(jb->comm, send_dev, recv_dev, per);
+    jb->t_wall = now_ms() - t_start;
+    gsh_upload(t_dev, &jb->t_wall, 8);
+    gsh_comm_all_reduce_f64(jb->comm, t_dev, 1, 1);
+    gsh_download(recv_host, recv_dev, per * (size_t)world);
+    gsh_download(&jb->t_wall_max, t_dev, 8);
+    for (i = 0; i < nf; i++) {
+      jb->all_sum[i] = jb->all_cnt[i] = 0;
+      for (r = 0; r < world; r++)
+        jb->all_sum[i] += recv_host[(size_t)r * 2 * (size_t)nf + (size_t)i], jb->all_cnt[i] += recv_host[(size_t)r * 2 * (size_t)nf + (size_t)nf + (size_t)i];
+    }
+    gsh_free(send_dev), gsh_free(recv_dev), gsh_free(t_dev);
+    free(send_host), free(recv_host);
+  }
   gsh_shutdown();
   return (void *)0;
 }
@@ -756,6 +836,7 @@ int main(int argc, char **argv) {
   const char *outdir = NULL, *cascade_path = getenv("GSBATCH_CASCADE");
   struct cascade_file cf;
   struct job *jobs;
+  gsh_comm **comms;
   pthread_t *th;
   int verbose = 0, pos = 1, ns, nf, i, ngroups = 0, rc = 0, ngpus = 1, d;
   double t_io0, t_read, t0;
@@ -834,12 +915,22 @@ int main(int argc, char **argv) {
 
   jobs = (struct job *)calloc((size_t)ngpus, sizeof *jobs);
   th = (pthread_t *)calloc((size_t)ngpus, sizeof *th);
-  if (!jobs || !th) return 1;
+  comms = (gsh_comm **)calloc((size_t)ngpus, sizeof *comms);
+  if (!jobs || !th || !comms) return 1;
+  /* one RCCL communicator per GPU, created together (ncclCommInitAll); librccl is looked up at run time and a single
+   * GPU works without it */
+  if (gsh_comm_init_all(comms, ngpus, NULL) != 0) {
+    fprintf(stderr, "Error: --gpus %d needs RCCL (librccl.so)\n", ngpus);
+    return 1;
+  }
   t0 = now_ms();
   for (d = 0; d < ngpus; d++) {
     struct job *jb = &jobs[d];
     jb->device = d, jb->ndev = ngpus, jb->verbose = verbose, jb->st = st, jb->ns = ns, jb->fr = fr, jb->nf = nf;
-    jb->ngroups = ngroups, jb->outdir = outdir, jb->cascade = &cf.c;
+    jb->ngroups = ngroups, jb->outdir = outdir, jb->cascade = &cf, jb->comm = comms[d];
+    jb->file_sum = (uint64_t *)calloc((size_t)nf * 4, 8);
+    if (!jb->file_sum) return 1;
+    jb->file_cnt = jb->file_sum + nf, jb->all_sum = jb->file_cnt + nf, jb->all_cnt = jb->all_sum + nf;
     if (ngpus == 1) {
       worker(jb); /* the calling thread is the one worker */
     } else if (pthread_create(&th[d], NULL, worker, jb) != 0) {
@@ -852,12 +943,21 @@ int main(int argc, char **argv) {
     rc |= jobs[d].rc;
   }
   if (verbose) {
+    /* what the collectives delivered, as worker 0 holds it: SURVEY 8(e)'s "checksum of checksums" over the files in
+     * command-line order -- the digest bench.py prints as output_checksum_of_checksums for the same frames and chain */
+    unsigned long long digest = 1469598103934665603ull, total = 0;
+    for (i = 0; i < nf; i++) digest = (digest ^ jobs[0].all_sum[i]) * 1099511628211ull, total += jobs[0].all_cnt[i];
+    fprintf(stderr, "collectives: %s | checksum of checksums %016llx over %d file(s), %llu result record(s) | job wall %.2f ms "
+                    "(all-reduce max over %d worker(s))\n", gsh_comm_backend(comms[0]), digest, nf, total, jobs[0].t_wall_max, ngpus);
     fprintf(stderr, "files %d groups %d gpus %d | headers %.2f ms, workers %.2f ms wall\n", nf, ngroups, ngpus, t_read,
             now_ms() - t0);
     for (d = 0; d < ngpus; d++)
       fprintf(stderr, "gpu %d: alloc %.2f ms, read %.2f ms, upload %.2f ms, stages %.2f ms, download %.2f ms, write %.2f ms\n", d,
               jobs[d].t_alloc, jobs[d].t_read, jobs[d].t_up, jobs[d].t_run, jobs[d].t_down, jobs[d].t_write);
   }
+  gsh_comm_destroy_all(comms, ngpus);
+  for (d = 0; d < ngpus; d++) free(jobs[d].file_sum);
+  free(comms);
   free(cf.raw);
   free(jobs);
   free(th);

@@ -190,6 +190,26 @@ void gsh_synth_batch(uint8_t *dst, unsigned w, unsigned h, unsigned n, uint32_t 
 /* sums[f] = order-independent 64-bit checksum of frame f (sum of (i+1)*FNVmix(byte)) */
 void gsh_checksum_batch(const uint8_t *img, size_t frame_bytes, unsigned n, uint64_t *sums);
 
+/* ---- multi-GPU control plane for one-process host programs ---------
+ * One host thread per device (gsh_set_device) and one communicator per device, created together by
+ * ncclCommInitAll over the listed devices (devices == NULL: 0 .. ndev-1).  RCCL over xGMI carries control traffic
+ * only -- the cascade blob, per-file counts and checksums, the closing max of the elapsed time; frames shard by
+ * file / frame and never cross GPUs (the reference has no counterpart: grayskull.h holds no state across images).
+ * librccl.so is dlopen()ed by gsh_comm_init_all: ndev == 1 works without it (local copies), ndev > 1 returns -1.
+ * Every collective takes DEVICE buffers, must be called by the thread that drives that communicator's device and is
+ * enqueued on that thread's stream (gsh_sync() before the host reads a result).  Precondition failures and RCCL
+ * errors abort like everything else here. */
+typedef struct gsh_comm gsh_comm;
+int gsh_comm_init_all(gsh_comm **comms, int ndev, const int *devices); /* 0, or -1: RCCL unavailable for ndev > 1 */
+void gsh_comm_destroy_all(gsh_comm **comms, int ndev);
+int gsh_comm_rank(const gsh_comm *c);
+int gsh_comm_world(const gsh_comm *c);
+const char *gsh_comm_backend(const gsh_comm *c); /* "rccl 2.x.y (ncclCommInitAll, N ranks)" | "local copies ..." */
+void gsh_comm_broadcast(gsh_comm *c, void *buf_dev, size_t bytes, int root);
+void gsh_comm_all_gather(gsh_comm *c, const void *send_dev, void *recv_dev, size_t bytes_per_rank);
+void gsh_comm_all_reduce_u64(gsh_comm *c, unsigned long long *buf_dev, size_t n, int op); /* op: 0 sum, 1 max; in place */
+void gsh_comm_all_reduce_f64(gsh_comm *c, double *buf_dev, size_t n, int op);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,4 +1,4 @@
-"""Kernel LOGIC parity on CPU: the same kernel sources (grayskull_amd/csrc/k_*.h + gs_api.cpp)
+"""Kernel LOGIC parity on CPU: the same kernel sources (grayskull_amd/csrc/k_*.h + gs_*.cpp)
 compiled for the host-fiber SIMT emulator (tests/emu) and compared with the oracle on tiny
 inputs.  This is a development/CI aid for a container without a GPU -- the real parity tests are
 the `-m gpu` ones in test_gpu_parity.py, which run the HIP build on the MI355X."""

@@ -470,7 +470,7 @@ def test_gsbatch_two_workers_asan_clean(tmp_path):
     lib = str(tmp_path / "libgs_kernel_emu.so")
     san = ["-fsanitize=address", "-fno-omit-frame-pointer", "-g", "-O1"]
     subprocess.check_call(["g++", "-DGS_EMU", "-DGS_BOXR_MAX=3", *san, "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-w",
-                           "-I" + emu_dir, "-I" + csrc, os.path.join(csrc, "gs_api.cpp"), os.path.join(csrc, "gs_fused.cpp"), os.path.join(csrc, "gs_box.cpp"),
+                           "-I" + emu_dir, "-I" + csrc, *[os.path.join(csrc, u + ".cpp") for u in ("gs_ctx", "gs_stencil", "gs_detect", "gs_comm", "gs_fused", "gs_box")],
                            os.path.join(emu_dir, "hip_emu.cpp"), "-o", lib])
     exe = str(tmp_path / "gsbatch_asan")
     subprocess.check_call(["gcc", "-std=c99", *san, "-I" + os.path.join(ROOT, "include"), SRC, "-o", exe,
@@ -485,3 +485,96 @@ def test_gsbatch_two_workers_asan_clean(tmp_path):
                            capture_output=True, timeout=900, env=env)
         err = r.stderr.decode()
         assert r.returncode == 0 and "ERROR: AddressSanitizer" not in err and "LeakSanitizer" not in err, err[-1500:]
+
+
+def _digest_of(sums):
+    d = 1469598103934665603
+    for v in sums:
+        d = ((d ^ int(v)) * 1099511628211) & 0xffffffffffffffff
+    return d
+
+
+def _wsum(a):
+    b = np.ascontiguousarray(a).view(np.uint8).reshape(-1).astype(np.uint64)
+    return int(np.sum(np.arange(1, b.size + 1, dtype=np.uint64) * (b + np.uint64(1)), dtype=np.uint64))
+
+
+@pytest.mark.parametrize("gpus", [1, 2, 3])
+def test_gsbatch_collectives_checksum_of_checksums_emulated(tmp_path, gpus):
+    """SURVEY 8(e) in the C driver: the cascade blob is broadcast, every worker's per-file counts and output checksums
+    are all-gathered, the wall time all-reduced (gsh_comm_*: RCCL on GPUs, a rendezvous of the emulated devices' threads
+    here).  `-v` prints the checksum of checksums over the files in command-line order: the same for 1, 2 and 3
+    workers, and equal to the digest bench.py computes (FNV-style fold of the per-frame wsum of the oracle's outputs)"""
+    import re
+    from oracle.pyoracle import Oracle
+    exe = build_emu(tmp_path)
+    o = Oracle("port")
+    files, sums = [], []
+    for k, (w, h) in enumerate([(160, 120), (160, 120), (131, 101), (160, 120), (160, 120)]):
+        p = str(tmp_path / ("cs%d.pgm" % k))
+        a = Oracle.synth(w, h, 1000 + k)
+        write_pgm(p, a)
+        files.append(p)
+        e = o.sobel(o.blur(a, 2))
+        sums.append(_wsum(o.threshold(e, o.otsu_threshold(e))))
+    outdir = tmp_path / "cs_out"
+    outdir.mkdir()
+    env = dict(os.environ, GS_EMU_DEVICES=str(gpus))
+    r = subprocess.run([exe, "-v", "--gpus", str(gpus), "-o", str(outdir), "blur", "2", ":", "sobel", ":", "threshold", "otsu", "--", *files],
+                       capture_output=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-800:]
+    m = re.search(rb"collectives: (.*?) \| checksum of checksums ([0-9a-f]{16}) over (\d+) file\(s\), (\d+) result record", r.stderr)
+    assert m, r.stderr.decode()[-800:]
+    assert int(m.group(3)) == len(files) and int(m.group(2), 16) == _digest_of(sums), (m.group(2), "%016x" % _digest_of(sums))
+    assert (b"emulated rendezvous of %d host threads" % gpus) in m.group(1)
+    # faces: the blob reaches every worker through the broadcast; counts come back through the all-gather
+    from grayskull_amd.cascade import Cascade
+    casc = Cascade.from_blob(CASCADE)
+    outdir2 = tmp_path / "cs_faces"
+    outdir2.mkdir()
+    r = subprocess.run([exe, "-v", "--gpus", str(gpus), "--cascade", CASCADE, "-o", str(outdir2), "faces", "1", "--", *files],
+                       capture_output=True, timeout=1800, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-800:]
+    m = re.search(rb"over (\d+) file\(s\), (\d+) result record", r.stderr)
+    want = sum(len(o.lbp_detect(casc, o.integral(read_pgm(f)), 100, 1.2, 1.0, 4.0, 1)) for f in files)
+    assert m and int(m.group(2)) == want, (m and m.group(2), want)
+
+
+@pytest.mark.gpu
+def test_gsbatch_rccl_world1_on_gpu(tmp_path):
+    """the C driver's collectives over REAL RCCL (librccl.so looked up at run time, ncclCommInitAll over one device):
+    broadcast of the cascade blob, all-gather of counts + checksums, all-reduce(max) of the wall time.  The digest `-v`
+    prints equals the FNV fold of the per-file wsum of the oracle's outputs, i.e. bench.py's output_checksum_of_checksums"""
+    import re
+    from oracle.pyoracle import Oracle
+    from grayskull_amd.cascade import Cascade
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "grayskull_amd", "csrc"), "tool"])
+    exe = os.path.join(ROOT, "grayskull_amd", "gsbatch")
+    o = Oracle("port")
+    files, sums = [], []
+    for k in range(6):
+        w, h = (640, 360) if k < 4 else (333, 201)
+        a = Oracle.synth(w, h, 1000 + k)
+        p = str(tmp_path / ("r%d.pgm" % k))
+        write_pgm(p, a)
+        files.append(p)
+        e = o.sobel(o.blur(a, 2))
+        sums.append(_wsum(o.threshold(e, o.otsu_threshold(e))))
+    out = tmp_path / "o1"
+    out.mkdir()
+    r = subprocess.run([exe, "-v", "--gpus", "1", "-o", str(out), "blur", "2", ":", "sobel", ":", "threshold", "otsu", "--", *files],
+                       capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-800:]
+    m = re.search(rb"collectives: (.*?) \| checksum of checksums ([0-9a-f]{16}) over (\d+) file", r.stderr)
+    assert m, r.stderr.decode()[-800:]
+    assert m.group(1).startswith(b"rccl "), m.group(1)           # the real library, not the local fallback
+    assert int(m.group(2), 16) == _digest_of(sums)
+    casc = Cascade.from_blob(CASCADE)
+    out2 = tmp_path / "o2"
+    out2.mkdir()
+    r = subprocess.run([exe, "-v", "--gpus", "1", "--cascade", CASCADE, "-o", str(out2), "faces", "1", "--", *files[:3]],
+                       capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-800:]
+    m = re.search(rb"collectives: (rccl .*?) \| .* over (\d+) file\(s\), (\d+) result record", r.stderr)
+    want = sum(len(o.lbp_detect(casc, o.integral(read_pgm(f)), 100, 1.2, 1.0, 4.0, 1)) for f in files[:3])
+    assert m and int(m.group(3)) == want, (r.stderr.decode()[-400:], want)
