@@ -7,10 +7,8 @@
 #include "gs_internal.h"
 
 #include "k_fast.h"
-#include "k_fast_fused.h"
 #include "k_fast_nms.h"
 #include "k_lbp.h"
-#include "k_lbp_dense.h"
 #include "k_orb.h"
 
 namespace gsi {
@@ -98,35 +96,8 @@ void launch_fast(const uint8_t *img, uint8_t *score, unsigned w, unsigned h, uns
     return;
   }
   const size_t fb = (size_t)w * h;
-  /* key 7 = 6: both passes in one walk (k_fast_fused.h).  Measured and NOT the default: 32 x 720p block noise 127 us against
-   * 63 + 23 for the two passes below -- the walk executes 50 M VALU + 21 M SALU wave-instructions where the two passes
-   * execute 40 M + 18 M (ownership / interior masks, the border handling of the score tile, three barriers per step) at
-   * 4 waves per SIMD instead of 8 (profiles/r03t_fast_fused_not_kept.log, r03u_pmc_fast_fused.txt). */
-  if (g_tune[7] == 6 && g_tune[19] != 1 && threshold <= 0xffffff00u && !(clip_w && n == 1 && (clip_w < w || clip_h < h)) &&
-      (unsigned long long)((w + 63) / 64) * 64 * h < (1ull << 32)) {
-    const unsigned wpr = (w + 63) / 64, nwords = wpr * h, nchunks = (nwords + kChunkWords - 1) / kChunkWords;
-    unsigned long long *mask = (unsigned long long *)ctx().scratch(SL_MASK, (size_t)n * nchunks * kChunkWords * 8);
-    unsigned *cnt = (unsigned *)ctx().scratch(SL_CNT, (size_t)n * nchunks * 4);
-    unsigned *pfx = (unsigned *)ctx().scratch(SL_PFX, (size_t)n * nchunks * 4);
-    GS_HIP(hipMemsetAsync(mask, 0, (size_t)n * nchunks * kChunkWords * 8, st));
-    GS_HIP(hipMemsetAsync(cnt, 0, (size_t)n * nchunks * 4, st));
-    /* bands of 16 m - 2 rows: ~4 rounds of the 2048 blocks the chip holds, at least 30 rows (2 of every 16 m score rows
-     * are computed twice), at most 254 */
-    const unsigned strips = (w - 6 + kFfCols - 1) / kFfCols, rows = h - 6;
-    const unsigned long long cols = (unsigned long long)strips * n;
-    const unsigned want = (unsigned)std::max<unsigned long long>(1, 8192 / cols);
-    unsigned m = g_tune[0] > 0 ? (unsigned)g_tune[0] : (rows / want + 2 + 15) / 16;
-    m = std::max(2u, std::min(16u, m));
-    const unsigned bands = (rows + 16 * m - 3) / (16 * m - 2);
-    const unsigned long long nt = cols * bands;
-    GS_ASSERT(nt <= 0x7ffffff0ull);
-    const unsigned share = (g_tune[18] == 1 || !topo().eight_xcds()) ? 0u : (unsigned)((nt + 7) / 8);
-    FastFusedArgs fa{img, score, w, h, fb, threshold, strips, bands, m, (unsigned)nt, share, mask, cnt, wpr, nchunks};
-    GS_LAUNCH(k_fast_fused, dim3(share ? share * 8u : (unsigned)nt), dim3(64, 4), 0, st, fa);
-    run_compaction(mask, cnt, nchunks, n, nkps, counts,
-                   FastEmitPadded{score, w, wpr * 64u, fb, kps, nkps, ((uintptr_t)kps & 15) == 0}, st, pfx);
-    return;
-  }
+  /* (Both passes in one walk -- score tile, NMS and mask words from LDS, round 3's k_fast_fused -- measured 127 us against
+   * 63 + 23 per 32 x 720p and was removed in round 4: scripts/experiments/not_kept/, profiles/r03t_fast_fused_not_kept.log.) */
   /* pass 2 in strip form (k_fast_nms.h) when the score map qualifies for the strip machinery: items numbered over
    * rows padded to whole mask words.  Key 19 = 1: the item-by-item kernel k_fast_nms (round 2). */
   if (g_tune[19] != 1 && strip_ok(w, h, score, score) && w >= 32 && (unsigned long long)((w + 63) / 64) * 64 * h < (1ull << 32)) {
@@ -191,15 +162,13 @@ struct gsh_cascade {
   LbpWeak *d_weak = nullptr;
   LbpStage *d_stage = nullptr;
   int32_t *d_subsets = nullptr;
-  unsigned *d_pass_lut = nullptr; /* per stage: truth table of the stage decision over its match bits (k_lbp_dense.h) */
-  unsigned pre_max = 0;           /* leading stages with <= kPreMaxWeaks weak classifiers */
   unsigned long long id = 0; /* unique per handle: key of the calling threads' geometry caches */
 };
 
 namespace gsi {
 /* the device tables of a handle, without touching any context (used while a context is being released) */
 void gsh_cascade_tables_deleter::operator()(gsh_cascade *dc) const {
-  (void)hipFree(dc->d_weak), (void)hipFree(dc->d_stage), (void)hipFree(dc->d_subsets), (void)hipFree(dc->d_pass_lut);
+  (void)hipFree(dc->d_weak), (void)hipFree(dc->d_stage), (void)hipFree(dc->d_subsets);
   delete dc;
 }
 }  // namespace gsi
@@ -209,8 +178,7 @@ namespace {
 /* The reference's scale loop and per-feature truncation (ref :819-821, :799-804), float32. */
 void build_scales(const gsh_cascade &c, unsigned iw, unsigned ih, float scale_factor,
                   float min_scale, float max_scale, int step, std::vector<LbpScale> &scales,
-                  std::vector<LbpGeom> &geom, bool &guard, unsigned long long &nwin,
-                  unsigned long long *max_cell_px = nullptr) {
+                  std::vector<LbpGeom> &geom, bool &guard, unsigned long long &nwin) {
   scales.clear();
   geom.clear();
   guard = false;
@@ -238,7 +206,6 @@ void build_scales(const gsh_cascade &c, unsigned iw, unsigned ih, float scale_fa
       if (fh < 1) fh = 1;
       if (fx < 0 || fy < 0 || fx + 3 * fw > win_w || fy + 3 * fh > win_h) guard = true;
       geom.push_back(LbpGeom{(fy * (int)S + fx) * 4, fw * 4, fh * (int)S * 4, fh});
-      if (max_cell_px) *max_cell_px = std::max(*max_cell_px, (unsigned long long)fw * (unsigned long long)fh);
     }
     scales.push_back(sc);
     if (scales.size() >= 4096 || !(scale_factor > 1.0f)) break; /* the reference would not terminate */
@@ -256,8 +223,7 @@ LbpGeomCache &cascade_prepare(const gsh_cascade *dc, unsigned iw, unsigned ih, f
   if (gc.iw == iw && gc.ih == ih && gc.sf == sf && gc.mn == mn && gc.mx == mx && gc.step == step && gc.d_scales)
     return gc;
   std::vector<LbpGeom> geom;
-  gc.max_cell_px = 0;
-  build_scales(*dc, iw, ih, sf, mn, mx, step, gc.scales, geom, gc.guard, gc.nwindows, &gc.max_cell_px);
+  build_scales(*dc, iw, ih, sf, mn, mx, step, gc.scales, geom, gc.guard, gc.nwindows);
   cx.sync(); /* tables may be in use by an earlier launch of this thread */
   const size_t sb = std::max<size_t>(1, gc.scales.size()) * sizeof(LbpScale);
   const size_t gb = std::max<size_t>(1, geom.size()) * sizeof(LbpGeom);
@@ -280,26 +246,6 @@ LbpGeomCache &cascade_prepare(const gsh_cascade *dc, unsigned iw, unsigned ih, f
     gc.total_chunks += sc.nchunks;
     gc.max_chunks = std::max(gc.max_chunks, sc.nchunks);
   }
-  /* prefilter layout: one bit per window, window rows padded to whole u64 words; 64 x 64-window tiles */
-  gc.pre_words = 0, gc.max_tiles = 0;
-  if (step == 1 && !gc.scales.empty()) {
-    std::vector<LbpPreScale> pre;
-    for (auto &sc : gc.scales) {
-      LbpPreScale ps;
-      ps.word_base = gc.pre_words, ps.wpr = (sc.nx + 63u) / 64u, ps.tiles_x = ps.wpr;
-      ps.ntiles = ps.tiles_x * ((sc.ny + kPreTile - 1u) / kPreTile), ps.pad = 0;
-      gc.pre_words += (unsigned long long)ps.wpr * sc.ny;
-      gc.max_tiles = std::max(gc.max_tiles, ps.ntiles);
-      pre.push_back(ps);
-    }
-    const size_t pb = pre.size() * sizeof(LbpPreScale);
-    if (gc.d_pre_cap < pb) {
-      if (gc.d_pre) GS_HIP(hipFree(gc.d_pre));
-      GS_HIP(hipMalloc((void **)&gc.d_pre, pb));
-      gc.d_pre_cap = pb;
-    }
-    GS_HIP(hipMemcpy(gc.d_pre, pre.data(), pb, hipMemcpyHostToDevice));
-  }
   gc.iw = iw, gc.ih = ih, gc.sf = sf, gc.mn = mn, gc.mx = mx, gc.step = step;
   return gc;
 }
@@ -307,7 +253,7 @@ LbpGeomCache &cascade_prepare(const gsh_cascade *dc, unsigned iw, unsigned ih, f
 /* padded: n frames of (iw+1)*(ih+1) u32 on device */
 void launch_lbp_padded(const gsh_cascade *dc, const LbpGeomCache &gc, const unsigned *padded, unsigned iw,
                        unsigned ih, unsigned n, unsigned *rects, unsigned *counts, unsigned max_rects,
-                       int step, const unsigned *not_integral) {
+                       int step) {
   hipStream_t st = ctx().s();
   if (gc.scales.empty() || max_rects == 0) {
     GS_HIP(hipMemsetAsync(counts, 0, (size_t)n * 4, st));
@@ -341,7 +287,6 @@ void launch_lbp_padded(const gsh_cascade *dc, const LbpGeomCache &gc, const unsi
   a.scales = gc.d_scales, a.geom = gc.d_geom, a.weak = dc->d_weak, a.stage = dc->d_stage;
   a.subsets = dc->d_subsets;
   a.mask = mask, a.chunk_count = cnt, a.total_chunks = nch;
-  a.pre_bitmap = nullptr, a.pre_scales = gc.d_pre, a.pre_words = gc.pre_words, a.pre_stages = 0;
   const unsigned nsc = (unsigned)gc.scales.size();
   /* XCD-aware chunk mapping (k_lbp.h) once the integral image no longer fits one XCD's 4 MB L2: 1080p -3 %, 4K block
    * noise -4 %, 4K edge maps -12 % (5.76 -> 5.08 ms per frame); 720p (3.7 MB) is 1-4 % better off in dispatch order
@@ -392,59 +337,21 @@ void launch_lbp_padded(const gsh_cascade *dc, const LbpGeomCache &gc, const unsi
     }
   }
   const size_t lds_all = ((lds + 15) & ~(size_t)15) + 2 * kChunkItems * 2 + 64 * 4 + 16;
-  /* Prefilter (k_lbp_dense.h, OPTIONAL, key 14 = k > 0: that many stages; default off): stages [0, pre) for every
-   * window with the table rows shared down the columns of 64 x 64-window tiles; the cascade kernel then starts from
-   * the surviving set.  Needs unit step, in-window geometry, the adaptive preset and stages of <= 5 weak classifiers.
-   * Measured (profiles/r03a_lbp_prefilter_first.log, r03d_pmc_lbp.txt): 2.8x fewer gather instructions per weak
-   * classifier, but 0.22 ms per classifier and 4K frame against 0.18 for the dense phase of k_lbp_cascade -- ~1000
-   * tiles per XCD walk 64-row bands of the table at once, half their L2 requests miss (the cascade kernel's chunks
-   * stay inside a 3 MB band: 1 % misses) and the texture path stalls on pending misses half the time.
-   * The prefilter cannot see detections of its own launch, so the scales are issued in GROUPS (prefilter, then
-   * cascade, group after group on the stream): a group's tiles skip once the groups before it hold max_rects
-   * detections -- the reference stops scanning there (ref :819-823) -- while the chunk-granular exit inside the
-   * cascade kernel stays as it was.  A group is at least ~16 M windows (key 15 overrides, a test hook), so a
-   * launch always fills the chip: 8 x 4K = one scale per group, one 1080p frame = two groups. */
-  const int k14 = g_tune[14] >= 100 ? g_tune[14] - 100 : g_tune[14];
-  unsigned pre = k14 > 0 ? (unsigned)k14 : 0u; /* off by default: measured slower than the dense phase it replaces (see above) */
-  pre = std::min(pre, std::min(dc->pre_max, dc->nstages > 0 ? dc->nstages - 1u : 0u));
-  if (step != 1 || gc.guard || !ph.adaptive_max || !gc.d_pre || !dc->d_pass_lut || a.frame_stride * 4 >= (1ull << 31)) pre = 0;
-  LbpPreArgs pa;
-  pa.pass_lut = dc->d_pass_lut, pa.bitmap = nullptr, pa.xcd_swizzle = a.xcd_swizzle;
-  pa.not_integral = not_integral;
-  /* sign-bit compares (k_lbp_dense.h: lbp_code8) need every cell sum < 2^31: cells of the prefiltered classifiers
-   * cover at most max_cell_px pixels of <= 255 each.  Key 14 + 100 forces the general compare (A/B, tests). */
-  pa.small_cells = (not_integral && gc.max_cell_px < (1ull << 31) / 255ull && g_tune[14] < 100) ? 1u : 0u;
-  if (pre) {
-    pa.bitmap = (unsigned long long *)ctx().scratch(SL_PRE, (size_t)n * gc.pre_words * 8);
-    a.pre_bitmap = pa.bitmap, a.pre_stages = pre;
-  }
-  const unsigned long long group_windows = g_tune[15] > 0 ? (unsigned long long)g_tune[15] : 16ull << 20;
-  for (unsigned s0 = 0; s0 < nsc;) {
-    unsigned s1 = s0;
-    unsigned long long wsum = 0;
-    unsigned mc = 0, mt = 0;
-    do {
-      wsum += (unsigned long long)n * gc.scales[s1].nx * gc.scales[s1].ny;
-      mc = std::max(mc, gc.scales[s1].nchunks);
-      mt = std::max(mt, (gc.scales[s1].nx + 63u) / 64u * ((gc.scales[s1].ny + kPreTile - 1u) / kPreTile));
-      s1++;
-    } while (pre && s1 < nsc && wsum < group_windows);
-    if (!pre) /* no prefilter: one launch over all scales, as before */
-      for (; s1 < nsc; s1++) mc = std::max(mc, gc.scales[s1].nchunks);
-    a.scale0 = s0;
-    if (pre) {
-      const unsigned nblk = (mt + 3u) / 4u;
-      const dim3 gd(pa.xcd_swizzle ? (nblk + 7u) & ~7u : nblk, s1 - s0, n);
-      if (a.evaluated) GS_LAUNCH(k_lbp_dense<true>, gd, dim3(256), lds + 16, st, a, pa);
-      else GS_LAUNCH(k_lbp_dense<false>, gd, dim3(256), lds + 16, st, a, pa);
-    }
-    const dim3 g(a.xcd_swizzle ? (mc + 7u) & ~7u : mc, s1 - s0, n);
+  /* One launch over all scales.  (Round 3's row-sharing stage prefilter k_lbp_dense -- stages 0..1 for every window with the
+   * table rows handed down the columns of 64 x 64-window tiles, 2.8x fewer gathers per classifier -- lost to the dense
+   * phase it replaced: on the configs[4] input 56.9 + 21.6 ms against 71.2 ms per 16 frames, half of its L2 requests
+   * missing and 62 % of its wave cycles stalled (profiles/r04j_lbp_counters_*.txt).  Removed in round 4; the kernel and
+   * its launcher live on in scripts/experiments/not_kept/.) */
+  {
+    unsigned mc = 0;
+    for (unsigned s1 = 0; s1 < nsc; s1++) mc = std::max(mc, gc.scales[s1].nchunks);
+    a.scale0 = 0;
+    const dim3 g(a.xcd_swizzle ? (mc + 7u) & ~7u : mc, nsc, n);
     if (a.evaluated) { /* counting build: the same kernel + one register that counts classifier evaluations */
       if (gc.guard) GS_LAUNCH((k_lbp_cascade<true, true>), g, dim3(256), lds_all, st, a, ph);
       else GS_LAUNCH((k_lbp_cascade<false, true>), g, dim3(256), lds_all, st, a, ph);
     } else if (gc.guard) GS_LAUNCH(k_lbp_cascade<true>, g, dim3(256), lds_all, st, a, ph);
     else GS_LAUNCH(k_lbp_cascade<false>, g, dim3(256), lds_all, st, a, ph);
-    s0 = s1;
   }
   if (g_tune[16] == 1) return; /* timing aid (scripts/bench_lbp_stages.py): the cascade kernels alone, no rect emission */
   run_compaction(mask, cnt, nch, n, max_rects, counts,
@@ -463,16 +370,9 @@ void launch_lbp_unpadded(const gsh_cascade *dc, const unsigned *ii, unsigned iw,
   for (unsigned f0 = 0; f0 < n; f0 += kLbpGroup) {
     const unsigned nn = std::min(kLbpGroup, n - f0);
     unsigned *padded = (unsigned *)ctx().scratch(SL_PAD, pp * 4 * nn);
-    /* "is this table an integral image of bytes" is only asked by the optional stage prefilter (key 14 > 0): without it
-     * the padding pass skips the three extra table loads per element and the flag buffer is never touched */
-    unsigned *notii = nullptr;
-    if (g_tune[14] > 0) {
-      notii = (unsigned *)ctx().scratch(SL_NOTII, (size_t)nn * 4);
-      GS_HIP(hipMemsetAsync(notii, 0, (size_t)nn * 4, st));
-    }
-    launch_integral_pad(dim3((iw + 64) / 64, (ih + 4) / 4, nn), st, ii + fp * f0, iw, ih, padded, notii);
+    launch_integral_pad(dim3((iw + 64) / 64, (ih + 4) / 4, nn), st, ii + fp * f0, iw, ih, padded);
     launch_lbp_padded(dc, gc, padded, iw, ih, nn, rects + (size_t)f0 * max_rects * 4, counts + f0,
-                      max_rects, step, notii);
+                      max_rects, step);
   }
 }
 
@@ -639,29 +539,6 @@ gsh_cascade *gsh_cascade_create(const struct gs_lbp_cascade *c) {
   GS_HIP(hipMemcpy(dc->d_weak, wk.data(), wk.size() * sizeof(LbpWeak), hipMemcpyHostToDevice));
   GS_HIP(hipMemcpy(dc->d_stage, stg.data(), stg.size() * sizeof(LbpStage), hipMemcpyHostToDevice));
   GS_HIP(hipMemcpy(dc->d_subsets, c->subsets, (size_t)nsub * 4, hipMemcpyHostToDevice));
-  /* Truth tables of the stage decisions (k_lbp_dense.h): for every combination b of a stage's match bits the
-   * reference's own sequence -- sum = 0.0f; sum += match ? left : right in weak order; pass unless
-   * sum < threshold (ref :796-810) -- evaluated here in float32 (this file is built -ffp-contract=off). */
-  std::vector<unsigned> lut(std::max<size_t>(1, stg.size()), 0u);
-  dc->pre_max = 0;
-  bool leading = true;
-  for (unsigned si = 0; si < c->nstages; si++) {
-    if (stg[si].count > kPreMaxWeaks) {
-      leading = false;
-      continue;
-    }
-    for (unsigned b = 0; b < (1u << stg[si].count); b++) {
-      volatile float sum = 0.0f;
-      for (unsigned k = 0; k < stg[si].count; k++) {
-        const LbpWeak &w = wk[stg[si].first + k];
-        sum = sum + (((b >> k) & 1u) ? w.left : w.right);
-      }
-      if (!(sum < stg[si].threshold)) lut[si] |= 1u << b;
-    }
-    if (leading) dc->pre_max = si + 1;
-  }
-  GS_HIP(hipMalloc((void **)&dc->d_pass_lut, lut.size() * 4));
-  GS_HIP(hipMemcpy(dc->d_pass_lut, lut.data(), lut.size() * 4, hipMemcpyHostToDevice));
   return dc;
 }
 void gsh_cascade_destroy(gsh_cascade *dc) {
@@ -673,7 +550,6 @@ void gsh_cascade_destroy(gsh_cascade *dc) {
   if (it != ctx().geom_cache.end()) {
     if (it->second.d_scales) (void)hipFree(it->second.d_scales);
     if (it->second.d_geom) (void)hipFree(it->second.d_geom);
-    if (it->second.d_pre) (void)hipFree(it->second.d_pre);
     ctx().geom_cache.erase(it);
   }
   gsh_cascade_tables_deleter()(dc);

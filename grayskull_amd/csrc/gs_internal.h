@@ -72,7 +72,7 @@ using namespace gs;
 namespace gsi {
 
 /* ------------------------------------------------------------------ per-thread context */
-enum Slot { SL_IN = 0, SL_OUT, SL_AUX, SL_AUX2, SL_II, SL_PAD, SL_MASK, SL_CNT, SL_PFX, SL_TOT, SL_PRE, SL_NOTII,
+enum Slot { SL_IN = 0, SL_OUT, SL_AUX, SL_AUX2, SL_II, SL_PAD, SL_MASK, SL_CNT, SL_PFX, SL_TOT, SL_PRE,
             SL_HISTP, SL_HIST, SL_THR, SL_KPS, SL_MOM, SL_KIN, SL_DESC, SL_TAB, SL_JUMP, SL_LEV,
             SL_BEST, SL_COUNT };
 
@@ -93,12 +93,6 @@ struct LbpGeomCache {
   unsigned total_chunks = 0, max_chunks = 0;
   bool guard = false;
   unsigned long long nwindows = 0;
-  /* prefilter geometry (k_lbp_dense.h), only built for step == 1 */
-  LbpPreScale *d_pre = nullptr;
-  size_t d_pre_cap = 0;
-  unsigned long long pre_words = 0; /* u64 words of one frame's "alive" bitmap */
-  unsigned long long max_cell_px = 0; /* largest fw x fh over all (scale, classifier) */
-  unsigned max_tiles = 0;
 };
 struct gsh_cascade_tables_deleter { void operator()(struct ::gsh_cascade *dc) const; };
 /* Events that order the library's own streams on ONE device need no system-scope fence: a plain
@@ -146,7 +140,6 @@ struct Ctx {
     for (auto &kv : geom_cache) {
       if (kv.second.d_scales) (void)hipFree(kv.second.d_scales);
       if (kv.second.d_geom) (void)hipFree(kv.second.d_geom);
-      if (kv.second.d_pre) (void)hipFree(kv.second.d_pre);
     }
     geom_cache.clear();
   }
@@ -356,7 +349,7 @@ inline unsigned max_frames_per_launch() { return g_tune[8] > 0 ? (unsigned)g_tun
 void launch_sobel(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned n, bool keep_cols = true); /* gs_stencil.cpp */
 void launch_blur(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned n, unsigned radius);
 void launch_integral(const uint8_t *src, unsigned w, unsigned h, unsigned n, unsigned *ii);
-void launch_integral_pad(dim3 grid, hipStream_t st, const unsigned *ii, unsigned w, unsigned h, unsigned *padded, unsigned *not_integral); /* k_integral_pad */
+void launch_integral_pad(dim3 grid, hipStream_t st, const unsigned *ii, unsigned w, unsigned h, unsigned *padded); /* k_integral_pad */
 
 }  // namespace gsi
 using namespace gs;

@@ -193,7 +193,7 @@ void launch_box_generic(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h
       const unsigned nn = std::min(kMaxZ, n - f0);
       /* r <= 16: the window's raw rows stay in registers (k_box16r: 2 B/px instead of 3-4; 64 x 4K: 0.22 ms for r <= 9,
        * 0.28 up to 16, against 0.31-0.42 -- profiles/r03r_box_ring.log).  Key 6 = 4: k_box16 always. */
-      const bool ring = g_tune[6] != 4 && !ragged(w) && r <= box_ring_max() && w >= 32 && h >= 2 * r + 1 && (MODE == 0 || (c > -(1 << 30) && c < (1 << 30)));
+      const bool ring = g_tune[6] != 4 && r <= box_ring_max() && w >= 32 && h >= 2 * r + 1 && (MODE == 0 || (c > -(1 << 30) && c < (1 << 30)));
       /* band height: the launch should be whole rounds of the blocks the chip holds (256 CUs x 4 of them, fewer for the
        * register-heavy ring kernels of r >= 8 / 10), and a band first loads 2r+1 rows it does not output -- loads and
        * adds only since the vertical-first form, ~0.3 of an output row each.  Pick the band count with the smallest
@@ -366,8 +366,8 @@ void synth_jump_table(SynthJump &J) {
     }
 }
 
-void launch_integral_pad(dim3 grid, hipStream_t st, const unsigned *ii, unsigned w, unsigned h, unsigned *padded, unsigned *not_integral) {
-  GS_LAUNCH(k_integral_pad, grid, dim3(64, 4), 0, st, ii, w, h, padded, not_integral);
+void launch_integral_pad(dim3 grid, hipStream_t st, const unsigned *ii, unsigned w, unsigned h, unsigned *padded) {
+  GS_LAUNCH(k_integral_pad, grid, dim3(64, 4), 0, st, ii, w, h, padded);
 }
 
 }  // namespace gsi

@@ -301,23 +301,13 @@ __global__ __launch_bounds__(256) void k_integral_wave(const uint8_t *src, unsig
   }
 }
 
-/* grid (ceil((w+1)/64), ceil((h+1)/4), n), block (64,4).  not_integral (n flags, pre-zeroed, or NULL): set when the
- * table is NOT an integral image of bytes -- some 1 x 1 cell D + A - B - C exceeds 255 -- which is what lets
- * k_lbp_dense treat every box sum as a small non-negative number (k_lbp_dense.h: lbp_code8); a table from
- * gs_integral always passes, even when its entries wrapped mod 2^32 */
-__global__ __launch_bounds__(256) void k_integral_pad(const unsigned *ii, unsigned w, unsigned h,
-                                                      unsigned *padded, unsigned *not_integral) {
+/* grid (ceil((w+1)/64), ceil((h+1)/4), n), block (64,4) */
+__global__ __launch_bounds__(256) void k_integral_pad(const unsigned *ii, unsigned w, unsigned h, unsigned *padded) {
   const unsigned x = blockIdx.x * 64u + threadIdx.x, y = blockIdx.y * 4u + threadIdx.y;
   if (x > w || y > h) return;
   const unsigned *f = ii + (size_t)blockIdx.z * w * h;
   const unsigned v = (x && y) ? f[(size_t)(y - 1) * w + (x - 1)] : 0u;
   padded[(size_t)blockIdx.z * (w + 1) * (h + 1) + (size_t)y * (w + 1) + x] = v;
-  if (not_integral && x && y) {
-    const unsigned left = x > 1 ? f[(size_t)(y - 1) * w + (x - 2)] : 0u;
-    const unsigned up = y > 1 ? f[(size_t)(y - 2) * w + (x - 1)] : 0u;
-    const unsigned diag = (x > 1 && y > 1) ? f[(size_t)(y - 2) * w + (x - 2)] : 0u;
-    if (v - left - up + diag > 255u) not_integral[blockIdx.z] = 1u;
-  }
 }
 
 }  // namespace gs

@@ -46,9 +46,7 @@ struct LbpArgs {
    * precede it in the reference's scan order -- and skips when that reaches the cap. */
   unsigned *hits_group;         /* n frames x ngroups   (pre-zeroed) */
   unsigned *hits_super;         /* n frames x nsupers   (pre-zeroed) */
-  unsigned *hits_total;         /* n frames (pre-zeroed): all detections published so far; the launcher issues the
-                                   scales in groups, and a group's prefilter tiles skip once the groups before it
-                                   (complete by stream order) reached the cap */
+  unsigned *hits_total;         /* n frames (pre-zeroed): all detections published so far */
   unsigned scale0;              /* first scale of this launch (blockIdx.y counts from it) */
   unsigned ngroups, nsupers;
   unsigned nscales, cap;        /* cap = max_rects */
@@ -56,14 +54,8 @@ struct LbpArgs {
   unsigned xcd_swizzle;         /* 1: chunk = (blockIdx.x % 8) * ceil(nchunks / 8) + blockIdx.x / 8 */
   unsigned long long *evaluated; /* optional (COUNT kernels): [0] += windows of every chunk that was not
                                     skipped, [1] += weak classifiers evaluated, summed over windows, [2] += dword
-                                    corner loads issued, summed over lanes, [3] += windows that went through the
-                                    prefilter (k_lbp_dense) */
-  /* prefilter (k_lbp_dense.h): when pre_stages > 0 the windows' starting set is the bitmap written by
-   * k_lbp_dense (alive after stages [0, pre_stages)) and the cascade resumes at stage pre_stages */
-  const unsigned long long *pre_bitmap; /* n frames x pre_words */
-  const LbpPreScale *pre_scales;
-  unsigned long long pre_words;
-  unsigned pre_stages;
+                                    corner loads issued, summed over lanes, [3] unused (round 3's stage prefilter
+                                    counted here; the buffer keeps its four entries) */
 };
 constexpr unsigned kLbpGroupShift = 5, kLbpSuperShift = 10; /* chunks per group / super-group (log2) */
 
@@ -350,21 +342,10 @@ __global__ __launch_bounds__(256) void k_lbp_cascade(LbpArgs a, LbpPhases ph) {
     __syncthreads();
     unsigned slot = 0;
     unsigned alive = 0; /* bit k: window k * 256 + tid of the chunk is still alive */
-    if (a.pre_stages) { /* starting set = what k_lbp_dense left alive */
-      const LbpPreScale ps = a.pre_scales[si];
-      const unsigned long long *bm = a.pre_bitmap + (size_t)blockIdx.z * a.pre_words + ps.word_base;
 #pragma unroll
-      for (unsigned k = 0; k < kChunkItems / 256u; k++)
-        if (k * 256u + tid < n_in) {
-          const unsigned idx = first + k * 256u + tid, yi = idx / sc.nx, xi = idx - yi * sc.nx;
-          alive |= (unsigned)((bm[(size_t)yi * ps.wpr + (xi >> 6)] >> (xi & 63u)) & 1ull) << k;
-        }
-    } else {
-#pragma unroll
-      for (unsigned k = 0; k < kChunkItems / 256u; k++) alive |= (k * 256u + tid < n_in ? 1u : 0u) << k;
-    }
-    /* stages [s_prev, e) are evaluated per iteration; with a prefilter the first iteration only counts */
-    unsigned s_prev = a.pre_stages, e = a.pre_stages ? a.pre_stages : (ph.end[0] < a.nstages ? ph.end[0] : a.nstages);
+    for (unsigned k = 0; k < kChunkItems / 256u; k++) alive |= (k * 256u + tid < n_in ? 1u : 0u) << k;
+    /* stages [s_prev, e) are evaluated per iteration */
+    unsigned s_prev = 0, e = ph.end[0] < a.nstages ? ph.end[0] : a.nstages;
     for (;;) { /* block-uniform */
       if (e > s_prev)
         for (unsigned k = 0; k < kChunkItems / 256u; k++) { /* uniform trip count; dead lanes idle */

@@ -12,8 +12,5 @@ struct LbpScale {          /* one entry per visited scale (host-computed, float3
   unsigned nchunks;
 };
 struct LbpGeom { int off0, fw, fh_stride, pad; };      /* per (scale, weak): BYTE offsets in the padded table; pad = fh in rows */
-/* per scale: where its windows' "alive after the prefiltered stages" bits live (k_lbp_dense.h): window
- * (xi, yi) is bit xi % 64 of word word_base + yi * wpr + xi / 64; tiles of 64 x 64 windows, row-major */
-struct LbpPreScale { unsigned long long word_base; unsigned wpr, tiles_x, ntiles, pad; };
 }  // namespace gs
 #endif

@@ -42,20 +42,22 @@ void gsh_sync(void);                      /* hipStreamSynchronize(current stream
  * box kernel, 4 = the any-radius box kernel k_box16 also for radii <= 16 (instead of the register-ring form k_box16r),
  * 7 score kernel of gs_fast: 0 = LDS tile, 4 px per thread through the compass filter, candidates queued (default),
  * 1 = strip kernel (lane = 4 px, image rows in registers), 2 = one global byte load per ring pixel (round 1), 3 = LDS tile, one
- * pixel per lane + candidate queue, 4 = LDS tile, one pixel per lane, whole wave rows scored (round 2), 6 = score, NMS and
- * mask words in one walk down column strips (k_fast_fused; key 0 = steps per band; measured, not the default),
+ * pixel per lane + candidate queue, 4 = LDS tile, one pixel per lane, whole wave rows scored (round 2),
  * 8 frames per launch (test hook for the batch splitting of every launcher), 9 LBP: stages / survivor
  * share at which a block first re-packs (max stages + 16 * tenths [+ later points]; key 4 >= 1000 = custom fixed split),
  * 10 trips per block gs_histogram aims at, 11 its blocks per frame, 12 bytes per histogram piece (test
  * hook for images above 1 GiB), 13 chunk-to-XCD mapping of the LBP cascade (1 = dispatch order, 2 = XCD-aware always),
- * 14 stages the optional LBP prefilter k_lbp_dense takes (0 = off, the default; k = k stages; + 100 = full unsigned compares),
- * 15 windows per scale group of gs_lbp_detect (test hook; 0 = default 16 M), 16 = 1: gs_lbp_detect runs its cascade
+ * 14, 15 unused (round 3's optional LBP stage prefilter, removed in round 4), 16 = 1: gs_lbp_detect runs its cascade
  * kernels but emits nothing (timing aid; counts / rects are NOT written), 17 = 1: the cascade evaluates re-packed windows
  * one per lane instead of one per quad of lanes, 18 band-to-XCD mapping of the strip kernels and tile-to-XCD mapping of the gs_fast score pass (1 = dispatch order, 2 = XCD-aware
  * always), 19 = 1: pass 2 of gs_fast item by item (k_fast_nms, round 2) instead of the strip form.
  * 20 = 1: gs_match_template on the VALU dot-product kernels instead of the matrix cores (2 / 3: the matrix-core kernel with
- * 64 x 128 tiles / with 32 x 64 tiles and the template rows split over four waves, whatever the image size).
- * Results never change (key 16 excepted). */
+ * 64 x 128 tiles / with 32 x 64 tiles and the template rows split over four waves, whatever the image size),
+ * 21 = 1: the round-3 rule for the strip kernels (whole 16-px strips at 16-byte aligned addresses only; everything else per
+ * pixel), 22 = 1: gs_sobel without the reads that preserve columns 0 / w-1 (probe; those columns receive junk), 23 = 1: the
+ * strip-copy probe keeps the stencils' halo load, 24 the realigning strip flavour (1 = never, 2 = always; 0 = by address
+ * phase and width, csrc/gs_stencil.cpp strip_mode).  Process-wide, every entry an atomic.
+ * Results never change (keys 16 and 22 excepted). */
 void gsh_tune(int key, int value);
 /* measurement aid for bench.py: while on, gsh_edge_pipeline_batch brackets every launch of its
  * fused blur+sobel+histogram kernel with HIP events on the stream it is launched on (up to 4096
@@ -127,9 +129,9 @@ void gsh_lbp_detect_batch(const gsh_cascade *dc, const unsigned *ii, unsigned iw
  * of this thread adds [0] the number of windows it really evaluated -- chunks skipped because
  * max_rects detections precede them in scan order (ref :819-823) are not counted --, [1] the
  * number of weak classifiers evaluated, summed over windows (every window pays the classifiers of the stages
- * it enters, like the reference), [2] the dword table loads the kernels issued, summed over lanes (the
- * prefilter k_lbp_dense shares table rows between windows, so this is less than 16 x [1]), [3] the windows
- * that went through the prefilter.  NULL = off (the default kernels). */
+ * it enters, like the reference), [2] the dword table loads the kernels issued, summed over lanes, [3] nothing
+ * any more (round 3's stage prefilter counted its windows here; the buffer keeps four entries so that callers of
+ * either round stay inside their allocation).  NULL = off (the default kernels). */
 void gsh_lbp_count_evaluated(unsigned long long *counter_dev);
 /* number of windows gs_lbp_detect visits for this geometry (for Mwin/s reporting) */
 uint64_t gsh_lbp_window_count(const struct gs_lbp_cascade *c, unsigned iw, unsigned ih,
