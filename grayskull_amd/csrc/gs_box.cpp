@@ -1,7 +1,7 @@
 /*
  * gs_box.cpp -- the sliding-box kernels (k_box.h) in their own translation unit: k_box16r is one kernel per radius
- * (1 .. 16) and mode, each unrolled 2 r + 1 rows deep -- 32 instantiations that take longer to compile than the rest of the
- * library together, so the Makefile builds this file beside the others; the 32 ragged-row forms are in gs_boxr.cpp.
+ * (1 .. 16) and mode, each unrolled 2 r + 1 rows deep -- 32 instantiations that take longer to compile than the rest
+ * of the library together, so the Makefile builds this file beside gs_api.cpp.
  */
 #include "k_box.h"
 
@@ -11,19 +11,12 @@
 
 namespace gs {
 
-void launch_box_ragged(int mode, unsigned ring_radius, dim3 grid, unsigned threads, hipStream_t st, uint8_t *dst, const uint8_t *src,
-                       unsigned w, unsigned h, unsigned T, size_t frame_bytes, int c); /* gs_boxr.cpp */
-
 unsigned box_ring_max() { return GS_BOXR_MAX; }
 
 /* mode 0: gs_blur, 1: gs_adaptive_threshold (constant c).  ring_radius in 1 .. 16: the register-ring kernel for exactly
  * that radius (callers check its preconditions: w >= 32, h >= 2 r + 1, MODE 1: |c| < 2^30); 0: the any-radius kernel. */
 void launch_box(int mode, unsigned ring_radius, dim3 grid, unsigned threads, hipStream_t st, uint8_t *dst, const uint8_t *src, unsigned w,
                 unsigned h, unsigned T, size_t frame_bytes, unsigned r, int c) {
-  if ((w & 15u) != 0u && ring_radius >= 1 && ring_radius <= GS_BOXR_MAX) { /* ragged rows: the RAGGED form of the ring kernels (gs_boxr.cpp) */
-    launch_box_ragged(mode, ring_radius, grid, threads, st, dst, src, w, h, T, frame_bytes, c);
-    return;
-  }
   switch (ring_radius) {
 #define GS_BOXR(RR)                                                                                              \
   case RR:                                                                                                       \

@@ -67,12 +67,20 @@ bool launch_fast_score(hipStream_t on, const uint8_t *img, uint8_t *score, unsig
     GS_LAUNCH(k_fast_score_tile, dim3((w - 6 + 63) / 64, (h - 6 + kFastTileRows - 1) / kFastTileRows, n), dim3(64, 4), 0, on,
               img, score, w, h, fb, threshold);
   } else { /* LDS tile, 4 px per thread through the compass filter, candidates queued (k_fast.h) */
-    const unsigned tx = (w - 6 + 63) / 64, ty = (h - 6 + kFastTileRows - 1) / kFastTileRows;
+    /* tile height (k_fast.h): 48 rows by default (32 x 720p block noise: gs_fast 101 us at 16 rows, 94 at 32, 92 at 48 / 64;
+     * flat frames 55 -> 47; 8 x 4K 178 -> 151 at 64; profiles/r04l_fast_tile_rows.log), key 25 = 16 / 32 / 48 / 64 */
+    const unsigned rows = g_tune[25] == 16 ? 16u : g_tune[25] == 32 ? 32u : g_tune[25] == 64 ? 64u : 48u;
+    const unsigned tx = (w - 6 + 63) / 64, ty = (h - 6 + rows - 1) / rows;
     const unsigned long long nt = (unsigned long long)tx * ty * n;
-    GS_ASSERT(nt <= 0x7ffffff0ull); /* 2^31 tiles = 2^41 pixels in one call */
+    GS_ASSERT(nt < (1ull << 24)); /* the kernel's 32-bit strides (zeroing loop, tile index) stay clear of 2^32: 2^24 tiles = 2^34 pixels per call */
     const unsigned share = (g_tune[18] == 1 || !topo().eight_xcds()) ? 0u : (unsigned)((nt + 7) / 8); /* key 18 = 1: tiles in launch order */
-    GS_LAUNCH(k_fast_score_q4, dim3(share ? share * 8u : (unsigned)nt), dim3(64, 4), 0, on, img, score, w, h, fb, threshold, tx,
-              ty, (unsigned)nt, share, zero_words, zero_n);
+    const dim3 grid(share ? share * 8u : (unsigned)nt), block(64, 4);
+    switch (rows) {
+      case 16: GS_LAUNCH(k_fast_score_q4<16>, grid, block, 0, on, img, score, w, h, fb, threshold, tx, ty, (unsigned)nt, share, zero_words, zero_n); break;
+      case 32: GS_LAUNCH(k_fast_score_q4<32>, grid, block, 0, on, img, score, w, h, fb, threshold, tx, ty, (unsigned)nt, share, zero_words, zero_n); break;
+      case 64: GS_LAUNCH(k_fast_score_q4<64>, grid, block, 0, on, img, score, w, h, fb, threshold, tx, ty, (unsigned)nt, share, zero_words, zero_n); break;
+      default: GS_LAUNCH(k_fast_score_q4<48>, grid, block, 0, on, img, score, w, h, fb, threshold, tx, ty, (unsigned)nt, share, zero_words, zero_n);
+    }
     return true;
   }
   return false;

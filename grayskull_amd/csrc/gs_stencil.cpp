@@ -193,7 +193,10 @@ void launch_box_generic(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h
       const unsigned nn = std::min(kMaxZ, n - f0);
       /* r <= 16: the window's raw rows stay in registers (k_box16r: 2 B/px instead of 3-4; 64 x 4K: 0.22 ms for r <= 9,
        * 0.28 up to 16, against 0.31-0.42 -- profiles/r03r_box_ring.log).  Key 6 = 4: k_box16 always. */
-      const bool ring = g_tune[6] != 4 && r <= box_ring_max() && w >= 32 && h >= 2 * r + 1 && (MODE == 0 || (c > -(1 << 30) && c < (1 << 30)));
+      /* ragged rows take the any-radius kernel: a RAGGED form of the ring kernels (per-pixel choice between two edge
+       * divisors, shifted tail loads) was built in round 4 and was no faster -- 116-152 registers at r = 4..5 instead of 84-92,
+       * one wave per SIMD from r = 12 (profiles/r04k_box_ring_ragged_not_kept.log: 3838 x 2160 r = 5 0.446 vs 0.434 ms, r = 16 0.73 vs 0.53) */
+      const bool ring = g_tune[6] != 4 && !ragged(w) && r <= box_ring_max() && w >= 32 && h >= 2 * r + 1 && (MODE == 0 || (c > -(1 << 30) && c < (1 << 30)));
       /* band height: the launch should be whole rounds of the blocks the chip holds (256 CUs x 4 of them, fewer for the
        * register-heavy ring kernels of r >= 8 / 10), and a band first loads 2r+1 rows it does not output -- loads and
        * adds only since the vertical-first form, ~0.3 of an output row each.  Pick the band count with the smallest

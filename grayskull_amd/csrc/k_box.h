@@ -61,6 +61,7 @@ __global__ __launch_bounds__(256) void k_box16(uint8_t *dst, const uint8_t *src,
   const unsigned m = w & 15u;                   /* block-uniform: bytes of the last strip inside the row */
   const bool tail = act && x0 + 16u > w;        /* m != 0 and this thread owns that strip */
   const uint32_t ld_off = !act ? kOOB : tail ? w - 16u : x0, st_off = (act && !tail) ? x0 : kOOB;
+  const bool tail_wave = ballot(tail) != 0ull; /* wave-uniform */
   const BufRsrc S = make_buf(src + (size_t)blockIdx.z * frame_bytes, frame_bytes);
   const BufRsrc D = make_buf(dst + (size_t)blockIdx.z * frame_bytes, frame_bytes);
   const int y0 = (int)(blockIdx.y * T);
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(256) void k_box16(uint8_t *dst, const uint8_t *src,
   auto row_load = [&](int yy) { /* this thread's 16 B of row yy, zeros outside the image */
     const U4 v = buf_load16(S, (yy >= 0 && yy < (int)h) ? (uint32_t)yy * w + ld_off : kOOB);
     uint32_t a = v.x, b = v.y, c = v.z, d = v.w; /* scalars: hipcc selects / merges whole structs through scratch memory */
-    if (m) { /* block-uniform */
+    if (tail_wave) { /* wave-uniform: only the wave that holds the tail strip pays for the shift */
       const U4 sh = shift_down_bytes(v, 16u - m);
       a = tail ? sh.x : a, b = tail ? sh.y : b, c = tail ? sh.z : c, d = tail ? sh.w : d;
     }
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(256) void k_box16(uint8_t *dst, const uint8_t *src,
       od[j >> 2] |= o << (8 * (j & 3));
     }
     buf_store16(D, (uint32_t)y * w + st_off, U4{od[0], od[1], od[2], od[3]}); /* st_off = kOOB: dropped */
-    if (m) buf_store_first(D, tail ? (uint32_t)y * w + x0 : kOOB, od[0], od[1], od[2], od[3], m);
+    if (tail_wave) buf_store_first(D, tail ? (uint32_t)y * w + x0 : kOOB, od[0], od[1], od[2], od[3], m);
   }
 }
 
@@ -208,12 +209,7 @@ template <int RR> struct BoxMagic {
 #ifndef GS_BOXR_ATTR
 #define GS_BOXR_ATTR
 #endif
-/* RAGGED (w % 16 != 0, round 4): as in k_box16 the strips stay on the grid, the tail strip loads the row's last 16 bytes
- * and shifts them into grid position (zeros entering) and stores its w % 16 result bytes as 8 + 4 + 2 + 1-byte stores.
- * Pixels less than RR columns from the right edge now sit in TWO threads -- the tail thread (pixel j: w % 16 - 1 - j columns
- * to its right) and, when w % 16 < RR, the thread before it (15 + w % 16 - j) -- at positions that depend on w, so every
- * pixel's divisor is chosen between the interior one and two wave-uniform edge candidates. */
-template <int MODE, int RR, bool RAGGED = false>
+template <int MODE, int RR>
 __global__ __launch_bounds__(256) GS_BOXR_ATTR void k_box16r(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned T,
                                                 size_t frame_bytes, int c) {
   constexpr int N = 2 * RR + 1;
@@ -222,9 +218,6 @@ __global__ __launch_bounds__(256) GS_BOXR_ATTR void k_box16r(uint8_t *dst, const
   __shared__ __attribute__((aligned(16))) uint8_t rows[2][kBoxRowBytes];
   const unsigned tid = threadIdx.x, x0 = tid * 16u;
   const bool act = x0 < w, first = x0 == 0, last = x0 + 16u == w;
-  const unsigned m = w & 15u;                                         /* RAGGED: != 0 */
-  const bool tail = RAGGED && act && x0 + 16u > w, prevl = RAGGED && x0 + 16u == (w & ~15u); /* the partial strip, the full one before it */
-  const uint32_t ld_off = !act ? kOOB : tail ? w - 16u : x0, st_off = (act && !tail) ? x0 : kOOB;
   const BufRsrc S = make_buf(src + (size_t)blockIdx.z * frame_bytes, frame_bytes);
   const BufRsrc D = make_buf(dst + (size_t)blockIdx.z * frame_bytes, frame_bytes);
   const int y0 = (int)(blockIdx.y * T);
@@ -232,11 +225,7 @@ __global__ __launch_bounds__(256) GS_BOXR_ATTR void k_box16r(uint8_t *dst, const
   const int nrows = ((int)h - y0) < (int)T ? ((int)h - y0) : (int)T;
   for (unsigned i = tid; i < 2u * kBoxRowBytes / 4u; i += blockDim.x) ((uint32_t *)&rows[0][0])[i] = 0;
   auto row_load = [&](int yy) {
-    const U4 v = buf_load16(S, (yy >= 0 && yy < (int)h) ? (uint32_t)yy * w + ld_off : kOOB);
-    if constexpr (!RAGGED) return v;
-    const U4 sh = shift_down_bytes(v, 16u - m);
-    /* opaque(): the row is final here -- four registers in the ring, not the raw row plus a shift to be done later */
-    return U4{opaque(tail ? sh.x : v.x), opaque(tail ? sh.y : v.y), opaque(tail ? sh.z : v.z), opaque(tail ? sh.w : v.w)};
+    return buf_load16(S, (act && yy >= 0 && yy < (int)h) ? (uint32_t)yy * w + x0 : kOOB);
   };
   uint32_t Vc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   auto vc_add = [&](const U4 &v) {
@@ -309,35 +298,21 @@ __global__ __launch_bounds__(256) GS_BOXR_ATTR void k_box16r(uint8_t *dst, const
          * its last thread on the right (j >= 16 - RR: RR + 16 - j); constants once unrolled */
         const int el = j < RR ? j : RR, er = j >= 16 - RR ? 15 - j : RR;
         const bool cl = j < RR && first, cr = j >= 16 - RR && last;
-        /* RAGGED: columns right of pixel j inside the row, in the tail thread / in the thread before it (wave-uniform) */
-        const int erT = (int)m - 1 - j, erP = 15 + (int)m - j;
-        const bool eT = RAGGED && erT >= 0 && erT < RR, eP = RAGGED && erP < RR;
         unsigned o;
         if (MODE == 0) {
           const unsigned a = cy - (unsigned)(RR + 1);
           /* uniform(): the three multipliers are scalars picked per lane, not a load from a per-lane address */
           const uint32_t ml = uniform(kMagic.m[a][el]), mr = uniform(kMagic.m[a][er]), mc = uniform(kMagic.m[a][RR]);
-          uint32_t mul = cl ? ml : cr ? mr : mc;
-          if constexpr (RAGGED) {
-            const uint32_t mT = eT ? uniform(kMagic.m[a][eT ? erT : 0]) : mc, mP = eP ? uniform(kMagic.m[a][eP ? erP : 0]) : mc;
-            mul = cl ? ml : tail ? mT : prevl ? mP : mc;
-          }
-          o = __umulhi(H[j], mul) & 0xffu;
+          o = __umulhi(H[j], cl ? ml : cr ? mr : mc) & 0xffu;
         } else {
           const unsigned cc = (unsigned)N * cy, ccl = (unsigned)(RR + 1 + el) * cy, ccr = (unsigned)(RR + 1 + er) * cy; /* scalar */
           const int k = (int)((cd[j >> 2] >> (8 * (j & 3))) & 0xffu) + c;
           const unsigned kc = (unsigned)(k < 0 ? 0 : k > 256 ? 256 : k);
-          unsigned cnt = cl ? ccl : cr ? ccr : cc;
-          if constexpr (RAGGED) {
-            const unsigned ccT = eT ? (unsigned)(RR + 1 + erT) * cy : cc, ccP = eP ? (unsigned)(RR + 1 + erP) * cy : cc;
-            cnt = cl ? ccl : tail ? ccT : prevl ? ccP : cc;
-          }
-          o = kc * cnt > H[j] ? 255u : 0u;
+          o = kc * (cl ? ccl : cr ? ccr : cc) > H[j] ? 255u : 0u;
         }
         od[j >> 2] |= o << (8 * (j & 3));
       }
-      buf_store16(D, (uint32_t)y * w + st_off, U4{od[0], od[1], od[2], od[3]}); /* st_off = kOOB: dropped */
-      if constexpr (RAGGED) buf_store_first(D, tail ? (uint32_t)y * w + x0 : kOOB, od[0], od[1], od[2], od[3], m);
+      buf_store16(D, act ? (uint32_t)y * w + x0 : kOOB, U4{od[0], od[1], od[2], od[3]});
     });
   }
 }

@@ -259,13 +259,19 @@ __global__ __launch_bounds__(256) void k_fast_score_cq(const uint8_t *img, uint8
  * scored from the tile's bytes with fast_score -- the same function as every other score kernel, and a pixel the
  * filter rejects has no run of 9, so the stored zero IS its score.  One pass over the 64 x 16 tile per block
  * (256 threads x 4 px) instead of four.  grid: one block per tile, 1-D (see the tile mapping below); block (64, 4). */
+/* ROWS (round 4): tile height, a multiple of 16.  A block's life is one round trip to memory for its tile plus two barriers;
+ * on flat frames that latency, not arithmetic, is the whole cost (35 of the 60 us per 32 x 720p at ROWS = 16: ~2.5 us per
+ * block with 8 blocks per CU resident).  Taller tiles halve the blocks and the halo share (6 extra rows per 32 instead of
+ * per 16) for the same round trip; each thread then filters 4 pixels of ROWS / 16 tile rows. */
 typedef uint32_t gs_u32_unaligned __attribute__((aligned(1)));
+template <unsigned ROWS>
 __global__ __launch_bounds__(256) void k_fast_score_q4(const uint8_t *img, uint8_t *score, unsigned w, unsigned h,
                                                        size_t frame_bytes, unsigned threshold, unsigned tiles_x,
                                                        unsigned tiles_y, unsigned ntiles, unsigned xcd_share,
                                                        unsigned *zero_words, unsigned zero_n) {
-  __shared__ uint32_t tile32[(kFastTileRows + 6) * kFastTileDw + 2]; /* + 2: the last thread's third centre dword */
-  __shared__ uint16_t queue[64 * kFastTileRows];
+  static_assert(ROWS % 16 == 0 && ROWS >= 16 && ROWS <= 64, "a thread takes one row of every group of 16; queue entries are 16-bit");
+  __shared__ uint32_t tile32[(ROWS + 6) * kFastTileDw + 2]; /* + 2: the last thread's third centre dword */
+  __shared__ uint16_t queue[64 * ROWS];
   __shared__ unsigned qn;
   /* tile of this block.  Workgroups go to the 8 XCDs round robin and each XCD has its own L2: with neighbouring tiles on
    * different XCDs every L2 fetches the shared halo rows and the 128-byte lines a 70-byte tile row straddles for itself
@@ -283,9 +289,9 @@ __global__ __launch_bounds__(256) void k_fast_score_q4(const uint8_t *img, uint8
   const uint8_t *frame = img + (size_t)tframe * frame_bytes;
   uint8_t *out = score + (size_t)tframe * frame_bytes;
   const unsigned tid = threadIdx.y * 64u + threadIdx.x;
-  const unsigned x_t = tcol * 64u, y_t = trow * kFastTileRows;
-  if (tid == 0) qn = 0, tile32[(kFastTileRows + 6) * kFastTileDw] = 0, tile32[(kFastTileRows + 6) * kFastTileDw + 1] = 0;
-  for (unsigned i = tid; i < (kFastTileRows + 6) * kFastTileDw; i += 256u) {
+  const unsigned x_t = tcol * 64u, y_t = trow * ROWS;
+  if (tid == 0) qn = 0, tile32[(ROWS + 6) * kFastTileDw] = 0, tile32[(ROWS + 6) * kFastTileDw + 1] = 0;
+  for (unsigned i = tid; i < (ROWS + 6) * kFastTileDw; i += 256u) {
     const unsigned r = i / kFastTileDw, c = i - r * kFastTileDw;
     const size_t off = (size_t)(y_t + r) * w + x_t + c * 4u;
     uint32_t v = 0;
@@ -299,15 +305,18 @@ __global__ __launch_bounds__(256) void k_fast_score_q4(const uint8_t *img, uint8
   }
   __syncthreads();
   /* thread -> tile row ry, pixels 4 xg .. 4 xg + 3 of it (tile byte columns 4 xg + 3 .. 4 xg + 6) */
-  const unsigned ry = tid >> 4, xg = tid & 15u;
-  const unsigned x = 3 + x_t + 4u * xg, y = 3 + y_t + ry;
+  const unsigned xg = tid & 15u, x = 3 + x_t + 4u * xg;
+  const uint32_t t16 = threshold < 256u ? threshold : 256u, tt = t16 | (t16 << 16);
+  unsigned cands[ROWS / 16]; /* per row group, bit k: pixel k passes the compass filter */
+#pragma unroll
+  for (unsigned rg = 0; rg < ROWS / 16; rg++) {
+  const unsigned ry = rg * 16u + (tid >> 4), y = 3 + y_t + ry;
   const uint32_t *rc = tile32 + (ry + 3) * kFastTileDw + xg, *ru = tile32 + ry * kFastTileDw + xg,
                  *rd = tile32 + (ry + 6) * kFastTileDw + xg;
   const uint32_t d0 = rc[0], d1 = rc[1], d2 = rc[2];
   const uint32_t C = alignbit(d1, d0, 24), L = d0, Rr = alignbit(d2, d1, 16); /* p; (x - 3, y); (x + 3, y) */
   const uint32_t U = alignbit(ru[1], ru[0], 24), D = alignbit(rd[1], rd[0], 24); /* (x, y - 3); (x, y + 3) */
-  const uint32_t t16 = threshold < 256u ? threshold : 256u, tt = t16 | (t16 << 16);
-  unsigned cand = 0; /* bit k: pixel k passes the compass filter */
+  unsigned cand = 0;
 #pragma unroll
   for (int hp = 0; hp < 2; hp++) {
     const uint32_t P = hp ? unpack_hi(C) : unpack_lo(C), a = hp ? unpack_hi(U) : unpack_lo(U), c = hp ? unpack_hi(D) : unpack_lo(D);
@@ -342,21 +351,27 @@ __global__ __launch_bounds__(256) void k_fast_score_q4(const uint8_t *img, uint8
       if (ck) queue[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(ry * 64u + 4u * xg + k);
     }
   }
+  cands[rg] = cand;
+  }
   __syncthreads(); /* orders the zero stores above before the candidates' stores below (workgroup-scope release / acquire) */
   const unsigned ncand = qn;
   const uint8_t *tb = (const uint8_t *)tile32;
   constexpr int S = (int)kFastTileDw * 4;
-  if (ncand * 2u >= 64u * kFastTileRows) { /* most of the tile passes (noise, p < t regions): the queue would only add a round trip
+  if (ncand * 2u >= 64u * ROWS) { /* most of the tile passes (noise, p < t regions): the queue would only add a round trip
                                               and scatter the LDS reads -- every thread scores its own pixels (32 x 720p random
                                               bytes: 138 us through the queue, 110 in place) */
 #pragma unroll
-    for (unsigned k = 0; k < 4; k++) {
-      if (ballot((cand >> k) & 1u) == 0) continue; /* wave-uniform */
-      const uint8_t *c = tb + (ry + 3) * S + 4u * xg + k + 3;
-      const unsigned v[16] = {c[-3 * S],     c[-3 * S + 1], c[-2 * S + 2], c[-S + 3], c[3],  c[S + 3],  c[2 * S + 2],  c[3 * S + 1],
-                              c[3 * S],      c[3 * S - 1],  c[2 * S - 2],  c[S - 3],  c[-3], c[-S - 3], c[-2 * S - 2], c[-3 * S - 1]};
-      const unsigned sc = fast_score(c[0], v, threshold);
-      if (((cand >> k) & 1u) && sc) out[(size_t)y * w + x + k] = (uint8_t)sc;
+    for (unsigned rg = 0; rg < ROWS / 16; rg++) {
+      const unsigned cand = cands[rg], ry = rg * 16u + (tid >> 4), y = 3 + y_t + ry;
+#pragma unroll
+      for (unsigned k = 0; k < 4; k++) {
+        if (ballot((cand >> k) & 1u) == 0) continue; /* wave-uniform */
+        const uint8_t *c = tb + (ry + 3) * S + 4u * xg + k + 3;
+        const unsigned v[16] = {c[-3 * S],     c[-3 * S + 1], c[-2 * S + 2], c[-S + 3], c[3],  c[S + 3],  c[2 * S + 2],  c[3 * S + 1],
+                                c[3 * S],      c[3 * S - 1],  c[2 * S - 2],  c[S - 3],  c[-3], c[-S - 3], c[-2 * S - 2], c[-3 * S - 1]};
+        const unsigned sc = fast_score(c[0], v, threshold);
+        if (((cand >> k) & 1u) && sc) out[(size_t)y * w + x + k] = (uint8_t)sc;
+      }
     }
     return;
   }

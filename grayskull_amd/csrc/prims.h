@@ -515,13 +515,18 @@ GS_DEV int wave_sum_i(int v) { return (int)wave_sum((uint32_t)v); }
 /* 16 bytes shifted down by nb = 1..15 bytes, zeros entering at the top (nb wave-uniform: the dword part of the shift
  * is a scalar choice, the byte part one v_alignbyte_b32 per dword) */
 GS_DEV U4 shift_down_bytes(U4 v, unsigned nb) {
-  /* as two 64-bit halves (chains of selects on nb / 4 end up as a table in scratch memory with hipcc) */
-  const uint64_t lo = v.x | ((uint64_t)v.y << 32), hi = v.z | ((uint64_t)v.w << 32);
-  const unsigned sh = 8u * nb; /* 8 .. 120 */
-  uint64_t olo, ohi;
-  if (sh < 64u) olo = (lo >> sh) | (hi << (64u - sh)), ohi = hi >> sh;
-  else olo = hi >> (sh - 64u), ohi = 0;
-  return U4{(uint32_t)olo, (uint32_t)(olo >> 32), (uint32_t)ohi, (uint32_t)(ohi >> 32)};
+  /* the dword part of the shift is a wave-uniform SWITCH (a chain of selects on nb / 4 ends up as a table in scratch memory
+   * with hipcc, 64-bit shifts run at a quarter of the rate), the byte part one v_perm_b32 per dword with a selector that
+   * reads bytes b .. b + 3 of the pair {hi, lo} */
+  uint32_t e0, e1, e2, e3;
+  switch (nb >> 2) {
+    case 0: e0 = v.x, e1 = v.y, e2 = v.z, e3 = v.w; break;
+    case 1: e0 = v.y, e1 = v.z, e2 = v.w, e3 = 0u; break;
+    case 2: e0 = v.z, e1 = v.w, e2 = 0u, e3 = 0u; break;
+    default: e0 = v.w, e1 = 0u, e2 = 0u, e3 = 0u; break;
+  }
+  const uint32_t sel = 0x03020100u + 0x01010101u * (nb & 3u);
+  return U4{perm_b32(e1, e0, sel), perm_b32(e2, e1, sel), perm_b32(e3, e2, sel), perm_b32(0u, e3, sel)};
 }
 /* the first m = 1..15 bytes of o to buffer offset off (m wave-uniform): 8 + 4 + 2 + 1 byte stores as m's bits say.
  * Lanes that must not store pass off = kOOB. */

@@ -75,6 +75,21 @@ def test_fast(emu, oracle, shape):
             emu.tune(7, 0)
 
 
+@pytest.mark.parametrize("rows", [16, 32, 48, 64])
+def test_fast_score_tile_heights(emu, oracle, rows):
+    """k_fast_score_q4<ROWS> (gsh_tune key 25; 48 by default since round 4): a thread filters 4 pixels of ROWS / 16 tile rows,
+    the candidate queue and the in-place path for dense tiles span the taller tile; heights that leave ragged last tiles"""
+    rs = np.random.RandomState(31)
+    try:
+        emu.tune(25, rows)
+        for (w, h) in ((70, 23), (131, 77), (64, 38), (200, 135)):
+            pc.fast(emu, oracle, Oracle.synth(w, h, 5), MEM)
+            pc.fast(emu, oracle, rs.randint(0, 256, (h, w)).astype(np.uint8), MEM, threshold=5, caps=(5000,))   # dense: scored in place
+            pc.fast(emu, oracle, (rs.randint(0, 256, (h, w)) * (rs.rand(h, w) < 0.2)).astype(np.uint8), MEM, threshold=40)
+    finally:
+        emu.tune(25, 0)
+
+
 def test_fast_strip_kernel_equals_per_pixel_kernel(emu, oracle):
     """k_fast_score4 (w % 4 == 0: lane = 4 px, rows in registers, compass filter) against k_fast_score_tile
     (the default), k_fast_score_px and the oracle; gsh_tune key 7 = 1 selects the strip kernel, 2 the per-pixel global-load kernel:

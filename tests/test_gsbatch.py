@@ -470,7 +470,7 @@ def test_gsbatch_two_workers_asan_clean(tmp_path):
     lib = str(tmp_path / "libgs_kernel_emu.so")
     san = ["-fsanitize=address", "-fno-omit-frame-pointer", "-g", "-O1"]
     subprocess.check_call(["g++", "-DGS_EMU", "-DGS_BOXR_MAX=3", *san, "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-w",
-                           "-I" + emu_dir, "-I" + csrc, *[os.path.join(csrc, u + ".cpp") for u in ("gs_ctx", "gs_stencil", "gs_detect", "gs_comm", "gs_fused", "gs_box", "gs_boxr")],
+                           "-I" + emu_dir, "-I" + csrc, *[os.path.join(csrc, u + ".cpp") for u in ("gs_ctx", "gs_stencil", "gs_detect", "gs_comm", "gs_fused", "gs_box")],
                            os.path.join(emu_dir, "hip_emu.cpp"), "-o", lib])
     exe = str(tmp_path / "gsbatch_asan")
     subprocess.check_call(["gcc", "-std=c99", *san, "-I" + os.path.join(ROOT, "include"), SRC, "-o", exe,
