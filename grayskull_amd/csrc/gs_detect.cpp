@@ -74,7 +74,13 @@ bool launch_fast_score(hipStream_t on, const uint8_t *img, uint8_t *score, unsig
     const unsigned long long nt = (unsigned long long)tx * ty * n;
     GS_ASSERT(nt < (1ull << 24)); /* the kernel's 32-bit strides (zeroing loop, tile index) stay clear of 2^32: 2^24 tiles = 2^34 pixels per call */
     const unsigned share = (g_tune[18] == 1 || !topo().eight_xcds()) ? 0u : (unsigned)((nt + 7) / 8); /* key 18 = 1: tiles in launch order */
-    const dim3 grid(share ? share * 8u : (unsigned)nt), block(64, 4);
+    const dim3 grid(share ? share * 8u : (unsigned)nt), block(64, g_tune[26] == 128 ? 2 : 4);
+    if (g_tune[26] == 128) { /* experiment: 128 threads per tile */
+      if (rows == 32) GS_LAUNCH((k_fast_score_q4<32, 128>), grid, block, 0, on, img, score, w, h, fb, threshold, tx, ty, (unsigned)nt, share, zero_words, zero_n);
+      else if (rows == 64) GS_LAUNCH((k_fast_score_q4<64, 128>), grid, block, 0, on, img, score, w, h, fb, threshold, tx, ty, (unsigned)nt, share, zero_words, zero_n);
+      else GS_LAUNCH((k_fast_score_q4<48, 128>), grid, block, 0, on, img, score, w, h, fb, threshold, tx, ty, (unsigned)nt, share, zero_words, zero_n);
+      return true;
+    }
     switch (rows) {
       case 16: GS_LAUNCH(k_fast_score_q4<16>, grid, block, 0, on, img, score, w, h, fb, threshold, tx, ty, (unsigned)nt, share, zero_words, zero_n); break;
       case 32: GS_LAUNCH(k_fast_score_q4<32>, grid, block, 0, on, img, score, w, h, fb, threshold, tx, ty, (unsigned)nt, share, zero_words, zero_n); break;

@@ -264,12 +264,14 @@ __global__ __launch_bounds__(256) void k_fast_score_cq(const uint8_t *img, uint8
  * block with 8 blocks per CU resident).  Taller tiles halve the blocks and the halo share (6 extra rows per 32 instead of
  * per 16) for the same round trip; each thread then filters 4 pixels of ROWS / 16 tile rows. */
 typedef uint32_t gs_u32_unaligned __attribute__((aligned(1)));
-template <unsigned ROWS>
-__global__ __launch_bounds__(256) void k_fast_score_q4(const uint8_t *img, uint8_t *score, unsigned w, unsigned h,
+/* NT: threads per block (64 x NT / 64): fewer threads per tile = more tiles in flight per CU for the same registers */
+template <unsigned ROWS, unsigned NT = 256>
+__global__ __launch_bounds__(NT) void k_fast_score_q4(const uint8_t *img, uint8_t *score, unsigned w, unsigned h,
                                                        size_t frame_bytes, unsigned threshold, unsigned tiles_x,
                                                        unsigned tiles_y, unsigned ntiles, unsigned xcd_share,
                                                        unsigned *zero_words, unsigned zero_n) {
-  static_assert(ROWS % 16 == 0 && ROWS >= 16 && ROWS <= 64, "a thread takes one row of every group of 16; queue entries are 16-bit");
+  static_assert(ROWS % 16 == 0 && ROWS >= 16 && ROWS <= 64 && (NT == 128 || NT == 256), "a thread takes one row of every group of NT / 16; queue entries are 16-bit");
+  constexpr unsigned RG = NT / 16; /* tile rows per row group */
   __shared__ uint32_t tile32[(ROWS + 6) * kFastTileDw + 2]; /* + 2: the last thread's third centre dword */
   __shared__ uint16_t queue[64 * ROWS];
   __shared__ unsigned qn;
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(256) void k_fast_score_q4(const uint8_t *img, uint8
    * grid of 8 * xcd_share blocks, XCD k walks tiles [k * xcd_share, (k + 1) * xcd_share) in order, so the tiles in flight
    * on one XCD are a few consecutive tile rows of one frame. */
   /* the chunk counters of pass 2 are zeroed here (zero_n words, spread over the grid) instead of by a 5-us fill launch */
-  for (unsigned i = blockIdx.x * 256u + threadIdx.y * 64u + threadIdx.x; i < zero_n; i += gridDim.x * 256u) zero_words[i] = 0;
+  for (unsigned i = blockIdx.x * NT + threadIdx.y * 64u + threadIdx.x; i < zero_n; i += gridDim.x * NT) zero_words[i] = 0;
   unsigned tile = blockIdx.x;
   if (xcd_share) {
     tile = (blockIdx.x & 7u) * xcd_share + (blockIdx.x >> 3);
@@ -291,26 +293,42 @@ __global__ __launch_bounds__(256) void k_fast_score_q4(const uint8_t *img, uint8
   const unsigned tid = threadIdx.y * 64u + threadIdx.x;
   const unsigned x_t = tcol * 64u, y_t = trow * ROWS;
   if (tid == 0) qn = 0, tile32[(ROWS + 6) * kFastTileDw] = 0, tile32[(ROWS + 6) * kFastTileDw + 1] = 0;
-  for (unsigned i = tid; i < (ROWS + 6) * kFastTileDw; i += 256u) {
-    const unsigned r = i / kFastTileDw, c = i - r * kFastTileDw;
-    const size_t off = (size_t)(y_t + r) * w + x_t + c * 4u;
-    uint32_t v = 0;
-    if (off + 4 <= frame_bytes) {
-      v = load_u32_unaligned(frame + off);
-    } else {
-      for (unsigned b = 0; b < 4; b++)
-        if (off + b < frame_bytes) v |= (uint32_t)frame[off + b] << (8 * b);
+  /* block-uniform: every dword of the tile region lies inside the frame (all tiles but those of the last tile row) -- then
+   * the copy is a plain loop: (row, column) advance by NT = 14 x 18 + 4 dwords without a division, no bounds test per load */
+  const bool tile_inside = ((size_t)(y_t + ROWS + 5u) * w + x_t + kFastTileDw * 4u <= frame_bytes) && frame_bytes < 0x7fffffffull;
+  if (tile_inside) {
+    constexpr unsigned dr = NT / kFastTileDw, dc = NT - dr * kFastTileDw;
+    unsigned r = tid / kFastTileDw, c = tid - r * kFastTileDw;
+    const uint8_t *p0 = frame + (size_t)y_t * w + x_t;
+#pragma unroll
+    for (unsigned i = tid, it = 0; it < ((ROWS + 6) * kFastTileDw + NT - 1) / NT; it++, i += NT) {
+      if (i < (ROWS + 6) * kFastTileDw) tile32[i] = load_u32_unaligned(p0 + r * w + c * 4u);
+      r += dr, c += dc;
+      if (c >= kFastTileDw) c -= kFastTileDw, r++;
     }
-    tile32[i] = v;
+  } else {
+    for (unsigned i = tid; i < (ROWS + 6) * kFastTileDw; i += NT) {
+      const unsigned r = i / kFastTileDw, c = i - r * kFastTileDw;
+      const size_t off = (size_t)(y_t + r) * w + x_t + c * 4u;
+      uint32_t v = 0;
+      if (off + 4 <= frame_bytes) {
+        v = load_u32_unaligned(frame + off);
+      } else {
+        for (unsigned b = 0; b < 4; b++)
+          if (off + b < frame_bytes) v |= (uint32_t)frame[off + b] << (8 * b);
+      }
+      tile32[i] = v;
+    }
   }
   __syncthreads();
+  const bool tile_interior = x_t + 69u < w && y_t + ROWS + 5u < h; /* block-uniform: every pixel of the tile is an interior pixel */
   /* thread -> tile row ry, pixels 4 xg .. 4 xg + 3 of it (tile byte columns 4 xg + 3 .. 4 xg + 6) */
   const unsigned xg = tid & 15u, x = 3 + x_t + 4u * xg;
   const uint32_t t16 = threshold < 256u ? threshold : 256u, tt = t16 | (t16 << 16);
-  unsigned cands[ROWS / 16]; /* per row group, bit k: pixel k passes the compass filter */
+  unsigned cands[ROWS / RG]; /* per row group, bit k: pixel k passes the compass filter */
 #pragma unroll
-  for (unsigned rg = 0; rg < ROWS / 16; rg++) {
-  const unsigned ry = rg * 16u + (tid >> 4), y = 3 + y_t + ry;
+  for (unsigned rg = 0; rg < ROWS / RG; rg++) {
+  const unsigned ry = rg * RG + (tid >> 4), y = 3 + y_t + ry;
   const uint32_t *rc = tile32 + (ry + 3) * kFastTileDw + xg, *ru = tile32 + ry * kFastTileDw + xg,
                  *rd = tile32 + (ry + 6) * kFastTileDw + xg;
   const uint32_t d0 = rc[0], d1 = rc[1], d2 = rc[2];
@@ -328,9 +346,12 @@ __global__ __launch_bounds__(256) void k_fast_score_q4(const uint8_t *img, uint8
     cand |= ((pass & 0xffffu) ? 1u : 0u) << (2 * hp) | ((pass >> 16) ? 1u : 0u) << (2 * hp + 1);
   }
   /* pixels of the interior only (3 <= x < w - 3, 3 <= y < h - 3); the tile may stick out of it */
-  unsigned inmask = 0;
+  unsigned inmask = 15u;
+  if (!tile_interior) {
+    inmask = 0;
 #pragma unroll
-  for (unsigned k = 0; k < 4; k++) inmask |= (x + k + 3u < w && y + 3u < h ? 1u : 0u) << k;
+    for (unsigned k = 0; k < 4; k++) inmask |= (x + k + 3u < w && y + 3u < h ? 1u : 0u) << k;
+  }
   cand &= inmask;
   if (inmask == 15u) {
     *(gs_u32_unaligned *)(out + (size_t)y * w + x) = 0u; /* candidates are overwritten behind the barrier */
@@ -339,6 +360,7 @@ __global__ __launch_bounds__(256) void k_fast_score_q4(const uint8_t *img, uint8
     for (unsigned k = 0; k < 4; k++)
       if ((inmask >> k) & 1u) out[(size_t)y * w + x + k] = 0;
   }
+  if (ballot(cand != 0u) != 0ull) { /* wave-uniform: most wave rows of a frame hold no candidate at all */
 #pragma unroll
   for (unsigned k = 0; k < 4; k++) { /* queue the candidates: one LDS atomic per wave and slot */
     const bool ck = (cand >> k) & 1u;
@@ -351,6 +373,7 @@ __global__ __launch_bounds__(256) void k_fast_score_q4(const uint8_t *img, uint8
       if (ck) queue[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(ry * 64u + 4u * xg + k);
     }
   }
+  }
   cands[rg] = cand;
   }
   __syncthreads(); /* orders the zero stores above before the candidates' stores below (workgroup-scope release / acquire) */
@@ -361,8 +384,8 @@ __global__ __launch_bounds__(256) void k_fast_score_q4(const uint8_t *img, uint8
                                               and scatter the LDS reads -- every thread scores its own pixels (32 x 720p random
                                               bytes: 138 us through the queue, 110 in place) */
 #pragma unroll
-    for (unsigned rg = 0; rg < ROWS / 16; rg++) {
-      const unsigned cand = cands[rg], ry = rg * 16u + (tid >> 4), y = 3 + y_t + ry;
+    for (unsigned rg = 0; rg < ROWS / RG; rg++) {
+      const unsigned cand = cands[rg], ry = rg * RG + (tid >> 4), y = 3 + y_t + ry;
 #pragma unroll
       for (unsigned k = 0; k < 4; k++) {
         if (ballot((cand >> k) & 1u) == 0) continue; /* wave-uniform */
@@ -375,7 +398,7 @@ __global__ __launch_bounds__(256) void k_fast_score_q4(const uint8_t *img, uint8
     }
     return;
   }
-  for (unsigned i0 = 0; i0 < ncand; i0 += 256u) { /* block-uniform trip count */
+  for (unsigned i0 = 0; i0 < ncand; i0 += NT) { /* block-uniform trip count */
     const unsigned i = i0 + tid;
     if (i0 + (tid & ~63u) >= ncand) continue; /* whole wave past the queue's end */
     const unsigned e = queue[i < ncand ? i : ncand - 1u], qy = e >> 6, qx = e & 63u;
