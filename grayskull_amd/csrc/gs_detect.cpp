@@ -44,8 +44,14 @@ void run_compaction(unsigned long long *mask, unsigned *cnt, unsigned nchunks, u
  * unsigned wrap, and a 256-px span almost always touches one).  Key 7 = 2: one global byte load per ring pixel
  * (the round-1 form: texture-addresser bound, 4.9 vs 4.2 us per frame). */
 /* zero_words / zero_n: words the default kernel clears on the side (pass 2's chunk counters); returns whether it did */
+/* nz / nz_frame_words: the default kernel also leaves the bitmap of scored pixels (k_fast.h); fast_score_leaves_bitmap() says
+ * whether the call will take that kernel */
+bool fast_score_leaves_bitmap(unsigned threshold) {
+  return !(g_tune[7] >= 1 && g_tune[7] <= 4) && threshold <= 0xffffff00u;
+}
 bool launch_fast_score(hipStream_t on, const uint8_t *img, uint8_t *score, unsigned w, unsigned h, unsigned n,
-                       unsigned threshold, unsigned *zero_words = nullptr, unsigned zero_n = 0) {
+                       unsigned threshold, unsigned *zero_words = nullptr, unsigned zero_n = 0,
+                       unsigned long long *nz = nullptr, size_t nz_frame_words = 0) {
   const size_t fb = (size_t)w * h;
   if (g_tune[7] == 1 && w % 4 == 0 && fb < 0x7fffffffull && ((uintptr_t)img & 3) == 0 && ((uintptr_t)score & 3) == 0 &&
       threshold <= 0xffffff00u) {
@@ -76,16 +82,16 @@ bool launch_fast_score(hipStream_t on, const uint8_t *img, uint8_t *score, unsig
     const unsigned share = (g_tune[18] == 1 || !topo().eight_xcds()) ? 0u : (unsigned)((nt + 7) / 8); /* key 18 = 1: tiles in launch order */
     const dim3 grid(share ? share * 8u : (unsigned)nt), block(64, g_tune[26] == 128 ? 2 : 4);
     if (g_tune[26] == 128) { /* experiment: 128 threads per tile */
-      if (rows == 32) GS_LAUNCH((k_fast_score_q4<32, 128>), grid, block, 0, on, img, score, w, h, fb, threshold, tx, ty, (unsigned)nt, share, zero_words, zero_n);
-      else if (rows == 64) GS_LAUNCH((k_fast_score_q4<64, 128>), grid, block, 0, on, img, score, w, h, fb, threshold, tx, ty, (unsigned)nt, share, zero_words, zero_n);
-      else GS_LAUNCH((k_fast_score_q4<48, 128>), grid, block, 0, on, img, score, w, h, fb, threshold, tx, ty, (unsigned)nt, share, zero_words, zero_n);
+      if (rows == 32) GS_LAUNCH((k_fast_score_q4<32, 128>), grid, block, 0, on, img, score, w, h, fb, threshold, tx, ty, (unsigned)nt, share, zero_words, zero_n, nz, nz_frame_words);
+      else if (rows == 64) GS_LAUNCH((k_fast_score_q4<64, 128>), grid, block, 0, on, img, score, w, h, fb, threshold, tx, ty, (unsigned)nt, share, zero_words, zero_n, nz, nz_frame_words);
+      else GS_LAUNCH((k_fast_score_q4<48, 128>), grid, block, 0, on, img, score, w, h, fb, threshold, tx, ty, (unsigned)nt, share, zero_words, zero_n, nz, nz_frame_words);
       return true;
     }
     switch (rows) {
-      case 16: GS_LAUNCH(k_fast_score_q4<16>, grid, block, 0, on, img, score, w, h, fb, threshold, tx, ty, (unsigned)nt, share, zero_words, zero_n); break;
-      case 32: GS_LAUNCH(k_fast_score_q4<32>, grid, block, 0, on, img, score, w, h, fb, threshold, tx, ty, (unsigned)nt, share, zero_words, zero_n); break;
-      case 64: GS_LAUNCH(k_fast_score_q4<64>, grid, block, 0, on, img, score, w, h, fb, threshold, tx, ty, (unsigned)nt, share, zero_words, zero_n); break;
-      default: GS_LAUNCH(k_fast_score_q4<48>, grid, block, 0, on, img, score, w, h, fb, threshold, tx, ty, (unsigned)nt, share, zero_words, zero_n);
+      case 16: GS_LAUNCH(k_fast_score_q4<16>, grid, block, 0, on, img, score, w, h, fb, threshold, tx, ty, (unsigned)nt, share, zero_words, zero_n, nz, nz_frame_words); break;
+      case 32: GS_LAUNCH(k_fast_score_q4<32>, grid, block, 0, on, img, score, w, h, fb, threshold, tx, ty, (unsigned)nt, share, zero_words, zero_n, nz, nz_frame_words); break;
+      case 64: GS_LAUNCH(k_fast_score_q4<64>, grid, block, 0, on, img, score, w, h, fb, threshold, tx, ty, (unsigned)nt, share, zero_words, zero_n, nz, nz_frame_words); break;
+      default: GS_LAUNCH(k_fast_score_q4<48>, grid, block, 0, on, img, score, w, h, fb, threshold, tx, ty, (unsigned)nt, share, zero_words, zero_n, nz, nz_frame_words);
     }
     return true;
   }
@@ -112,6 +118,29 @@ void launch_fast(const uint8_t *img, uint8_t *score, unsigned w, unsigned h, uns
   const size_t fb = (size_t)w * h;
   /* (Both passes in one walk -- score tile, NMS and mask words from LDS, round 3's k_fast_fused -- measured 127 us against
    * 63 + 23 per 32 x 720p and was removed in round 4: scripts/experiments/not_kept/, profiles/r03t_fast_fused_not_kept.log.) */
+  /* pass 2, sparse (round 4 default; k_fast_nms.h): the score kernel leaves a bitmap of the scored pixels, one word per
+   * 64-px tile row of the interior, and only those are tested.  Key 19 = 2: the strip NMS over every pixel (round 3's
+   * default), 1: the item-by-item kernel (round 2). */
+  {
+    const unsigned tx = (w - 6 + 63) / 64;
+    const unsigned long long nw = (unsigned long long)tx * (h - 6);
+    if (g_tune[19] != 1 && g_tune[19] != 2 && fast_score_leaves_bitmap(threshold) && nw * 64 < (1ull << 32)) {
+      const unsigned nwords = (unsigned)nw, nchunks = (nwords + kChunkWords - 1) / kChunkWords;
+      GS_ASSERT((unsigned long long)n * nchunks < (1ull << 32));
+      unsigned long long *nz = (unsigned long long *)ctx().scratch(SL_NZ, (size_t)n * nchunks * kChunkWords * 8);
+      unsigned long long *mask = (unsigned long long *)ctx().scratch(SL_MASK, (size_t)n * nchunks * kChunkWords * 8);
+      unsigned *cnt = (unsigned *)ctx().scratch(SL_CNT, (size_t)n * nchunks * 4);
+      unsigned *pfx = (unsigned *)ctx().scratch(SL_PFX, (size_t)n * nchunks * 4);
+      launch_fast_score(st, img, score, w, h, n, threshold, nullptr, 0, nz, (size_t)nchunks * kChunkWords);
+      if (clip_w && n == 1 && (clip_w < w || clip_h < h))
+        GS_LAUNCH(k_fast_clip, grid2d(w, h, 1), dim3(64, 4), 0, st, score, w, h, clip_w, clip_h);
+      GS_LAUNCH(k_fast_nms_sparse, dim3((nchunks + 3) / 4, n), dim3(256), 0, st, (const uint8_t *)score, w, fb,
+                (const unsigned long long *)nz, mask, cnt, tx, nwords, nchunks);
+      run_compaction(mask, cnt, nchunks, n, nkps, counts,
+                     FastEmitPadded{score, w, tx * 64u, fb, kps, nkps, ((uintptr_t)kps & 15) == 0, 3u}, st, pfx);
+      return;
+    }
+  }
   /* pass 2 in strip form (k_fast_nms.h) when the score map qualifies for the strip machinery: items numbered over
    * rows padded to whole mask words.  Key 19 = 1: the item-by-item kernel k_fast_nms (round 2). */
   if (g_tune[19] != 1 && strip_ok(w, h, score, score) && w >= 32 && (unsigned long long)((w + 63) / 64) * 64 * h < (1ull << 32)) {

@@ -74,7 +74,7 @@ namespace gsi {
 /* ------------------------------------------------------------------ per-thread context */
 enum Slot { SL_IN = 0, SL_OUT, SL_AUX, SL_AUX2, SL_II, SL_PAD, SL_MASK, SL_CNT, SL_PFX, SL_TOT, SL_PRE,
             SL_HISTP, SL_HIST, SL_THR, SL_KPS, SL_MOM, SL_KIN, SL_DESC, SL_TAB, SL_JUMP, SL_LEV,
-            SL_BEST, SL_COUNT };
+            SL_BEST, SL_NZ, SL_COUNT };
 
 /* gsh_edge_pipeline_batch: frames per chunk (measured best for 64..512-frame batches of 4K frames:
  * profiles/r01g_chunk_overlap.log) and the most chunks per call */

@@ -269,12 +269,17 @@ template <unsigned ROWS, unsigned NT = 256>
 __global__ __launch_bounds__(NT) void k_fast_score_q4(const uint8_t *img, uint8_t *score, unsigned w, unsigned h,
                                                        size_t frame_bytes, unsigned threshold, unsigned tiles_x,
                                                        unsigned tiles_y, unsigned ntiles, unsigned xcd_share,
-                                                       unsigned *zero_words, unsigned zero_n) {
+                                                       unsigned *zero_words, unsigned zero_n,
+                                                       unsigned long long *nz = nullptr, size_t nz_frame_words = 0) {
   static_assert(ROWS % 16 == 0 && ROWS >= 16 && ROWS <= 64 && (NT == 128 || NT == 256), "a thread takes one row of every group of NT / 16; queue entries are 16-bit");
   constexpr unsigned RG = NT / 16; /* tile rows per row group */
   __shared__ uint32_t tile32[(ROWS + 6) * kFastTileDw + 2]; /* + 2: the last thread's third centre dword */
   __shared__ uint16_t queue[64 * ROWS];
   __shared__ unsigned qn;
+  /* nz != nullptr (round 4): the pixels with a non-zero score as a bitmap for the sparse NMS pass (k_fast_nms.h) -- word
+   * (y - 3) * tiles_x + tcol of the frame's nz_frame_words, bit qx <-> pixel x = 3 + 64 tcol + qx: a tile row is exactly
+   * one word.  Every word of the interior rows is written (zeros included), so the bitmap needs no clearing. */
+  __shared__ uint32_t nzw[2 * ROWS];
   /* tile of this block.  Workgroups go to the 8 XCDs round robin and each XCD has its own L2: with neighbouring tiles on
    * different XCDs every L2 fetches the shared halo rows and the 128-byte lines a 70-byte tile row straddles for itself
    * (FETCH_SIZE 4.1 x the frame bytes, WRITE_SIZE 1.46 x from the split lines of the score map).  xcd_share != 0: a 1-D
@@ -293,6 +298,7 @@ __global__ __launch_bounds__(NT) void k_fast_score_q4(const uint8_t *img, uint8_
   const unsigned tid = threadIdx.y * 64u + threadIdx.x;
   const unsigned x_t = tcol * 64u, y_t = trow * ROWS;
   if (tid == 0) qn = 0, tile32[(ROWS + 6) * kFastTileDw] = 0, tile32[(ROWS + 6) * kFastTileDw + 1] = 0;
+  if (tid < 2 * ROWS) nzw[tid] = 0;
   /* block-uniform: every dword of the tile region lies inside the frame (all tiles but those of the last tile row) -- then
    * the copy is a plain loop: (row, column) advance by NT = 14 x 18 + 4 dwords without a division, no bounds test per load */
   const bool tile_inside = ((size_t)(y_t + ROWS + 5u) * w + x_t + kFastTileDw * 4u <= frame_bytes) && frame_bytes < 0x7fffffffull;
@@ -360,19 +366,23 @@ __global__ __launch_bounds__(NT) void k_fast_score_q4(const uint8_t *img, uint8_
     for (unsigned k = 0; k < 4; k++)
       if ((inmask >> k) & 1u) out[(size_t)y * w + x + k] = 0;
   }
-  if (ballot(cand != 0u) != 0ull) { /* wave-uniform: most wave rows of a frame hold no candidate at all */
+  const uint64_t many = ballot(cand != 0u);
+  if (many != 0ull) { /* wave-uniform: most wave rows of a frame hold no candidate at all */
+    /* queue the candidates (order irrelevant): ONE LDS atomic per wave reserves the slots of all four pixel positions, the
+     * four ballots only rank the lanes (round 4; one atomic and one round trip per position before) */
+    uint64_t mk[4];
+    unsigned nk = 0;
 #pragma unroll
-  for (unsigned k = 0; k < 4; k++) { /* queue the candidates: one LDS atomic per wave and slot */
-    const bool ck = (cand >> k) & 1u;
-    const uint64_t m = ballot(ck);
-    if (m) {
-      const unsigned lane = lane_id();
-      unsigned base = 0;
-      if (lane == 0) base = atomicAdd(&qn, (unsigned)__popcll(m));
-      base = readlane0(base);
-      if (ck) queue[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(ry * 64u + 4u * xg + k);
+    for (unsigned k = 0; k < 4; k++) mk[k] = ballot((cand >> k) & 1u), nk += (unsigned)__popcll(mk[k]);
+    const unsigned lane = lane_id();
+    unsigned base = 0;
+    if (lane == 0) base = atomicAdd(&qn, nk);
+    base = readlane0(base);
+#pragma unroll
+    for (unsigned k = 0; k < 4; k++) {
+      if ((cand >> k) & 1u) queue[base + mbcnt(mk[k])] = (uint16_t)(ry * 64u + 4u * xg + k);
+      base += (unsigned)__popcll(mk[k]);
     }
-  }
   }
   cands[rg] = cand;
   }
@@ -393,20 +403,32 @@ __global__ __launch_bounds__(NT) void k_fast_score_q4(const uint8_t *img, uint8_
         const unsigned v[16] = {c[-3 * S],     c[-3 * S + 1], c[-2 * S + 2], c[-S + 3], c[3],  c[S + 3],  c[2 * S + 2],  c[3 * S + 1],
                                 c[3 * S],      c[3 * S - 1],  c[2 * S - 2],  c[S - 3],  c[-3], c[-S - 3], c[-2 * S - 2], c[-3 * S - 1]};
         const unsigned sc = fast_score(c[0], v, threshold);
-        if (((cand >> k) & 1u) && sc) out[(size_t)y * w + x + k] = (uint8_t)sc;
+        if (((cand >> k) & 1u) && sc) {
+          out[(size_t)y * w + x + k] = (uint8_t)sc;
+          atomicOr(&nzw[2u * ry + (xg >> 3)], 1u << ((4u * xg + k) & 31u));
+        }
       }
     }
-    return;
+  } else {
+    for (unsigned i0 = 0; i0 < ncand; i0 += NT) { /* block-uniform trip count */
+      const unsigned i = i0 + tid;
+      if (i0 + (tid & ~63u) >= ncand) continue; /* whole wave past the queue's end */
+      const unsigned e = queue[i < ncand ? i : ncand - 1u], qy = e >> 6, qx = e & 63u;
+      const uint8_t *c = tb + (qy + 3) * S + qx + 3;
+      const unsigned v[16] = {c[-3 * S],     c[-3 * S + 1], c[-2 * S + 2], c[-S + 3], c[3],  c[S + 3],  c[2 * S + 2],  c[3 * S + 1],
+                              c[3 * S],      c[3 * S - 1],  c[2 * S - 2],  c[S - 3],  c[-3], c[-S - 3], c[-2 * S - 2], c[-3 * S - 1]};
+      const unsigned sc = fast_score(c[0], v, threshold);
+      if (i < ncand && sc) {
+        out[(size_t)(3 + y_t + qy) * w + 3 + x_t + qx] = (uint8_t)sc;
+        atomicOr(&nzw[2u * qy + (qx >> 5)], 1u << (qx & 31u));
+      }
+    }
   }
-  for (unsigned i0 = 0; i0 < ncand; i0 += NT) { /* block-uniform trip count */
-    const unsigned i = i0 + tid;
-    if (i0 + (tid & ~63u) >= ncand) continue; /* whole wave past the queue's end */
-    const unsigned e = queue[i < ncand ? i : ncand - 1u], qy = e >> 6, qx = e & 63u;
-    const uint8_t *c = tb + (qy + 3) * S + qx + 3;
-    const unsigned v[16] = {c[-3 * S],     c[-3 * S + 1], c[-2 * S + 2], c[-S + 3], c[3],  c[S + 3],  c[2 * S + 2],  c[3 * S + 1],
-                            c[3 * S],      c[3 * S - 1],  c[2 * S - 2],  c[S - 3],  c[-3], c[-S - 3], c[-2 * S - 2], c[-3 * S - 1]};
-    const unsigned sc = fast_score(c[0], v, threshold);
-    if (i < ncand && sc) out[(size_t)(3 + y_t + qy) * w + 3 + x_t + qx] = (uint8_t)sc;
+  if (nz) {
+    if (ncand) __syncthreads(); /* block-uniform */
+    if (tid < ROWS && y_t + tid + 6u < h)
+      nz[(size_t)tframe * nz_frame_words + (size_t)(y_t + tid) * tiles_x + tcol] =
+          ncand ? (unsigned long long)nzw[2u * tid] | ((unsigned long long)nzw[2u * tid + 1u] << 32) : 0ull;
   }
 }
 

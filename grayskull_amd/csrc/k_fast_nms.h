@@ -50,11 +50,20 @@ __global__ __launch_bounds__(256) void k_fast_nms16(const uint8_t *score, unsign
     }
   };
   uint32_t ring[3][8], C[2][8]; /* horizontal maxima of rows y-1, y, y+1; own pairs of the last two rows loaded */
+  /* The arithmetic per row is a few dozen instructions and the launch is a few thousand waves (32 x 720p: 5,760), all
+   * resident at once: a wave's time is its chain of row loads.  So the loads run six rows ahead (round 4; one row ahead:
+   * 32 x 720p NMS 18 us) -- a band of 8 rows has all but two of its 10 loads in flight before the first one is used. */
+  constexpr int PF = 6;
+  RawRow raws[PF];
   {
+    const RawRow ra = S.load(y0 - 1), rb = S.load(y0);
+#pragma unroll
+    for (int j = 0; j < PF; j++)
+      if (j < nrows) raws[j] = S.load(y0 + 1 + j); /* wave-uniform */
     uint32_t U[12];
-    S.unpack(S.load(y0 - 1), U);
+    S.unpack(ra, U);
     hpass(U, ring[0]);
-    S.unpack(S.load(y0), U);
+    S.unpack(rb, U);
     hpass(U, ring[1]);
 #pragma unroll
     for (int k = 0; k < 8; k++) C[1][k] = U[k + 2];
@@ -73,7 +82,6 @@ __global__ __launch_bounds__(256) void k_fast_nms16(const uint8_t *score, unsign
         for (size_t i = (size_t)h * wpr; i < (size_t)nchunks * kChunkWords; i++) mf[i] = 0ull;
     }
   }
-  RawRow raw = S.load(y0 + 1);
   for (int base = 0; base < nrows; base += 6) {
     static_for<6>([&](auto I) {
       constexpr int ii = decltype(I)::value, ia = ii % 3, ib = (ii + 1) % 3, ic = (ii + 2) % 3, cc = (ii + 1) % 2, cn = ii % 2;
@@ -82,8 +90,8 @@ __global__ __launch_bounds__(256) void k_fast_nms16(const uint8_t *score, unsign
       const int y = y0 + i;
       /* a 1024-px span of a score row is empty more often than not (55 % of them on the configs[3] frames): then its
        * horizontal maxima are 0 without unpacking anything (round 4; wave-uniform) */
-      const RawRow cur = raw;
-      raw = S.load(y + 2); /* in flight during the arithmetic */
+      const RawRow cur = raws[ii];
+      if (i + PF < nrows) raws[ii] = S.load(y + 1 + PF); /* wave-uniform; PF == the unroll, so the slots are static */
       const uint32_t rowany = cur.v.x | cur.v.y | cur.v.z | cur.v.w | cur.hh;
       if (ballot(rowany != 0) != 0) {
         uint32_t U[12];
@@ -127,6 +135,68 @@ __global__ __launch_bounds__(256) void k_fast_nms16(const uint8_t *score, unsign
   }
 }
 
+/* pass 2, sparse (round 4; the default behind k_fast_score_q4, which leaves a bitmap of the pixels with a non-zero score).
+ * On the configs[3] frames 3 % of the pixels have a score and k_fast_nms16 above spends its 23 us per 32 x 720p running the
+ * 3 x 3 maximum over the other 97 %.  Here only the scored pixels are visited: one wave per chunk of 32 bitmap words (the
+ * item numbering of k_emit: word (y - 3) * tiles_x + tcol, bit qx <-> pixel (3 + 64 tcol + qx, y)); the set bits are
+ * expanded into an LDS queue -- a lane takes the 32 items of half a word -- so that every lane then tests ONE scored pixel
+ * per trip: its 3 x 3 neighbourhood is three unaligned dword loads from the score map (x - 1 .. x + 2 of the rows y - 1, y,
+ * y + 1: inside the row because x <= w - 4), a pixel is kept when its score is non-zero (the clip pass may have
+ * zeroed it since) and no neighbour's is larger (ref :518-528; ties keep both, like k_fast_nms16).  The kept bits are
+ * collected per word in LDS and the wave stores the chunk's 32 mask words and its counter: no atomics in memory, nothing to
+ * zero beforehand.  Raster order of the items is the reference's emit order.  grid (ceil(nchunks / 4), n), block 256. */
+__global__ __launch_bounds__(256) void k_fast_nms_sparse(const uint8_t *score, unsigned w, size_t frame_bytes,
+                                                         const unsigned long long *nz, unsigned long long *mask,
+                                                         unsigned *chunk_count, unsigned tiles_x, unsigned nwords,
+                                                         unsigned nchunks) {
+  __shared__ uint16_t queue[4][kChunkItems];
+  __shared__ uint32_t kept[4][2 * kChunkWords], wy[4][kChunkWords], wc[4][kChunkWords];
+  const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  const unsigned c = uniform(blockIdx.x * 4u + wv);
+  const bool live = c < nchunks; /* whole wave; the block's barriers are reached by all four */
+  const size_t fc = (size_t)blockIdx.y * nchunks + (live ? c : 0u);
+  const unsigned W = c * kChunkWords + lane; /* lanes < 32: word of the frame */
+  const unsigned long long mine = (live && lane < kChunkWords && W < nwords) ? nz[fc * kChunkWords + lane] : 0ull;
+  if (lane < kChunkWords) {
+    const unsigned y = W / tiles_x;
+    wy[wv][lane] = y, wc[wv][lane] = W - y * tiles_x;
+  }
+  kept[wv][lane] = 0;
+  const uint32_t mlo = (uint32_t)mine, mhi = (uint32_t)(mine >> 32);
+  const uint32_t hlo = shfl(mlo, (int)(lane >> 1)), hhi = shfl(mhi, (int)(lane >> 1));
+  uint32_t half = (lane & 1u) ? hhi : hlo; /* items 32 lane .. 32 lane + 31 of the chunk */
+  const unsigned pc = (unsigned)__popc(half), incl = wave_incl_scan(pc);
+  const unsigned total = readlane_at(incl, 63);
+  unsigned at = incl - pc;
+  while (half != 0u) {
+    const unsigned b = (unsigned)__ffs((int)half) - 1u;
+    half &= half - 1u;
+    queue[wv][at++] = (uint16_t)(lane * 32u + b);
+  }
+  __syncthreads();
+  const uint8_t *sf = score + (size_t)blockIdx.y * frame_bytes;
+  for (unsigned j = lane; j < total; j += 64u) {
+    const unsigned e = queue[wv][j], k = e >> 6;
+    const unsigned x = 3u + 64u * wc[wv][k] + (e & 63u), y = 3u + wy[wv][k];
+    const uint8_t *p = sf + (size_t)y * w + x - 1u;
+    const uint32_t a = load_u32_unaligned(p - w), m = load_u32_unaligned(p), b = load_u32_unaligned(p + w);
+    const unsigned sc = (m >> 8) & 0xffu;
+    unsigned mx = umax(umax(a & 0xffu, (a >> 8) & 0xffu), (a >> 16) & 0xffu);
+    mx = umax(mx, umax(m & 0xffu, (m >> 16) & 0xffu));
+    mx = umax(mx, umax(umax(b & 0xffu, (b >> 8) & 0xffu), (b >> 16) & 0xffu));
+    if (sc != 0u && mx <= sc) atomicOr(&kept[wv][e >> 5], 1u << (e & 31u));
+  }
+  __syncthreads();
+  if (!live) return;
+  unsigned long long word = 0;
+  if (lane < kChunkWords) {
+    word = (unsigned long long)kept[wv][2u * lane] | ((unsigned long long)kept[wv][2u * lane + 1u] << 32);
+    mask[fc * kChunkWords + lane] = word;
+  }
+  const unsigned n = wave_sum((unsigned)__popcll(word));
+  if (lane == 0) chunk_count[fc] = n;
+}
+
 /* compaction functor for the padded item numbering: item -> gs_keypoint {{x,y}, score, 0, {0}} (ref :530) */
 struct FastEmitPadded {
   const uint8_t *score;
@@ -135,8 +205,9 @@ struct FastEmitPadded {
   unsigned *kps; /* n frames x nkps x 12 u32 */
   unsigned nkps;
   bool aligned16;
+  unsigned off = 0; /* item (0, 0) is pixel (off, off): 3 behind k_fast_nms_sparse, whose words start at the interior */
   GS_DEV void operator()(unsigned frame, size_t item, unsigned r) const {
-    const unsigned it = (unsigned)item, y = it / wp, x = it - y * wp;
+    const unsigned it = (unsigned)item, y0 = it / wp, x = it - y0 * wp + off, y = y0 + off;
     unsigned *o = kps + ((size_t)frame * nkps + r) * 12u;
     const unsigned sc = score[(size_t)frame * frame_bytes + (size_t)y * w + x];
     if (aligned16) {

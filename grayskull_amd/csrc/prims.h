@@ -41,6 +41,8 @@ constexpr uint32_t kOOB = 0x80000000u;
 #ifdef GS_EMU
 /* ------------------------------------------------------------------ emulation */
 GS_DEV unsigned lane_id() { return emu::lane_id(); }
+/* set bits of `m` below this lane (v_mbcnt_lo/hi) */
+GS_DEV unsigned mbcnt(uint64_t m) { return (unsigned)__builtin_popcountll(m & ((1ull << emu::lane_id()) - 1ull)); }
 GS_DEV uint64_t ballot(bool p) {
   return emu::wave_exchange(p ? 1 : 0, [](const uint64_t *s, const bool *v) {
     uint64_t m = 0;
@@ -220,6 +222,8 @@ GS_DEV void mfma_i32_32x32x32_i8(const U4 &a, const U4 &b, int32_t (&c)[16]) {
 #else
 /* ------------------------------------------------------------------ gfx950 */
 GS_DEV unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+/* set bits of `m` below this lane */
+GS_DEV unsigned mbcnt(uint64_t m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 GS_DEV uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 /* v_mov_b32_dpp wave_shr:1 -- lane i receives lane i-1; lane 0 keeps `fill` */
 GS_DEV uint32_t wave_shr1(uint32_t x, uint32_t fill) {
@@ -445,6 +449,7 @@ GS_DEV uint32_t sub2(uint32_t a, uint32_t b) { return pk_sub_u16(a, b); }
 /* |a - b| per field for unsigned fields: max - min (the difference cannot borrow) */
 GS_DEV uint32_t absdiff2(uint32_t a, uint32_t b) { return sub2(pk_max_u16(a, b), pk_min_u16(a, b)); }
 GS_DEV unsigned umin(unsigned a, unsigned b) { return a < b ? a : b; }
+GS_DEV unsigned umax(unsigned a, unsigned b) { return a > b ? a : b; }
 /* |a - b| for a, b < 65536 (v_sad_u16 with zero high halves on the GPU) */
 GS_DEV unsigned absdiff_u16(unsigned a, unsigned b) {
 #ifdef GS_EMU

@@ -115,8 +115,9 @@ def test_fast_strip_kernel_equals_per_pixel_kernel(emu, oracle):
 
 @pytest.mark.parametrize("shape", [(96, 80), (64, 40), (1040, 9), (32, 7), (272, 33)])
 def test_fast_nms_strip_kernel_equals_item_kernel(emu, oracle, shape):
-    """pass 2 of gs_fast: k_fast_nms16 (strip form, items over word-padded rows; default when w % 16 == 0) and
-    k_fast_nms (item by item, gsh_tune key 19 = 1) give the oracle's keypoints in the oracle's order -- plateaus
+    """pass 2 of gs_fast: k_fast_nms_sparse (default: only the pixels of the score kernel's bitmap), k_fast_nms16 (strip
+    form over every pixel, items over word-padded rows; gsh_tune key 19 = 2) and k_fast_nms (item by item, key 19 = 1)
+    give the oracle's keypoints in the oracle's order -- plateaus
     (ties survive), peaks next to the never-written 3-px frame of a caller's non-zero score map, caps that cut the
     list inside a row, every strip band height"""
     w, h = shape
@@ -124,8 +125,8 @@ def test_fast_nms_strip_kernel_equals_item_kernel(emu, oracle, shape):
     flat = np.full((h, w), 100, np.uint8)
     flat[::3, ::3] = 140                      # a lattice of equal corners: plateaus / ties everywhere
     imgs = [Oracle.synth(w, h, 8), rs.randint(0, 256, (h, w)).astype(np.uint8), flat]
-    for key19 in (0, 1):
-        for T in (0, 1, 3):
+    for key19 in (0, 2, 1):
+        for T in ((0, 1, 3) if key19 == 2 else (0,)):
             try:
                 emu.tune(19, key19), emu.tune(0, T)
                 for img in imgs:

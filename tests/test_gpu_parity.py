@@ -142,6 +142,23 @@ def test_fast_strip_kernel_equals_per_pixel_kernel(hip, oracle):
                 hip.tune(7, 0)
 
 
+def test_fast_three_nms_kernels(hip, oracle):
+    """pass 2: the sparse kernel behind the score kernel's bitmap (default), the strip kernel over every pixel (key 19 = 2)
+    and the item-by-item kernel (1): the oracle's keypoints in the oracle's order, caps that cut the list, a caller's
+    non-zero score-map frame, widths that are no multiple of 64 / 16"""
+    rs = np.random.RandomState(5)
+    for (w, h) in ((1280, 720), (1000, 333), (70, 71), (131, 64)):
+        flat = np.full((h, w), 100, np.uint8)
+        flat[::3, ::3] = 140
+        for img in (Oracle.synth(w, h, 8), rs.randint(0, 256, (h, w)).astype(np.uint8), flat):
+            for key19 in (0, 2, 1):
+                hip.tune(19, key19)
+                try:
+                    pc.fast(hip, oracle, img, DEV, threshold=12, caps=(30000, 9, 1))
+                finally:
+                    hip.tune(19, 0)
+
+
 def test_fast_quirk(hip, oracle):
     pc.fast_unsigned_wrap_quirk(hip, oracle, HOST)
     pc.fast_unsigned_wrap_quirk(hip, oracle, DEV)
