@@ -50,13 +50,15 @@ void gsh_sync(void);                      /* hipStreamSynchronize(current stream
  * 14, 15 unused (round 3's optional LBP stage prefilter, removed in round 4), 16 = 1: gs_lbp_detect runs its cascade
  * kernels but emits nothing (timing aid; counts / rects are NOT written), 17 = 1: the cascade evaluates re-packed windows
  * one per lane instead of one per quad of lanes, 18 band-to-XCD mapping of the strip kernels and tile-to-XCD mapping of the gs_fast score pass (1 = dispatch order, 2 = XCD-aware
- * always), 19 = 1: pass 2 of gs_fast item by item (k_fast_nms, round 2) instead of the strip form.
+ * always), 19: pass 2 of gs_fast -- 0 the sparse kernel behind the score kernel's bitmap of scored pixels (round 4), 2 the
+ * strip kernel over every pixel (round 3), 1 item by item (round 2).
  * 20 = 1: gs_match_template on the VALU dot-product kernels instead of the matrix cores (2 / 3: the matrix-core kernel with
  * 64 x 128 tiles / with 32 x 64 tiles and the template rows split over four waves, whatever the image size),
  * 21 = 1: the round-3 rule for the strip kernels (whole 16-px strips at 16-byte aligned addresses only; everything else per
  * pixel), 22 = 1: gs_sobel without the reads that preserve columns 0 / w-1 (probe; those columns receive junk), 23 = 1: the
  * strip-copy probe keeps the stencils' halo load, 24 the realigning strip flavour (1 = never, 2 = always; 0 = by address
- * phase and width, csrc/gs_stencil.cpp strip_mode).  Process-wide, every entry an atomic.
+ * phase and width, csrc/gs_stencil.cpp strip_mode), 25 = 16 / 32 / 64: tile rows of the gs_fast score kernel (default 48), 26 = 128: its
+ * 128-thread variant.  Process-wide, every entry an atomic.
  * Results never change (keys 16 and 22 excepted). */
 void gsh_tune(int key, int value);
 /* measurement aid for bench.py: while on, gsh_edge_pipeline_batch brackets every launch of its

@@ -3,7 +3,7 @@
 # rocprofv3 kernel stats of the full bench command, PMC traffic, the north-star launch alone, ragged shapes, box offsets.
 # Logs -> gpurun_out/
 R=${GRAFT_REPO_ROOT:-/root/repo}
-cd $R; mkdir -p gpurun_out; rm -rf gpurun_out/prof gpurun_out/pmc_* ; export TMPDIR=/tmp
+cd $R; mkdir -p gpurun_out; rm -rf gpurun_out/prof gpurun_out/pmc_* gpurun_out/sqfeat_*; export TMPDIR=/tmp
 echo "== smoke"; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee gpurun_out/smoke.log
 echo "== pytest -m gpu"; timeout 1800 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider --durations=6 2>&1 | tail -14 | tee gpurun_out/pytest_gpu.log
 echo "== bench"; timeout 900 python bench.py 2>gpurun_out/bench.err | tee gpurun_out/bench.json | cut -c1-500
@@ -22,6 +22,10 @@ for c in FETCH_SIZE WRITE_SIZE; do
   cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_$c -o pmc -- python $R/scripts/pmc_probe.py > $R/gpurun_out/pmc_$c.log 2>&1
 done
 cd $R; python scripts/pmc_summary.py gpurun_out 2>&1 | tee gpurun_out/pmc_summary.txt | tail -40
+echo "== PMC: feature kernels (VALU instructions of the gs_fast passes)"
+PMC_PROBE=scripts/pmc_probe_features.py PMC_FILTER=k_fast,k_emit PMC_TAG=sqfeat \
+  PMC_SETS="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_WAVES SQ_INSTS_LDS" bash scripts/pmc_fused.sh 2>&1 | grep -v amdgpu.ids | tee gpurun_out/pmc_features.txt
+python scripts/pmc_fast_json.py > gpurun_out/pmc_fast_json.log 2>&1; tail -2 gpurun_out/pmc_fast_json.log | cut -c1-300
 echo "== north-star launch alone"; cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_sobel4096 -o sobel4096 -- python $R/scripts/prof_sobel4096.py 2>&1 | grep "gs_sobel 64" | tee $R/gpurun_out/sobel4096.log
 cd $R; f=$(find gpurun_out/prof_sobel4096 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/sobel4096_kernel_stats.csv && head -3 "$f" | cut -c1-200
 echo "== ragged shapes"; RG_CHECK=0 timeout 500 python scripts/ubench_ragged.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/ragged.log | tail -40
