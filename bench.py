@@ -230,18 +230,21 @@ def cpu_baseline(w, h, radius, frames_target=48):
                       "thread), %s" % (frames, w, h, radius, cores, per, what)}
 
 
-def measurement(path):
+def measurement(path, only=None):
     """a committed measurement file of profiles/ plus whether the kernel sources it was taken from are still the
-    ones in the tree (scripts/stamp.py): returns (dict or None, stamp) -- a STALE file is not used"""
+    ones in the tree (scripts/stamp.py): returns (dict or None, stamp) -- a STALE file is not used.
+    only: the sources of the kernel whose row the caller uses (the file may hold rows of kernels from other sources)"""
     try:
         d = json.load(open(path))
     except Exception:
         return None, None
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     from stamp import fresh
-    ok = fresh(d)
+    ok = fresh(d, only)
     stamp = {"file": os.path.relpath(path, ROOT), "commit": d.get("stamped_at_commit"),
              "kernel_sources_unchanged": ok}
+    if only is not None:
+        stamp["sources_checked"] = list(only)
     return (None if ok is False else d), stamp
 
 
@@ -514,10 +517,13 @@ def main():
     n_ii = min(64, F)
     ii_buf = torch.empty((n_ii, h, w), dtype=torch.int32, device="cuda")
     moved_ii = 5.0 * n_ii * w * h
-    pt_all, pt_stamp = measurement(os.path.join(ROOT, "profiles", "pmc_traffic.json"))
+    csrc = "grayskull_amd/csrc/"
+    pt_all, pt_stamp = measurement(os.path.join(ROOT, "profiles", "pmc_traffic.json"),
+                                   only=[csrc + "k_fused.h", csrc + "gs_fused.cpp", csrc + "k_strip.h"])
+    pt_ii, _ = measurement(os.path.join(ROOT, "profiles", "pmc_traffic.json"), only=[csrc + "k_integral.h"])
     try:
-        if pt_all and (w, h, n_ii) == (3840, 2160, 64):
-            moved_ii = float(sum(v["total_bytes"] for k, v in pt_all["per_launch"].items() if k.startswith("gs::k_integral")))
+        if pt_ii and (w, h, n_ii) == (3840, 2160, 64):
+            moved_ii = float(sum(v["total_bytes"] for k, v in pt_ii["per_launch"].items() if k.startswith("gs::k_integral")))
     except Exception:
         pass
     kernels["gs_integral (3 launches: colsum, colbase, wave), %d frames" % n_ii] = (

@@ -20,12 +20,16 @@ def sha1(path):
     return hashlib.sha1(open(os.path.join(ROOT, path), "rb").read()).hexdigest()
 
 
-def fresh(d):
-    """True when every file named in d["kernel_sources"] still has the recorded hash (None: not stamped)"""
+def fresh(d, only=None):
+    """True when every file named in d["kernel_sources"] still has the recorded hash (None: not stamped).
+    only: check just these files of the stamp (a file with rows of several kernels; the caller names the sources of the
+    kernel whose row it uses) -- a file the stamp does not name counts as changed"""
     ks = d.get("kernel_sources")
     if not ks:
         return None
     try:
+        if only is not None:
+            return all(p in ks and sha1(p) == ks[p] for p in only)
         return all(sha1(p) == h for p, h in ks.items())
     except OSError:
         return False
