@@ -51,7 +51,11 @@ GS_DEV unsigned box_div(unsigned sum, unsigned cx, unsigned cy, float rx, float 
  * 16 - m columns past the row end are 0 like everything outside the image.  Its loads must not cross the row end
  * (behind the last row lies another frame, or nothing): it loads the row's last 16 bytes and shifts them down into
  * grid position, zeros entering; its m result bytes go out as 8 + 4 + 2 + 1-byte stores (no byte of the next row is
- * touched). */
+ * touched).  (Round 4, measured and not kept: loads from the dword-aligned address below a lane's pixels + v_alignbyte for
+ * rows at byte phases that are no multiple of 4, the REALIGN recipe of k_strip.h -- 3838 x 2160, r = 5: 1.95 x the aligned
+ * frame's time with and without it, profiles/r04p_box_realign_not_kept.log.  This kernel is issue-bound, and what ragged
+ * rows cost it is the tail strip's extra instructions -- shift, four partial stores -- in ONE wave that the per-row barrier
+ * makes the whole block wait for.) */
 template <int MODE>
 __global__ __launch_bounds__(256) void k_box16(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h,
                                                unsigned T, size_t frame_bytes, unsigned r, int c) {
@@ -62,16 +66,7 @@ __global__ __launch_bounds__(256) void k_box16(uint8_t *dst, const uint8_t *src,
   const bool tail = act && x0 + 16u > w;        /* m != 0 and this thread owns that strip */
   const uint32_t ld_off = !act ? kOOB : tail ? w - 16u : x0, st_off = (act && !tail) ? x0 : kOOB;
   const bool tail_wave = ballot(tail) != 0ull; /* wave-uniform */
-  /* Rows at byte phases that are not multiples of 4 (w % 4 != 0, or a frame at such an address): a 16-byte load there costs
-   * 30-45 % (k_strip.h, REALIGN), so such frames load from the dword-aligned address below a lane's pixels and move the bytes
-   * into place: one v_alignbyte_b32 per dword, the fifth dword from the next lane's load (v_mov_dpp) -- or from a load of
-   * the lane's own where the next lane's is not the next 16 bytes (lane 63, the tail strip and the strip before it).  The
-   * dwords that hold the frame's first and last byte lie in the pages those bytes lie in. */
-  const uint8_t *sbase = src + (size_t)blockIdx.z * frame_bytes;
-  const unsigned sd = (unsigned)((uintptr_t)sbase & 3u);
-  const bool realign = (sd | (w & 3u)) != 0u; /* block-uniform */
-  const BufRsrc S = realign ? make_buf(sbase - sd, (frame_bytes + sd + 3u) & ~(size_t)3u) : make_buf(sbase, frame_bytes);
-  const bool own_extra = act && (tail || (tid & 63u) == 63u || x0 + 32u > w);
+  const BufRsrc S = make_buf(src + (size_t)blockIdx.z * frame_bytes, frame_bytes);
   const BufRsrc D = make_buf(dst + (size_t)blockIdx.z * frame_bytes, frame_bytes);
   const int y0 = (int)(blockIdx.y * T);
   if (y0 >= (int)h) return; /* whole block */
@@ -97,20 +92,10 @@ __global__ __launch_bounds__(256) void k_box16(uint8_t *dst, const uint8_t *src,
 #pragma unroll
   for (int j = 0; j < 16; j++) Mi[j] = MODE == 0 ? 0xffffffffu / (cx[j] * (2u * r + 1u)) + 1u : 0u; /* cnt >= 4 */
   auto row_load = [&](int yy) { /* this thread's 16 B of row yy, zeros outside the image */
-    const bool ok = yy >= 0 && yy < (int)h;
-    uint32_t a, b, c, d; /* scalars: hipcc selects / merges whole structs through scratch memory */
-    if (realign) {
-      const uint32_t o = (uint32_t)yy * w + ld_off + sd, p = o & 3u, oa = o - p;
-      const U4 v = buf_load16(S, (ok && act) ? oa : kOOB);
-      const uint32_t e = buf_load4(S, (ok && own_extra) ? oa + 16u : kOOB);
-      const uint32_t nx = wave_shl1(v.x, 0u), x = own_extra ? e : nx;
-      a = alignbyte(v.y, v.x, p), b = alignbyte(v.z, v.y, p), c = alignbyte(v.w, v.z, p), d = alignbyte(x, v.w, p);
-    } else {
-      const U4 v = buf_load16(S, ok ? (uint32_t)yy * w + ld_off : kOOB);
-      a = v.x, b = v.y, c = v.z, d = v.w;
-    }
+    const U4 v = buf_load16(S, (yy >= 0 && yy < (int)h) ? (uint32_t)yy * w + ld_off : kOOB);
+    uint32_t a = v.x, b = v.y, c = v.z, d = v.w; /* scalars: hipcc selects / merges whole structs through scratch memory */
     if (tail_wave) { /* wave-uniform: only the wave that holds the tail strip pays for the shift */
-      const U4 sh = shift_down_bytes(U4{a, b, c, d}, 16u - m);
+      const U4 sh = shift_down_bytes(v, 16u - m);
       a = tail ? sh.x : a, b = tail ? sh.y : b, c = tail ? sh.z : c, d = tail ? sh.w : d;
     }
     return U4{a, b, c, d};
