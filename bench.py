@@ -781,10 +781,13 @@ def extras(g, torch, np, src, tmp, dst, w, h, reps, lo=0, args=None):
         "device_resident_orb_extract_ms_per_frame": round(ms_orb_dev / nf, 4),
         "device_resident_note": "gsh_orb_extract_batch_nostdlib, %d frames per call, the reference's GS_NO_STDLIB trig "
                                 "(ref :70-88), no host round trip; bit-exact vs the -DGS_NO_STDLIB reference build" % nf,
-        "gs_fast_roofline": hbm_block(3.0 * nf * 720 * 1280, ms_fast, bytes_per_px=3, frames=nf, limited_by="valu",
+        "gs_fast_roofline": hbm_block(2.0 * nf * 720 * 1280, ms_fast, bytes_per_px=2, frames=nf, limited_by="valu",
+                                      score_pass_ms=round(ms_fast_score, 4),
                                       score_pass_valu=fast_valu_block(nf * 720 * 1280, ms_fast_score),
-                                      note="score pass 1 R + 1 W, NMS 1 R; the score pass (LDS-tile kernel) is VALU work on "
-                                           "real candidates, the NMS / scan / emit passes behind it are latency-bound"),
+                                      note="score pass 1 R + 1 W (+ 1 bit per pixel: the bitmap of scored pixels); the sparse NMS "
+                                           "pass reads the bitmap and three dwords per scored pixel (round 3: a third pass over "
+                                           "every pixel, 3 B/px); the score pass (LDS-tile kernel) is VALU work on real "
+                                           "candidates, the NMS / emit passes behind it are latency-bound"),
         "reference_1core": "70 ms extract, 48.6 ms match (BASELINE.md)"}
     del s3, ii3, rc, cn, f7, sm7, kp7, ko7
     # configs[4], one GPU's share AT ITS REAL SIZE: every frame this GPU holds (512 by default = 4096 / 8) goes through
