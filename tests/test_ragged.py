@@ -178,6 +178,36 @@ def test_emu_box_integral_downsample_any_width(emu, request):
         check_more(emu, o, bufs, w, 23, off, rs, n=2)
 
 
+def check_ring_box(g, o, bufs, shapes, radii, rs, n=2):
+    """gs_blur / gs_adaptive_threshold with 4 <= r <= 16 on ragged rows tall enough for a whole window (the radii the
+    register-ring kernels take on whole-strip rows; ragged rows go to the any-radius kernel): a bright right edge, where a
+    wrong edge divisor would show, positive and negative c"""
+    sync = bufs.torch.cuda.synchronize if bufs.kind == "gpu" else (lambda: None)
+    for (w, h, off) in shapes:
+        img = rs.randint(0, 256, (n, h, w)).astype(np.uint8)
+        img[:, :, w - 20:] = rs.randint(200, 256, (n, h, 20))
+        d0 = rs.randint(0, 256, (n, h, w)).astype(np.uint8)
+        _, s = bufs.make(n, h, w, off, img)
+        for r in radii:
+            if h < 2 * r + 1:
+                continue
+            db, d = bufs.make(n, h, w, off, d0)
+            g.blur_batch(d, s, r), sync()
+            assert_same(bufs.host(d), np.stack([o.blur(img[i], r) for i in range(n)]), "blur r=%d %dx%d at base+%d" % (r, w, h, off))
+            assert bufs.guards_ok(db, off, n * h * w), "blur r=%d %dx%d wrote outside the frames" % (r, w, h)
+            for c in (3, -7):
+                db, d = bufs.make(n, h, w, off, d0)
+                g.adaptive_threshold_batch(d, s, r, c), sync()
+                assert_same(bufs.host(d), np.stack([o.adaptive_threshold(img[i], r, c) for i in range(n)]),
+                            "adaptive r=%d c=%d %dx%d at base+%d" % (r, c, w, h, off))
+                assert bufs.guards_ok(db, off, n * h * w), "adaptive r=%d %dx%d wrote outside the frames" % (r, w, h)
+
+
+def test_emu_ring_box_on_ragged_rows(emu, request):
+    o, bufs, rs = _oracle(request), Bufs("emu"), np.random.RandomState(17)
+    check_ring_box(emu, o, bufs, ((33, 40, 0), (47, 35, 1), (49, 70, 0), (100, 33, 3), (1039, 34, 0), (2049, 36, 2)), (4, 5, 8, 11, 16), rs)
+
+
 def test_emu_integral_wider_than_4096(emu, request):
     """column chunks of 4096 px: a row's prefix at the chunk edge waits in a lane register (k_integral_wave WIDE)"""
     o, rs = _oracle(request), np.random.RandomState(16)
@@ -223,6 +253,13 @@ def test_gpu_frames_at_odd_addresses(hip, request, off):
     o, bufs, rs = _oracle(request), Bufs("gpu"), np.random.RandomState(22 + off)
     for w in (32, 48, 61, 64, 100, 612, 1024, 1037, 1041, 1080, 2064, 2071, 3838, 3840):
         check_width(hip, o, bufs, w, 23, off, rs, n=3)
+
+
+@pytest.mark.gpu
+def test_gpu_ring_box_on_ragged_rows(hip, request):
+    o, bufs, rs = _oracle(request), Bufs("gpu"), np.random.RandomState(27)
+    check_ring_box(hip, o, bufs, ((33, 40, 0), (47, 35, 1), (100, 33, 3), (612, 816, 5), (1039, 64, 0), (1366, 200, 15), (3838, 150, 2)),
+                   (4, 5, 8, 9, 10, 12, 16), rs)
 
 
 @pytest.mark.gpu
