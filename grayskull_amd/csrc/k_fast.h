@@ -265,8 +265,9 @@ __global__ __launch_bounds__(256) void k_fast_score_cq(const uint8_t *img, uint8
  * per 16) for the same round trip; each thread then filters 4 pixels of ROWS / 16 tile rows. */
 typedef uint32_t gs_u32_unaligned __attribute__((aligned(1)));
 /* NT: threads per block (64 x NT / 64): fewer threads per tile = more tiles in flight per CU for the same registers */
+/* 256 threads, tiles up to 48 rows: held to 64 registers = 8 waves per SIMD (75 / 6 waves without the bound, no scratch with it) */
 template <unsigned ROWS, unsigned NT = 256>
-__global__ __launch_bounds__(NT) void k_fast_score_q4(const uint8_t *img, uint8_t *score, unsigned w, unsigned h,
+__global__ __launch_bounds__(NT, (NT == 256 && ROWS <= 48) ? 8 : 1) void k_fast_score_q4(const uint8_t *img, uint8_t *score, unsigned w, unsigned h,
                                                        size_t frame_bytes, unsigned threshold, unsigned tiles_x,
                                                        unsigned tiles_y, unsigned ntiles, unsigned xcd_share,
                                                        unsigned *zero_words, unsigned zero_n,
