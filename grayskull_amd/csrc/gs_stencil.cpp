@@ -835,16 +835,24 @@ void gs_match_template(struct gs_image img, struct gs_image tmpl, struct gs_imag
     static std::atomic<unsigned long long> lds_raised{0};
     const unsigned long long dev_bit = 1ull << ((unsigned)ctx().device & 63u);
     if (ctx().device >= 64 || !(lds_raised.load(std::memory_order_acquire) & dev_bit)) {
-      GS_HIP(hipFuncSetAttribute((const void *)k_match_template_mfma<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      GS_HIP(hipFuncSetAttribute((const void *)k_match_template_mfma<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      const void *fns[] = {(const void *)k_match_template_mfma<1, 3>, (const void *)k_match_template_mfma<1, 5>, (const void *)k_match_template_mfma<1, 9>,
+                           (const void *)k_match_template_mfma<4, 3>, (const void *)k_match_template_mfma<4, 5>, (const void *)k_match_template_mfma<4, 9>};
+      for (const void *fn : fns) GS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       lds_raised.fetch_or(dev_bit, std::memory_order_release);
     }
 #endif
     TmArgs ta{s, img.w, img.h, (const uint8_t *)tpad, (const unsigned *)tsqp, tmpl.w, tmpl.h, s2, d, result.w, result.h, nkc, istride, tstride};
-    if (tm_split)
-      GS_LAUNCH(k_match_template_mfma<4>, dim3((result.w + 63) / 64, (result.h + 31) / 32), dim3(256), tm_lds, st, ta);
-    else
-      GS_LAUNCH(k_match_template_mfma<1>, dim3((result.w + 127) / 128, (result.h + 63) / 64), dim3(256), tm_lds, st, ta);
+    /* the instantiation whose operand registers are sized for the smallest bound >= nkc (k_tmatch.h) */
+    const dim3 gs4((result.w + 63) / 64, (result.h + 31) / 32), gs1((result.w + 127) / 128, (result.h + 63) / 64);
+    if (tm_split) {
+      if (nkc <= 3) GS_LAUNCH((k_match_template_mfma<4, 3>), gs4, dim3(256), tm_lds, st, ta);
+      else if (nkc <= 5) GS_LAUNCH((k_match_template_mfma<4, 5>), gs4, dim3(256), tm_lds, st, ta);
+      else GS_LAUNCH((k_match_template_mfma<4, 9>), gs4, dim3(256), tm_lds, st, ta);
+    } else {
+      if (nkc <= 3) GS_LAUNCH((k_match_template_mfma<1, 3>), gs1, dim3(256), tm_lds, st, ta);
+      else if (nkc <= 5) GS_LAUNCH((k_match_template_mfma<1, 5>), gs1, dim3(256), tm_lds, st, ta);
+      else GS_LAUNCH((k_match_template_mfma<1, 9>), gs1, dim3(256), tm_lds, st, ta);
+    }
   } else if (tmpl.w <= kTmplTile - 3) {
     unsigned long long *tsq = (unsigned long long *)ctx().scratch(SL_PFX, 8);
     GS_LAUNCH(k_sum_squares, dim3(1), dim3(256), 0, ctx().s(), t, (unsigned long long)tb, tsq);

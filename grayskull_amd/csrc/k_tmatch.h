@@ -150,7 +150,9 @@ __global__ __launch_bounds__(64) void k_tm_colsq(const unsigned *P, unsigned iw,
 #ifndef GS_TM_VARIANT
 #define GS_TM_VARIANT 0 /* timing experiments (wrong results): 1 no MFMA, 2 no operand loads in the loop, 3 no image staging, 4 no template staging, 5 no epilogue */
 #endif
-template <int SPLIT>
+/* NK: upper bound of a.nkc this instantiation's operand registers are sized for (3: tw <= 65, 5: tw <= 129, 9: tw <= 257) --
+ * with the arrays sized for 9 steps whatever the template, a 128-px template ran with 178 registers and 144 B of scratch (round 4) */
+template <int SPLIT, unsigned NK = 9>
 __global__ __launch_bounds__(256) void k_match_template_mfma(TmArgs a) {
   GS_DYN_LDS(smem);
   const unsigned tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
@@ -164,23 +166,32 @@ __global__ __launch_bounds__(256) void k_match_template_mfma(TmArgs a) {
    * loop is one memory round trip per trip, and a block has ~10,000 dwords to fetch) */
   const unsigned i16 = idw / 4u, nitems = irows * i16; /* idw is a multiple of 8 */
   for (unsigned base = tid; base < (GS_TM_VARIANT == 3 ? 0u : nitems); base += 2048u) {
-    U4 v[8];
+    /* four scalar arrays, every index a constant once unrolled: an array of structs written under a condition, or bytes
+     * inserted at a run-time index, live in scratch memory with hipcc (144 B per lane and a round trip through it for every
+     * staged dword until round 4) */
+    uint32_t v0[8], v1[8], v2[8], v3[8];
 #pragma unroll
     for (unsigned u = 0; u < 8; u++) {
       const unsigned i = base + 256u * u;
-      v[u] = U4{0, 0, 0, 0};
+      v0[u] = v1[u] = v2[u] = v3[u] = 0;
       if (i < nitems) {
         const unsigned r = i / i16, c = i - r * i16;
         const unsigned y = by0 + r, x = bx0 + 16u * c;
         if (y < a.ih && x < a.iw) {
           const uint8_t *p = a.img + (size_t)y * a.iw + x;
           if (x + 16u <= a.iw) {
-            v[u] = U4{load_u32_unaligned(p) ^ 0x80808080u, load_u32_unaligned(p + 4) ^ 0x80808080u,
-                      load_u32_unaligned(p + 8) ^ 0x80808080u, load_u32_unaligned(p + 12) ^ 0x80808080u};
+            v0[u] = load_u32_unaligned(p) ^ 0x80808080u, v1[u] = load_u32_unaligned(p + 4) ^ 0x80808080u;
+            v2[u] = load_u32_unaligned(p + 8) ^ 0x80808080u, v3[u] = load_u32_unaligned(p + 12) ^ 0x80808080u;
           } else {
-            uint32_t d[4] = {0, 0, 0, 0};
-            for (unsigned b = 0; b < 16 && x + b < a.iw; b++) d[b >> 2] |= (uint32_t)(p[b] ^ 0x80u) << (8 * (b & 3));
-            v[u] = U4{d[0], d[1], d[2], d[3]};
+            uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+#pragma unroll
+            for (unsigned b = 0; b < 4; b++) {
+              if (x + b < a.iw) d0 |= (uint32_t)(p[b] ^ 0x80u) << (8 * b);
+              if (x + 4 + b < a.iw) d1 |= (uint32_t)(p[4 + b] ^ 0x80u) << (8 * b);
+              if (x + 8 + b < a.iw) d2 |= (uint32_t)(p[8 + b] ^ 0x80u) << (8 * b);
+              if (x + 12 + b < a.iw) d3 |= (uint32_t)(p[12 + b] ^ 0x80u) << (8 * b);
+            }
+            v0[u] = d0, v1[u] = d1, v2[u] = d2, v3[u] = d3;
           }
         }
       }
@@ -190,20 +201,25 @@ __global__ __launch_bounds__(256) void k_match_template_mfma(TmArgs a) {
       const unsigned i = base + 256u * u;
       if (i < nitems) {
         const unsigned r = i / i16, c = i - r * i16;
-        *(U4 *)(limg + (size_t)r * a.istride + 16u * c) = v[u];
+        *(U4 *)(limg + (size_t)r * a.istride + 16u * c) = U4{v0[u], v1[u], v2[u], v3[u]};
       }
     }
   }
   /* the padded template (k_tm_prep), 16 bytes per item */
   const unsigned nt16 = a.th * a.tstride / 16u;
   for (unsigned base = tid; base < (GS_TM_VARIANT == 4 ? 0u : nt16); base += 2048u) {
-    U4 v[8];
+    uint32_t v0[8], v1[8], v2[8], v3[8];
+#pragma unroll
+    for (unsigned u = 0; u < 8; u++) {
+      v0[u] = v1[u] = v2[u] = v3[u] = 0;
+      if (base + 256u * u < nt16) {
+        const U4 t = ((const U4 *)a.tpad)[base + 256u * u];
+        v0[u] = t.x, v1[u] = t.y, v2[u] = t.z, v3[u] = t.w;
+      }
+    }
 #pragma unroll
     for (unsigned u = 0; u < 8; u++)
-      if (base + 256u * u < nt16) v[u] = ((const U4 *)a.tpad)[base + 256u * u];
-#pragma unroll
-    for (unsigned u = 0; u < 8; u++)
-      if (base + 256u * u < nt16) ((U4 *)ltm)[base + 256u * u] = v[u];
+      if (base + 256u * u < nt16) ((U4 *)ltm)[base + 256u * u] = U4{v0[u], v1[u], v2[u], v3[u]};
   }
   __syncthreads();
   const unsigned wy = SPLIT == 1 ? (wave >> 1) * 32u : 0u, wx = SPLIT == 1 ? (wave & 1u) * 64u : 0u, m = lane & 31u, g = lane >> 5;
@@ -214,7 +230,7 @@ __global__ __launch_bounds__(256) void k_match_template_mfma(TmArgs a) {
   /* Row by row: the nkc + 1 image operands and nkc template operands of template row j sit in registers (static
    * indices: the loops are unrolled to kTmMaxK with wave-uniform guards) and the operands of row j + jstep are
    * requested before row j's 2 nkc MFMAs are issued. */
-  constexpr unsigned kTmMaxK = 9; /* tw <= 257 */
+  constexpr unsigned kTmMaxK = NK; /* a.nkc <= NK */
   U4 Ac[kTmMaxK + 1], Bc[kTmMaxK], An[kTmMaxK + 1], Bn[kTmMaxK];
   auto load_row = [&](unsigned j, U4 (&A)[kTmMaxK + 1], U4 (&B)[kTmMaxK]) {
     const uint8_t *ar = limg + (wy + m + j) * a.istride + wx + 16u * g;
