@@ -130,6 +130,25 @@ def _body_fast_strip_kernel(emu, oracle, w4, h, seed, kind, threshold, dark):
     assert_same(sm, smo, "gs_fast scoremap (strip kernel)")
 
 
+def _body_fast_wide(emu, oracle, w, h, seed, kind, threshold, cap, key19):
+    """gs_fast on frames several score tiles wide and tall (64 x 48-px tiles, bitmap words, chunks of 32 words that straddle
+    rows), a caller's non-zero score map, caps that cut the list; key19: 0 sparse NMS, 2 strip NMS, 1 item by item"""
+    rs = np.random.RandomState(seed)
+    img = _img(rs, w, h, kind)
+    if kind == 1:  # p < threshold regions: every pixel a candidate under the reference's unsigned wrap
+        img[h // 4: h // 2, w // 3: 2 * w // 3] = rs.randint(0, max(2, min(threshold, 255)), (h // 2 - h // 4, 2 * w // 3 - w // 3))
+    sm0 = rs.randint(0, 256, (h, w)).astype(np.uint8)
+    ko, smo = oracle.fast(img, cap, threshold, sm0)
+    emu.tune(19, key19)
+    try:
+        sm = sm0.copy()
+        k = emu.fast(img.copy(), sm, cap, threshold)
+    finally:
+        emu.tune(19, 0)
+    assert_same(k, ko, "gs_fast %dx%d t=%d cap=%d key19=%d" % (w, h, threshold, cap, key19))
+    assert_same(sm, smo, "gs_fast scoremap %dx%d" % (w, h))
+
+
 def _body_lbp_any_shape(emu, oracle, w, h, seed, cseed, sf, mx, step, cap):
     from util import random_cascade
     img = _img(np.random.RandomState(seed), w, h, seed % 3)
@@ -251,6 +270,21 @@ def test_fast_strip_kernel(emu, oracle, w4, h, seed, kind, threshold, dark):
        kind=st.integers(0, 2), threshold=st.sampled_from([0, 1, 5, 20, 60, 200, 255, 256, 300]), dark=st.booleans())
 def test_gpu_fast_strip_kernel(hip, oracle, w4, h, seed, kind, threshold, dark):
     _body_fast_strip_kernel(hip, oracle, w4=w4, h=h, seed=seed, kind=kind, threshold=threshold, dark=dark)
+
+
+@_cfg(10)
+@given(w=st.integers(60, 300), h=st.integers(40, 130), seed=st.integers(0, 2 ** 16), kind=st.integers(0, 2),
+       threshold=st.sampled_from([1, 12, 20, 60, 255]), cap=st.sampled_from([1, 50, 20000]), key19=st.sampled_from([0, 0, 2, 1]))
+def test_fast_wide_shapes(emu, oracle, w, h, seed, kind, threshold, cap, key19):
+    _body_fast_wide(emu, oracle, w, h, seed, kind, threshold, cap, key19)
+
+
+@pytest.mark.gpu
+@_cfg(25)
+@given(w=st.integers(60, 700), h=st.integers(40, 300), seed=st.integers(0, 2 ** 16), kind=st.integers(0, 2),
+       threshold=st.sampled_from([1, 12, 20, 60, 255]), cap=st.sampled_from([1, 50, 20000]), key19=st.sampled_from([0, 0, 2, 1]))
+def test_gpu_fast_wide_shapes(hip, oracle, w, h, seed, kind, threshold, cap, key19):
+    _body_fast_wide(hip, oracle, w, h, seed, kind, threshold, cap, key19)
 
 
 @pytest.mark.gpu
