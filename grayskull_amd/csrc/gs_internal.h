@@ -348,7 +348,7 @@ inline unsigned max_frames_per_launch() { return g_tune[8] > 0 ? (unsigned)g_tun
 /* launchers that cross translation units */
 void launch_sobel(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned n, bool keep_cols = true); /* gs_stencil.cpp */
 void launch_blur(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned n, unsigned radius);
-void launch_integral(const uint8_t *src, unsigned w, unsigned h, unsigned n, unsigned *ii);
+bool launch_integral(const uint8_t *src, unsigned w, unsigned h, unsigned n, unsigned *ii, bool sq = false);
 void launch_integral_pad(dim3 grid, hipStream_t st, const unsigned *ii, unsigned w, unsigned h, unsigned *padded); /* k_integral_pad */
 
 }  // namespace gsi

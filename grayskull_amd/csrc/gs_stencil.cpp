@@ -138,14 +138,17 @@ void launch_morph(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsi
   }
 }
 
-void launch_integral(const uint8_t *src, unsigned w, unsigned h, unsigned n, unsigned *ii) {
-  if (n == 0) return;
+/* sq: the table of (p - 128)^2 (gs_match_template); only the banded form builds it -- false is returned, and nothing launched,
+ * when this geometry would take the rows + columns form */
+bool launch_integral(const uint8_t *src, unsigned w, unsigned h, unsigned n, unsigned *ii, bool sq) {
+  if (n == 0) return true;
   hipStream_t st = ctx().s();
   const size_t fp = (size_t)w * h;
   /* the banded form takes any width >= 32 at any alignment (round 4: ragged rows, frames wider than 4096 px in column
    * chunks); key 6 = 1 or key 21 = 1: the rows + columns form */
   const bool banded = g_tune[6] != 1 && fp * 4 < 0x7fffffffull &&
                       (g_tune[21] == 1 ? (w % 16 == 0 && w <= 4096 && al16(src) && al16(ii)) : w >= 32);
+  if (sq && !banded) return false;
   for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
     const unsigned nn = std::min(kMaxZ, n - f0);
     if (banded) {
@@ -158,11 +161,17 @@ void launch_integral(const uint8_t *src, unsigned w, unsigned h, unsigned n, uns
       unsigned *cs = (unsigned *)ctx().scratch(SL_HISTP, (size_t)nn * nb * w * 4);
       const uint8_t *s = src + fp * f0;
       unsigned *o = ii + fp * f0;
-      GS_LAUNCH(k_integral_colsum, dim3((w + 4095) / 4096, nb, nn), dim3(256), 0, st, s, w, h, BH, nb, cs);
+      if (sq) GS_LAUNCH(k_integral_colsum<true>, dim3((w + 4095) / 4096, nb, nn), dim3(256), 0, st, s, w, h, BH, nb, cs);
+      else GS_LAUNCH(k_integral_colsum<false>, dim3((w + 4095) / 4096, nb, nn), dim3(256), 0, st, s, w, h, BH, nb, cs);
       GS_LAUNCH(k_integral_colbase, dim3((w + 63) / 64, nn), dim3(64, 16), 0, st, cs, w, nb);
       const dim3 gw(1, (nb + 3) / 4, nn);
       const bool rg = (w & 3u) != 0u;
-      if (g_tune[6] == 2 && !rg && !wide && w % 16 == 0) /* the block-per-band form (one barrier per row), kept for comparison */
+      if (sq) { /* 16 tiles whatever the width: four instantiations instead of six */
+        if (wide && rg) GS_LAUNCH((k_integral_wave<16, true, true, true>), gw, dim3(256), 0, st, s, w, h, BH, nb, (const unsigned *)cs, o);
+        else if (wide) GS_LAUNCH((k_integral_wave<16, false, true, true>), gw, dim3(256), 0, st, s, w, h, BH, nb, (const unsigned *)cs, o);
+        else if (rg) GS_LAUNCH((k_integral_wave<16, true, false, true>), gw, dim3(256), 0, st, s, w, h, BH, nb, (const unsigned *)cs, o);
+        else GS_LAUNCH((k_integral_wave<16, false, false, true>), gw, dim3(256), 0, st, s, w, h, BH, nb, (const unsigned *)cs, o);
+      } else if (g_tune[6] == 2 && !rg && !wide && w % 16 == 0) /* the block-per-band form (one barrier per row), kept for comparison */
         GS_LAUNCH(k_integral_band, dim3(1, nb, nn), dim3(256), 0, st, s, w, h, BH, nb, (const unsigned *)cs, o);
       else if (wide && rg) GS_LAUNCH((k_integral_wave<16, true, true>), gw, dim3(256), 0, st, s, w, h, BH, nb, (const unsigned *)cs, o);
       else if (wide) GS_LAUNCH((k_integral_wave<16, false, true>), gw, dim3(256), 0, st, s, w, h, BH, nb, (const unsigned *)cs, o);
@@ -175,6 +184,7 @@ void launch_integral(const uint8_t *src, unsigned w, unsigned h, unsigned n, uns
       GS_LAUNCH(k_integral_cols, dim3((w + 255) / 256, nn), dim3(256), 0, st, ii + fp * f0, w, h);
     }
   }
+  return true;
 }
 
 /* gs_blur for any radius: register strips for r = 1..3 on aligned frames, otherwise clipped box
@@ -818,7 +828,7 @@ void gs_match_template(struct gs_image img, struct gs_image tmpl, struct gs_imag
   const unsigned nkc = (tmpl.w + 31 + 31) / 32, istride = (tm_split ? 32 : 96) + 32 * nkc + 16, tstride = 32 * nkc + 48;
   const size_t tm_lds = std::max<size_t>((size_t)((tm_split ? 31 : 63) + tmpl.h) * istride + (size_t)tmpl.h * tstride + 16,
                                          tm_split ? 32768 : 0);
-  if (g_tune[20] != 1 && tmpl.w >= 16 && nkc <= 9 && tmpl.h >= 4 && (tb >= 512 || g_tune[20] >= 2) && tb <= 32768 && tm_lds <= 150 * 1024 &&
+  if (g_tune[20] != 1 && tmpl.w >= 16 && nkc <= 9 && tmpl.h >= 4 && (tb >= 512 || g_tune[20] == 2 || g_tune[20] == 3) && tb <= 32768 && tm_lds <= 150 * 1024 &&
       ib < 0x7fffffffull) {
     hipStream_t st = ctx().s();
     unsigned *rowp = (unsigned *)ctx().scratch(SL_II, (size_t)img.h * (img.w + 1) * 4);
@@ -826,9 +836,19 @@ void gs_match_template(struct gs_image img, struct gs_image tmpl, struct gs_imag
     uint8_t *tpad = (uint8_t *)ctx().scratch(SL_PRE, (size_t)tmpl.h * tstride + 16);
     unsigned *tsqp = (unsigned *)(tpad + (((size_t)tmpl.h * tstride + 3) & ~(size_t)3)); /* tstride is a multiple of 16 */
     GS_LAUNCH(k_tm_prep, dim3(1), dim3(1024), 0, st, t, tmpl.w, tmpl.h, tstride, tpad, tsqp);
-    GS_LAUNCH(k_tm_rowprefix, dim3((img.h + 3) / 4), dim3(64, 4), 0, st, s, img.w, img.h, rowp);
-    GS_LAUNCH(k_tm_colsq, dim3((result.w + 63) / 64, (result.h + kTmRun - 1) / kTmRun), dim3(64), 0, st, (const unsigned *)rowp,
-              img.w, tmpl.w, tmpl.h, result.w, result.h, s2);
+    /* window sums of (I - 128)^2: four corners of the banded integral table of squares (round 4) for frames of 4 Mpx and
+     * more -- 4K, 128 x 128: 0.269 -> 0.249 ms, 64 x 64: 0.135 -> 0.125; on a 720p frame the four short launches are 6-10 us
+     * SLOWER than the two passes of round 3 (row prefix + sliding columns), which stay for small frames, for key 20 = 4 and
+     * for geometries the banded integral does not take (key 20 = 5: the table route whatever the size);
+     * profiles/r04v_match_template_integral_squares.log */
+    if (g_tune[20] != 4 && (ib >= (4u << 20) || g_tune[20] == 5) && launch_integral(s, img.w, img.h, 1, rowp, /*sq=*/true)) {
+      GS_LAUNCH(k_tm_s2_corners, dim3((result.w + 255) / 256, result.h), dim3(256), 0, st, (const unsigned *)rowp, img.w, tmpl.w, tmpl.h,
+                result.w, result.h, s2);
+    } else {
+      GS_LAUNCH(k_tm_rowprefix, dim3((img.h + 3) / 4), dim3(64, 4), 0, st, s, img.w, img.h, rowp);
+      GS_LAUNCH(k_tm_colsq, dim3((result.w + 63) / 64, (result.h + kTmRun - 1) / kTmRun), dim3(64), 0, st, (const unsigned *)rowp,
+                img.w, tmpl.w, tmpl.h, result.w, result.h, s2);
+    }
 #ifndef GS_EMU
     /* more than the default 64 KB of dynamic LDS: a per-DEVICE attribute of the function (a thread that moved to
      * another device with gsh_set_device kept a thread-local "done" flag and the launch failed there) */

@@ -98,6 +98,13 @@ __global__ __launch_bounds__(256) void k_integral_cols(unsigned *ii, unsigned w,
 /* grid (ceil(w/4096), nbands, n frames), block 256.  Any w >= 16 and any alignment: the strip that would cross the row
  * end is anchored at w - 16 instead (it overlaps its neighbour; both store the same sums), so every load lies inside
  * the row. */
+/* SQ (k_integral_colsum, k_integral_wave): the table of (p - 128)^2 instead of p -- gs_match_template's window sums of
+ * squares are four corners of it (k_tmatch.h); u32 arithmetic modulo 2^32 like the plain table */
+GS_DEV unsigned integral_term(unsigned b, bool sq) {
+  const int v = (int)b - 128;
+  return sq ? (unsigned)(v * v) : b;
+}
+template <bool SQ = false>
 __global__ __launch_bounds__(256) void k_integral_colsum(const uint8_t *src, unsigned w, unsigned h,
                                                          unsigned BH, unsigned nbands,
                                                          unsigned *colsum) {
@@ -116,7 +123,7 @@ __global__ __launch_bounds__(256) void k_integral_colsum(const uint8_t *src, uns
     nxt = buf_load16(S, (act && y + 1 < y1) ? (y + 1) * w + x0 : kOOB);
     const uint32_t d[4] = {cur.x, cur.y, cur.z, cur.w};
 #pragma unroll
-    for (int k = 0; k < 16; k++) V[k] += (d[k >> 2] >> (8 * (k & 3))) & 0xffu;
+    for (int k = 0; k < 16; k++) V[k] += integral_term((d[k >> 2] >> (8 * (k & 3))) & 0xffu, SQ);
   }
   if (act) {
     unsigned *o = colsum + ((size_t)blockIdx.z * nbands + blockIdx.y) * w + x0;
@@ -231,7 +238,7 @@ __global__ __launch_bounds__(256) void k_integral_band(const uint8_t *src, unsig
  * bottom inside each; what a row hands from chunk to chunk -- its prefix at the chunk's left edge -- waits in a
  * register of lane (row - y0): v_readlane / one masked move per row, no LDS (BH <= kIntegralWideRows = 64). */
 constexpr unsigned kIntegralWideRows = 64;
-template <int TILES, bool RAGGED = false, bool WIDE = false>
+template <int TILES, bool RAGGED = false, bool WIDE = false, bool SQ = false>
 __global__ __launch_bounds__(256) void k_integral_wave(const uint8_t *src, unsigned w, unsigned h,
                                                        unsigned BH, unsigned nbands,
                                                        const unsigned *colbase, unsigned *ii) {
@@ -283,7 +290,8 @@ __global__ __launch_bounds__(256) void k_integral_wave(const uint8_t *src, unsig
 #pragma unroll
       for (int t = 0; t < TILES; t++) {
         const uint32_t d = cur[t];
-        V[t][0] += d & 0xffu, V[t][1] += (d >> 8) & 0xffu, V[t][2] += (d >> 16) & 0xffu, V[t][3] += d >> 24;
+        V[t][0] += integral_term(d & 0xffu, SQ), V[t][1] += integral_term((d >> 8) & 0xffu, SQ);
+        V[t][2] += integral_term((d >> 16) & 0xffu, SQ), V[t][3] += integral_term(d >> 24, SQ);
         const unsigned p0 = V[t][0], p1 = p0 + V[t][1], p2 = p1 + V[t][2], p3 = p2 + V[t][3];
         unsigned mine = p3; /* what this lane adds to the row's running sum */
         if constexpr (RAGGED) {

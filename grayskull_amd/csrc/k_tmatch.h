@@ -142,6 +142,23 @@ __global__ __launch_bounds__(64) void k_tm_colsq(const unsigned *P, unsigned iw,
   }
 }
 
+/* s2 from the integral table Q of (I - 128)^2 (k_integral.h, SQ; round 4): four corners per result, modulo 2^32 like the
+ * table -- three short launches for the table and this one instead of the row-prefix + sliding-column passes above, which
+ * move 140 MB through a u32 prefix table for a 4K frame (75 us; this route: see DESIGN.md 3).  grid (ceil(rw / 256), rh), block 256 */
+__global__ __launch_bounds__(256) void k_tm_s2_corners(const unsigned *Q, unsigned iw, unsigned tw, unsigned th, unsigned rw, unsigned rh,
+                                                      unsigned *s2) {
+  const unsigned x = blockIdx.x * 256u + threadIdx.x, y = blockIdx.y;
+  if (x >= rw) return;
+  const unsigned *lo = Q + (size_t)(y + th - 1u) * iw, *hi = y ? Q + (size_t)(y - 1u) * iw : nullptr;
+  unsigned s = lo[x + tw - 1u];
+  if (x) s -= lo[x - 1u];
+  if (hi) {
+    s -= hi[x + tw - 1u];
+    if (x) s += hi[x - 1u];
+  }
+  s2[(size_t)y * rw + x] = s;
+}
+
 /* SPLIT = 1: a block's four waves own 2 x 2 tiles of 32 rows x 64 columns (64 x 128 results per block; grid (ceil(rw / 128),
  * ceil(rh / 64))) -- least staging per result, for launches with enough blocks to fill the chip.  SPLIT = 4: the four
  * waves share ONE 32 x 64 tile and take every fourth template row each, their accumulators meet in LDS (grid (ceil(rw / 64),

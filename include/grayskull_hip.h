@@ -53,7 +53,9 @@ void gsh_sync(void);                      /* hipStreamSynchronize(current stream
  * always), 19: pass 2 of gs_fast -- 0 the sparse kernel behind the score kernel's bitmap of scored pixels (round 4), 2 the
  * strip kernel over every pixel (round 3), 1 item by item (round 2).
  * 20 = 1: gs_match_template on the VALU dot-product kernels instead of the matrix cores (2 / 3: the matrix-core kernel with
- * 64 x 128 tiles / with 32 x 64 tiles and the template rows split over four waves, whatever the image size),
+ * 64 x 128 tiles / with 32 x 64 tiles and the template rows split over four waves, whatever the image size; 4 / 5: its window
+ * sums of squares always from the row-prefix + sliding-column passes / always from the integral table of squares -- default: the
+ * table from 4 Mpx),
  * 21 = 1: the round-3 rule for the strip kernels (whole 16-px strips at 16-byte aligned addresses only; everything else per
  * pixel), 22 = 1: gs_sobel without the reads that preserve columns 0 / w-1 (probe; those columns receive junk), 23 = 1: the
  * strip-copy probe keeps the stencils' halo load, 24 the realigning strip flavour (1 = never, 2 = always; 0 = by address

@@ -162,7 +162,7 @@ def test_geometry_and_template_matching(emu, oracle, shape):
                                   (300, 200, 128, 128), (290, 66, 160, 3 + 1), (64, 64, 64, 64), (129, 65, 33, 33), (400, 40, 256, 8)])
 def test_match_template_on_the_matrix_cores(emu, oracle, case):
     """k_match_template_mfma (templates of 16 x 4 .. 32768 taps): the cross term as Toeplitz matrix products in the i8 MFMA
-    accumulator, sum I'^2 from the two sliding-sum kernels -- against the oracle and against the dot-product kernels
+    accumulator, sum I'^2 from the two sliding-sum kernels (key 20 = 5: from four corners of the integral table of squares, the route of frames of 4 Mpx and more) -- against the oracle and against the dot-product kernels
     (gsh_tune key 20 = 1): result sizes below, at and above the 128 x 64 block tile, widths that leave 1 .. 31 columns in
     the last K step, a template as large as the image, all-0 / all-255 images against all-255 / all-0 templates (the
     largest sums), and an exact sub-image (score 255 at its place)"""
@@ -176,7 +176,7 @@ def test_match_template_on_the_matrix_cores(emu, oracle, case):
     try:
         for im, t in zip(imgs, tmpls):
             ro = oracle.match_template(im, t)
-            for tiles in (2, 3):  # 64 x 128 tiles / 32 x 64 tiles with the template rows split over the block's waves
+            for tiles in (2, 3, 5):  # 64 x 128 tiles / 32 x 64 tiles with the template rows split over the block's waves / 5: sum I'^2 from the integral table of squares
                 emu.tune(20, tiles)
                 r = np.zeros((ih - th + 1, iw - tw + 1), np.uint8)
                 emu.match_template(im, t, r)
