@@ -855,23 +855,25 @@ void gs_match_template(struct gs_image img, struct gs_image tmpl, struct gs_imag
     static std::atomic<unsigned long long> lds_raised{0};
     const unsigned long long dev_bit = 1ull << ((unsigned)ctx().device & 63u);
     if (ctx().device >= 64 || !(lds_raised.load(std::memory_order_acquire) & dev_bit)) {
-      const void *fns[] = {(const void *)k_match_template_mfma<1, 3>, (const void *)k_match_template_mfma<1, 5>, (const void *)k_match_template_mfma<1, 9>,
-                           (const void *)k_match_template_mfma<4, 3>, (const void *)k_match_template_mfma<4, 5>, (const void *)k_match_template_mfma<4, 9>};
+#define GS_TM_FNS(S) (const void *)k_match_template_mfma<S, 2>, (const void *)k_match_template_mfma<S, 3>, (const void *)k_match_template_mfma<S, 4>, \
+                     (const void *)k_match_template_mfma<S, 5>, (const void *)k_match_template_mfma<S, 6>, (const void *)k_match_template_mfma<S, 7>, \
+                     (const void *)k_match_template_mfma<S, 8>, (const void *)k_match_template_mfma<S, 9>
+      const void *fns[] = {GS_TM_FNS(1), GS_TM_FNS(4)};
+#undef GS_TM_FNS
       for (const void *fn : fns) GS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       lds_raised.fetch_or(dev_bit, std::memory_order_release);
     }
 #endif
     TmArgs ta{s, img.w, img.h, (const uint8_t *)tpad, (const unsigned *)tsqp, tmpl.w, tmpl.h, s2, d, result.w, result.h, nkc, istride, tstride};
-    /* the instantiation whose operand registers are sized for the smallest bound >= nkc (k_tmatch.h) */
+    /* one instantiation per number of K steps (k_tmatch.h): nkc = 2 .. 9 for templates 16 .. 257 wide */
     const dim3 gs4((result.w + 63) / 64, (result.h + 31) / 32), gs1((result.w + 127) / 128, (result.h + 63) / 64);
-    if (tm_split) {
-      if (nkc <= 3) GS_LAUNCH((k_match_template_mfma<4, 3>), gs4, dim3(256), tm_lds, st, ta);
-      else if (nkc <= 5) GS_LAUNCH((k_match_template_mfma<4, 5>), gs4, dim3(256), tm_lds, st, ta);
-      else GS_LAUNCH((k_match_template_mfma<4, 9>), gs4, dim3(256), tm_lds, st, ta);
-    } else {
-      if (nkc <= 3) GS_LAUNCH((k_match_template_mfma<1, 3>), gs1, dim3(256), tm_lds, st, ta);
-      else if (nkc <= 5) GS_LAUNCH((k_match_template_mfma<1, 5>), gs1, dim3(256), tm_lds, st, ta);
-      else GS_LAUNCH((k_match_template_mfma<1, 9>), gs1, dim3(256), tm_lds, st, ta);
+    GS_ASSERT(nkc >= 2 && nkc <= 9);
+    switch (nkc * 2 + (tm_split ? 1 : 0)) {
+#define GS_TM_CASE(K)                                                                              \
+  case K * 2: GS_LAUNCH((k_match_template_mfma<1, K>), gs1, dim3(256), tm_lds, st, ta); break;     \
+  case K * 2 + 1: GS_LAUNCH((k_match_template_mfma<4, K>), gs4, dim3(256), tm_lds, st, ta); break;
+      GS_TM_CASE(2) GS_TM_CASE(3) GS_TM_CASE(4) GS_TM_CASE(5) GS_TM_CASE(6) GS_TM_CASE(7) GS_TM_CASE(8) GS_TM_CASE(9)
+#undef GS_TM_CASE
     }
   } else if (tmpl.w <= kTmplTile - 3) {
     unsigned long long *tsq = (unsigned long long *)ctx().scratch(SL_PFX, 8);

@@ -167,8 +167,10 @@ __global__ __launch_bounds__(256) void k_tm_s2_corners(const unsigned *Q, unsign
 #ifndef GS_TM_VARIANT
 #define GS_TM_VARIANT 0 /* timing experiments (wrong results): 1 no MFMA, 2 no operand loads in the loop, 3 no image staging, 4 no template staging, 5 no epilogue */
 #endif
-/* NK: upper bound of a.nkc this instantiation's operand registers are sized for (3: tw <= 65, 5: tw <= 129, 9: tw <= 257) --
- * with the arrays sized for 9 steps whatever the template, a 128-px template ran with 178 registers and 144 B of scratch (round 4) */
+/* NK = a.nkc, the K steps of this template width (2 .. 9: one instantiation each, round 4): the operand registers are sized
+ * for it (with arrays for 9 steps whatever the template, a 128-px template ran with 178 registers) and the row loop has no
+ * run-time guards -- one basic block per template row, so the next row's LDS reads are scheduled between this row's MFMAs
+ * (guards on a run-time nkc cut the loop into a block per MFMA pair) */
 template <int SPLIT, unsigned NK = 9>
 __global__ __launch_bounds__(256) void k_match_template_mfma(TmArgs a) {
   GS_DYN_LDS(smem);
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(256) void k_match_template_mfma(TmArgs a) {
   /* Row by row: the nkc + 1 image operands and nkc template operands of template row j sit in registers (static
    * indices: the loops are unrolled to kTmMaxK with wave-uniform guards) and the operands of row j + jstep are
    * requested before row j's 2 nkc MFMAs are issued. */
-  constexpr unsigned kTmMaxK = NK; /* a.nkc <= NK */
+  constexpr unsigned kTmMaxK = NK; /* == a.nkc (the launcher picks the instantiation) */
   U4 Ac[kTmMaxK + 1], Bc[kTmMaxK], An[kTmMaxK + 1], Bn[kTmMaxK];
   auto load_row = [&](unsigned j, U4 (&A)[kTmMaxK + 1], U4 (&B)[kTmMaxK]) {
     const uint8_t *ar = limg + (wy + m + j) * a.istride + wx + 16u * g;
@@ -255,31 +257,29 @@ __global__ __launch_bounds__(256) void k_match_template_mfma(TmArgs a) {
     const unsigned ob = 16u * g + 32u - m, sh = 8u * (ob & 3u); /* 32 kc keeps the byte phase */
     const uint32_t *tp = (const uint32_t *)(tr + (ob & ~3u));
 #pragma unroll
-    for (unsigned k = 0; k <= kTmMaxK; k++)
-      if (k <= a.nkc) A[k] = *(const U4 *)(ar + 32u * k);
+    for (unsigned k = 0; k <= kTmMaxK; k++) A[k] = *(const U4 *)(ar + 32u * k);
 #pragma unroll
-    for (unsigned k = 0; k < kTmMaxK; k++)
-      if (k < a.nkc) {
-        const uint32_t d0 = tp[8u * k], d1 = tp[8u * k + 1u], d2 = tp[8u * k + 2u], d3 = tp[8u * k + 3u], d4 = tp[8u * k + 4u];
-        B[k] = U4{alignbit(d1, d0, sh), alignbit(d2, d1, sh), alignbit(d3, d2, sh), alignbit(d4, d3, sh)};
-      }
+    for (unsigned k = 0; k < kTmMaxK; k++) {
+      const uint32_t d0 = tp[8u * k], d1 = tp[8u * k + 1u], d2 = tp[8u * k + 2u], d3 = tp[8u * k + 3u], d4 = tp[8u * k + 4u];
+      B[k] = U4{alignbit(d1, d0, sh), alignbit(d2, d1, sh), alignbit(d3, d2, sh), alignbit(d4, d3, sh)};
+    }
   };
   if (j0 < a.th) { /* wave-uniform */
     load_row(j0, Ac, Bc);
     for (unsigned j = j0; j < a.th; j += jstep) {
-      const bool more = j + jstep < a.th;
-      if (more && GS_TM_VARIANT != 2) load_row(j + jstep, An, Bn);
+      /* no branch inside a trip: the last one requests its own row again (and drops it) */
+      const unsigned jn = j + jstep < a.th ? j + jstep : j;
+      if (GS_TM_VARIANT != 2) load_row(jn, An, Bn);
 #pragma unroll
-      for (unsigned k = 0; k < kTmMaxK; k++)
-        if (k < a.nkc) {
+      for (unsigned k = 0; k < kTmMaxK; k++) {
 #if GS_TM_VARIANT == 1
-          acc0[0] += (int)(Ac[k].x ^ Bc[k].x), acc1[0] += (int)(Ac[k + 1].x ^ Bc[k].y);
+        acc0[0] += (int)(Ac[k].x ^ Bc[k].x), acc1[0] += (int)(Ac[k + 1].x ^ Bc[k].y);
 #else
-          mfma_i32_32x32x32_i8(Ac[k], Bc[k], acc0);
-          mfma_i32_32x32x32_i8(Ac[k + 1], Bc[k], acc1);
+        mfma_i32_32x32x32_i8(Ac[k], Bc[k], acc0);
+        mfma_i32_32x32x32_i8(Ac[k + 1], Bc[k], acc1);
 #endif
-        }
-      if (more && GS_TM_VARIANT != 2) {
+      }
+      if (GS_TM_VARIANT != 2) {
 #pragma unroll
         for (unsigned k = 0; k <= kTmMaxK; k++) Ac[k] = An[k];
 #pragma unroll
