@@ -31,3 +31,30 @@ cd $R; f=$(find gpurun_out/prof_sobel4096 -name "*kernel_stats.csv" | head -1); 
 echo "== ragged shapes"; RG_CHECK=0 timeout 500 python scripts/ubench_ragged.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/ragged.log | tail -40
 echo "== box offsets"; timeout 300 python scripts/ubench_box_offsets.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/box_offsets.log
 echo "== next rows"; timeout 300 python scripts/ubench_next_rows.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/next_rows.log | tail -12
+echo "== gs_match_template: matrix cores vs dot-product kernels"; timeout 300 python scripts/ubench_tmatch.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/tmatch.log | tail -12
+echo "== gs_fast, 32 x 720p: score pass and whole call, sparse vs strip NMS"
+timeout 300 python - <<'PY' 2>&1 | grep -v amdgpu.ids | tee gpurun_out/fast.log
+import sys, os
+sys.path.insert(0, os.getcwd())
+import torch, grayskull_amd as gs
+g = gs.lib(); g.use_torch_stream()
+def timeit(fn, reps=20):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn(); fn(); torch.cuda.synchronize(); e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+nf, h, w = 32, 720, 1280
+f = torch.empty((nf, h, w), dtype=torch.uint8, device="cuda"); g.synth_batch(f, 4)
+flat = torch.full((nf, h, w), 100, dtype=torch.uint8, device="cuda")
+rnd = torch.randint(0, 256, (nf, h, w), dtype=torch.uint8, device="cuda")
+sm = torch.zeros((nf, h, w), dtype=torch.uint8, device="cuda")
+kp = torch.zeros((nf, 2000, 12), dtype=torch.int32, device="cuda"); cn = torch.zeros(nf, dtype=torch.int32, device="cuda")
+for key19 in (0, 2, 0, 2):
+    g.tune(19, key19)
+    print("NMS %s: score us: block noise %.1f flat %.1f random %.1f | gs_fast us: block noise %.1f flat %.1f random %.1f" % (
+        "sparse" if key19 == 0 else "strips", timeit(lambda: g.probe_fast_score(sm, f, 20)), timeit(lambda: g.probe_fast_score(sm, flat, 20)),
+        timeit(lambda: g.probe_fast_score(sm, rnd, 20)), timeit(lambda: g.fast_batch(f, sm, kp, cn, 2000, 20)),
+        timeit(lambda: g.fast_batch(flat, sm, kp, cn, 2000, 20)), timeit(lambda: g.fast_batch(rnd, sm, kp, cn, 2000, 20))), flush=True)
+g.tune(19, 0)
+PY
