@@ -611,9 +611,16 @@ void gsh_filter_batch(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, 
       const unsigned nn = std::min(kMaxZ, n - f0);
       const int rg = strip_mode(w, src + fb * f0);
       const StripCfg c = strip_cfg(w, h, nn, 6, 2, 8, rg);
-      if (rg == 1) GS_LAUNCH(k_filter16<1>, c.grid, c.block, 0, st, dst + fb * f0, src + fb * f0, w, h, c.T, fb | c.xcd_flag, fk);
-      else if (rg == 2) GS_LAUNCH(k_filter16<2>, c.grid, c.block, 0, st, dst + fb * f0, src + fb * f0, w, h, c.T, fb | c.xcd_flag, fk);
-      else GS_LAUNCH(k_filter16<0>, c.grid, c.block, 0, st, dst + fb * f0, src + fb * f0, w, h, c.T, fb | c.xcd_flag, fk);
+      uint8_t *d = dst + fb * f0;
+      const uint8_t *s = src + fb * f0;
+      const size_t fa = fb | c.xcd_flag;
+      if (norm == 1) { /* multiplier 2^24: a shift (k_stencil.h) */
+        if (rg == 1) GS_LAUNCH((k_filter16<1, true>), c.grid, c.block, 0, st, d, s, w, h, c.T, fa, fk);
+        else if (rg == 2) GS_LAUNCH((k_filter16<2, true>), c.grid, c.block, 0, st, d, s, w, h, c.T, fa, fk);
+        else GS_LAUNCH((k_filter16<0, true>), c.grid, c.block, 0, st, d, s, w, h, c.T, fa, fk);
+      } else if (rg == 1) GS_LAUNCH(k_filter16<1>, c.grid, c.block, 0, st, d, s, w, h, c.T, fa, fk);
+      else if (rg == 2) GS_LAUNCH(k_filter16<2>, c.grid, c.block, 0, st, d, s, w, h, c.T, fa, fk);
+      else GS_LAUNCH(k_filter16<0>, c.grid, c.block, 0, st, d, s, w, h, c.T, fa, fk);
     }
     return;
   }

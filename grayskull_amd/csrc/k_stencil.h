@@ -219,7 +219,9 @@ __global__ __launch_bounds__(256) void k_strip_copy(uint8_t *dst, const uint8_t 
  * (one per kernel row) are formed with v_pk_mad_u16 (two's complement: the low 16 bits are the
  * signed result); out(y) = H0(y-1) + H1(y) + H2(y+1) is carried in two partial-sum sets.  The
  * quotient of the clamped non-negative sum is the top byte of sum * ceil(2^24 / norm)
- * (exact for sum <= 255*norm, norm <= 256: 255*norm*(norm-1) < 2^24), packed like k_blur16. */
+ * (exact for sum <= 255*norm, norm <= 256: 255*norm*(norm-1) < 2^24), packed like k_blur16.  Both factors are below 2^24 for
+ * norm >= 2, so the product is v_mul_u32_u24 (full rate; the 16 v_mul_lo_u32 of a row were a quarter of the row's issue
+ * slots until round 4); norm == 1 (NORM1: multiplier 2^24) is a shift. */
 struct FilterK { uint32_t k[3][3]; uint32_t mul, cap, neg_is_255; }; /* k: coefficient in both halves */
 
 GS_DEV void filter_hrow(const uint32_t (&U)[12], const uint32_t (&kr)[3], uint32_t (&H)[8]) {
@@ -231,7 +233,7 @@ GS_DEV void filter_hrow(const uint32_t (&U)[12], const uint32_t (&kr)[3], uint32
   }
 }
 
-template <int RG = 0>
+template <int RG = 0, bool NORM1 = false>
 __global__ __launch_bounds__(256) void k_filter16(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h,
                                                   unsigned T, size_t frame_bytes, FilterK fk) {
   const Strip<false, RG> S(src, dst, w, h, frame_bytes);
@@ -263,7 +265,8 @@ __global__ __launch_bounds__(256) void k_filter16(uint8_t *dst, const uint8_t *s
         P1[p] = pk_add_u16(P0[p], H1[p]), P0[p] = H0[p];
         negm[t] = pk_sar_i16(sum, 15);                                    /* 0xffff where negative */
         const uint32_t c = pk_min_u16(pk_max_i16(sum, 0u), fk.cap);       /* 0 .. min(255*norm, 32767) */
-        prod[2 * t] = (c & 0xffffu) * fk.mul, prod[2 * t + 1] = (c >> 16) * fk.mul; /* quotient = byte 3 */
+        if constexpr (NORM1) prod[2 * t] = c << 24, prod[2 * t + 1] = (c >> 16) << 24; /* c <= 255 */
+        else prod[2 * t] = mul_u24(c & 0xffffu, fk.mul), prod[2 * t + 1] = mul_u24(c >> 16, fk.mul); /* quotient = byte 3 */
       }
       const uint32_t q = perm_b32(prod[3], perm_b32(prod[2], perm_b32(prod[1], prod[0], 0x0c0c0703u), 0x0c070100u), 0x07020100u);
       od[g] = q | (pack_lohi(negm[0], negm[1]) & fk.neg_is_255);
