@@ -451,7 +451,13 @@ GS_DEV uint32_t absdiff2(uint32_t a, uint32_t b) { return sub2(pk_max_u16(a, b),
 GS_DEV unsigned umin(unsigned a, unsigned b) { return a < b ? a : b; }
 GS_DEV unsigned umax(unsigned a, unsigned b) { return a > b ? a : b; }
 /* low 32 bits of the product of the operands' low 24 bits: v_mul_u32_u24, a full-rate instruction (v_mul_lo_u32 runs at a quarter) */
-GS_DEV uint32_t mul_u24(uint32_t a, uint32_t b) { return (a & 0xffffffu) * (b & 0xffffffu); } /* the masks are what lets hipcc pick it */
+GS_DEV uint32_t mul_u24(uint32_t a, uint32_t b) {
+#ifdef GS_EMU
+  return (a & 0xffffffu) * (b & 0xffffffu);
+#else
+  return __ockl_mul24_u32(a, b); /* the intrinsic: a masked C product can be merged with a plain one and end up as v_mul_lo_u32 */
+#endif
+}
 /* |a - b| for a, b < 65536 (v_sad_u16 with zero high halves on the GPU) */
 GS_DEV unsigned absdiff_u16(unsigned a, unsigned b) {
 #ifdef GS_EMU
