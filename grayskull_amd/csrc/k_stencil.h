@@ -220,8 +220,8 @@ __global__ __launch_bounds__(256) void k_strip_copy(uint8_t *dst, const uint8_t 
  * signed result); out(y) = H0(y-1) + H1(y) + H2(y+1) is carried in two partial-sum sets.  The
  * quotient of the clamped non-negative sum is the top byte of sum * ceil(2^24 / norm)
  * (exact for sum <= 255*norm, norm <= 256: 255*norm*(norm-1) < 2^24), packed like k_blur16.  Both factors are below 2^24 for
- * norm >= 2, so the product is v_mul_u32_u24 (full rate; the 16 v_mul_lo_u32 of a row were a quarter of the row's issue
- * slots until round 4); norm == 1 (NORM1: multiplier 2^24) is a shift. */
+ * norm >= 2, so the product is v_mul_u32_u24 (full rate; the 16 quarter-rate v_mul_lo_u32 of a row until round 4: 1-3 % of
+ * the launch in a same-box A/B, profiles/r04x_filter_mul_u24.log); norm == 1 (NORM1: multiplier 2^24) is a shift. */
 struct FilterK { uint32_t k[3][3]; uint32_t mul, cap, neg_is_255; }; /* k: coefficient in both halves */
 
 GS_DEV void filter_hrow(const uint32_t (&U)[12], const uint32_t (&kr)[3], uint32_t (&H)[8]) {

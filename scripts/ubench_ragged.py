@@ -8,7 +8,7 @@ import numpy as np, torch
 import grayskull_amd as gs
 from oracle.pyoracle import Oracle
 
-g = gs.lib(); g.use_torch_stream()
+g = gs.Grayskull(os.environ["UB_LIB"]) if os.environ.get("UB_LIB") else gs.lib(); g.use_torch_stream()
 o = Oracle("port")
 rs = np.random.RandomState(4)
 GUARD = 256
