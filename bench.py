@@ -43,10 +43,11 @@ VALU_RATE_GINST = {"full": 1000.0, "half": 578.0}
 FUSED_OPS_PER_ROW_FILE = os.path.join(ROOT, "profiles", "fused_isa_mix.json")
 
 
-def time_stream(torch, fn, reps):
+def time_stream(torch, fn, reps, warm=1):
     """average ms per call of fn(), events recorded on the (shared) launch stream"""
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    fn()
+    for _ in range(warm):
+        fn()
     torch.cuda.synchronize()
     e0.record()
     for _ in range(reps):
@@ -769,8 +770,9 @@ def extras(g, torch, np, src, tmp, dst, w, h, reps, lo=0, args=None):
     sm7 = torch.zeros_like(f7)
     kp7 = torch.zeros((nf, 2000, 12), dtype=torch.int32, device="cuda")
     cn7 = torch.zeros(nf, dtype=torch.int32, device="cuda")
-    ms_fast = time_stream(torch, lambda: g.fast_batch(f7, sm7, kp7, cn7, 2000, 20), 5)
-    ms_fast_score = time_stream(torch, lambda: g.probe_fast_score(sm7, f7, 20), 5)
+    # calls of ~70 us: 5 repetitions behind one warm-up call read 12-15 % high (first launches after other work)
+    ms_fast = time_stream(torch, lambda: g.fast_batch(f7, sm7, kp7, cn7, 2000, 20), 30, warm=3)
+    ms_fast_score = time_stream(torch, lambda: g.probe_fast_score(sm7, f7, 20), 30, warm=3)
     # device-resident gs_orb_extract (GS_NO_STDLIB trig, no host round trip), same 32 frames, 500 keypoints each
     ko7 = torch.zeros((nf, 500, 12), dtype=torch.int32, device="cuda")
     ms_orb_dev = time_stream(torch, lambda: g.orb_extract_batch_nostdlib(f7, sm7, ko7, cn7, 500, 20), 5)
