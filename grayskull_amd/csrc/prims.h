@@ -161,6 +161,7 @@ GS_DEV uint32_t load_u32_unaligned(const uint8_t *p) {
 GS_DEV uint32_t mad_u32_u16_lo(uint32_t a, uint32_t b, uint32_t c) { return (a & 0xffffu) * (b & 0xffffu) + c; }
 GS_DEV uint32_t mad_u32_u16_hi(uint32_t a, uint32_t b, uint32_t c) { return (a >> 16) * (b & 0xffffu) + c; }
 GS_DEV void sched_fence() {}
+#define GS_SCHED_GROUP(mask, n) ((void)0)
 GS_DEV uint32_t opaque(uint32_t x) { return x; }
 GS_DEV void lds_add_through(unsigned *lds_base, uint32_t byte_off, uint32_t value, uint32_t &through) {
   (void)through;
@@ -334,6 +335,8 @@ GS_DEV uint32_t pk_mad2_u16(uint32_t a, uint32_t c) {
 }
 /* the instruction scheduler moves nothing across this point (keeps a prefetch where it was put) */
 GS_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+/* ask the scheduler for `n` instructions of class `mask` next (0x008 MFMA, 0x002 VALU, 0x100 LDS read): a pipeline's stages in order */
+#define GS_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 /* the value, with its history hidden from the optimiser (no instruction): keeps a packed value packed when the
  * compiler would rather keep an unpacked copy alive */
 GS_DEV uint32_t opaque(uint32_t x) {
