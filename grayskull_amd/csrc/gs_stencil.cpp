@@ -831,11 +831,15 @@ void gs_match_template(struct gs_image img, struct gs_image tmpl, struct gs_imag
    * smaller ones are as fast on the dot-product kernels: 1280x720, 16 x 16: 39 vs 47 us).
    * gsh_tune key 20 = 1: the VALU dot-product kernels below; 2 / 3: always 64 x 128 tiles / always 32 x 64 tiles with split rows. */
   /* few 64 x 128 tiles (video-sized images): 32 x 64 tiles, the template rows split over the block's four waves */
-  const bool tm_split = g_tune[20] == 3 || (g_tune[20] != 2 && (unsigned long long)((result.w + 127) / 128) * ((result.h + 63) / 64) < 512);
+  const bool tm_split = g_tune[20] == 3 || (g_tune[20] != 2 && g_tune[20] != 8 && (unsigned long long)((result.w + 127) / 128) * ((result.h + 63) / 64) < 512); /* key 20 = 8: 64 x 128 tiles, banded, whatever the size */
   const unsigned nkc = (tmpl.w + 31 + 31) / 32, istride = (tm_split ? 32 : 96) + 32 * nkc + 16, tstride = 32 * nkc + 48;
-  const size_t tm_lds = std::max<size_t>((size_t)((tm_split ? 31 : 63) + tmpl.h) * istride + (size_t)tmpl.h * tstride + 16,
+  /* SPLIT = 1 takes templates taller than a band kTmBand rows at a time (k_tmatch.h BAND: 33 KB of LDS per block instead of 79 at
+   * 128 x 128, four blocks per CU); key 20 = 2: the whole template resident, as in round 3 */
+  const bool tm_band = !tm_split && g_tune[20] != 2 && tmpl.h > kTmBand;
+  const unsigned tm_rows = tm_band ? kTmBand : tmpl.h;
+  const size_t tm_lds = std::max<size_t>((size_t)((tm_split ? 31 : 63) + tm_rows) * istride + (size_t)tm_rows * tstride + 16,
                                          tm_split ? 32768 : 0);
-  if (g_tune[20] != 1 && tmpl.w >= 16 && nkc <= 9 && tmpl.h >= 4 && (tb >= 512 || g_tune[20] == 2 || g_tune[20] == 3) && tb <= 32768 && tm_lds <= 150 * 1024 &&
+  if (g_tune[20] != 1 && tmpl.w >= 16 && nkc <= 9 && tmpl.h >= 4 && (tb >= 512 || g_tune[20] == 2 || g_tune[20] == 3 || g_tune[20] == 8) && tb <= 32768 && tm_lds <= 150 * 1024 &&
       ib < 0x7fffffffull) {
     hipStream_t st = ctx().s();
     unsigned *rowp = (unsigned *)ctx().scratch(SL_II, (size_t)img.h * (img.w + 1) * 4);
@@ -865,7 +869,10 @@ void gs_match_template(struct gs_image img, struct gs_image tmpl, struct gs_imag
 #define GS_TM_FNS(S) (const void *)k_match_template_mfma<S, 2>, (const void *)k_match_template_mfma<S, 3>, (const void *)k_match_template_mfma<S, 4>, \
                      (const void *)k_match_template_mfma<S, 5>, (const void *)k_match_template_mfma<S, 6>, (const void *)k_match_template_mfma<S, 7>, \
                      (const void *)k_match_template_mfma<S, 8>, (const void *)k_match_template_mfma<S, 9>
-      const void *fns[] = {GS_TM_FNS(1), GS_TM_FNS(4)};
+      const void *fns[] = {GS_TM_FNS(1), GS_TM_FNS(4),
+                           (const void *)k_match_template_mfma<1, 2, true>, (const void *)k_match_template_mfma<1, 3, true>, (const void *)k_match_template_mfma<1, 4, true>,
+                           (const void *)k_match_template_mfma<1, 5, true>, (const void *)k_match_template_mfma<1, 6, true>, (const void *)k_match_template_mfma<1, 7, true>,
+                           (const void *)k_match_template_mfma<1, 8, true>, (const void *)k_match_template_mfma<1, 9, true>};
 #undef GS_TM_FNS
       for (const void *fn : fns) GS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       lds_raised.fetch_or(dev_bit, std::memory_order_release);
@@ -875,10 +882,11 @@ void gs_match_template(struct gs_image img, struct gs_image tmpl, struct gs_imag
     /* one instantiation per number of K steps (k_tmatch.h): nkc = 2 .. 9 for templates 16 .. 257 wide */
     const dim3 gs4((result.w + 63) / 64, (result.h + 31) / 32), gs1((result.w + 127) / 128, (result.h + 63) / 64);
     GS_ASSERT(nkc >= 2 && nkc <= 9);
-    switch (nkc * 2 + (tm_split ? 1 : 0)) {
-#define GS_TM_CASE(K)                                                                              \
-  case K * 2: GS_LAUNCH((k_match_template_mfma<1, K>), gs1, dim3(256), tm_lds, st, ta); break;     \
-  case K * 2 + 1: GS_LAUNCH((k_match_template_mfma<4, K>), gs4, dim3(256), tm_lds, st, ta); break;
+    switch (nkc * 4 + (tm_split ? 1u : tm_band ? 2u : 0u)) {
+#define GS_TM_CASE(K)                                                                                   \
+  case K * 4: GS_LAUNCH((k_match_template_mfma<1, K>), gs1, dim3(256), tm_lds, st, ta); break;          \
+  case K * 4 + 1: GS_LAUNCH((k_match_template_mfma<4, K>), gs4, dim3(256), tm_lds, st, ta); break;      \
+  case K * 4 + 2: GS_LAUNCH((k_match_template_mfma<1, K, true>), gs1, dim3(256), tm_lds, st, ta); break;
       GS_TM_CASE(2) GS_TM_CASE(3) GS_TM_CASE(4) GS_TM_CASE(5) GS_TM_CASE(6) GS_TM_CASE(7) GS_TM_CASE(8) GS_TM_CASE(9)
 #undef GS_TM_CASE
     }

@@ -171,84 +171,93 @@ __global__ __launch_bounds__(256) void k_tm_s2_corners(const unsigned *Q, unsign
  * for it (with arrays for 9 steps whatever the template, a 128-px template ran with 178 registers) and the row loop has no
  * run-time guards -- one basic block per template row, so the next row's LDS reads are scheduled between this row's MFMAs
  * (guards on a run-time nkc cut the loop into a block per MFMA pair) */
-template <int SPLIT, unsigned NK = 9>
+/* BAND (SPLIT = 1; round 4): the template is taken kTmBand rows at a time -- per band the block stages the TR - 1 + kTmBand image
+ * rows those template rows meet and the band's template rows, between two barriers -- so a block holds 33 KB of LDS at
+ * tw = 128 instead of 79 and FOUR blocks (16 waves, four per SIMD) fit a CU instead of two: the kernel is paced by LDS
+ * latency under the occupancy its footprint allows.  The rows shared by consecutive bands are staged again
+ * (they come from the L2). */
+constexpr unsigned kTmBand = 32;
+template <int SPLIT, unsigned NK = 9, bool BAND = false>
 __global__ __launch_bounds__(256) void k_match_template_mfma(TmArgs a) {
+  static_assert(SPLIT == 1 || !BAND, "the split form keeps the whole template resident");
   GS_DYN_LDS(smem);
   const unsigned tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
   constexpr unsigned TR = SPLIT == 1 ? 64u : 32u, TC = SPLIT == 1 ? 128u : 64u;
   const unsigned bx0 = blockIdx.x * TC, by0 = blockIdx.y * TR;
-  const unsigned irows = TR - 1u + a.th, idw = (a.istride - 16u) / 4u;
+  const unsigned jband = BAND ? kTmBand : a.th; /* template rows resident at a time */
+  const unsigned irows = TR - 1u + jband, idw = (a.istride - 16u) / 4u;
   uint8_t *limg = (uint8_t *)smem;
   uint8_t *ltm = limg + (size_t)irows * a.istride;
-  /* the block's image region, as signed bytes (bytes outside the image: 0; they only ever meet template zeros or
-   * results that are not stored): 16 bytes per item, eight items per thread requested before the first is stored (the
-   * loop is one memory round trip per trip, and a block has ~10,000 dwords to fetch) */
-  const unsigned i16 = idw / 4u, nitems = irows * i16; /* idw is a multiple of 8 */
-  for (unsigned base = tid; base < (GS_TM_VARIANT == 3 ? 0u : nitems); base += 2048u) {
-    /* four scalar arrays, every index a constant once unrolled: an array of structs written under a condition, or bytes
-     * inserted at a run-time index, live in scratch memory with hipcc (144 B per lane and a round trip through it for every
-     * staged dword until round 4) */
-    uint32_t v0[8], v1[8], v2[8], v3[8];
+  const unsigned i16 = idw / 4u; /* idw is a multiple of 8 */
+  /* image rows by0 + jc .. + TR - 2 + nj of the block's columns, as signed bytes (bytes outside the image: 0; they only ever
+   * meet template zeros or results that are not stored), and template rows jc .. jc + nj - 1 (k_tm_prep's padded form): 16
+   * bytes per item, eight items per thread requested before the first is stored (a trip is one memory round trip) */
+  auto stage = [&](unsigned jc, unsigned nj) {
+    const unsigned nitems = (TR - 1u + nj) * i16;
+    for (unsigned base = tid; base < (GS_TM_VARIANT == 3 ? 0u : nitems); base += 2048u) {
+      /* four scalar arrays, every index a constant once unrolled: an array of structs written under a condition, or bytes
+       * inserted at a run-time index, live in scratch memory with hipcc (144 B per lane and a round trip through it for every
+       * staged dword until round 4) */
+      uint32_t v0[8], v1[8], v2[8], v3[8];
 #pragma unroll
-    for (unsigned u = 0; u < 8; u++) {
-      const unsigned i = base + 256u * u;
-      v0[u] = v1[u] = v2[u] = v3[u] = 0;
-      if (i < nitems) {
-        const unsigned r = i / i16, c = i - r * i16;
-        const unsigned y = by0 + r, x = bx0 + 16u * c;
-        if (y < a.ih && x < a.iw) {
-          const uint8_t *p = a.img + (size_t)y * a.iw + x;
-          if (x + 16u <= a.iw) {
-            v0[u] = load_u32_unaligned(p) ^ 0x80808080u, v1[u] = load_u32_unaligned(p + 4) ^ 0x80808080u;
-            v2[u] = load_u32_unaligned(p + 8) ^ 0x80808080u, v3[u] = load_u32_unaligned(p + 12) ^ 0x80808080u;
-          } else {
-            uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+      for (unsigned u = 0; u < 8; u++) {
+        const unsigned i = base + 256u * u;
+        v0[u] = v1[u] = v2[u] = v3[u] = 0;
+        if (i < nitems) {
+          const unsigned r = i / i16, c = i - r * i16;
+          const unsigned y = by0 + jc + r, x = bx0 + 16u * c;
+          if (y < a.ih && x < a.iw) {
+            const uint8_t *p = a.img + (size_t)y * a.iw + x;
+            if (x + 16u <= a.iw) {
+              v0[u] = load_u32_unaligned(p) ^ 0x80808080u, v1[u] = load_u32_unaligned(p + 4) ^ 0x80808080u;
+              v2[u] = load_u32_unaligned(p + 8) ^ 0x80808080u, v3[u] = load_u32_unaligned(p + 12) ^ 0x80808080u;
+            } else {
+              uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;
 #pragma unroll
-            for (unsigned b = 0; b < 4; b++) {
-              if (x + b < a.iw) d0 |= (uint32_t)(p[b] ^ 0x80u) << (8 * b);
-              if (x + 4 + b < a.iw) d1 |= (uint32_t)(p[4 + b] ^ 0x80u) << (8 * b);
-              if (x + 8 + b < a.iw) d2 |= (uint32_t)(p[8 + b] ^ 0x80u) << (8 * b);
-              if (x + 12 + b < a.iw) d3 |= (uint32_t)(p[12 + b] ^ 0x80u) << (8 * b);
+              for (unsigned b = 0; b < 4; b++) {
+                if (x + b < a.iw) d0 |= (uint32_t)(p[b] ^ 0x80u) << (8 * b);
+                if (x + 4 + b < a.iw) d1 |= (uint32_t)(p[4 + b] ^ 0x80u) << (8 * b);
+                if (x + 8 + b < a.iw) d2 |= (uint32_t)(p[8 + b] ^ 0x80u) << (8 * b);
+                if (x + 12 + b < a.iw) d3 |= (uint32_t)(p[12 + b] ^ 0x80u) << (8 * b);
+              }
+              v0[u] = d0, v1[u] = d1, v2[u] = d2, v3[u] = d3;
             }
-            v0[u] = d0, v1[u] = d1, v2[u] = d2, v3[u] = d3;
           }
         }
       }
-    }
 #pragma unroll
-    for (unsigned u = 0; u < 8; u++) {
-      const unsigned i = base + 256u * u;
-      if (i < nitems) {
-        const unsigned r = i / i16, c = i - r * i16;
-        *(U4 *)(limg + (size_t)r * a.istride + 16u * c) = U4{v0[u], v1[u], v2[u], v3[u]};
+      for (unsigned u = 0; u < 8; u++) {
+        const unsigned i = base + 256u * u;
+        if (i < nitems) {
+          const unsigned r = i / i16, c = i - r * i16;
+          *(U4 *)(limg + (size_t)r * a.istride + 16u * c) = U4{v0[u], v1[u], v2[u], v3[u]};
+        }
       }
     }
-  }
-  /* the padded template (k_tm_prep), 16 bytes per item */
-  const unsigned nt16 = a.th * a.tstride / 16u;
-  for (unsigned base = tid; base < (GS_TM_VARIANT == 4 ? 0u : nt16); base += 2048u) {
-    uint32_t v0[8], v1[8], v2[8], v3[8];
+    const unsigned nt16 = nj * a.tstride / 16u; /* tstride is a multiple of 16 */
+    const U4 *tsrc = (const U4 *)(a.tpad + (size_t)jc * a.tstride);
+    for (unsigned base = tid; base < (GS_TM_VARIANT == 4 ? 0u : nt16); base += 2048u) {
+      uint32_t v0[8], v1[8], v2[8], v3[8];
 #pragma unroll
-    for (unsigned u = 0; u < 8; u++) {
-      v0[u] = v1[u] = v2[u] = v3[u] = 0;
-      if (base + 256u * u < nt16) {
-        const U4 t = ((const U4 *)a.tpad)[base + 256u * u];
-        v0[u] = t.x, v1[u] = t.y, v2[u] = t.z, v3[u] = t.w;
+      for (unsigned u = 0; u < 8; u++) {
+        v0[u] = v1[u] = v2[u] = v3[u] = 0;
+        if (base + 256u * u < nt16) {
+          const U4 t = tsrc[base + 256u * u];
+          v0[u] = t.x, v1[u] = t.y, v2[u] = t.z, v3[u] = t.w;
+        }
       }
-    }
 #pragma unroll
-    for (unsigned u = 0; u < 8; u++)
-      if (base + 256u * u < nt16) ((U4 *)ltm)[base + 256u * u] = U4{v0[u], v1[u], v2[u], v3[u]};
-  }
-  __syncthreads();
+      for (unsigned u = 0; u < 8; u++)
+        if (base + 256u * u < nt16) ((U4 *)ltm)[base + 256u * u] = U4{v0[u], v1[u], v2[u], v3[u]};
+    }
+  };
   const unsigned wy = SPLIT == 1 ? (wave >> 1) * 32u : 0u, wx = SPLIT == 1 ? (wave & 1u) * 64u : 0u, m = lane & 31u, g = lane >> 5;
   const unsigned j0 = SPLIT == 1 ? 0u : wave, jstep = (unsigned)SPLIT;
   int32_t acc0[16], acc1[16];
 #pragma unroll
   for (int r = 0; r < 16; r++) acc0[r] = 0, acc1[r] = 0;
-  /* Row by row: the nkc + 1 image operands and nkc template operands of template row j sit in registers (static
-   * indices: the loops are unrolled to kTmMaxK with wave-uniform guards) and the operands of row j + jstep are
-   * requested before row j's 2 nkc MFMAs are issued. */
+  /* Row by row: the NK + 1 image operands and NK template operands of template row j sit in registers (static indices) and
+   * the operands of row j + jstep are requested before row j's 2 NK MFMAs are issued.  j counts inside the resident band. */
   constexpr unsigned kTmMaxK = NK; /* == a.nkc (the launcher picks the instantiation) */
   U4 Ac[kTmMaxK + 1], Bc[kTmMaxK], An[kTmMaxK + 1], Bn[kTmMaxK];
   auto load_row = [&](unsigned j, U4 (&A)[kTmMaxK + 1], U4 (&B)[kTmMaxK]) {
@@ -264,26 +273,32 @@ __global__ __launch_bounds__(256) void k_match_template_mfma(TmArgs a) {
       B[k] = U4{alignbit(d1, d0, sh), alignbit(d2, d1, sh), alignbit(d3, d2, sh), alignbit(d4, d3, sh)};
     }
   };
-  if (j0 < a.th) { /* wave-uniform */
-    load_row(j0, Ac, Bc);
-    for (unsigned j = j0; j < a.th; j += jstep) {
-      /* no branch inside a trip: the last one requests its own row again (and drops it) */
-      const unsigned jn = j + jstep < a.th ? j + jstep : j;
-      if (GS_TM_VARIANT != 2) load_row(jn, An, Bn);
+  for (unsigned jc = 0; jc < a.th; jc += jband) { /* block-uniform: one trip unless BAND */
+    const unsigned nj = a.th - jc < jband ? a.th - jc : jband;
+    if (jc) __syncthreads(); /* the previous band's operand reads are done */
+    stage(jc, nj);
+    __syncthreads();
+    if (j0 < nj) { /* wave-uniform */
+      load_row(j0, Ac, Bc);
+      for (unsigned j = j0; j < nj; j += jstep) {
+        /* no branch inside a trip: the last one requests its own row again (and drops it) */
+        const unsigned jn = j + jstep < nj ? j + jstep : j;
+        if (GS_TM_VARIANT != 2) load_row(jn, An, Bn);
 #pragma unroll
-      for (unsigned k = 0; k < kTmMaxK; k++) {
+        for (unsigned k = 0; k < kTmMaxK; k++) {
 #if GS_TM_VARIANT == 1
-        acc0[0] += (int)(Ac[k].x ^ Bc[k].x), acc1[0] += (int)(Ac[k + 1].x ^ Bc[k].y);
+          acc0[0] += (int)(Ac[k].x ^ Bc[k].x), acc1[0] += (int)(Ac[k + 1].x ^ Bc[k].y);
 #else
-        mfma_i32_32x32x32_i8(Ac[k], Bc[k], acc0);
-        mfma_i32_32x32x32_i8(Ac[k + 1], Bc[k], acc1);
+          mfma_i32_32x32x32_i8(Ac[k], Bc[k], acc0);
+          mfma_i32_32x32x32_i8(Ac[k + 1], Bc[k], acc1);
 #endif
-      }
-      if (GS_TM_VARIANT != 2) {
+        }
+        if (GS_TM_VARIANT != 2) {
 #pragma unroll
-        for (unsigned k = 0; k <= kTmMaxK; k++) Ac[k] = An[k];
+          for (unsigned k = 0; k <= kTmMaxK; k++) Ac[k] = An[k];
 #pragma unroll
-        for (unsigned k = 0; k < kTmMaxK; k++) Bc[k] = Bn[k];
+          for (unsigned k = 0; k < kTmMaxK; k++) Bc[k] = Bn[k];
+        }
       }
     }
   }

@@ -176,7 +176,7 @@ def test_match_template_on_the_matrix_cores(emu, oracle, case):
     try:
         for im, t in zip(imgs, tmpls):
             ro = oracle.match_template(im, t)
-            for tiles in (2, 3, 5):  # 64 x 128 tiles / 32 x 64 tiles with the template rows split over the block's waves / 5: sum I'^2 from the integral table of squares
+            for tiles in (2, 3, 8, 5):  # 8: 64 x 128 tiles with the template taken a band of 32 rows at a time; 64 x 128 tiles / 32 x 64 tiles with the template rows split over the block's waves / 5: sum I'^2 from the integral table of squares
                 emu.tune(20, tiles)
                 r = np.zeros((ih - th + 1, iw - tw + 1), np.uint8)
                 emu.match_template(im, t, r)
