@@ -69,6 +69,10 @@ _SIGS = {
     "gs_orb_extract": (C.c_uint, [GsImage, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p]),
     "gs_match_orb": (C.c_uint, [C.c_void_p, C.c_uint, C.c_void_p, C.c_uint, C.c_void_p, C.c_uint,
                                 C.c_float]),
+    # the reference's GS_NO_STDLIB trig flavour (ref :68-88): what include/grayskull.h binds under that macro
+    "gs_compute_orientation_nostdlib": (C.c_float, [GsImage, C.c_uint, C.c_uint, C.c_uint]),
+    "gs_brief_descriptor_nostdlib": (None, [GsImage, C.c_void_p]),
+    "gs_orb_extract_nostdlib": (C.c_uint, [GsImage, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p]),
     "gs_adaptive_threshold": (None, [GsImage, GsImage, C.c_uint, C.c_int]),
     "gs_filter": (None, [GsImage, GsImage, GsImage, C.c_uint]),
     "gs_downsample": (None, [GsImage, GsImage]),
@@ -334,6 +338,21 @@ class Grayskull:
     def orb_extract(self, img, nkps, threshold, scoremap):  # grayskull.h:651
         kps = np.zeros(max(nkps, 1), KEYPOINT_DTYPE)
         n = self.c.gs_orb_extract(_img(img), kps.ctypes.data, nkps, threshold, _ptr(scoremap))
+        return kps[:n].copy()
+
+    # the same three under -DGS_NO_STDLIB (include/grayskull.h binds them to these symbols; ref :68-88)
+    def compute_orientation_nostdlib(self, img, x, y, r=15):
+        return float(self.c.gs_compute_orientation_nostdlib(_img(img), x, y, r))
+
+    def brief_descriptor_nostdlib(self, img, x, y, angle):
+        kp = np.zeros(1, KEYPOINT_DTYPE)
+        kp["x"], kp["y"], kp["angle"] = x, y, angle
+        self.c.gs_brief_descriptor_nostdlib(_img(img), kp.ctypes.data)
+        return kp["desc"][0].copy()
+
+    def orb_extract_nostdlib(self, img, nkps, threshold, scoremap):
+        kps = np.zeros(max(nkps, 1), KEYPOINT_DTYPE)
+        n = self.c.gs_orb_extract_nostdlib(_img(img), kps.ctypes.data, nkps, threshold, _ptr(scoremap))
         return kps[:n].copy()
 
     def match_orb(self, k1, k2, max_matches, max_distance):  # grayskull.h:680

@@ -9,6 +9,7 @@
 #include "k_fast.h"
 #include "k_fast_nms.h"
 #include "k_lbp.h"
+#include "k_lbp_tile.h"
 #include "k_orb.h"
 
 namespace gsi {
@@ -205,13 +206,15 @@ struct gsh_cascade {
   LbpWeak *d_weak = nullptr;
   LbpStage *d_stage = nullptr;
   int32_t *d_subsets = nullptr;
+  uint32_t *d_truth = nullptr; /* per-stage truth tables (LbpStage::truth) */
+  unsigned ntruth = 0;
   unsigned long long id = 0; /* unique per handle: key of the calling threads' geometry caches */
 };
 
 namespace gsi {
 /* the device tables of a handle, without touching any context (used while a context is being released) */
 void gsh_cascade_tables_deleter::operator()(gsh_cascade *dc) const {
-  (void)hipFree(dc->d_weak), (void)hipFree(dc->d_stage), (void)hipFree(dc->d_subsets);
+  (void)hipFree(dc->d_weak), (void)hipFree(dc->d_stage), (void)hipFree(dc->d_subsets), (void)hipFree(dc->d_truth);
   delete dc;
 }
 }  // namespace gsi
@@ -329,6 +332,7 @@ void launch_lbp_padded(const gsh_cascade *dc, const LbpGeomCache &gc, const unsi
   a.nweaks = dc->nweaks, a.nstages = dc->nstages, a.nsub = dc->nsub;
   a.scales = gc.d_scales, a.geom = gc.d_geom, a.weak = dc->d_weak, a.stage = dc->d_stage;
   a.subsets = dc->d_subsets;
+  a.truth = dc->d_truth, a.ntruth = dc->ntruth;
   a.mask = mask, a.chunk_count = cnt, a.total_chunks = nch;
   const unsigned nsc = (unsigned)gc.scales.size();
   /* XCD-aware chunk mapping (k_lbp.h) once the integral image no longer fits one XCD's 4 MB L2: 1080p -3 %, 4K block
@@ -380,21 +384,97 @@ void launch_lbp_padded(const gsh_cascade *dc, const LbpGeomCache &gc, const unsi
     }
   }
   const size_t lds_all = ((lds + 15) & ~(size_t)15) + 2 * kChunkItems * 2 + 64 * 4 + 16;
-  /* One launch over all scales.  (Round 3's row-sharing stage prefilter k_lbp_dense -- stages 0..1 for every window with the
-   * table rows handed down the columns of 64 x 64-window tiles, 2.8x fewer gathers per classifier -- lost to the dense
-   * phase it replaced: on the configs[4] input 56.9 + 21.6 ms against 71.2 ms per 16 frames, half of its L2 requests
-   * missing and 62 % of its wave cycles stalled (profiles/r04j_lbp_counters_*.txt).  Removed in round 4; the kernel and
-   * its launcher live on in scripts/experiments/not_kept/.) */
+  /* (Round 3's row-sharing stage prefilter k_lbp_dense -- stages 0..1 for every window with the table rows handed down
+   * the columns of 64 x 64-window tiles, 2.8x fewer gathers per classifier -- lost to the dense phase it replaced: on the
+   * configs[4] input 56.9 + 21.6 ms against 71.2 ms per 16 frames, half of its L2 requests missing and 62 % of its wave
+   * cycles stalled (profiles/r04j_lbp_counters_*.txt).  Removed in round 4; sources in scripts/experiments/not_kept/.)
+   *
+   * Round 5: scales whose table tile fits the LDS run on k_lbp_tile (k_lbp_tile.h: corners from an LDS tile, survivors one
+   * lane per (window, classifier) pair); the others -- and GUARD geometries, fixed phase presets -- on k_lbp_cascade.
+   * Consecutive scales with the same choice share a launch; launches go out in scale order, which the max_rects exit
+   * wants anyway.  Key 14: 0 = by rule, 1 = k_lbp_cascade for every scale, 2 + i = tile shape i wherever it fits. */
+  struct TileCfg {
+    unsigned nt, tw, th, want_blocks; /* want_blocks: the rule takes the shape when at least that many blocks fit a CU */
+    void (*fn)(LbpArgs, LbpPhases);
+    void (*fn_count)(LbpArgs, LbpPhases);
+  };
+  /* in the rule's order of preference (profiles/r05a_lbp_tile.log, r05b_*: per-scale times of every shape) */
+  static const TileCfg cfgs[] = {
+      {512, 128, 32, 3, k_lbp_tile<512, 128, 32>, k_lbp_tile<512, 128, 32, true>},
+      {1024, 128, 32, 2, k_lbp_tile<1024, 128, 32>, k_lbp_tile<1024, 128, 32, true>},
+      {1024, 64, 32, 2, k_lbp_tile<1024, 64, 32>, k_lbp_tile<1024, 64, 32, true>},
+      {1024, 64, 16, 2, k_lbp_tile<1024, 64, 16>, k_lbp_tile<1024, 64, 16, true>},
+      {512, 64, 32, 2, k_lbp_tile<512, 64, 32>, k_lbp_tile<512, 64, 32, true>},
+  };
+  constexpr int kNumCfgs = (int)(sizeof(cfgs) / sizeof(cfgs[0]));
+  constexpr size_t kLdsPerCu = 160 * 1024, kLdsDyn = kLdsPerCu - 1024; /* the kernels' static __shared__ words count against the CU's LDS */
+#ifndef GS_EMU
   {
-    unsigned mc = 0;
-    for (unsigned s1 = 0; s1 < nsc; s1++) mc = std::max(mc, gc.scales[s1].nchunks);
-    a.scale0 = 0;
-    const dim3 g(a.xcd_swizzle ? (mc + 7u) & ~7u : mc, nsc, n);
-    if (a.evaluated) { /* counting build: the same kernel + one register that counts classifier evaluations */
-      if (gc.guard) GS_LAUNCH((k_lbp_cascade<true, true>), g, dim3(256), lds_all, st, a, ph);
-      else GS_LAUNCH((k_lbp_cascade<false, true>), g, dim3(256), lds_all, st, a, ph);
-    } else if (gc.guard) GS_LAUNCH(k_lbp_cascade<true>, g, dim3(256), lds_all, st, a, ph);
-    else GS_LAUNCH(k_lbp_cascade<false>, g, dim3(256), lds_all, st, a, ph);
+    static std::atomic<unsigned long long> lds_raised{0};
+    const unsigned long long dev_bit = 1ull << ((unsigned)ctx().device & 63u);
+    if (ctx().device >= 64 || !(lds_raised.load(std::memory_order_acquire) & dev_bit)) {
+      for (const TileCfg &c : cfgs) {
+        GS_HIP(hipFuncSetAttribute((const void *)c.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsDyn));
+        GS_HIP(hipFuncSetAttribute((const void *)c.fn_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsDyn));
+      }
+      lds_raised.fetch_or(dev_bit, std::memory_order_release);
+    }
+  }
+#endif
+  auto tile_lds = [&](const TileCfg &c, const LbpScale &sc) {
+    const size_t ts = (size_t)(c.tw - 1) * step + sc.win_w + 1, tr = (size_t)(c.th - 1) * step + sc.win_h + 1;
+    return lbp_tile_lds_bytes(dc->nstages, dc->nweaks, dc->nsub, dc->ntruth, c.tw * c.th, ts * tr);
+  };
+  auto tile_blocks = [&](const TileCfg &c, const LbpScale &sc) { /* blocks a CU holds: LDS, and 32 waves */
+    const size_t need = tile_lds(c, sc);
+    return need > kLdsDyn ? 0u : (unsigned)std::min<size_t>(kLdsPerCu / (need + 1024), 32u * 64u / c.nt);
+  };
+  struct Choice { int cfg; unsigned blocks; bool operator==(const Choice &o) const { return cfg == o.cfg && blocks == o.blocks; } };
+  auto tile_choice = [&](const LbpScale &sc) -> Choice { /* cfg -1: k_lbp_cascade */
+    if (gc.guard || !ph.adaptive_max || g_tune[14] == 1) return Choice{-1, 0};
+    if (g_tune[14] >= 2) { /* experiments: one shape wherever its tile fits */
+      const int i = g_tune[14] - 2;
+      const unsigned b = i < kNumCfgs ? tile_blocks(cfgs[i], sc) : 0u;
+      return b ? Choice{i, b} : Choice{-1, 0};
+    }
+    const int ncand = g_tune[15] > 0 ? std::min(g_tune[15], kNumCfgs) : 4; /* experiments: only the first key-15 shapes */
+    for (int i = 0; i < ncand; i++) {
+      const unsigned b = tile_blocks(cfgs[i], sc);
+      if (b >= cfgs[i].want_blocks) return Choice{i, b};
+    }
+    return Choice{-1, 0};
+  };
+  /* Consecutive scales with the same shape AND the same blocks per CU share a launch (its dynamic LDS is the largest
+   * member's, which by construction still fits that many blocks: a launch never lowers a member's occupancy -- with one
+   * launch for all scales the small ones ran at the big ones' one block per CU, 14 instead of 4 ms). */
+  for (unsigned s0 = 0; s0 < nsc;) {
+    const Choice choice = tile_choice(gc.scales[s0]);
+    unsigned s1 = s0 + 1;
+    while (s1 < nsc && tile_choice(gc.scales[s1]) == choice) s1++;
+    a.scale0 = s0;
+    if (choice.cfg < 0) {
+      unsigned mc = 0;
+      for (unsigned s = s0; s < s1; s++) mc = std::max(mc, gc.scales[s].nchunks);
+      const dim3 g(a.xcd_swizzle ? (mc + 7u) & ~7u : mc, s1 - s0, n);
+      if (a.evaluated) { /* counting build: the same kernel + one register that counts classifier evaluations */
+        if (gc.guard) GS_LAUNCH((k_lbp_cascade<true, true>), g, dim3(256), lds_all, st, a, ph);
+        else GS_LAUNCH((k_lbp_cascade<false, true>), g, dim3(256), lds_all, st, a, ph);
+      } else if (gc.guard) GS_LAUNCH(k_lbp_cascade<true>, g, dim3(256), lds_all, st, a, ph);
+      else GS_LAUNCH(k_lbp_cascade<false>, g, dim3(256), lds_all, st, a, ph);
+    } else {
+      const TileCfg &c = cfgs[choice.cfg];
+      unsigned mt = 0;
+      size_t need = 0;
+      for (unsigned s = s0; s < s1; s++) {
+        const LbpScale &sc = gc.scales[s];
+        mt = std::max(mt, ((sc.nx + c.tw - 1) / c.tw) * ((sc.ny + c.th - 1) / c.th));
+        need = std::max(need, tile_lds(c, sc));
+      }
+      const dim3 g(a.xcd_swizzle ? (mt + 7u) & ~7u : mt, s1 - s0, n);
+      if (a.evaluated) GS_LAUNCH(c.fn_count, g, dim3(c.nt), need, st, a, ph);
+      else GS_LAUNCH(c.fn, g, dim3(c.nt), need, st, a, ph);
+    }
+    s0 = s1;
   }
   if (g_tune[16] == 1) return; /* timing aid (scripts/bench_lbp_stages.py): the cascade kernels alone, no rect emission */
   run_compaction(mask, cnt, nch, n, max_rects, counts,
@@ -565,7 +645,7 @@ gsh_cascade *gsh_cascade_create(const struct gs_lbp_cascade *c) {
   dc->weak_feature_idx.clear();
   unsigned nsub = 0;
   for (unsigned si = 0; si < c->nstages; si++) {
-    stg[si] = LbpStage{(unsigned)wk.size(), c->stage_nweaks[si], c->stage_threshold[si], 0.0f};
+    stg[si] = LbpStage{(unsigned)wk.size(), c->stage_nweaks[si], c->stage_threshold[si], 0u};
     for (unsigned k = 0; k < c->stage_nweaks[si]; k++) {
       const unsigned i = (unsigned)c->stage_weak_start[si] + k;
       wk.push_back(LbpWeak{c->weak_left_val[i], c->weak_right_val[i], c->weak_subset_offset[i],
@@ -576,6 +656,28 @@ gsh_cascade *gsh_cascade_create(const struct gs_lbp_cascade *c) {
   }
   dc->nweaks = (unsigned)wk.size(); /* classifiers actually reachable through the stages */
   dc->nsub = nsub;
+  /* stage truth tables (LbpStage::truth): the stage's verdict for every pattern of subset-lookup results, formed exactly
+   * as ref :796-810 forms it -- float sum = 0; sum += hit ? left : right in weak order; pass = !(sum < threshold) -- in
+   * IEEE float32 adds (this unit is built -ffp-contract=off; there is nothing to contract anyway) */
+  std::vector<uint32_t> truth;
+  for (unsigned si = 0; si < c->nstages; si++) {
+    const unsigned cnt = stg[si].count;
+    if (cnt < 1 || cnt > 12) continue;
+    const unsigned words = std::max(1u, (1u << cnt) / 32u), off = (unsigned)truth.size();
+    truth.resize(off + words, 0u);
+    for (unsigned pat = 0; pat < (1u << cnt); pat++) {
+      volatile float sum = 0.0f; /* volatile: one rounded float32 add per classifier, whatever the optimiser thinks */
+      for (unsigned k = 0; k < cnt; k++) {
+        const LbpWeak &q = wk[stg[si].first + k];
+        sum = sum + (((pat >> k) & 1u) ? q.left : q.right);
+      }
+      if (!(sum < stg[si].threshold)) truth[off + (pat >> 5)] |= 1u << (pat & 31u);
+    }
+    stg[si].truth = off + 1u;
+  }
+  dc->ntruth = (unsigned)truth.size();
+  GS_HIP(hipMalloc((void **)&dc->d_truth, std::max<size_t>(1, truth.size()) * 4));
+  if (!truth.empty()) GS_HIP(hipMemcpy(dc->d_truth, truth.data(), truth.size() * 4, hipMemcpyHostToDevice));
   GS_HIP(hipMalloc((void **)&dc->d_weak, std::max<size_t>(1, wk.size()) * sizeof(LbpWeak)));
   GS_HIP(hipMalloc((void **)&dc->d_stage, std::max<size_t>(1, stg.size()) * sizeof(LbpStage)));
   GS_HIP(hipMalloc((void **)&dc->d_subsets, std::max<size_t>(1, nsub) * 4));
@@ -964,8 +1066,27 @@ static const uint8_t *stage_patch(struct gs_image img, int x, int y, int r, int 
   return d;
 }
 
+/* the two moments of ref :610-619 as floats (exact integers for r <= kOrientExactR, the reference's own float32
+ * accumulation order beyond) */
+static void orientation_moments(struct gs_image img, unsigned x, unsigned y, unsigned r, float &m01, float &m10);
+
 float gs_compute_orientation(struct gs_image img, unsigned x, unsigned y, unsigned r) { /* ref :608 */
   GS_ASSERT(GS_VALID(img) && x >= r && y >= r && x < img.w - r && y < img.h - r);
+  float m01, m10;
+  orientation_moments(img, x, y, r, m01, m10);
+  return atan2f(m01, m10); /* ref :620 -> libm, as the reference (ref :100) */
+}
+/* The reference's other trig flavour: built -DGS_NO_STDLIB its gs_atan2 / gs_sin are the float32 polynomials of
+ * ref :70-88 (what examples/wasm/grayskull.c:31-35 ships) and gs_assert is compiled out (ref :69).  include/grayskull.h
+ * binds gs_compute_orientation / gs_brief_descriptor / gs_orb_extract to these three symbols under the same macro, so a
+ * caller built that way keeps bit-for-bit parity with ITS reference build.  No precondition aborts, like ref :69. */
+float gs_compute_orientation_nostdlib(struct gs_image img, unsigned x, unsigned y, unsigned r) {
+  if (!(GS_VALID(img) && x >= r && y >= r && x < img.w - r && y < img.h - r)) return 0.0f; /* the reference reads out of bounds as 0 here; no abort */
+  float m01, m10;
+  orientation_moments(img, x, y, r, m01, m10);
+  return gs_atan2_poly(m01, m10);
+}
+static void orientation_moments(struct gs_image img, unsigned x, unsigned y, unsigned r, float &m01, float &m10) {
   hipStream_t st = ctx().s();
   const uint8_t *patch = stage_patch(img, (int)x, (int)y, (int)r, SL_AUX2);
   if (r > kOrientExactR) { /* partial sums can pass 2^24: the reference's float32 order, one thread */
@@ -974,7 +1095,8 @@ float gs_compute_orientation(struct gs_image img, unsigned x, unsigned y, unsign
     float mf[2];
     GS_HIP(hipMemcpyAsync(mf, df, 8, hipMemcpyDeviceToHost, st));
     ctx().sync();
-    return atan2f(mf[0], mf[1]);
+    m01 = mf[0], m10 = mf[1];
+    return;
   }
   unsigned pt[2] = {r, r};
   unsigned *dp = (unsigned *)ctx().scratch(SL_KIN, 16);
@@ -985,11 +1107,19 @@ float gs_compute_orientation(struct gs_image img, unsigned x, unsigned y, unsign
   int m[2];
   GS_HIP(hipMemcpyAsync(m, dm, 8, hipMemcpyDeviceToHost, st));
   ctx().sync();
-  return atan2f((float)m[0], (float)m[1]); /* ref :620 -> libm, as the reference (ref :100) */
+  m01 = (float)m[0], m10 = (float)m[1];
 }
 
+static void brief_descriptor(struct gs_image img, struct gs_keypoint *kp, bool poly);
 void gs_brief_descriptor(struct gs_image img, struct gs_keypoint *kp) { /* ref :623 */
   GS_ASSERT(GS_VALID(img) && kp);
+  brief_descriptor(img, kp, false);
+}
+void gs_brief_descriptor_nostdlib(struct gs_image img, struct gs_keypoint *kp) { /* ref :623 built -DGS_NO_STDLIB */
+  if (!(GS_VALID(img) && kp)) return;
+  brief_descriptor(img, kp, true);
+}
+static void brief_descriptor(struct gs_image img, struct gs_keypoint *kp, bool poly) {
   hipStream_t st = ctx().s();
   const int R = 22; /* |pattern| <= 15 rotated reaches <= 21 px */
   gs_keypoint k;
@@ -997,7 +1127,8 @@ void gs_brief_descriptor(struct gs_image img, struct gs_keypoint *kp) { /* ref :
   else k = *kp;
   const uint8_t *patch = stage_patch(img, (int)k.pt.x, (int)k.pt.y, R, SL_AUX2);
   const float angle = k.angle;
-  KpIn in{(unsigned)R, (unsigned)R, sinf(angle), sinf((float)(angle + 1.57079f))};
+  KpIn in{(unsigned)R, (unsigned)R, poly ? gs_sin_poly(angle) : sinf(angle),
+          poly ? gs_sin_poly((float)(angle + 1.57079f)) : sinf((float)(angle + 1.57079f))}; /* ref :626 */
   KpIn *dk = (KpIn *)ctx().scratch(SL_KIN, sizeof in);
   uint32_t *dd = (uint32_t *)ctx().scratch(SL_DESC, 32);
   GS_HIP(hipMemcpyAsync(dk, &in, sizeof in, hipMemcpyHostToDevice, st));
@@ -1006,6 +1137,30 @@ void gs_brief_descriptor(struct gs_image img, struct gs_keypoint *kp) { /* ref :
   ctx().sync();
   if (is_dev(kp)) gsh_upload(kp, &k, sizeof k);
   else memcpy(kp->descriptor, k.descriptor, 32);
+}
+
+/* gs_orb_extract of a reference built -DGS_NO_STDLIB (ref :651-669 with the trig of :70-88): the device-resident path
+ * (FAST -> k_orb_select -> k_orb_describe, no host round trip between them); host buffers are staged like everywhere. */
+unsigned gs_orb_extract_nostdlib(struct gs_image img, struct gs_keypoint *kps, unsigned nkps,
+                                 unsigned threshold, uint8_t *scoremap_buffer) {
+  if (!(GS_VALID(img) && kps && nkps > 0 && scoremap_buffer)) return 0; /* gs_assert is compiled out (ref :69) */
+  const unsigned w = img.w, h = img.h;
+  if (w < 7 || h < 7) return 0;
+  const size_t nb = (size_t)w * h;
+  hipStream_t st = ctx().s();
+  const uint8_t *s = (const uint8_t *)stage_in(img.data, nb, SL_IN);
+  const bool mhost = !is_dev(scoremap_buffer), khost = !is_dev(kps);
+  uint8_t *dm = mhost ? (uint8_t *)ctx().scratch(SL_AUX, nb) : scoremap_buffer;
+  if (mhost) GS_HIP(hipMemcpyAsync(dm, scoremap_buffer, nb, hipMemcpyHostToDevice, st));
+  gs_keypoint *dk = khost ? (gs_keypoint *)ctx().scratch(SL_DESC, (size_t)nkps * sizeof(gs_keypoint)) : kps;
+  unsigned *dcnt = (unsigned *)ctx().scratch(SL_KIN, 16); /* slots the batch entry below does not touch */
+  gsh_orb_extract_batch_nostdlib(s, w, h, 1, dm, dk, dcnt, nkps, threshold);
+  unsigned n = 0;
+  GS_HIP(hipMemcpyAsync(&n, dcnt, 4, hipMemcpyDeviceToHost, st));
+  if (mhost) GS_HIP(hipMemcpyAsync(scoremap_buffer, dm, nb, hipMemcpyDeviceToHost, st));
+  ctx().sync();
+  if (khost && n) GS_HIP(hipMemcpy(kps, dk, (size_t)n * sizeof(gs_keypoint), hipMemcpyDeviceToHost));
+  return n;
 }
 
 unsigned gs_orb_extract(struct gs_image img, struct gs_keypoint *kps, unsigned nkps,

@@ -22,7 +22,11 @@
 namespace gs {
 
 struct LbpWeak { float left, right; unsigned sub_off, nsub; };
-struct LbpStage { unsigned first, count; float threshold, pad; };
+/* truth: 0, or 1 + the word offset of the stage's TRUTH TABLE in LbpArgs::truth -- bit P of it says whether the stage passes
+ * when bit i of P is classifier i's subset-lookup result, i.e. !(sum < threshold) with the reference's sequential float32
+ * adds of left / right in weak order (ref :796-810) carried out on the host for all 2^count patterns (stages of <= 12
+ * classifiers; gsh_cascade_create).  k_lbp_tile's pair phase decides a stage with one lookup instead of count adds. */
+struct LbpStage { unsigned first, count; float threshold; unsigned truth; };
 
 struct LbpArgs {
   const unsigned *padded;       /* n frames of (iw+1)*(ih+1) u32 */
@@ -36,6 +40,8 @@ struct LbpArgs {
   const LbpWeak *weak;
   const LbpStage *stage;
   const int32_t *subsets;
+  const uint32_t *truth;         /* stage truth tables (LbpStage::truth), ntruth words; may be null when ntruth = 0 */
+  unsigned ntruth;
   unsigned long long *mask;     /* n frames x total_chunks*kChunkWords (pre-zeroed) */
   unsigned *chunk_count;        /* n frames x total_chunks (pre-zeroed) */
   unsigned total_chunks;

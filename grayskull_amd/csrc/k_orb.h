@@ -112,8 +112,10 @@ __global__ __launch_bounds__(256) void k_brief(const uint8_t *img, unsigned w, u
 /* The reference's own trig for builds without libm (ref :70-88, used by examples/wasm/grayskull.c:32):
  * two float32 polynomials made of + - x / and compares only, so the GPU reproduces them bit for bit
  * (fp contract off; hipcc's float division is correctly rounded by default).  With them the whole of
- * gs_orb_extract (ref :651-669) runs on the device with no host round trip. */
-GS_DEV float gs_atan2_poly(float y, float x) { /* ref :70-78 */
+ * gs_orb_extract (ref :651-669) runs on the device with no host round trip.  (Host-callable too: the drop-in's
+ * single-keypoint entry points of the GS_NO_STDLIB flavour return their float to the host anyway; the library's host
+ * code is built -ffp-contract=off like the reference, so both sides round alike.) */
+GS_HD float gs_atan2_poly(float y, float x) { /* ref :70-78 */
   if (x == 0.0f) return y > 0.0f ? 1.570796f : (y < 0.0f ? -1.570796f : 0.0f);
   float r, angle;
   const float abs_y = y >= 0.0f ? y : -y;
@@ -126,7 +128,7 @@ GS_DEV float gs_atan2_poly(float y, float x) { /* ref :70-78 */
   }
   return y < 0.0f ? -angle : angle;
 }
-GS_DEV float gs_sin_poly(float x) { /* ref :80-88 */
+GS_HD float gs_sin_poly(float x) { /* ref :80-88 */
   while (x > 3.141592f) x -= 6.283185f;
   while (x < -3.141592f) x += 6.283185f;
   int sign = 1;

@@ -21,6 +21,7 @@
 #include <string.h>
 
 #define GS_DEV __device__ __forceinline__
+#define GS_HD __host__ __device__ __forceinline__
 #ifndef GS_MAD2_OPAQUE
 #define GS_MAD2_OPAQUE 1
 #endif
@@ -519,6 +520,18 @@ GS_DEV uint32_t readlane_last(uint32_t x) {
   return shfl(x, 63);
 #else
   return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+#endif
+}
+/* Orders this wave's LDS accesses across LANES: what any lane stored before it is visible to every lane's loads after
+ * it.  The hardware executes a wave's DS instructions in order, so this only has to stop the compiler from moving
+ * memory operations across it (s_waitcnt-free: v_nop-sized); the emulator's lanes are fibers and really meet here. */
+GS_DEV void wave_sync() {
+#ifdef GS_EMU
+  (void)emu::wave_exchange(0, [](const uint64_t *, const bool *) { return 0; });
+#else
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #endif
 }
 GS_DEV uint32_t wave_sum(uint32_t v) {

@@ -28,8 +28,10 @@
 
 #include <limits.h>
 #include <stdint.h>
+#ifndef GS_NO_STDLIB /* ref :68: "no asserts, no memory allocation, no file I/O" */
 #include <stdio.h>
 #include <stdlib.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -81,10 +83,12 @@ static inline void gs_set(struct gs_image img, unsigned x, unsigned y, uint8_t v
 }
 static inline uint32_t gs_integral_sum(const unsigned *ii, unsigned iw, unsigned x, unsigned y,
                                        unsigned w, unsigned h) {
-  if (!(ii && iw > 0 && x + w <= iw)) { /* gs_assert of ref :756, same message and abort() */
+#ifndef GS_NO_STDLIB /* gs_assert of ref :756, same message and abort(); compiled out under GS_NO_STDLIB like ref :69 */
+  if (!(ii && iw > 0 && x + w <= iw)) {
     fprintf(stderr, "Assertion failed: %s\n", "ii && iw > 0 && x + w <= iw");
     abort();
   }
+#endif
   unsigned x2 = x + w - 1, y2 = y + h - 1;
   unsigned A = (x > 0 && y > 0) ? ii[(y - 1) * iw + (x - 1)] : 0;
   unsigned B = (y > 0) ? ii[(y - 1) * iw + x2] : 0;
@@ -128,6 +132,23 @@ GS_API unsigned gs_match_orb(const struct gs_keypoint *kps1, unsigned n1,
                              const struct gs_keypoint *kps2, unsigned n2,
                              struct gs_match *matches, unsigned max_matches,
                              float max_distance);                               /* ref :680 */
+
+/* The reference has TWO trig flavours, chosen at compile time (ref :68-101): libm's atan2f / sinf, or -- under
+ * GS_NO_STDLIB, what examples/wasm/grayskull.c:31-35 builds -- two float32 polynomials (ref :70-88) with gs_assert
+ * compiled out (ref :69).  Angles and, through the (int) truncation of ref :633, descriptor bits differ between the
+ * two.  A caller built -DGS_NO_STDLIB therefore gets the polynomial flavour here as well, so that it stays bit-exact
+ * against ITS OWN reference build: the three functions that reach gs_atan2 / gs_sin bind to the *_nostdlib symbols
+ * (polynomials evaluated on the device for gs_orb_extract, no host round trip between FAST, selection, orientation and
+ * BRIEF; no precondition aborts).  Everything else is integer arithmetic and identical in both flavours. */
+GS_API float gs_compute_orientation_nostdlib(struct gs_image img, unsigned x, unsigned y, unsigned r);
+GS_API void gs_brief_descriptor_nostdlib(struct gs_image img, struct gs_keypoint *kp);
+GS_API unsigned gs_orb_extract_nostdlib(struct gs_image img, struct gs_keypoint *kps, unsigned nkps,
+                                        unsigned threshold, uint8_t *scoremap_buffer);
+#ifdef GS_NO_STDLIB
+#define gs_compute_orientation gs_compute_orientation_nostdlib
+#define gs_brief_descriptor gs_brief_descriptor_nostdlib
+#define gs_orb_extract gs_orb_extract_nostdlib
+#endif
 
 /* "next" rows of SURVEY.md 8(f), same machinery as the stencils above */
 GS_API void gs_adaptive_threshold(struct gs_image dst, struct gs_image src, unsigned radius,

@@ -76,6 +76,66 @@ def test_c99_dropin_program_against_emulated_kernels(tmp_path, emu):
     assert "all passed" in out
 
 
+def run_nostdlib_program(tmp_path, libdir, libname, frame, nkps, threshold):
+    """tests/c/test_nostdlib.c built -std=c99 -pedantic -DGS_NO_STDLIB against the drop-in header, linked with `libname`;
+    returns (keypoints, [(angle bits, descriptor)] of the separate single-keypoint calls)"""
+    import numpy as np
+    from grayskull_amd import KEYPOINT_DTYPE
+    exe = tmp_path / "nostdlib"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-DGS_NO_STDLIB", "-I", INC,
+                           os.path.join(ROOT, "tests", "c", "test_nostdlib.c"), "-o", str(exe),
+                           "-L", libdir, "-l:" + libname, "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib",
+                           "-Wl,-rpath-link,/opt/rocm/lib"])
+    # the object must reference the *_nostdlib symbols, and none of the libm-flavour ones
+    nm = subprocess.check_output(["nm", "-u", str(exe)]).decode()
+    undef = {ln.split()[-1].split("@")[0] for ln in nm.splitlines() if ln.strip()}
+    assert {"gs_orb_extract_nostdlib", "gs_compute_orientation_nostdlib", "gs_brief_descriptor_nostdlib"} <= undef
+    assert not ({"gs_orb_extract", "gs_compute_orientation", "gs_brief_descriptor"} & undef)
+    h, w = frame.shape
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(fin, "wb") as f:
+        f.write(np.array([w, h, nkps, threshold], np.uint32).tobytes())
+        f.write(np.ascontiguousarray(frame, np.uint8).tobytes())
+    subprocess.check_call([str(exe), str(fin), str(fout)])
+    raw = open(fout, "rb").read()
+    n = int(np.frombuffer(raw[:4], np.uint32)[0])
+    kps = np.frombuffer(raw[4:4 + 48 * n], KEYPOINT_DTYPE).copy()
+    rest = np.frombuffer(raw[4 + 48 * n:], np.uint32).reshape(-1, 9)
+    return kps, [(int(r[0]), r[1:].copy()) for r in rest]
+
+
+def check_nostdlib_program(tmp_path, libdir, libname, ref_ns, frame, nkps, threshold=20):
+    import numpy as np
+    kps, singles = run_nostdlib_program(tmp_path, libdir, libname, frame, nkps, threshold)
+    ko = ref_ns.orb_extract(frame, nkps, threshold)
+    assert len(kps) == len(ko), "%d vs %d keypoints" % (len(kps), len(ko))
+    assert kps.tobytes() == ko.tobytes(), "gs_orb_extract under -DGS_NO_STDLIB differs from the reference built the same way"
+    assert len(singles) == min(len(ko), 8)
+    for (abits, desc), k in zip(singles, ko):
+        assert abits == int(np.float32(ref_ns.orientation(frame, int(k["x"]), int(k["y"]), 15)).view(np.uint32))
+        assert abits == int(np.float32(k["angle"]).view(np.uint32))
+        assert np.array_equal(desc, ref_ns.brief(frame, int(k["x"]), int(k["y"]), float(k["angle"])))
+        assert np.array_equal(desc, k["desc"])
+
+
+def test_c99_nostdlib_caller_gets_the_polynomial_flavour(tmp_path, emu):
+    """the GS_NO_STDLIB seam of include/grayskull.h (ref :68-101; examples/wasm/grayskull.c:31-35) against the emulator
+    build: a C99 caller compiled -DGS_NO_STDLIB equals the reference header compiled -DGS_NO_STDLIB, bit for bit --
+    and differs from the libm flavour, or the seam would prove nothing"""
+    import numpy as np
+    from oracle import pyoracle
+    from oracle.pyoracle import Oracle
+    if not pyoracle.have_reference_nostdlib():
+        pytest.skip("oracle/_ref/libgs_ref_nostdlib.so not present")
+    ref_ns = Oracle("reference_nostdlib")
+    emu_dir = os.path.join(ROOT, "tests", "emu")
+    frame = Oracle.synth(320, 240, 5)
+    check_nostdlib_program(tmp_path, emu_dir, "libgs_kernel_emu.so", ref_ns, frame, 120)
+    libm = Oracle("port").orb_extract(frame, 120, 20)
+    ns = ref_ns.orb_extract(frame, 120, 20)
+    assert len(libm) == len(ns) > 8 and libm.tobytes() != ns.tobytes()
+
+
 def test_blur_magic_divisions_are_exact():
     """(s*MUL) >> 24 == s // d over the whole reachable range, product < 2^32, MUL < 2^24
     (k_stencil.h BlurMagic: the quotient is the top byte of a v_mul_u32_u24 product)"""

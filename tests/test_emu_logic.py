@@ -384,6 +384,30 @@ def test_lbp_cap_reached_in_early_scales(emu, oracle, cascade):
     pc.lbp(emu, oracle, Oracle.synth(64, 48, 9), MEM, random_cascade(1), params=((3, 1.25, 1.0, 2.0, 1), (200, 1.1, 1.0, 2.0, 1)))
 
 
+@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5, 6])
+def test_lbp_tile_shapes_never_change_results(emu, oracle, cascade, mode):
+    """key 14: 1 = k_lbp_cascade for every scale, 2 + i = tile shape i of k_lbp_tile (k_lbp_tile.h: corners from an LDS tile,
+    per-wave dense phase, survivors one lane per (window, classifier) pair) wherever its tile fits -- partial tiles at the
+    right / bottom edge, steps 1..3, caps inside and across scales, stages longer than 32 classifiers (window-parallel
+    fallback of the pair phase), a cascade that ends inside the dense phase"""
+    edges = oracle.sobel(oracle.blur(Oracle.synth(200, 150, 1000), 2))
+    try:
+        emu.tune(14, mode)
+        pc.lbp(emu, oracle, edges, MEM, cascade, params=((4096, 1.1, 1.0, 4.0, 1), (7, 1.1, 1.0, 4.0, 1), (60, 1.3, 1.0, 3.0, 2)))
+        pc.lbp(emu, oracle, Oracle.synth(96, 80, 7), MEM, cascade, params=((4096, 1.1, 1.0, 4.0, 1), (10, 1.3, 1.0, 2.0, 3)))
+        pc.lbp(emu, oracle, Oracle.synth(130, 70, 9), MEM, random_cascade(1), params=((4096, 1.25, 1.0, 2.0, 1), (37, 1.25, 1.0, 2.0, 1), (1, 1.5, 1.0, 1.6, 1)))
+        pc.lbp(emu, oracle, Oracle.synth(80, 60, 11), MEM, random_cascade(4, nstages=6, weaks_per_stage=2), params=((500, 1.2, 1.0, 2.5, 1),))
+        pc.lbp(emu, oracle, Oracle.synth(80, 60, 12), MEM, random_cascade(5, nstages=4, weaks_per_stage=40), params=((500, 1.2, 1.0, 2.5, 1),))
+        pc.lbp(emu, oracle, Oracle.synth(80, 60, 13), MEM, random_cascade(6, nstages=2, weaks_per_stage=7), params=((500, 1.2, 1.0, 2.5, 1),))
+        pc.lbp(emu, oracle, Oracle.synth(80, 60, 13), MEM, random_cascade(7, nstages=3, weaks_per_stage=3, permissive=False), params=((500, 1.2, 1.0, 2.5, 1),))
+        # tables that are no integral images (mod 2^32 arithmetic must hold in the tile as in the table)
+        rnd = np.random.RandomState(5).randint(0, 2 ** 32, (60, 80), dtype=np.uint64).astype(np.uint32)
+        rc = random_cascade(2)
+        assert_same(emu.lbp_detect(rc, rnd.copy(), 4096, 1.2, 1.0, 3.0, 1), oracle.lbp_detect(rc, rnd, 4096, 1.2, 1.0, 3.0, 1), "random table")
+    finally:
+        emu.tune(14, 0)
+
+
 def test_lbp_chunk_granular_early_exit(emu, oracle, cascade):
     """max_rects early exit at chunk-group granularity (ref :819-831): a chunk is skipped once the
     detections published by the groups that wholly precede it reach the cap.  The result must be the

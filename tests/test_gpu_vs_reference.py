@@ -138,3 +138,22 @@ def test_device_resident_orb_nostdlib_at_the_kat_sizes(hip):
 def test_fast_score_map_of_another_size_vs_reference(hip, reference):
     from test_emu_logic import test_fast_with_a_score_map_of_another_size as body
     body(hip, reference)
+
+
+def test_c99_caller_built_with_gs_no_stdlib_gets_the_polynomial_flavour(hip, tmp_path):
+    """the GS_NO_STDLIB seam of include/grayskull.h (ref :68-101; examples/wasm/grayskull.c:31-35) through the C ABI on the
+    MI355X: tests/c/test_nostdlib.c compiled -std=c99 -pedantic -DGS_NO_STDLIB and linked against libgrayskull_hip.so
+    equals oracle/_ref/libgs_ref_nostdlib.so (the reference header compiled with the same macro) bit for bit -- keypoints,
+    angles, descriptors of gs_orb_extract and of separate gs_compute_orientation / gs_brief_descriptor calls"""
+    from oracle import pyoracle
+    import grayskull_amd as G
+    from test_abi import check_nostdlib_program
+    if not pyoracle.have_reference_nostdlib():
+        pytest.skip("oracle/_ref/libgs_ref_nostdlib.so was not prebuilt")
+    ref_ns = Oracle("reference_nostdlib")
+    libdir, libname = os.path.split(G.HIP_LIBRARY)
+    for i, (w, h, seed, nkps) in enumerate(((1280, 720, 4, 500), (320, 240, 5, 2000), (67, 45, 5, 500))):
+        d = tmp_path / ("case%d" % i)
+        d.mkdir()
+        check_nostdlib_program(d, libdir, libname, ref_ns, Oracle.synth(w, h, seed), nkps)
+
