@@ -291,6 +291,14 @@ def spawn_ranks_if_needed(args):
     os.execv(sys.executable, cmd)
 
 
+def rank_times(sh, torch, dt_local, steps):
+    """every rank's own time for the timed steps (its clock stops at its own synchronize, before the closing barrier),
+    gathered in rank order, with the skew the slowest rank imposes on the job"""
+    t = sh.all_gather_frames(torch.tensor([dt_local / steps * 1e3], dtype=torch.float64), sh.world).tolist()
+    return {"per_rank": [round(x, 4) for x in t], "max": round(max(t), 4), "min": round(min(t), 4),
+            "skew_max_over_min": round(max(t) / min(t), 4) if min(t) > 0 else None}
+
+
 def run_cfg4(args, sh, g, torch, np, w, h, F, r, lo, total):
     """BASELINE configs[4]: every frame goes through gs_blur(r) -> gs_sobel (zeroed dst) -> gs_integral ->
     gs_lbp_detect(frontalface, sf 1.1, scales 1..4, step 1, max_rects 4096) on the GPU that owns it; frames
@@ -326,8 +334,10 @@ def run_cfg4(args, sh, g, torch, np, w, h, F, r, lo, total):
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0
     sh.barrier()
     dt = sh.max_over_ranks(time.perf_counter() - t0)
+    rank_ms = rank_times(sh, torch, dt_local, args.steps)
     g.lbp_count_evaluated(evaluated)  # one more, untimed step with the counting build of the cascade kernel
     step()
     torch.cuda.synchronize()
@@ -379,7 +389,7 @@ def run_cfg4(args, sh, g, torch, np, w, h, F, r, lo, total):
             "windows_per_frame_full_scan": nwin,
             "windows_evaluated_per_frame": round(ev_total / (total * args.steps), 1),
             "Gwindows/s_evaluated": round(ev_total / dt / 1e9, 2),
-            "rccl_ranks_seen": sh.ranks_seen(), "backend": sh.backend,
+            "rccl_ranks_seen": sh.ranks_seen(), "backend": sh.backend, "rank_ms_per_step": rank_ms,
             "collectives": ["broadcast(cascade blob, %d B)" % len(blob), "barrier", "all_reduce(max, sum)",
                             "all_gather(counts)", "all_gather(packed gs_rect lists, %d records)" % int(all_rects.shape[0])],
             "parity": parity,
@@ -453,14 +463,19 @@ def main():
     w, h, r = args.width, args.height, args.radius
     if args.scaling == "strong":  # the global batch is fixed: contiguous balanced blocks (grayskull_amd/shard.py frame_range)
         from grayskull_amd.shard import frame_range
-        total = args.frames or 4096
+        total = 4096 if args.frames is None else args.frames
         lo, hi = frame_range(sh.rank, sh.world, total)
         F = hi - lo
     else:  # weak scaling: every rank owns F frames, global index lo..lo+F
-        F = args.frames or 512
+        F = 512 if args.frames is None else args.frames
         lo, total = sh.rank * F, F * sh.world
-    if args.workload == "cfg4":
+    if total < 1:
+        sys.exit("bench.py: --frames must be >= 1")
+    if args.workload == "cfg4":  # ranks that own no frame (world > frames) take part in every collective with empty shares
         return run_cfg4(args, sh, g, torch, np, w, h, F, r, lo, total)
+    if total < sh.world:  # the same verdict on every rank: nobody is left waiting in a collective
+        sys.exit("bench.py: %d frames cannot be split over %d ranks in the configs[1] workload (per-launch figures need a "
+                 "non-empty share on every rank); use --workload cfg4 to rehearse empty shares" % (total, sh.world))
     src = torch.empty((F, h, w), dtype=torch.uint8, device="cuda")
     tmp = torch.empty_like(src)
     dst = torch.empty_like(src)
@@ -488,8 +503,10 @@ def main():
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0
     sh.barrier()
     dt = sh.max_over_ranks(time.perf_counter() - t0)
+    rank_ms = rank_times(sh, torch, dt_local, args.steps)
     nl, tot_ms = g.profile_read()  # launches of the timed region
     g.profile(False)
     npx = F * w * h
@@ -582,6 +599,25 @@ def main():
     ns = other = None
     if sh.world == 1 and not args.no_other:
         ns, other = extras(g, torch, np, src, tmp, dst, w, h, reps, lo, args)
+        # flat copies of what north_star sets a target on and of SURVEY 8(d)'s other per-path figures: the driver's record
+        # keeps the scalar entries of `roofline`
+        roof["north_star_kernel"] = "k_sobel16, gs_sobel alone on %d distinct 4096x4096 frames per launch" % ns["frames"]
+        roof["north_star_Mpix_s"], roof["north_star_frac"], roof["north_star_ms"] = ns["Mpix/s"], ns["frac_hbm_peak"], ns["ms_per_launch"]
+        roof["north_star_target_frac"] = 0.6
+        try:
+            c3 = other["configs[3] gs_orb_extract x2 + gs_match_orb 1280x720 threshold=20 nkps=500"]
+            for k, v in c3["gs_match_orb_device_resident"].items():
+                roof["match_orb_%s_Gpairs_s" % k], roof["match_orb_%s_ms" % k] = v["Gpairs/s"], v["ms"]
+                roof["match_orb_issue_bound_Gpairs_s"] = v["issue_bound_Gpairs/s"]
+            roof["gs_fast_32x720p_ms"] = c3["gs_fast_roofline"]["ms"]
+            roof["orb_extract_libm_batch_us_per_frame"] = round(c3["libm_batch_orb_extract_ms_per_frame"] * 1e3, 2)
+            roof["orb_extract_nostdlib_us_per_frame"] = round(c3["device_resident_orb_extract_ms_per_frame"] * 1e3, 2)
+            c2 = other["configs[2] gs_integral + gs_lbp_detect(frontalface) 1920x1080 sf=1.1 scales 1..4 step 1"]
+            roof["cfg2_lbp_ms_per_frame"] = c2["lbp_ms_per_frame"]
+            c4 = [v for k, v in other.items() if k.startswith("configs[4]")][0]
+            roof["cfg4_frames_per_s_per_gpu"], roof["cfg4_lbp_ms_per_frame"] = c4["frames_per_s_per_gpu"], c4["lbp_ms_per_frame"]
+        except Exception as e:  # a missing side block must not cost the headline line
+            roof["side_blocks_error"] = repr(e)
 
     # ---- verification (outside the timed region) ----------------------------------------------
     # (1) EVERY rank checks sample frames of its own shard bit for bit against the CPU oracle (the compiled
@@ -639,7 +675,7 @@ def main():
                                "%dx%d uint8, %d frames on this GPU resident in HBM (%d in the job, %s scaling)" % (r, w, h, F, total, args.scaling),
                    "frames_per_gpu": F, "global_frames": total, "sharding": "by frame, contiguous balanced blocks, no data-path collective",
                    "chain_algorithmic_bytes_per_px_unfused": 7, "hbm_peak_GBs": HBM_PEAK_GBS},
-        "rccl_ranks_seen": ranks_seen, "backend": sh.backend,
+        "rccl_ranks_seen": ranks_seen, "backend": sh.backend, "rank_ms_per_step": rank_ms,
         "fused": {"ms_per_step": round(ms_fused, 4), "Mpix/s": round(npx / ms_fused / 1e3, 1),
                   "hbm_bytes_per_px": 4, "hbm_GB/s": round(4.0 * npx / ms_fused / 1e6, 1),
                   "hbm_frac_of_peak": round(4.0 * npx / ms_fused / 1e6 / HBM_PEAK_GBS, 4), "note": "blur+sobel+histogram in one kernel per 32-frame chunk; each chunk's threshold pass runs under the next chunk's fused kernel"},
@@ -713,10 +749,14 @@ def extras(g, torch, np, src, tmp, dst, w, h, reps, lo=0, args=None):
     a4 = torch.empty((n4, 4096, 4096), dtype=torch.uint8, device="cuda")
     b4 = torch.zeros_like(a4)
     g.synth_batch(a4, 2)
-    ms = time_stream(torch, lambda: g.sobel_batch(b4, a4), reps)
+    # 100 launches behind 10 untimed ones: the first ~20 launches of this shape after other work read up to 15 % slow
+    # (profiles/r05_sobel4096.log: per-launch HIP events over 320 launches of a fresh process, clocks beside them)
+    ns_reps = max(reps, 100)
+    ms = time_stream(torch, lambda: g.sobel_batch(b4, a4), ns_reps, warm=10)
     by = float(n4 * (4096 * 4096 + 4094 * 4094))
     ns = {"Mpix/s": round(n4 * 4096 * 4096 / ms / 1e3, 1), "GB/s": round(by / ms / 1e6, 1),
-          "frac_hbm_peak": round(by / ms / 1e6 / HBM_PEAK_GBS, 4), "frames": n4}
+          "frac_hbm_peak": round(by / ms / 1e6 / HBM_PEAK_GBS, 4), "frames": n4, "ms_per_launch": round(ms, 4),
+          "launches_timed": ns_reps, "target_frac": 0.6, "target_Mpix/s": 2.40e6}
     del a4, b4
 
     other = {}
@@ -776,10 +816,42 @@ def extras(g, torch, np, src, tmp, dst, w, h, reps, lo=0, args=None):
     # device-resident gs_orb_extract (GS_NO_STDLIB trig, no host round trip), same 32 frames, 500 keypoints each
     ko7 = torch.zeros((nf, 500, 12), dtype=torch.int32, device="cuda")
     ms_orb_dev = time_stream(torch, lambda: g.orb_extract_batch_nostdlib(f7, sm7, ko7, cn7, 500, 20), 5)
+    # the libm-flavour batch entry (device-side selection, host libm for atan2f / sinf, two host round trips for all 32 frames)
+    g.orb_extract_batch_dev(f7, sm7, 500, 20)
+    t1 = time.perf_counter()
+    for _ in range(5):
+        g.orb_extract_batch_dev(f7, sm7, 500, 20)
+    t_orb_batch = (time.perf_counter() - t1) / 5
+    # gs_match_orb device-resident (pairs/s against the XOR + popcount issue bound), 500 x 500 and 2500 x 2500
+    match_blocks = {}
+    pair = torch.stack([dA, dB])
+    smp = torch.zeros_like(pair)
+    for nk in (500, 2500):
+        kk = torch.zeros((2, nk, 12), dtype=torch.int32, device="cuda")
+        ck = torch.zeros(2, dtype=torch.int32, device="cuda")
+        g.orb_extract_batch_nostdlib(pair, smp, kk, ck, nk, 20)
+        torch.cuda.synchronize()
+        n1, n2 = int(ck[0]), int(ck[1])
+        mt = torch.zeros((max(nk, 1), 3), dtype=torch.int32, device="cuda")
+        mc = torch.zeros(1, dtype=torch.int32, device="cuda")
+        ms_m = time_stream(torch, lambda: g.match_orb_dev(kk[0], n1, kk[1], n2, mt, mc, nk, 60.0), 30, warm=3)
+        # per pair of descriptors: 8 v_xor_b32 (full-rate encoding) + 8 v_bcnt_u32_b32 (VOP3: the 578 G rate), profiles/r02*_ubench_valu
+        bound = 64.0 / (8.0 / (VALU_RATE_GINST["full"] * 1e9) + 8.0 / (VALU_RATE_GINST["half"] * 1e9))
+        match_blocks["%dx%d" % (n1, n2)] = {
+            "ms": round(ms_m, 4), "pairs": n1 * n2, "Gpairs/s": round(n1 * n2 / ms_m / 1e6, 2), "matches": int(mc[0]),
+            "issue_bound_Gpairs/s": round(bound / 1e9, 1), "frac_of_issue_bound": round(n1 * n2 / ms_m / 1e3 / bound, 4),
+            "note": "gsh_match_orb_dev, keypoints and matches resident in HBM, no host sync inside the timed region; the bound "
+                    "is 64 lanes x the chip's measured VALU issue rate over 8 XOR + 8 popcount-accumulate per pair; at these "
+                    "sizes the call is three dependent launches (match, scan-free emit) of microseconds each: latency, not issue"}
+    del pair, smp
     other["configs[3] gs_orb_extract x2 + gs_match_orb 1280x720 threshold=20 nkps=500"] = {
         "orb_extract_ms": round(t_orb * 1e3, 3), "keypoints": int(len(ka)), "match_ms": round(t_match * 1e3, 3),
         "matches": int(len(mm)), "expected_matches (reference KAT)": 337,
         "note": "wall time incl. the host round trips (host libm atan2f/sinf, stable sort)",
+        "gs_match_orb_device_resident": match_blocks,
+        "libm_batch_orb_extract_ms_per_frame": round(t_orb_batch * 1e3 / nf, 4),
+        "libm_batch_note": "gsh_orb_extract_batch, %d frames per call, glibc atan2f / sinf on the host (the default flavour, bit-exact "
+                           "vs the reference built without GS_NO_STDLIB), wall time incl. its two host round trips" % nf,
         "device_resident_orb_extract_ms_per_frame": round(ms_orb_dev / nf, 4),
         "device_resident_note": "gsh_orb_extract_batch_nostdlib, %d frames per call, the reference's GS_NO_STDLIB trig "
                                 "(ref :70-88), no host round trip; bit-exact vs the -DGS_NO_STDLIB reference build" % nf,

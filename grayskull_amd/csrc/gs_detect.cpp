@@ -377,6 +377,8 @@ void launch_lbp_padded(const gsh_cascade *dc, const LbpGeomCache &gc, const unsi
     /* with quad-lane survivors (profiles/r03f_lbp_adaptive_quad.log, r03k_lbp_adaptive_next.log): +1 +2 +4 is best on
      * block noise (8 x 1080p 0.76 vs 0.80 ms for +1 +3 +6, 4K 3.15 vs 3.17) and within 0.5 % of the best on edge maps */
     ph.adaptive_next[0] = 1u, ph.adaptive_next[1] = 2u, ph.adaptive_next[2] = 4u;
+    ph.tile_first = 1u, ph.tile_tenths = 7u;
+    if (g_tune[15] > 0) ph.tile_first = (unsigned)g_tune[15] & 15u, ph.tile_tenths = ((unsigned)g_tune[15] >> 4) & 15u; /* experiments: first + 16 * tenths */
     if (ph.adaptive_max && g_tune[9] > 0) { /* experiments: key 9 = max + 16 * tenths (+ 256 d1 + 4096 d2 + 65536 d3: later points) */
       const unsigned v = (unsigned)g_tune[9];
       ph.adaptive_max = v & 15u, ph.adaptive_tenths = (v >> 4) & 15u;
@@ -422,7 +424,7 @@ void launch_lbp_padded(const gsh_cascade *dc, const LbpGeomCache &gc, const unsi
   }
 #endif
   auto tile_lds = [&](const TileCfg &c, const LbpScale &sc) {
-    const size_t ts = (size_t)(c.tw - 1) * step + sc.win_w + 1, tr = (size_t)(c.th - 1) * step + sc.win_h + 1;
+    const size_t ts = lbp_tile_stride(c.tw, (unsigned)step, (unsigned)sc.win_w), tr = (size_t)(c.th - 1) * step + sc.win_h + 1;
     return lbp_tile_lds_bytes(dc->nstages, dc->nweaks, dc->nsub, dc->ntruth, c.tw * c.th, ts * tr);
   };
   auto tile_blocks = [&](const TileCfg &c, const LbpScale &sc) { /* blocks a CU holds: LDS, and 32 waves */
@@ -437,11 +439,15 @@ void launch_lbp_padded(const gsh_cascade *dc, const LbpGeomCache &gc, const unsi
       const unsigned b = i < kNumCfgs ? tile_blocks(cfgs[i], sc) : 0u;
       return b ? Choice{i, b} : Choice{-1, 0};
     }
-    const int ncand = g_tune[15] > 0 ? std::min(g_tune[15], kNumCfgs) : 4; /* experiments: only the first key-15 shapes */
-    for (int i = 0; i < ncand; i++) {
+    /* profiles/r05c_lbp_tile_v3_own_tables_addc.log, per scale: 512 threads on 128 x 32 windows while three blocks fit a CU
+     * (scales 1, 1.1), 1024 threads on it while two fit (to 2.36), then 1024 threads on 64 x 32 while two fit (to 3.45), and
+     * for what is left (3.8: 124 KB of tile) one 1024-thread block per CU still beats k_lbp_cascade (0.47 vs 0.52 ms); the
+     * last two shapes lost at every scale */
+    for (int i = 0; i < 3; i++) {
       const unsigned b = tile_blocks(cfgs[i], sc);
       if (b >= cfgs[i].want_blocks) return Choice{i, b};
     }
+    if (g_tune[14] != -1 && tile_blocks(cfgs[1], sc) >= 1u) return Choice{1, 1u}; /* key 14 = -1: k_lbp_cascade for these */
     return Choice{-1, 0};
   };
   /* Consecutive scales with the same shape AND the same blocks per CU share a launch (its dynamic LDS is the largest
@@ -513,11 +519,126 @@ __global__ void k_lbp_single(LbpArgs a, const LbpGeom *geom, unsigned *out) {
 
 /* ------------------------------------------------------------------ ORB host logic */
 
-/* gs_orb_extract (ref :651-669) for up to 4 independent images (pyramid levels) with TWO host round
- * trips in total: (1) FAST + NMS + ordered emit + disc moments of every candidate slot, per level,
- * then one copy-back of counts + records + moments; host: stable sort (desc response, ref :639),
- * 15-px border filter, atan2f / sinf from libm (ref :100-101); (2) BRIEF for the kept keypoints of
- * all levels, one copy-back of the descriptors. */
+/* gs_orb_extract (ref :651-669) in the libm flavour for a list of JOBS -- a job is n frames of one size (the batch entry:
+ * one job; the pyramid driver: one single-frame job per level) -- with TWO host round trips in total:
+ *   (1) device: FAST + NMS + ordered emit, then the reference's selection -- stable descending sort by response (ref :639),
+ *       15-px border filter, cap at nkps -- as a rank computation (k_orb_select, the kernel the GS_NO_STDLIB flavour uses),
+ *       then the disc moments of the SELECTED keypoints; one copy-back of counts + records + moments;
+ *       host: atan2f / sinf from libm (ref :100-101) -- the reference's angle IS whatever glibc returns, and the BRIEF
+ *       bits depend on it through the (int) truncation of ref :633 -- spread over a few threads from 4096 keypoints;
+ *   (2) device: BRIEF for every kept keypoint of every job, one launch per job; one copy-back of the descriptors.
+ * (Round 4 copied every FAST candidate back -- up to 5000 x 48 B per frame -- and sorted on the host: 153 us per 720p
+ * frame, of which ~100 were the copy and the sort.) */
+struct OrbJob {
+  const uint8_t *img;
+  unsigned w, h, n; /* n frames, w * h bytes apart */
+  uint8_t *score;
+  gs_keypoint *out; /* host: n x nkps records */
+  unsigned *counts; /* host: n (may be null for single-frame jobs: see got) */
+  unsigned nkps;    /* wanted per frame */
+  unsigned got;     /* keypoints of frame 0 */
+};
+
+void orb_extract_libm(OrbJob *J, unsigned nj, unsigned threshold) {
+  hipStream_t st = ctx().s();
+  std::vector<size_t> koff(nj), foff(nj);
+  size_t ktot = 0, ftot = 0, candmax = 0, cntmax = 0;
+  for (unsigned j = 0; j < nj; j++) {
+    J[j].got = 0;
+    if (J[j].counts)
+      for (unsigned f = 0; f < J[j].n; f++) J[j].counts[f] = 0;
+    const bool run = J[j].nkps && J[j].n && J[j].w >= 7 && J[j].h >= 7;
+    koff[j] = ktot, foff[j] = ftot;
+    if (!run) {
+      J[j].n = 0;
+      continue;
+    }
+    ktot += (size_t)J[j].n * J[j].nkps, ftot += J[j].n;
+    candmax = std::max(candmax, (size_t)J[j].n * std::min(J[j].nkps * 4u, 5000u));
+    cntmax = std::max<size_t>(cntmax, J[j].n);
+  }
+  if (!ktot) return;
+  unsigned *cand = (unsigned *)ctx().scratch(SL_KPS, candmax * 48 + 16);
+  unsigned *cnt = (unsigned *)ctx().scratch(SL_TOT, cntmax * 4 + 16);
+  unsigned *sel = (unsigned *)ctx().scratch(SL_BEST, ktot * 48 + 16);
+  unsigned *selcnt = (unsigned *)ctx().scratch(SL_LEV, ftot * 4 + 16);
+  int *mom = (int *)ctx().scratch(SL_MOM, ktot * 8);
+  for (unsigned j = 0; j < nj; j++) {
+    const OrbJob &q = J[j];
+    if (!q.n) continue;
+    const unsigned cap = std::min(q.nkps * 4u, 5000u);
+    const size_t fb = (size_t)q.w * q.h;
+    launch_fast(q.img, q.score, q.w, q.h, q.n, cand, cnt, cap, threshold);
+    GS_LAUNCH(k_orb_select, dim3(q.n), dim3(64), 0, st, (const unsigned *)cand, (const unsigned *)cnt, cap, q.w, q.h, q.nkps,
+              sel + koff[j] * 12, selcnt + foff[j]);
+    GS_LAUNCH(k_orient_moments, dim3(q.nkps, q.n), dim3(64), 0, st, q.img, q.w, q.h, (const unsigned *)(sel + koff[j] * 12), 12u, 15u,
+              mom + koff[j] * 2, (const unsigned *)(selcnt + foff[j]), fb);
+  }
+  std::vector<unsigned> hk(ktot * 12), hn(ftot);
+  std::vector<int> hm(ktot * 2);
+  GS_HIP(hipMemcpyAsync(hn.data(), selcnt, ftot * 4, hipMemcpyDeviceToHost, st));
+  GS_HIP(hipMemcpyAsync(hk.data(), sel, ktot * 48, hipMemcpyDeviceToHost, st));
+  GS_HIP(hipMemcpyAsync(hm.data(), mom, ktot * 8, hipMemcpyDeviceToHost, st));
+  ctx().sync();
+  /* host half of ref :662-665: the angle and the two sines of every kept keypoint, frame by frame */
+  std::vector<KpIn> kin(ktot);
+  struct Item { unsigned j, f; };
+  std::vector<Item> items;
+  size_t kept_total = 0;
+  for (unsigned j = 0; j < nj; j++)
+    for (unsigned f = 0; f < J[j].n; f++) items.push_back(Item{j, f}), kept_total += std::min(hn[foff[j] + f], J[j].nkps);
+  auto do_items = [&](size_t a, size_t b) {
+    for (size_t it = a; it < b; it++) {
+      const OrbJob &q = J[items[it].j];
+      const unsigned f = items[it].f, m = std::min(hn[foff[items[it].j] + f], q.nkps);
+      const size_t base = koff[items[it].j] + (size_t)f * q.nkps;
+      for (unsigned i = 0; i < m; i++) {
+        const unsigned *r = &hk[(base + i) * 12];
+        gs_keypoint &k = q.out[(size_t)f * q.nkps + i];
+        k.pt.x = r[0], k.pt.y = r[1], k.response = r[2];
+        k.angle = atan2f((float)hm[(base + i) * 2], (float)hm[(base + i) * 2 + 1]); /* ref :620, :100 */
+        const float angle = k.angle;
+        kin[base + i] = KpIn{r[0], r[1], sinf(angle), sinf((float)(angle + 1.57079f))}; /* ref :626 */
+      }
+    }
+  };
+  unsigned nthreads = 1;
+  if (kept_total >= 4096 && items.size() > 1)
+    nthreads = (unsigned)std::min<size_t>({8, std::max(1u, std::thread::hardware_concurrency()), items.size(), kept_total / 2048});
+  if (nthreads > 1) {
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nthreads; t++) th.emplace_back(do_items, items.size() * t / nthreads, items.size() * (t + 1) / nthreads);
+    do_items(0, items.size() / nthreads);
+    for (auto &x : th) x.join();
+  } else {
+    do_items(0, items.size());
+  }
+  for (unsigned j = 0; j < nj; j++)
+    for (unsigned f = 0; f < J[j].n; f++) {
+      const unsigned m = std::min(hn[foff[j] + f], J[j].nkps);
+      if (J[j].counts) J[j].counts[f] = m;
+      if (f == 0) J[j].got = m;
+    }
+  if (!kept_total) return;
+  KpIn *dk = (KpIn *)ctx().scratch(SL_KIN, ktot * sizeof(KpIn));
+  uint32_t *dd = (uint32_t *)ctx().scratch(SL_DESC, ktot * 32);
+  GS_HIP(hipMemcpyAsync(dk, kin.data(), ktot * sizeof(KpIn), hipMemcpyHostToDevice, st));
+  for (unsigned j = 0; j < nj; j++)
+    if (J[j].n)
+      GS_LAUNCH(k_brief, dim3(J[j].nkps, J[j].n), dim3(256), 0, st, J[j].img, J[j].w, J[j].h, (const KpIn *)(dk + koff[j]),
+                dd + koff[j] * 8, (const unsigned *)(selcnt + foff[j]), (size_t)J[j].w * J[j].h);
+  std::vector<uint32_t> hd(ktot * 8);
+  GS_HIP(hipMemcpyAsync(hd.data(), dd, ktot * 32, hipMemcpyDeviceToHost, st));
+  ctx().sync();
+  for (unsigned j = 0; j < nj; j++)
+    for (unsigned f = 0; f < J[j].n; f++) {
+      const unsigned m = std::min(hn[foff[j] + f], J[j].nkps);
+      const size_t base = koff[j] + (size_t)f * J[j].nkps;
+      for (unsigned i = 0; i < m; i++) memcpy(J[j].out[(size_t)f * J[j].nkps + i].descriptor, &hd[(base + i) * 8], 32);
+    }
+}
+
+/* the pyramid driver's view: single frames of different sizes */
 struct OrbLevel {
   const uint8_t *img;
   unsigned w, h;
@@ -526,77 +647,11 @@ struct OrbLevel {
   unsigned nkps;    /* wanted */
   unsigned got;
 };
-
 void orb_extract_levels(OrbLevel *L, unsigned nl, unsigned threshold) {
-  hipStream_t st = ctx().s();
-  unsigned cap[4], coff[4], ctot = 0;
-  for (unsigned l = 0; l < nl; l++) {
-    cap[l] = (L[l].nkps && L[l].w >= 7 && L[l].h >= 7) ? std::min(L[l].nkps * 4u, 5000u) : 0u;
-    coff[l] = ctot, ctot += cap[l], L[l].got = 0;
-  }
-  if (!ctot) return;
-  unsigned *kps = (unsigned *)ctx().scratch(SL_KPS, (size_t)ctot * 48 + 16);
-  unsigned *cnt = (unsigned *)ctx().scratch(SL_TOT, 16);
-  int *mom = (int *)ctx().scratch(SL_MOM, (size_t)ctot * 8);
-  for (unsigned l = 0; l < nl; l++) {
-    if (!cap[l]) continue;
-    launch_fast(L[l].img, L[l].score, L[l].w, L[l].h, 1, kps + (size_t)coff[l] * 12, cnt + l, cap[l], threshold);
-    /* moments of every candidate slot (blocks beyond the device-side count exit) */
-    GS_LAUNCH(k_orient_moments, dim3(cap[l]), dim3(64), 0, st, L[l].img, L[l].w, L[l].h,
-              (const unsigned *)(kps + (size_t)coff[l] * 12), 12u, 15u, mom + (size_t)coff[l] * 2,
-              (const unsigned *)(cnt + l));
-  }
-  std::vector<unsigned> hk((size_t)ctot * 12);
-  std::vector<int> hm((size_t)ctot * 2);
-  unsigned hn[4] = {0, 0, 0, 0};
-  GS_HIP(hipMemcpyAsync(hn, cnt, 16, hipMemcpyDeviceToHost, st));
-  GS_HIP(hipMemcpyAsync(hk.data(), kps, (size_t)ctot * 48, hipMemcpyDeviceToHost, st));
-  GS_HIP(hipMemcpyAsync(hm.data(), mom, (size_t)ctot * 8, hipMemcpyDeviceToHost, st));
-  ctx().sync();
-  /* host half of ref :657-667 */
-  struct Cand { unsigned x, y, response; int m01, m10; };
-  std::vector<KpIn> kin;
-  unsigned koff[4], ktot = 0;
-  const unsigned r = 15;
-  for (unsigned l = 0; l < nl; l++) {
-    koff[l] = ktot;
-    if (!cap[l]) continue;
-    const unsigned n = std::min(hn[l], cap[l]);
-    std::vector<Cand> cand(n);
-    for (unsigned i = 0; i < n; i++) {
-      const size_t q = (size_t)coff[l] + i;
-      cand[i] = Cand{hk[q * 12], hk[q * 12 + 1], hk[q * 12 + 2], hm[2 * q], hm[2 * q + 1]};
-    }
-    std::stable_sort(cand.begin(), cand.end(),
-                     [](const Cand &a, const Cand &b) { return a.response > b.response; });
-    unsigned kept = 0;
-    for (size_t i = 0; i < cand.size() && kept < L[l].nkps; i++) {
-      const Cand &c = cand[i];
-      if (c.x >= r && c.y >= r && c.x < L[l].w - r && c.y < L[l].h - r) {
-        gs_keypoint &k = L[l].out[kept];
-        k.pt.x = c.x, k.pt.y = c.y, k.response = c.response;
-        k.angle = atan2f((float)c.m01, (float)c.m10); /* ref :620, :100 */
-        const float angle = k.angle;
-        kin.push_back(KpIn{c.x, c.y, sinf(angle), sinf((float)(angle + 1.57079f))}); /* ref :626 */
-        kept++;
-      }
-    }
-    L[l].got = kept, ktot += kept;
-  }
-  if (!ktot) return;
-  KpIn *dk = (KpIn *)ctx().scratch(SL_KIN, (size_t)ktot * sizeof(KpIn));
-  uint32_t *dd = (uint32_t *)ctx().scratch(SL_DESC, (size_t)ktot * 32);
-  GS_HIP(hipMemcpyAsync(dk, kin.data(), (size_t)ktot * sizeof(KpIn), hipMemcpyHostToDevice, st));
-  for (unsigned l = 0; l < nl; l++)
-    if (L[l].got)
-      GS_LAUNCH(k_brief, dim3(L[l].got), dim3(256), 0, st, L[l].img, L[l].w, L[l].h,
-                (const KpIn *)(dk + koff[l]), dd + (size_t)koff[l] * 8);
-  std::vector<uint32_t> hd((size_t)ktot * 8);
-  GS_HIP(hipMemcpyAsync(hd.data(), dd, (size_t)ktot * 32, hipMemcpyDeviceToHost, st));
-  ctx().sync();
-  for (unsigned l = 0; l < nl; l++)
-    for (unsigned i = 0; i < L[l].got; i++)
-      memcpy(L[l].out[i].descriptor, &hd[((size_t)koff[l] + i) * 8], 32);
+  OrbJob J[4];
+  for (unsigned l = 0; l < nl; l++) J[l] = OrbJob{L[l].img, L[l].w, L[l].h, 1u, L[l].score, L[l].out, nullptr, L[l].nkps, 0u};
+  orb_extract_libm(J, nl, threshold);
+  for (unsigned l = 0; l < nl; l++) L[l].got = J[l].got;
 }
 
 void launch_match(const uint32_t *k1, unsigned n1, const uint32_t *k2, unsigned n2,
@@ -732,80 +787,17 @@ unsigned gsh_orb_extract(const uint8_t *img_dev, unsigned w, unsigned h, uint8_t
   orb_extract_levels(&L, 1, threshold);
   return L.got;
 }
-/* gs_orb_extract (ref :651-669) for n frames of one size with two host round trips in total:
- * FAST + NMS + emit and the disc moments run as batch launches over all frames. */
+/* gs_orb_extract (ref :651-669), libm flavour, for n frames of one size: orb_extract_libm with one job */
 void gsh_orb_extract_batch(const uint8_t *img_dev, unsigned w, unsigned h, unsigned n,
                            uint8_t *scoremap_dev, struct gs_keypoint *kps_host, unsigned *counts_host,
                            unsigned nkps, unsigned threshold) {
   GS_ASSERT(img_dev && scoremap_dev && kps_host && counts_host && nkps > 0 && w > 0 && h > 0);
-  constexpr unsigned kOrbGroup = 4096; /* frames per pass: bounds the host-side candidate buffers and grid.y */
-  if (n > kOrbGroup) {
-    for (unsigned f0 = 0; f0 < n; f0 += kOrbGroup)
-      gsh_orb_extract_batch(img_dev + (size_t)w * h * f0, w, h, std::min(kOrbGroup, n - f0),
-                            scoremap_dev + (size_t)w * h * f0, kps_host + (size_t)f0 * nkps, counts_host + f0, nkps,
-                            threshold);
-    return;
+  constexpr unsigned kOrbGroup = 4096; /* frames per pass: bounds the host-side buffers and grid.y */
+  for (unsigned f0 = 0; f0 < n; f0 += kOrbGroup) {
+    OrbJob q{img_dev + (size_t)w * h * f0, w, h, std::min(kOrbGroup, n - f0), scoremap_dev + (size_t)w * h * f0,
+             kps_host + (size_t)f0 * nkps, counts_host + f0, nkps, 0u};
+    orb_extract_libm(&q, 1, threshold);
   }
-  for (unsigned f = 0; f < n; f++) counts_host[f] = 0;
-  if (n == 0 || w < 7 || h < 7) return;
-  hipStream_t st = ctx().s();
-  const size_t fb = (size_t)w * h;
-  const unsigned cap = std::min(nkps * 4u, 5000u), r = 15;
-  unsigned *kps = (unsigned *)ctx().scratch(SL_KPS, (size_t)n * cap * 48 + 16);
-  unsigned *cnt = (unsigned *)ctx().scratch(SL_TOT, (size_t)n * 4 + 16);
-  int *mom = (int *)ctx().scratch(SL_MOM, (size_t)n * cap * 8);
-  launch_fast(img_dev, scoremap_dev, w, h, n, kps, cnt, cap, threshold);
-  GS_LAUNCH(k_orient_moments, dim3(cap, n), dim3(64), 0, st, img_dev, w, h, (const unsigned *)kps, 12u, r, mom,
-            (const unsigned *)cnt, fb);
-  std::vector<unsigned> hk((size_t)n * cap * 12), hn(n);
-  std::vector<int> hm((size_t)n * cap * 2);
-  GS_HIP(hipMemcpyAsync(hn.data(), cnt, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-  GS_HIP(hipMemcpyAsync(hk.data(), kps, hk.size() * 4, hipMemcpyDeviceToHost, st));
-  GS_HIP(hipMemcpyAsync(hm.data(), mom, hm.size() * 4, hipMemcpyDeviceToHost, st));
-  ctx().sync();
-  struct Cand { unsigned x, y, response; int m01, m10; };
-  std::vector<KpIn> kin;
-  std::vector<unsigned> koff(n);
-  std::vector<Cand> cand;
-  for (unsigned f = 0; f < n; f++) { /* host half of ref :657-667, frame by frame */
-    koff[f] = (unsigned)kin.size();
-    const unsigned m = std::min(hn[f], cap);
-    cand.resize(m);
-    for (unsigned i = 0; i < m; i++) {
-      const size_t q = (size_t)f * cap + i;
-      cand[i] = Cand{hk[q * 12], hk[q * 12 + 1], hk[q * 12 + 2], hm[2 * q], hm[2 * q + 1]};
-    }
-    std::stable_sort(cand.begin(), cand.end(),
-                     [](const Cand &a, const Cand &b) { return a.response > b.response; });
-    unsigned kept = 0;
-    gs_keypoint *out = kps_host + (size_t)f * nkps;
-    for (size_t i = 0; i < cand.size() && kept < nkps; i++) {
-      const Cand &c = cand[i];
-      if (c.x >= r && c.y >= r && c.x < w - r && c.y < h - r) {
-        gs_keypoint &k = out[kept];
-        k.pt.x = c.x, k.pt.y = c.y, k.response = c.response;
-        k.angle = atan2f((float)c.m01, (float)c.m10); /* ref :620, :100 */
-        const float angle = k.angle;
-        kin.push_back(KpIn{c.x, c.y, sinf(angle), sinf((float)(angle + 1.57079f))}); /* ref :626 */
-        kept++;
-      }
-    }
-    counts_host[f] = kept;
-  }
-  if (kin.empty()) return;
-  KpIn *dk = (KpIn *)ctx().scratch(SL_KIN, kin.size() * sizeof(KpIn));
-  uint32_t *dd = (uint32_t *)ctx().scratch(SL_DESC, kin.size() * 32);
-  GS_HIP(hipMemcpyAsync(dk, kin.data(), kin.size() * sizeof(KpIn), hipMemcpyHostToDevice, st));
-  for (unsigned f = 0; f < n; f++)
-    if (counts_host[f])
-      GS_LAUNCH(k_brief, dim3(counts_host[f]), dim3(256), 0, st, img_dev + fb * f, w, h,
-                (const KpIn *)(dk + koff[f]), dd + (size_t)koff[f] * 8);
-  std::vector<uint32_t> hd(kin.size() * 8);
-  GS_HIP(hipMemcpyAsync(hd.data(), dd, hd.size() * 4, hipMemcpyDeviceToHost, st));
-  ctx().sync();
-  for (unsigned f = 0; f < n; f++)
-    for (unsigned i = 0; i < counts_host[f]; i++)
-      memcpy(kps_host[(size_t)f * nkps + i].descriptor, &hd[((size_t)koff[f] + i) * 8], 32);
 }
 
 /* gs_orb_extract (ref :651-669) for n frames, everything on the device, no host round trip: FAST ->

@@ -27,6 +27,7 @@
 #include <algorithm>
 #include <atomic>
 #include <map>
+#include <thread>
 #include <vector>
 
 

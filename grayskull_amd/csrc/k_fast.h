@@ -55,19 +55,20 @@ GS_DEV unsigned fast_score_u32(unsigned p, const unsigned (&v)[16], unsigned thr
 
 GS_DEV unsigned fast_score(unsigned p, const unsigned (&v)[16], unsigned threshold) {
   if (threshold > 0xffffff00u) return fast_score_u32(p, v, threshold); /* kernel argument: uniform */
-  /* v, p <= 255; t in [256, 2^32-256] behaves like 256 (never brighter, p - t wraps): clamp so the
-   * signed differences below cannot overflow */
-  const int t = (int)(threshold < 256u ? threshold : 256u), hi = (int)p + t, lo = (int)p - t;
+  /* v, p <= 255; t in [256, 2^32-256] behaves like 256 (never brighter, p - t wraps).  Round 5: the class bits are pushed
+   * into the masks with compare + add-with-carry pairs (push_gt_u32: two full-rate instructions per ring pixel and class;
+   * the sign-bit form before it paid a half-rate v_alignbit_b32 each), in the reference's own UNSIGNED arithmetic:
+   * lo = p - t wraps to a huge value when p < t and every ring pixel then compares below it. */
+  const unsigned t = threshold < 256u ? threshold : 256u, hi = p + t, lo = p - t;
   uint32_t bright = 0, dark = 0;
   unsigned mind = 255;
 #pragma unroll
   for (int j = 0; j < 16; j++) {
-    bright = alignbit(bright, (uint32_t)(hi - (int)v[j]), 31); /* sign set <=> v > p + t */
-    dark = alignbit(dark, (uint32_t)((int)v[j] - lo), 31);     /* sign set <=> v < p - t (no wrap) */
+    bright = push_gt_u32(bright, v[j], hi); /* v > p + t */
+    dark = push_gt_u32(dark, lo, v[j]);     /* v < p - t (unsigned) */
     mind = umin(mind, absdiff_u16(v[j], p));
   }
-  bright &= 0xffffu, dark &= 0xffffu;
-  if (lo < 0) dark = bright ^ 0xffffu; /* unsigned wrap of p - t in the reference */
+  if (p < t) dark = bright ^ 0xffffu; /* the wrap: d = !b && v < huge = !b (ref :496-498) */
   return (ring_has_run9(bright) || ring_has_run9(dark)) ? mind : 0u;
 }
 

@@ -271,6 +271,12 @@ struct LbpPhases { /* phase p = stages [end[p-1], end[p]) */
   unsigned adaptive_tenths; /* re-pack once alive <= tenths/10 of the chunk */
   unsigned adaptive_next[3]; /* later re-packing points, in stages after the first one (0 = none) */
   unsigned quad;             /* 1: re-packed survivors are evaluated four lanes per window (lbp_quad_stages) */
+  /* k_lbp_tile (k_lbp_tile.h): a WAVE runs its windows densely through stages [0, tile_first) and then stage by stage while more
+   * than tile_tenths/10 of them are alive (and fewer than adaptive_max stages are done); after that one lane per (window,
+   * classifier) pair.  A pair costs about twice a dense lane-evaluation, so the switch pays from half the windows dead:
+   * 1 and 7 (profiles/r05c_lbp_tile_v3_own_tables_addc.log: 4/10 3.67, 5/10 3.55, 6/10 3.53, 7/10 3.53 ms per 4K edge map; two dense
+   * stages first: 3.70). */
+  unsigned tile_first, tile_tenths;
 };
 
 /* grid (max chunks per scale, nscales, n frames), block 256;

@@ -4,30 +4,37 @@
  * Why (round 5): k_lbp_cascade's survivor phases (stages >= 2, 3.0 of 4.4 ms per 4K edge map) sit on the texture
  * path, which pays per 64-byte LINE a gather touches -- ~6 lines per window and classifier once the windows are
  * re-packed, against 1 in the dense phase.  The LDS has no line granularity: a scattered ds_read_b32 costs its bank
- * conflicts only (~3.5-way for 32 random dwords over 32 banks = 7 cycles per wave-instruction instead of 2), and a
- * dense one (64 consecutive dwords) 2 cycles against ~4 on the vector L1.
+ * conflicts only (measured: 0.7 extra cycles on top of 2 per wave-instruction, profiles/r05b_lbp_counters_tile_rule.txt),
+ * and a dense one (64 consecutive dwords) 2 cycles against ~4 on the vector L1.
  *
  * A block owns a TILE of TW x TH window positions of one scale and copies the table region those windows can touch
  * -- ((TW-1) step + win_w + 1) x ((TH-1) step + win_h + 1) dwords of the zero-bordered table -- into LDS once.
  * After that one barrier the block's waves never meet again:
  *
  *   dense phase   a wave owns R = TW*TH/NT wave-rows (64 horizontally consecutive windows each, one per lane) and
- *                 runs them stage by stage (dead windows masked) while more than `adaptive_tenths`/10 of ITS windows
+ *                 runs them stage by stage (dead windows masked) while more than `tile_tenths`/10 of ITS windows
  *                 are alive and fewer than `adaptive_max` stages are done -- the per-block rule of k_lbp_cascade,
  *                 decided per wave;
  *   pair phase    the wave's survivors go to the wave's own LDS queue and every later stage is evaluated with one
  *                 LANE PER (window, weak classifier) pair: a stage of n classifiers takes floor(64 / n) windows per
  *                 wave iteration, lane l evaluating classifier l % n of window l / n.  One ballot collects the
- *                 64 subset-lookup bits; every lane then forms its window's stage sum as the reference does --
- *                 sequential float32 adds of left/right in weak order (ref :796-810), the leaf values read
- *                 wave-uniformly -- so the group decides as one, survivors are compacted in place (the write index
- *                 never passes the read index) and a stage costs ONE pass over the wave's survivors instead of n.
- *                 That also removes the tail: a lone window that reaches stage 19 costs 18 wave iterations, not 136.
+ *                 64 subset-lookup bits and every lane of a group looks its window's n bits up in the stage's TRUTH
+ *                 TABLE (LbpStage::truth: the verdict of the reference's sequential float32 sum, ref :796-810, for every
+ *                 pattern of lookup results, built by the host with the same float adds), so the group decides as one,
+ *                 survivors are compacted in place (the write index never passes the read index) and a stage costs ONE
+ *                 pass over the wave's survivors instead of n.  That also removes the tail: a lone window that reaches
+ *                 stage 19 costs 18 wave iterations, not 136.  Stages without a table (more than 12 classifiers) add
+ *                 left / right in weak order like the reference; stages of more than 32 run a window per lane.
  *
  * Detections are rare (<= max_rects per frame matter): a window that passes the last stage sets its bit in the
  * frame's raster-order mask with one global atomicOr and bumps its chunk's counter, so k_compact.h sees exactly
  * what k_lbp_cascade would have published.  The max_rects early exit keeps its exact form: a tile is skipped when
  * the detections published by chunks that lie wholly before the tile's FIRST window reach the cap.
+ *
+ * Counters (8 x 4K edge maps, profiles/r05b_*): the LDS pipe is 72 % busy and the VALU 60-90 % (by the issue-rate table
+ * of scripts/ubench_valu.cpp), the texture path 3 % -- both on-chip pipes near their limit, which is why the block's own
+ * LDS tables are kept small (no leaf values: the truth tables replace them) and the code bits are assembled with
+ * full-rate compare + add-with-carry pairs (push_ge_u32).
  *
  * Not for GUARD geometries (feature rectangles that leave the window: scale < 1) -- those stay with k_lbp_cascade.
  */
@@ -35,18 +42,36 @@
 #define GS_K_LBP_TILE_H
 #include "k_lbp.h"
 
+#ifndef GS_LBP_TILE_ODD_STRIDE
+#define GS_LBP_TILE_ODD_STRIDE 1
+#endif
+
 namespace gs {
 
-/* per-stage lane layout of the pair phase, built once per block next to the cascade tables */
+/* per (scale, classifier), re-based to the tile's row stride: BYTE offsets inside the tile; sub = sub_off | min(nsub, 8) << 16 */
+struct LbpTileGeom { unsigned off0, fw, fh_stride, sub; };
+/* per-stage lane layout of the pair phase */
 struct LbpPairStage { unsigned wn, magic; }; /* windows per wave iteration (0: stage too long, window-parallel); lane / n = lane * magic >> 16 */
 
-/* dynamic LDS of a block: cascade tables | pair-phase lane layouts | stage truth tables | the waves' queues | the tile */
+struct LbpTileTables {
+  const LbpStage *stage;      /* LDS */
+  const LbpTileGeom *geom;    /* LDS */
+  const int32_t *subsets;     /* LDS */
+  const uint32_t *truth;      /* LDS */
+  const LbpPairStage *pst;    /* LDS */
+  const LbpWeak *weak_global; /* leaf values of stages WITHOUT a truth table: wave-uniform loads from global memory */
+};
+
+GS_HD size_t lbp_tile_align16(size_t b) { return (b + 15) & ~(size_t)15; }
+GS_HD unsigned lbp_tile_stride(unsigned tw, unsigned step, unsigned win_w) { return ((tw - 1u) * step + win_w + 1u) | (GS_LBP_TILE_ODD_STRIDE ? 1u : 0u); }
+/* dynamic LDS of a block: stages | geometry | subsets | truth tables | pair-phase lane layouts | the waves' queues | the tile */
 GS_HD size_t lbp_tile_lds_bytes(unsigned nstages, unsigned nweaks, unsigned nsub, unsigned ntruth, unsigned tile_windows, size_t tile_dwords) {
-  const size_t tables = (size_t)nstages * sizeof(LbpStage) + (size_t)nweaks * (sizeof(LbpWeak) + sizeof(LbpGeom)) + (size_t)nsub * 4;
-  return ((tables + 15) & ~(size_t)15) + (((size_t)nstages * sizeof(LbpPairStage) + 15) & ~(size_t)15) + (((size_t)ntruth * 4 + 15) & ~(size_t)15) +
-         (((size_t)tile_windows * 2 + 15) & ~(size_t)15) + tile_dwords * 4 + 16;
+  return lbp_tile_align16((size_t)nstages * sizeof(LbpStage)) + lbp_tile_align16((size_t)nweaks * sizeof(LbpTileGeom)) +
+         lbp_tile_align16((size_t)nsub * 4) + lbp_tile_align16((size_t)ntruth * 4) + lbp_tile_align16((size_t)nstages * sizeof(LbpPairStage)) +
+         lbp_tile_align16((size_t)tile_windows * 2) + tile_dwords * 4 + 16;
 }
 
+/* the 8-bit LBP code of ref :769-783 from the 4 x 4 corner grid: tl tc tr r br bc bl l = bits 7..0, most significant first */
 GS_DEV unsigned lbp_code_of(const unsigned (&G)[4][4]) {
   unsigned D[3][4], c[3][3];
 #pragma unroll
@@ -58,27 +83,75 @@ GS_DEV unsigned lbp_code_of(const unsigned (&G)[4][4]) {
 #pragma unroll
     for (int i = 0; i < 3; i++) c[j][i] = D[j][i + 1] - D[j][i];
   const unsigned ctr = c[1][1];
-  return ((c[0][0] >= ctr) << 7) | ((c[0][1] >= ctr) << 6) | ((c[0][2] >= ctr) << 5) | ((c[1][2] >= ctr) << 4) |
-         ((c[2][2] >= ctr) << 3) | ((c[2][1] >= ctr) << 2) | ((c[2][0] >= ctr) << 1) | ((c[1][0] >= ctr) << 0);
+  unsigned code = 0;
+  code = push_ge_u32(code, c[0][0], ctr), code = push_ge_u32(code, c[0][1], ctr), code = push_ge_u32(code, c[0][2], ctr);
+  code = push_ge_u32(code, c[1][2], ctr), code = push_ge_u32(code, c[2][2], ctr), code = push_ge_u32(code, c[2][1], ctr);
+  code = push_ge_u32(code, c[2][0], ctr), code = push_ge_u32(code, c[1][0], ctr);
+  return code;
+}
+/* the subset bit of a code (ref :785-788); sub = sub_off | nsub << 16 */
+GS_DEV unsigned lbp_subset_bit(const int32_t *subsets, unsigned sub, unsigned code) {
+  const unsigned word = code >> 5, nsub = sub >> 16;
+  const unsigned v = (uint32_t)subsets[(sub & 0xffffu) + (word < nsub ? word : 0u)];
+  return word < nsub ? (v >> (code & 31u)) & 1u : 0u;
 }
 
-/* one (window, classifier) pair, geometry per lane: the subset bit of the window's LBP code (ref :769-788).  The tile
- * kernel re-bases the staged geometry to the tile's row stride and packs the classifier's subset range into the spare
- * word (pad = sub_off | min(nsub, 8) << 16), so a pair costs one 16-byte table read. */
-GS_DEV bool lbp_pair_hit(const LbpLds &t, const unsigned *tile, unsigned origin, unsigned wi) {
-  const LbpGeom g = t.geom[wi];
-  const unsigned base = origin + (unsigned)g.off0, sub_off = (unsigned)g.pad & 0xffffu, nsub = (unsigned)g.pad >> 16;
+/* one (window, classifier) pair, geometry per lane */
+GS_DEV bool lbp_pair_hit(const LbpTileTables &t, const unsigned *tile, unsigned origin, unsigned wi) {
+  const LbpTileGeom g = t.geom[wi];
+  const unsigned base = origin + g.off0;
   unsigned G[4][4];
 #pragma unroll
   for (int j = 0; j < 4; j++)
 #pragma unroll
-    for (int i = 0; i < 4; i++)
-      G[j][i] = *(const unsigned *)((const char *)tile + (base + (unsigned)j * (unsigned)g.fh_stride + (unsigned)i * (unsigned)g.fw));
-  const unsigned code = opaque(lbp_code_of(G)); /* opaque: all 16 corners are fetched in ONE LDS round trip (the optimiser otherwise tests
-                                                    word < nsub on the code's top bits first and sinks six loads behind that branch) */
-  const unsigned word = code >> 5;
-  const unsigned v = (uint32_t)t.subsets[sub_off + (word < nsub ? word : 0u)];
-  return word < nsub && ((v >> (code & 31u)) & 1u);
+    for (int i = 0; i < 4; i++) G[j][i] = *(const unsigned *)((const char *)tile + (base + (unsigned)j * g.fh_stride + (unsigned)i * g.fw));
+  return lbp_subset_bit(t.subsets, g.sub, lbp_code_of(G)) != 0u;
+}
+
+/* stages [s0, s1) for ONE window per lane, every lane on the same classifier (geometry wave-uniform, ds_read_b32 of 64
+ * consecutive dwords: conflict-free); the next classifier's corners are requested before the current one's arithmetic, as
+ * in lbp_window_stages.  A stage's verdict comes from its truth table (bit k of the pattern = classifier k's lookup). */
+template <bool COUNT>
+GS_DEV bool lbp_tile_window_stages(const LbpTileTables &t, const unsigned *tile, unsigned origin, unsigned s0, unsigned s1,
+                                   unsigned *evals) {
+  const unsigned wend = uniform(t.stage[s1 - 1].first) + uniform(t.stage[s1 - 1].count);
+  unsigned wi = uniform(t.stage[s0].first);
+  auto gather = [&](unsigned w, unsigned (&G)[4][4]) {
+    const LbpTileGeom g = t.geom[w];
+    const unsigned base = origin + uniform(g.off0), fw = uniform(g.fw), fhs = uniform(g.fh_stride);
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) G[j][i] = *(const unsigned *)((const char *)tile + (base + (unsigned)j * fhs + (unsigned)i * fw));
+  };
+  unsigned Q[4][4];
+  gather(wi, Q);
+  for (unsigned s = s0; s < s1; s++) {
+    const LbpStage st = t.stage[s];
+    const unsigned count = uniform(st.count), tt = uniform(st.truth);
+    unsigned pat = 0;
+    float sum = 0.0f;
+    for (unsigned k = 0; k < count; k++, wi++) {
+      unsigned G[4][4];
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) G[j][i] = Q[j][i];
+      if constexpr (COUNT) ++*evals;
+      const unsigned sub = uniform(t.geom[wi].sub);
+      if (wi + 1u < wend) gather(wi + 1u, Q); /* wave-uniform */
+      const unsigned bit = lbp_subset_bit(t.subsets, sub, lbp_code_of(G));
+      if (tt) {
+        pat |= bit << k;
+      } else { /* no table for this stage: the reference's adds, leaf values from global memory (wave-uniform) */
+        const LbpWeak wk = t.weak_global[wi];
+        sum += bit ? wk.left : wk.right;
+      }
+    }
+    const bool pass = tt ? ((t.truth[tt - 1u + (pat >> 5)] >> (pat & 31u)) & 1u) != 0u : !(sum < st.threshold);
+    if (!pass) return false;
+  }
+  return true;
 }
 
 struct LbpTilePos { unsigned x0w, y0w, nwx, nwy; }; /* the tile's first window (in window indices) and its extent */
@@ -99,9 +172,9 @@ GS_DEV void lbp_tile_publish(const LbpArgs &a, const LbpScale &sc, const LbpTile
 }
 
 /* grid (max tiles per scale [rounded up to 8 with the XCD mapping], scales of this launch, n frames), block NT;
- * dynamic LDS = lbp_tile_lds_bytes(...) for the LARGEST scale of the launch */
-/* 1024-thread blocks are held to 64 registers (two blocks = 32 waves per CU is what the rule picks them for = 8 waves per SIMD, the bound's second argument; 69-72 without
- * the bound, no scratch with it) */
+ * dynamic LDS = lbp_tile_lds_bytes(...) for the LARGEST scale of the launch.
+ * 1024-thread blocks are held to 64 registers (two blocks = 32 waves per CU is what the rule picks them for = 8 waves per
+ * SIMD, the bound's second argument; 69-72 without it). */
 template <unsigned NT, unsigned TW, unsigned TH, bool COUNT = false>
 __global__ __launch_bounds__(NT, NT == 1024 ? 8 : 1) void k_lbp_tile(LbpArgs a, LbpPhases ph) {
 #ifndef GS_EMU
@@ -147,37 +220,46 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 8 : 1) void k_lbp_tile(LbpArgs a, 
     __syncthreads();
     if (before_s >= a.cap) return;
   }
-  /* ---- LDS: cascade tables (geometry re-based to the tile's row stride), pair-phase lane layouts, truth tables, queues, tile */
+  /* ---- LDS: stages | geometry re-based to the tile's row stride | subsets | truth tables | lane layouts | queues | tile */
   const unsigned step = (unsigned)a.step;
-  const unsigned TS = (TW - 1u) * step + (unsigned)sc.win_w + 1u, TR = (TH - 1u) * step + (unsigned)sc.win_h + 1u;
-  LbpLds t = lbp_stage_tables(smem, a, a.geom + (size_t)si * a.nweaks, tid, NT);
-  char *extra = smem + ((lbp_lds_bytes(a.nstages, a.nweaks, a.nsub) + 15) & ~(size_t)15);
-  LbpPairStage *pst = (LbpPairStage *)extra;
-  extra += ((size_t)a.nstages * sizeof(LbpPairStage) + 15) & ~(size_t)15;
-  uint32_t *truth = (uint32_t *)extra;
-  extra += ((size_t)a.ntruth * 4 + 15) & ~(size_t)15;
-  uint16_t *queue_all = (uint16_t *)extra; /* [NW][R * 64]: dword offsets of the survivors' top-left corners inside the tile */
-  unsigned *tile = (unsigned *)(extra + (((size_t)TW * TH * 2 + 15) & ~(size_t)15));
+  /* row stride of the tile in dwords: the columns the windows can touch, made ODD -- survivors cluster spatially, and with a
+   * stride that shares a factor with the 32 banks vertically neighbouring windows would meet in the same banks */
+  const unsigned TS = lbp_tile_stride(TW, step, (unsigned)sc.win_w), TR = (TH - 1u) * step + (unsigned)sc.win_h + 1u;
+  char *p = smem;
+  LbpStage *l_stage = (LbpStage *)p;
+  p += lbp_tile_align16((size_t)a.nstages * sizeof(LbpStage));
+  LbpTileGeom *l_geom = (LbpTileGeom *)p;
+  p += lbp_tile_align16((size_t)a.nweaks * sizeof(LbpTileGeom));
+  int32_t *l_sub = (int32_t *)p;
+  p += lbp_tile_align16((size_t)a.nsub * 4);
+  uint32_t *l_truth = (uint32_t *)p;
+  p += lbp_tile_align16((size_t)a.ntruth * 4);
+  LbpPairStage *l_pst = (LbpPairStage *)p;
+  p += lbp_tile_align16((size_t)a.nstages * sizeof(LbpPairStage));
+  uint16_t *queue_all = (uint16_t *)p; /* [NW][R * 64]: dword offsets of the survivors' top-left corners inside the tile */
+  p += lbp_tile_align16((size_t)TW * TH * 2);
+  unsigned *tile = (unsigned *)p;
   for (unsigned s = tid; s < a.nstages; s += NT) {
-    const unsigned n = a.stage[s].count;
-    LbpPairStage p;
-    p.wn = (n >= 1u && n <= 32u) ? 64u / n : 0u;
-    p.magic = p.wn ? 65536u / n + 1u : 0u;
-    pst[s] = p;
+    const LbpStage st = a.stage[s];
+    l_stage[s] = st;
+    LbpPairStage q;
+    q.wn = (st.count >= 1u && st.count <= 32u) ? 64u / st.count : 0u;
+    q.magic = q.wn ? 65536u / st.count + 1u : 0u;
+    l_pst[s] = q;
   }
-  for (unsigned i = tid; i < a.ntruth; i += NT) truth[i] = a.truth[i];
-  __syncthreads(); /* lbp_stage_tables' copies are visible */
-  /* the staged geometry holds byte offsets for the table's row stride a.S: re-base to TS (fy = off0 / (4 S), fx the rest);
-   * the spare word takes the classifier's subset range (lbp_pair_hit) */
-  for (unsigned i = tid; i < a.nweaks; i += NT) {
-    LbpGeom *gp = (LbpGeom *)t.geom + i;
-    const LbpGeom g = *gp;
-    const LbpWeak wk = t.weak[i];
-    const unsigned o = (unsigned)g.off0 >> 2, fy = o / a.S, fx = o - fy * a.S;
-    LbpGeom r;
-    r.off0 = (int)((fy * TS + fx) * 4u), r.fw = g.fw, r.fh_stride = (int)((unsigned)g.pad * TS * 4u);
-    r.pad = (int)((wk.sub_off & 0xffffu) | ((wk.nsub < 8u ? wk.nsub : 8u) << 16)); /* a code has 8 bits: words >= 8 never match */
-    *gp = r;
+  for (unsigned i = tid; i < a.nsub; i += NT) l_sub[i] = a.subsets[i];
+  for (unsigned i = tid; i < a.ntruth; i += NT) l_truth[i] = a.truth[i];
+  { /* the host's geometry holds byte offsets for the table's row stride a.S: re-base to TS (fy = off0 / (4 S), fx the rest) */
+    const LbpGeom *gs_ = a.geom + (size_t)si * a.nweaks;
+    for (unsigned i = tid; i < a.nweaks; i += NT) {
+      const LbpGeom g = gs_[i];
+      const LbpWeak wk = a.weak[i];
+      const unsigned o = (unsigned)g.off0 >> 2, fy = o / a.S, fx = o - fy * a.S;
+      LbpTileGeom r;
+      r.off0 = (fy * TS + fx) * 4u, r.fw = (unsigned)g.fw, r.fh_stride = (unsigned)g.pad * TS * 4u;
+      r.sub = (wk.sub_off & 0xffffu) | ((wk.nsub < 8u ? wk.nsub : 8u) << 16); /* a code has 8 bits: words >= 8 never match */
+      l_geom[i] = r;
+    }
   }
   {
     const unsigned *Pg = a.padded + (size_t)blockIdx.z * a.frame_stride;
@@ -199,6 +281,7 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 8 : 1) void k_lbp_tile(LbpArgs a, 
   }
   __syncthreads();
   /* ---- from here on the waves are on their own */
+  const LbpTileTables t{l_stage, l_geom, l_sub, l_truth, l_pst, a.weak};
   uint16_t *queue = queue_all + wave * (R * 64u);
   unsigned evals = 0;
   /* wave-row k of this wave: q = wave + NW k (interleaved, so every wave gets rows from all over the tile); the dword offset
@@ -219,16 +302,16 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 8 : 1) void k_lbp_tile(LbpArgs a, 
   if (nvalid) {
     const unsigned emax = ph.adaptive_max ? ph.adaptive_max : ph.end[0];
     unsigned s_prev = 0;
-    e = ph.end[0] < a.nstages ? ph.end[0] : a.nstages;
+    e = ph.tile_first < a.nstages ? ph.tile_first : a.nstages;
     for (;;) { /* wave-uniform */
 #pragma clang loop unroll(disable) /* one copy of the stage loop, not R: registers (64 for the 1024-thread shapes) and code size */
       for (unsigned k = 0; k < R; k++) {
         if ((alive >> k) & 1u) {
-          if (!lbp_window_stages<false, COUNT>(t, tile, odw_of(k) * 4u, 0u, s_prev, e, &evals)) alive &= ~(1u << k);
+          if (!lbp_tile_window_stages<COUNT>(t, tile, odw_of(k) * 4u, s_prev, e, &evals)) alive &= ~(1u << k);
         }
       }
       const unsigned c = wave_sum((unsigned)__popc(alive));
-      if (e >= a.nstages || c == 0u || c * 10u <= ph.adaptive_tenths * nvalid || e >= emax) {
+      if (e >= a.nstages || c == 0u || c * 10u <= ph.tile_tenths * nvalid || e >= emax) {
         m = c;
         break;
       }
@@ -259,7 +342,7 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 8 : 1) void k_lbp_tile(LbpArgs a, 
     const LbpStage st = t.stage[s];
     const unsigned n = uniform(st.count), first = uniform(st.first), tt = uniform(st.truth);
     const bool lastst = s + 1u == a.nstages;
-    const LbpPairStage ps = pst[s];
+    const LbpPairStage ps = t.pst[s];
     const unsigned wn = uniform(ps.wn);
     unsigned out = 0;
     wave_sync(); /* the queue as the previous stage (or the re-packing) left it */
@@ -280,11 +363,11 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 8 : 1) void k_lbp_tile(LbpArgs a, 
         const uint32_t mine = (uint32_t)(hm >> sh) & pmask;
         bool pass;
         if (tt) { /* the stage's verdict for this pattern of lookup results, precomputed with the reference's float adds */
-          pass = (truth[tt - 1u + (mine >> 5)] >> (mine & 31u)) & 1u;
+          pass = (t.truth[tt - 1u + (mine >> 5)] >> (mine & 31u)) & 1u;
         } else {
           float sum = 0.0f;
-          for (unsigned i = 0; i < n; i++) { /* the reference's order of adds; the leaf values are wave-uniform reads */
-            const LbpWeak wk = t.weak[first + i];
+          for (unsigned i = 0; i < n; i++) { /* the reference's order of adds; the leaf values are wave-uniform loads */
+            const LbpWeak wk = t.weak_global[first + i];
             sum += ((mine >> i) & 1u) ? wk.left : wk.right;
           }
           pass = !(sum < st.threshold);
@@ -306,7 +389,7 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 8 : 1) void k_lbp_tile(LbpArgs a, 
         const bool live = j < m;
         const unsigned odw = queue[live ? j : 0u];
         bool pass = false;
-        if (live) pass = lbp_window_stages<false, COUNT>(t, tile, odw * 4u, 0u, s, s + 1u, &evals);
+        if (live) pass = lbp_tile_window_stages<COUNT>(t, tile, odw * 4u, s, s + 1u, &evals);
         const uint64_t pm = ballot(pass);
         if (pm) {
           if (lastst) {

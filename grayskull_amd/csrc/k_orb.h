@@ -81,12 +81,18 @@ __global__ void k_orient_moments_seq(const uint8_t *img, unsigned w, unsigned h,
   out[0] = m01, out[1] = m10;
 }
 
-/* grid nkp, block 256 (thread = one of the 256 point pairs); desc: nkp x 8 u32 */
+/* grid nkp, block 256 (thread = one of the 256 point pairs); desc: nkp x 8 u32.
+ * blockIdx.y = frame of a batch (frames frame_bytes apart; kin / desc hold gridDim.x slots per frame, count_dev[frame] of them
+ * filled); single images launch with gridDim.y = 1 and no count */
 __global__ __launch_bounds__(256) void k_brief(const uint8_t *img, unsigned w, unsigned h,
-                                               const KpIn *kin, uint32_t *desc) {
+                                               const KpIn *kin, uint32_t *desc, const unsigned *count_dev = nullptr,
+                                               size_t frame_bytes = 0) {
 #ifndef GS_EMU
 #pragma clang fp contract(off)
 #endif
+  if (count_dev && blockIdx.x >= count_dev[blockIdx.y]) return; /* whole block */
+  img += (size_t)blockIdx.y * frame_bytes;
+  kin += (size_t)blockIdx.y * gridDim.x, desc += (size_t)blockIdx.y * gridDim.x * 8u;
   const KpIn kp = kin[blockIdx.x];
   const unsigned i = threadIdx.x;
   const int p0 = k_brief_pattern[4 * i], p1 = k_brief_pattern[4 * i + 1];

@@ -164,6 +164,8 @@ GS_DEV uint32_t mad_u32_u16_hi(uint32_t a, uint32_t b, uint32_t c) { return (a >
 GS_DEV void sched_fence() {}
 #define GS_SCHED_GROUP(mask, n) ((void)0)
 GS_DEV uint32_t opaque(uint32_t x) { return x; }
+GS_DEV uint32_t push_ge_u32(uint32_t acc, uint32_t a, uint32_t b) { return acc * 2u + (a >= b ? 1u : 0u); }
+GS_DEV uint32_t push_gt_u32(uint32_t acc, uint32_t a, uint32_t b) { return acc * 2u + (a > b ? 1u : 0u); }
 GS_DEV void lds_add_through(unsigned *lds_base, uint32_t byte_off, uint32_t value, uint32_t &through) {
   (void)through;
   atomicAdd((unsigned *)((char *)lds_base + byte_off), value);
@@ -343,6 +345,17 @@ GS_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 GS_DEV uint32_t opaque(uint32_t x) {
   asm volatile("" : "+v"(x));
   return x;
+}
+/* acc = 2 acc + (a >= b), unsigned: v_cmp_ge_u32 (VOPC) + v_addc_co_u32 (VOP2), both full-rate encodings -- hipcc's own
+ * compare + v_cndmask_b32_e64 + v_or3_b32 per bit of a code are VOP3 forms, which issue at 0.58 of that rate on gfx950
+ * (scripts/ubench_valu.cpp).  No hazard: a VALU write of VCC may feed the next instruction's carry-in. */
+GS_DEV uint32_t push_ge_u32(uint32_t acc, uint32_t a, uint32_t b) {
+  asm("v_cmp_ge_u32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
+  return acc;
+}
+GS_DEV uint32_t push_gt_u32(uint32_t acc, uint32_t a, uint32_t b) { /* acc = 2 acc + (a > b) */
+  asm("v_cmp_gt_u32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
+  return acc;
 }
 /* LDS atomic add (no return value) at byte address `lds_byte` of the block's LDS, tied into the
  * dependency chain of `through`: the instruction is issued after `through` has been produced and

@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, grayskull_amd as gs
 from grayskull_amd.cascade import Cascade
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-g = gs.lib(); g.use_torch_stream()
+g = gs.Grayskull(os.environ["UB_LIB"]) if os.environ.get("UB_LIB") else gs.lib(); g.use_torch_stream()
 casc = Cascade.from_blob(os.path.join(ROOT, "tests/golden/frontalface_cascade.bin"))
 dc = g.cascade_create(casc)
 SHAPES = {1: "k_lbp_cascade", 2: "tile 512thr 128x32", 3: "tile 1024thr 128x32", 4: "tile 1024thr 64x32", 5: "tile 1024thr 64x16", 6: "tile 512thr 64x32", 0: "rule"}
@@ -41,16 +41,12 @@ for (kind, w, h, n) in (("edges", 3840, 2160, 8), ("noise", 1920, 1080, 8), ("no
             ms = timeit(run)
             print("%s %dx%d whole scan, %-22s %.3f ms/frame  same=%s" % (kind, w, h, SHAPES[mode] + ":", ms / n, check("all")), flush=True)
     g.tune(14, 0)
-    for k in (1, 2, 3, 4):
-        g.tune(15, k)
-        ms = timeit(run)
-        print("%s %dx%d whole scan, rule over the first %d shapes: %.3f ms/frame  same=%s" % (kind, w, h, k, ms / n, check("all")), flush=True)
+    for first in (1, 2):
+        for tenths in (4, 5, 6, 7, 8):  # a wave goes from dense to pair-parallel once <= tenths/10 of its windows are alive
+            g.tune(15, first + 16 * tenths)
+            ms = timeit(run)
+            print("%s %dx%d whole scan, rule, dense stages >= %d, re-pack at <= %d/10 alive: %.3f ms/frame  same=%s" % (kind, w, h, first, tenths, ms / n, check("all")), flush=True)
     g.tune(15, 0)
-    for tenths in (2, 3, 4, 5):  # share of a wave's windows at which it re-packs (key 9 = max stages + 16 * tenths)
-        g.tune(9, 8 + 16 * tenths)
-        ms = timeit(run)
-        print("%s %dx%d whole scan, rule, re-pack at <= %d/10 alive: %.3f ms/frame  same=%s" % (kind, w, h, tenths, ms / n, check("all")), flush=True)
-    g.tune(9, 0)
     if quick or (w, h) != (3840, 2160): continue
     s = 1.0
     while s <= 4.0:

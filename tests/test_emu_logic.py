@@ -408,6 +408,20 @@ def test_lbp_tile_shapes_never_change_results(emu, oracle, cascade, mode):
         emu.tune(14, 0)
 
 
+@pytest.mark.parametrize("knob", [1 + 16 * 2, 2 + 16 * 8, 3 + 16 * 0, 1 + 16 * 10])
+def test_lbp_tile_dense_to_pair_switch_never_changes_results(emu, oracle, cascade, knob):
+    """key 15 = first + 16 * tenths: how long a wave of k_lbp_tile stays dense (stages [0, first), then while more than
+    tenths/10 of its windows live) before it goes to one lane per (window, classifier) pair -- early, late, never-early"""
+    edges = oracle.sobel(oracle.blur(Oracle.synth(200, 150, 1000), 2))
+    try:
+        emu.tune(15, knob)
+        pc.lbp(emu, oracle, edges, MEM, cascade, params=((4096, 1.1, 1.0, 4.0, 1), (7, 1.1, 1.0, 4.0, 1)))
+        pc.lbp(emu, oracle, Oracle.synth(130, 70, 9), MEM, random_cascade(1), params=((4096, 1.25, 1.0, 2.0, 1), (37, 1.25, 1.0, 2.0, 1)))
+        pc.lbp(emu, oracle, Oracle.synth(80, 60, 12), MEM, random_cascade(5, nstages=4, weaks_per_stage=14), params=((500, 1.2, 1.0, 2.5, 1),))
+    finally:
+        emu.tune(15, 0)
+
+
 def test_lbp_chunk_granular_early_exit(emu, oracle, cascade):
     """max_rects early exit at chunk-group granularity (ref :819-831): a chunk is skipped once the
     detections published by the groups that wholly precede it reach the cap.  The result must be the

@@ -160,6 +160,55 @@ def test_gloo_world2_cascade_broadcast_and_variable_length_gather():
         assert ok == 0.0
 
 
+def _run_world(target, world, port, extra=(), timeout=300):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=target, args=(r, world, port, q) + tuple(extra)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=timeout) for _ in ps]
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    return sorted(res)
+
+
+def test_gloo_world8_every_collective_with_ranks_that_own_no_frame():
+    """the world size north_star is quoted on (8 GPUs), on CPU over gloo: the 7- and 5-frame jobs of the world-2 tests split
+    over EIGHT ranks -- ranks 5..7 (resp. 7) own no frame and must still pass every collective: barrier, max / sum, the
+    rank-ordered all-gather of per-frame results, the cascade broadcast and the packed variable-length gather"""
+    res = _run_world(_worker, 8, 35500 + (os.getpid() % 2000))
+    for rank, mx, sm, allv in res:
+        assert mx == 8.0 and sm == 7.0
+        assert allv == [10 * f + 1 for f in range(7)]
+    res = _run_world(_collectives_worker, 8, 37500 + (os.getpid() % 2000))
+    exp_counts = [(3 * f) % 7 for f in range(5)]
+    exp_recs = [[f, k, f * 100 + k, 7] for f in range(5) for k in range(exp_counts[f])]
+    for rank, blob, call, rall, ok in res:
+        assert blob == b"LBPC" + bytes(range(200))
+        assert call == exp_counts and rall == exp_recs
+        assert ok == 0.0
+
+
+def test_gloo_world8_sharded_pipeline_equals_oracle_on_every_frame():
+    """configs[1] sharding at world 8 on CPU (kernel sources in their emulator build): 5 frames over 8 ranks, three of
+    them idle; every rank sees all frames' Otsu thresholds and output hashes == the oracle's"""
+    import subprocess
+    from oracle.pyoracle import Oracle
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "grayskull_amd", "csrc"), "emu"])
+    emu_so = os.path.join(ROOT, "tests", "emu", "libgs_kernel_emu.so")
+    o = Oracle("port")
+    exp_thr, exp_sum = [], []
+    for f in range(5):
+        e = o.sobel(o.blur(Oracle.synth(64, 24, 1000 + f), 2))
+        t = o.otsu_threshold(e)
+        exp_thr.append(int(t))
+        exp_sum.append(int(Oracle.fnv1a(o.threshold(e, t))))
+    for rank, thr, sums in _run_world(_pipeline_worker, 8, 39500 + (os.getpid() % 2000), extra=(emu_so,)):
+        assert thr == exp_thr, "rank %d thresholds" % rank
+        assert sums == exp_sum, "rank %d output hashes" % rank
+
+
 def test_forced_world1_uses_the_same_collectives(monkeypatch):
     """GS_BENCH_FORCE_DIST=1: a process group even at world 1 (gloo here, nccl == RCCL on the GPU box)"""
     from grayskull_amd.shard import Sharder
