@@ -377,6 +377,7 @@ def run_cfg4(args, sh, g, torch, np, w, h, F, r, lo, total):
             parity = ("MISMATCH at frames %s" % bad if bad else
                       "rect lists of frames %s (of %d, all ranks) == reference golden (count + checksum)%s"
                       % (checked, total, "; frame 0 bit-exact vs %s oracle live" % o.kind if live else ""))
+    ranks_seen = sh.ranks_seen()  # a collective: every rank takes part (it used to sit inside rank 0's print -- found by the 8-rank rehearsal)
     if sh.rank == 0:
         print(json.dumps({
             "metric": "frames/s for gs_blur->gs_sobel->gs_integral->gs_lbp_detect on 4K uint8 (BASELINE configs[4])",
@@ -389,7 +390,7 @@ def run_cfg4(args, sh, g, torch, np, w, h, F, r, lo, total):
             "windows_per_frame_full_scan": nwin,
             "windows_evaluated_per_frame": round(ev_total / (total * args.steps), 1),
             "Gwindows/s_evaluated": round(ev_total / dt / 1e9, 2),
-            "rccl_ranks_seen": sh.ranks_seen(), "backend": sh.backend, "rank_ms_per_step": rank_ms,
+            "rccl_ranks_seen": ranks_seen, "backend": sh.backend, "rank_ms_per_step": rank_ms,
             "collectives": ["broadcast(cascade blob, %d B)" % len(blob), "barrier", "all_reduce(max, sum)",
                             "all_gather(counts)", "all_gather(packed gs_rect lists, %d records)" % int(all_rects.shape[0])],
             "parity": parity,
@@ -812,7 +813,7 @@ def extras(g, torch, np, src, tmp, dst, w, h, reps, lo=0, args=None):
     cn7 = torch.zeros(nf, dtype=torch.int32, device="cuda")
     # calls of ~70 us: 5 repetitions behind one warm-up call read 12-15 % high (first launches after other work)
     ms_fast = time_stream(torch, lambda: g.fast_batch(f7, sm7, kp7, cn7, 2000, 20), 30, warm=3)
-    ms_fast_score = time_stream(torch, lambda: g.probe_fast_score(sm7, f7, 20), 30, warm=3)
+    ms_fast_score = time_stream(torch, lambda: g.fast_score_batch(sm7, f7, 20), 30, warm=3)
     # device-resident gs_orb_extract (GS_NO_STDLIB trig, no host round trip), same 32 frames, 500 keypoints each
     ko7 = torch.zeros((nf, 500, 12), dtype=torch.int32, device="cuda")
     ms_orb_dev = time_stream(torch, lambda: g.orb_extract_batch_nostdlib(f7, sm7, ko7, cn7, 500, 20), 5)
@@ -925,21 +926,23 @@ def extras(g, torch, np, src, tmp, dst, w, h, reps, lo=0, args=None):
     return ns, other
 
 
-L1_LINE_GBS = 64.0 * 256 * 2.4  # one 64-byte line per clock per CU (vector L1 -> texture path), 256 CUs at 2.4 GHz
+LDS_B32_GBS = 128.0 * 256 * 2.4  # ds_read_b32: 128 B per clock and CU (MI355X_MICROARCH.md, LDS table), 256 CUs at 2.4 GHz
 
 
 def lbp_gather_block(weak_evals, dword_loads, ms):
-    """The cascade is bound by the texture path (TA busy 95 %, profiles/r03d_pmc_lbp.txt), so its roofline is the rate
-    at which the vector L1 hands lines to it: ONE peak, 64 B per clock and CU = 39.3 TB/s (the dense phase, whose gathers
-    are 64 consecutive dwords, runs at that width: 4 cycles per 256-byte gather).  achieved = the dwords the lanes really
-    loaded (gsh_lbp_count_evaluated[2]) x 4 B / time -- scattered survivor gathers fetch a whole line per dword or two,
-    which is exactly what the fraction shows."""
+    """Since round 5 the cascade's corner gathers come from an LDS tile (k_lbp_tile; k_lbp_cascade on the texture path only
+    for the scales whose tile does not fit).  achieved = the table dwords the lanes really loaded (gsh_lbp_count_evaluated[2])
+    x 4 B / time against the ds_read_b32 rate of the chip.  The kernel is not bound by that pipe alone: on the configs[4]
+    input the LDS is 75 % busy -- 37 % of its cycles are bank conflicts of the scattered survivor gathers -- and the VALU
+    60-90 % (profiles/r05c_lbp_counters_tile_rule_v3.txt), i.e. both on-chip pipes sit near their limit."""
     gbs = dword_loads * 4.0 / ms / 1e6
-    return {"bound": "vector L1 / texture path line rate", "weak_classifier_evaluations": weak_evals,
+    return {"bound": "LDS pipe (ds_read_b32 gathers from the block's table tile) + VALU issue", "weak_classifier_evaluations": weak_evals,
             "dword_loads": dword_loads, "bytes": dword_loads * 4.0, "ms": round(ms, 4), "GB/s": round(gbs, 1),
-            "peak_GB/s": round(L1_LINE_GBS, 1), "frac": round(gbs / L1_LINE_GBS, 4),
-            "note": "bytes = table dwords loaded by the lanes (lane-level count of the counting build) x 4; peak = 64 B/clk/CU "
-                    "x 256 CUs x 2.4 GHz; 16 dwords per evaluated weak classifier"}
+            "peak_GB/s": round(LDS_B32_GBS, 1), "frac": round(gbs / LDS_B32_GBS, 4),
+            "lds_pipe_busy_pmc": 0.75, "lds_bank_conflict_share_pmc": 0.37,
+            "note": "bytes = table dwords loaded by the lanes (lane-level count of the counting build) x 4; peak = 128 B/clk/CU x "
+                    "256 CUs x 2.4 GHz (conflict-free ds_read_b32); 16 dwords per evaluated weak classifier; the busy / conflict "
+                    "shares are rocprofv3 counters of the same kernels on 8 x 4K edge maps (SQ_LDS_IDX_ACTIVE, SQ_LDS_BANK_CONFLICT)"}
 
 
 if __name__ == "__main__":

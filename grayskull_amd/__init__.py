@@ -93,8 +93,7 @@ _SIGS = {
     "gsh_tune": (None, [C.c_int, C.c_int]),
     "gsh_profile": (None, [C.c_int]),
     "gsh_profile_read": (C.c_uint, [C.POINTER(C.c_double)]),
-    "gsh_probe_strip_copy": (None, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint]),
-    "gsh_probe_fast_score": (None, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_uint]),
+    "gsh_fast_score_batch": (None, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_uint]),
     "gsh_shutdown": (None, []),
     "gsh_malloc": (C.c_void_p, [C.c_size_t]),
     "gsh_free": (None, [C.c_void_p]),
@@ -156,6 +155,10 @@ _SIGS = {
     "gsh_comm_all_reduce_f64": (None, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
 }
 EXPORTED_SYMBOLS = tuple(sorted(_SIGS))
+# -DGS_EXPERIMENT builds only (build_variants/libgs_experiment.so): bound when the library has them
+_EXPERIMENT_SIGS = {
+    "gsh_probe_strip_copy": (None, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint]),
+}
 
 
 def _share_torch_hip_runtime():
@@ -201,6 +204,10 @@ class Grayskull:
         for name, (res, args) in _SIGS.items():
             f = getattr(self.c, name)
             f.restype, f.argtypes = res, args
+        for name, (res, args) in _EXPERIMENT_SIGS.items():
+            if hasattr(self.c, name):
+                f = getattr(self.c, name)
+                f.restype, f.argtypes = res, args
 
     # ------------------------------------------------------------------ runtime
     def version(self):
@@ -243,11 +250,20 @@ class Grayskull:
         n = self.c.gsh_profile_read(C.byref(ms))
         return int(n), float(ms.value)
 
-    def probe_fast_score(self, score, img, threshold):
+    def fast_score_batch(self, score, img, threshold):
+        """pass 1 of gs_fast alone: the score map of n frames"""
         n, h, w = self._nhw(img)
-        self.c.gsh_probe_fast_score(_ptr(score), _ptr(img), w, h, n, threshold)
+        self.c.gsh_fast_score_batch(_ptr(score), _ptr(img), w, h, n, threshold)
+
+    probe_fast_score = fast_score_batch  # the name the measurement scripts of rounds 2-4 use
+
+    @property
+    def experiment(self):
+        """whether this is a -DGS_EXPERIMENT build (probes and result-changing tune keys available)"""
+        return hasattr(self.c, "gsh_probe_strip_copy")
 
     def probe_strip_copy(self, dst, src):
+        """experiment builds only (UB_LIB=build_variants/libgs_experiment.so)"""
         n, h, w = self._nhw(src)
         self.c.gsh_probe_strip_copy(_ptr(dst), _ptr(src), w, h, n)
 

@@ -5,10 +5,14 @@
  * never cross GPUs.  The C99 batch driver (grayskull_amd/host/gsbatch.c --gpus N) is the caller; bench.py reaches the
  * same RCCL through torch.distributed, one process per GPU.
  *
- * librccl.so is dlopen()ed on first use, so the library itself does not depend on it: a one-GPU program works without
- * RCCL installed (a world of one does its "collectives" as stream-ordered local copies), a multi-GPU program without it is
- * refused.  The kernel-logic emulator build (GS_EMU, a test tool) has no devices to connect: its collectives are
- * rendezvous copies between the emulated devices' host threads.
+ * librccl.so is dlopen()ed on first use, so the library itself does not depend on it.  Three backends behind one interface:
+ *   RCCL   ncclCommInitAll over the worker devices (several GPUs; one GPU only when GS_COMM_RCCL=1 asks for it -- a CLI run of
+ *          milliseconds should not pay a communicator for a world of one);
+ *   LOCAL  a world of one: the "collectives" are stream-ordered local copies;
+ *   HOST   several workers without a usable librccl (or GS_COMM_BACKEND=host), and the kernel-logic emulator build (GS_EMU, a
+ *          test tool, whose "devices" are host threads): the KB-scale payloads bounce through host memory and the workers'
+ *          threads meet at a rendezvous -- slower than RCCL by a host round trip per collective, which is nothing next to
+ *          refusing to run.
  */
 #include <condition_variable>
 #include <mutex>
@@ -96,12 +100,12 @@ Rccl &rccl() {
 
 struct gsh_comm {
   int rank = 0, world = 1, device = 0;
-  enum Kind { LOCAL, RCCL, EMU } kind = LOCAL;
-  Meet *meet = nullptr; /* shared by the world's handles (EMU; LOCAL has a world of one) */
+  enum Kind { LOCAL, RCCL, HOST } kind = LOCAL;
+  Meet *meet = nullptr; /* shared by the world's handles (HOST; LOCAL has a world of one) */
 #ifndef GS_EMU
   ncclComm_t nc = nullptr;
 #endif
-  char backend[64] = "local copies (world of 1, librccl not needed)";
+  char backend[96] = "local copies (world of 1, librccl not needed)";
 };
 
 namespace {
@@ -115,32 +119,43 @@ void check_thread(const gsh_comm *c) {
   }
 #endif
 }
-/* rendezvous collectives of the emulator / world-1 path: buffers are reachable by plain copies */
-void meet_copy(void *dst, const void *src, size_t bytes) {
+/* world-1 path: a stream-ordered local copy */
+void local_copy(void *dst, const void *src, size_t bytes) {
   if (!bytes || dst == src) return;
-#ifdef GS_EMU
-  memcpy(dst, src, bytes);
-#else
   GS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx().s()));
-#endif
 }
-template <class T> void meet_reduce(gsh_comm *c, T *buf, size_t n, int op) {
-  if (c->world == 1) return;
+/* HOST backend: every worker's `bytes` from its device buffer, in rank order, in host memory of every worker */
+void host_collect(gsh_comm *c, const void *dev_src, size_t bytes, std::vector<char> &all) {
+  std::vector<char> mine(bytes);
+  GS_HIP(hipMemcpyAsync(mine.data(), dev_src, bytes, hipMemcpyDeviceToHost, ctx().s()));
+  ctx().sync();
   Meet &m = *c->meet;
-  m.ptr[c->rank] = buf;
+  m.ptr[c->rank] = mine.data();
   m.wait();
+  all.resize((size_t)c->world * bytes);
+  for (int r = 0; r < c->world; r++) memcpy(all.data() + (size_t)r * bytes, m.ptr[r], bytes);
+  m.wait(); /* everybody has copied: `mine` may go */
+}
+void host_put(void *dev_dst, const void *host_src, size_t bytes) { /* the source is a local: done before it goes */
+  GS_HIP(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx().s()));
+  ctx().sync();
+}
+template <class T> void host_reduce(gsh_comm *c, T *buf, size_t n, int op) {
+  if (c->world == 1) return;
+  std::vector<char> all;
+  host_collect(c, buf, n * sizeof(T), all);
   std::vector<T> acc(n);
   for (size_t i = 0; i < n; i++) {
-    T a = ((const T *)m.ptr[0])[i];
+    T a;
+    memcpy(&a, all.data() + i * sizeof(T), sizeof(T));
     for (int r = 1; r < c->world; r++) {
-      const T b = ((const T *)m.ptr[r])[i];
+      T b;
+      memcpy(&b, all.data() + ((size_t)r * n + i) * sizeof(T), sizeof(T));
       a = op == 0 ? (T)(a + b) : (b > a ? b : a);
     }
     acc[i] = a;
   }
-  m.wait(); /* everybody has read everybody's input */
-  for (size_t i = 0; i < n; i++) buf[i] = acc[i];
-  m.wait();
+  host_put(buf, acc.data(), n * sizeof(T));
 }
 }  // namespace
 
@@ -152,20 +167,26 @@ int gsh_comm_init_all(gsh_comm **comms, int ndev, const int *devices) {
     comms[i] = new gsh_comm();
     comms[i]->rank = i, comms[i]->world = ndev, comms[i]->device = devices ? devices[i] : i;
   }
+  auto host_backend = [&](const char *why) {
+    Meet *m = new Meet(ndev);
+    for (int i = 0; i < ndev; i++) {
+      comms[i]->kind = gsh_comm::HOST, comms[i]->meet = m;
+      snprintf(comms[i]->backend, sizeof comms[i]->backend, "host rendezvous of %d worker threads (%s)", ndev, why);
+    }
+    return 0;
+  };
 #ifdef GS_EMU
-  Meet *m = new Meet(ndev);
-  for (int i = 0; i < ndev; i++) {
-    comms[i]->kind = gsh_comm::EMU, comms[i]->meet = m;
-    snprintf(comms[i]->backend, sizeof comms[i]->backend, "emulated rendezvous of %d host threads (test tool)", ndev);
-  }
-  return 0;
+  return ndev == 1 ? 0 : host_backend("emulator build, a test tool");
 #else
+  const char *force = getenv("GS_COMM_BACKEND");
+  if (ndev == 1 && !(getenv("GS_COMM_RCCL") && getenv("GS_COMM_RCCL")[0] == '1')) return 0; /* LOCAL: a world of one needs no RCCL */
+  if (force && !strcmp(force, "host")) return ndev == 1 ? 0 : host_backend("GS_COMM_BACKEND=host");
   Rccl &r = rccl();
   if (!r.ok) {
-    if (ndev == 1) return 0; /* a world of one needs no RCCL */
-    fprintf(stderr, "grayskull_hip: %d GPUs need RCCL and librccl.so cannot be used: %s\n", ndev, r.why.c_str());
-    for (int i = 0; i < ndev; i++) delete comms[i], comms[i] = nullptr;
-    return -1;
+    if (ndev == 1) return 0;
+    fprintf(stderr, "grayskull_hip: librccl.so cannot be used (%s): the %d workers exchange their results through host memory\n",
+            r.why.c_str(), ndev);
+    return host_backend("librccl unavailable");
   }
   int before = 0;
   (void)hipGetDevice(&before);
@@ -213,11 +234,9 @@ void gsh_comm_broadcast(gsh_comm *c, void *buf, size_t bytes, int root) {
   }
 #endif
   if (c->world == 1) return;
-  Meet &m = *c->meet;
-  m.ptr[c->rank] = buf;
-  m.wait();
-  if (c->rank != root) meet_copy(buf, m.ptr[root], bytes);
-  m.wait();
+  std::vector<char> all;
+  host_collect(c, buf, bytes, all);
+  if (c->rank != root) host_put(buf, all.data() + (size_t)root * bytes, bytes);
 }
 
 void gsh_comm_all_gather(gsh_comm *c, const void *send, void *recv, size_t bytes_per_rank) {
@@ -231,14 +250,12 @@ void gsh_comm_all_gather(gsh_comm *c, const void *send, void *recv, size_t bytes
   }
 #endif
   if (c->world == 1) {
-    meet_copy(recv, send, bytes_per_rank);
+    local_copy(recv, send, bytes_per_rank);
     return;
   }
-  Meet &m = *c->meet;
-  m.ptr[c->rank] = send;
-  m.wait();
-  for (int r = 0; r < c->world; r++) meet_copy((char *)recv + (size_t)r * bytes_per_rank, m.ptr[r], bytes_per_rank);
-  m.wait();
+  std::vector<char> all;
+  host_collect(c, send, bytes_per_rank, all);
+  host_put(recv, all.data(), all.size());
 }
 
 /* op: 0 = sum, 1 = max; in place */
@@ -252,7 +269,7 @@ void gsh_comm_all_reduce_u64(gsh_comm *c, unsigned long long *buf, size_t n, int
     return;
   }
 #endif
-  meet_reduce(c, buf, n, op);
+  host_reduce(c, buf, n, op);
 }
 void gsh_comm_all_reduce_f64(gsh_comm *c, double *buf, size_t n, int op) {
   check_thread(c);
@@ -264,7 +281,7 @@ void gsh_comm_all_reduce_f64(gsh_comm *c, double *buf, size_t n, int op) {
     return;
   }
 #endif
-  meet_reduce(c, buf, n, op);
+  host_reduce(c, buf, n, op);
 }
 
 }  /* extern "C" */

@@ -80,6 +80,12 @@ unsigned gsh_profile_read(double *total_ms) {
   return n;
 }
 void gsh_tune(int key, int value) {
+#ifndef GS_EXPERIMENT
+  if ((key == 16 || key == 22 || key == 23) && value != 0) { /* the keys that change results exist in experiment builds only */
+    fprintf(stderr, "grayskull_hip: gsh_tune(%d, %d) ignored: that probe needs a -DGS_EXPERIMENT build (make experiment)\n", key, value);
+    return;
+  }
+#endif
   if (key >= 0 && key < 32) g_tune.set(key, value);
 }
 void gsh_sync(void) { ctx().sync(); }

@@ -38,65 +38,27 @@ void run_compaction(unsigned long long *mask, unsigned *cnt, unsigned nchunks, u
 }
 
 /* ------------------------------------------------------------------ FAST */
-/* gs_fast pass 1 (w, h >= 7, n <= kMaxZ): the LDS-tile kernel by default.  The strip kernel (gsh_tune key 7 = 1)
- * decides per 256-px row span instead of per 64 px: on 32 x 720p (profiles/r02i_fast_tile.log) it is 1.25x faster on
- * flat frames (1.6 vs 2.0 us per frame), equal on bright frames and 1.1-1.4x SLOWER on texture and on frames with
- * large p < t regions (the block-noise frames of configs[3]: there every pixel is a candidate under the reference's
- * unsigned wrap, and a 256-px span almost always touches one).  Key 7 = 2: one global byte load per ring pixel
- * (the round-1 form: texture-addresser bound, 4.9 vs 4.2 us per frame). */
-/* zero_words / zero_n: words the default kernel clears on the side (pass 2's chunk counters); returns whether it did */
-/* nz / nz_frame_words: the default kernel also leaves the bitmap of scored pixels (k_fast.h); fast_score_leaves_bitmap() says
- * whether the call will take that kernel */
-bool fast_score_leaves_bitmap(unsigned threshold) {
-  return !(g_tune[7] >= 1 && g_tune[7] <= 4) && threshold <= 0xffffff00u;
-}
+/* gs_fast pass 1 (w, h >= 7, n <= kMaxZ): k_fast_score_q4 (LDS tile, 4 px per thread through the compass filter, candidates
+ * queued; 48-row tiles: 32 x 720p block noise 101 us at 16 rows, 94 at 32, 92 at 48 / 64, profiles/r04l_fast_tile_rows.log),
+ * which also leaves the bitmap of scored pixels for the sparse NMS pass.  Thresholds above 0xffffff00 (p + t wraps in 32 bits)
+ * and gsh_tune key 7 = 2 take k_fast_score_px: one global byte load per ring pixel, the literal form of ref :491-513.
+ * Returns whether the bitmap was written. */
+bool fast_score_leaves_bitmap(unsigned threshold) { return g_tune[7] != 2 && threshold <= 0xffffff00u; }
 bool launch_fast_score(hipStream_t on, const uint8_t *img, uint8_t *score, unsigned w, unsigned h, unsigned n,
-                       unsigned threshold, unsigned *zero_words = nullptr, unsigned zero_n = 0,
-                       unsigned long long *nz = nullptr, size_t nz_frame_words = 0) {
+                       unsigned threshold, unsigned long long *nz = nullptr, size_t nz_frame_words = 0) {
   const size_t fb = (size_t)w * h;
-  if (g_tune[7] == 1 && w % 4 == 0 && fb < 0x7fffffffull && ((uintptr_t)img & 3) == 0 && ((uintptr_t)score & 3) == 0 &&
-      threshold <= 0xffffff00u) {
-    /* strip kernel: ~6 waves per SIMD when the batch allows, bands of >= 8 rows */
-    const unsigned cw = (w + 255) / 256, rows = h - 6;
-    unsigned long long T = ((unsigned long long)rows * cw * n + 6143) / 6144;
-    T = T < 8 ? 8 : T > 64 ? 64 : T;
-    const unsigned nb = (rows + (unsigned)T - 1) / (unsigned)T;
-    GS_LAUNCH(k_fast_score4, dim3(cw, (nb + 3) / 4, n), dim3(64, 4), 0, on, img, score, w, h, (unsigned)T, fb, threshold);
-  } else if (g_tune[7] == 2) {
+  if (!fast_score_leaves_bitmap(threshold)) {
     GS_LAUNCH(k_fast_score_px, grid2d(w - 6, h - 6, n), dim3(64, 4), 0, on, img, score, w, h, fb, threshold);
-  } else if (g_tune[7] == 3) {
-    /* LDS tile + block-local candidate queue: measured and NOT the default (profiles/r03i_fast_candidate_queue.log, 32 x 720p
-     * score pass): block noise 72.7 -> 69.9 us, tiled lena 109 -> 92, but +8 % on bright noise, flat and random frames --
-     * half of the pass is the tile load, the compass filter and the byte stores, which the queue does not touch */
-    GS_LAUNCH(k_fast_score_cq, dim3((w - 6 + 63) / 64, (h - 6 + kFastTileRows - 1) / kFastTileRows, n), dim3(64, 4), 0, on,
-              img, score, w, h, fb, threshold);
-  } else if (g_tune[7] == 4 || threshold > 0xffffff00u) { /* round-2 default: one pixel per lane, whole wave rows scored */
-    GS_LAUNCH(k_fast_score_tile, dim3((w - 6 + 63) / 64, (h - 6 + kFastTileRows - 1) / kFastTileRows, n), dim3(64, 4), 0, on,
-              img, score, w, h, fb, threshold);
-  } else { /* LDS tile, 4 px per thread through the compass filter, candidates queued (k_fast.h) */
-    /* tile height (k_fast.h): 48 rows by default (32 x 720p block noise: gs_fast 101 us at 16 rows, 94 at 32, 92 at 48 / 64;
-     * flat frames 55 -> 47; 8 x 4K 178 -> 151 at 64; profiles/r04l_fast_tile_rows.log), key 25 = 16 / 32 / 48 / 64 */
-    const unsigned rows = g_tune[25] == 16 ? 16u : g_tune[25] == 32 ? 32u : g_tune[25] == 64 ? 64u : 48u;
-    const unsigned tx = (w - 6 + 63) / 64, ty = (h - 6 + rows - 1) / rows;
-    const unsigned long long nt = (unsigned long long)tx * ty * n;
-    GS_ASSERT(nt < (1ull << 24)); /* the kernel's 32-bit strides (zeroing loop, tile index) stay clear of 2^32: 2^24 tiles = 2^34 pixels per call */
-    const unsigned share = (g_tune[18] == 1 || !topo().eight_xcds()) ? 0u : (unsigned)((nt + 7) / 8); /* key 18 = 1: tiles in launch order */
-    const dim3 grid(share ? share * 8u : (unsigned)nt), block(64, g_tune[26] == 128 ? 2 : 4);
-    if (g_tune[26] == 128) { /* experiment: 128 threads per tile */
-      if (rows == 32) GS_LAUNCH((k_fast_score_q4<32, 128>), grid, block, 0, on, img, score, w, h, fb, threshold, tx, ty, (unsigned)nt, share, zero_words, zero_n, nz, nz_frame_words);
-      else if (rows == 64) GS_LAUNCH((k_fast_score_q4<64, 128>), grid, block, 0, on, img, score, w, h, fb, threshold, tx, ty, (unsigned)nt, share, zero_words, zero_n, nz, nz_frame_words);
-      else GS_LAUNCH((k_fast_score_q4<48, 128>), grid, block, 0, on, img, score, w, h, fb, threshold, tx, ty, (unsigned)nt, share, zero_words, zero_n, nz, nz_frame_words);
-      return true;
-    }
-    switch (rows) {
-      case 16: GS_LAUNCH(k_fast_score_q4<16>, grid, block, 0, on, img, score, w, h, fb, threshold, tx, ty, (unsigned)nt, share, zero_words, zero_n, nz, nz_frame_words); break;
-      case 32: GS_LAUNCH(k_fast_score_q4<32>, grid, block, 0, on, img, score, w, h, fb, threshold, tx, ty, (unsigned)nt, share, zero_words, zero_n, nz, nz_frame_words); break;
-      case 64: GS_LAUNCH(k_fast_score_q4<64>, grid, block, 0, on, img, score, w, h, fb, threshold, tx, ty, (unsigned)nt, share, zero_words, zero_n, nz, nz_frame_words); break;
-      default: GS_LAUNCH(k_fast_score_q4<48>, grid, block, 0, on, img, score, w, h, fb, threshold, tx, ty, (unsigned)nt, share, zero_words, zero_n, nz, nz_frame_words);
-    }
-    return true;
+    return false;
   }
-  return false;
+  constexpr unsigned rows = 48;
+  const unsigned tx = (w - 6 + 63) / 64, ty = (h - 6 + rows - 1) / rows;
+  const unsigned long long nt = (unsigned long long)tx * ty * n;
+  GS_ASSERT(nt < (1ull << 24)); /* the kernel's 32-bit strides (tile index) stay clear of 2^32: 2^24 tiles = 2^34 pixels per call */
+  const unsigned share = (g_tune[18] == 1 || !topo().eight_xcds()) ? 0u : (unsigned)((nt + 7) / 8); /* key 18 = 1: tiles in launch order */
+  const dim3 grid(share ? share * 8u : (unsigned)nt), block(64, 4);
+  GS_LAUNCH(k_fast_score_q4<rows>, grid, block, 0, on, img, score, w, h, fb, threshold, tx, ty, (unsigned)nt, share, nz, nz_frame_words);
+  return true;
 }
 
 /* clip_w / clip_h (single frame only): the caller's score map is smaller than the image; positions
@@ -119,20 +81,20 @@ void launch_fast(const uint8_t *img, uint8_t *score, unsigned w, unsigned h, uns
   const size_t fb = (size_t)w * h;
   /* (Both passes in one walk -- score tile, NMS and mask words from LDS, round 3's k_fast_fused -- measured 127 us against
    * 63 + 23 per 32 x 720p and was removed in round 4: scripts/experiments/not_kept/, profiles/r03t_fast_fused_not_kept.log.) */
-  /* pass 2, sparse (round 4 default; k_fast_nms.h): the score kernel leaves a bitmap of the scored pixels, one word per
-   * 64-px tile row of the interior, and only those are tested.  Key 19 = 2: the strip NMS over every pixel (round 3's
-   * default), 1: the item-by-item kernel (round 2). */
+  /* pass 2, sparse (k_fast_nms.h): the score kernel leaves a bitmap of the scored pixels, one word per 64-px tile row of
+   * the interior, and only those are tested.  Key 19 = 1, and the calls whose score pass is k_fast_score_px: the
+   * item-by-item kernel k_fast_nms below. */
   {
     const unsigned tx = (w - 6 + 63) / 64;
     const unsigned long long nw = (unsigned long long)tx * (h - 6);
-    if (g_tune[19] != 1 && g_tune[19] != 2 && fast_score_leaves_bitmap(threshold) && nw * 64 < (1ull << 32)) {
+    if (g_tune[19] != 1 && fast_score_leaves_bitmap(threshold) && nw * 64 < (1ull << 32)) {
       const unsigned nwords = (unsigned)nw, nchunks = (nwords + kChunkWords - 1) / kChunkWords;
       GS_ASSERT((unsigned long long)n * nchunks < (1ull << 32));
       unsigned long long *nz = (unsigned long long *)ctx().scratch(SL_NZ, (size_t)n * nchunks * kChunkWords * 8);
       unsigned long long *mask = (unsigned long long *)ctx().scratch(SL_MASK, (size_t)n * nchunks * kChunkWords * 8);
       unsigned *cnt = (unsigned *)ctx().scratch(SL_CNT, (size_t)n * nchunks * 4);
       unsigned *pfx = (unsigned *)ctx().scratch(SL_PFX, (size_t)n * nchunks * 4);
-      launch_fast_score(st, img, score, w, h, n, threshold, nullptr, 0, nz, (size_t)nchunks * kChunkWords);
+      launch_fast_score(st, img, score, w, h, n, threshold, nz, (size_t)nchunks * kChunkWords);
       if (clip_w && n == 1 && (clip_w < w || clip_h < h))
         GS_LAUNCH(k_fast_clip, grid2d(w, h, 1), dim3(64, 4), 0, st, score, w, h, clip_w, clip_h);
       GS_LAUNCH(k_fast_nms_sparse, dim3((nchunks + 3) / 4, n), dim3(256), 0, st, (const uint8_t *)score, w, fb,
@@ -141,32 +103,6 @@ void launch_fast(const uint8_t *img, uint8_t *score, unsigned w, unsigned h, uns
                      FastEmitPadded{score, w, tx * 64u, fb, kps, nkps, ((uintptr_t)kps & 15) == 0, 3u}, st, pfx);
       return;
     }
-  }
-  /* pass 2 in strip form (k_fast_nms.h) when the score map qualifies for the strip machinery: items numbered over
-   * rows padded to whole mask words.  Key 19 = 1: the item-by-item kernel k_fast_nms (round 2). */
-  if (g_tune[19] != 1 && strip_ok(w, h, score, score) && w >= 32 && (unsigned long long)((w + 63) / 64) * 64 * h < (1ull << 32)) {
-    const unsigned wpr = (w + 63) / 64, nwords = wpr * h, nchunks = (nwords + kChunkWords - 1) / kChunkWords;
-    unsigned long long *mask = (unsigned long long *)ctx().scratch(SL_MASK, (size_t)n * nchunks * kChunkWords * 8);
-    unsigned *cnt = (unsigned *)ctx().scratch(SL_CNT, (size_t)n * nchunks * 4);
-    unsigned *pfx = (unsigned *)ctx().scratch(SL_PFX, (size_t)n * nchunks * 4);
-    /* the default score kernel zeroes the chunk counters on the side (a fill launch costs 5 us of a 100-us call) */
-    GS_ASSERT((unsigned long long)n * nchunks < (1ull << 32)); /* n <= 65535 frames of < 2^32 padded items */
-    const bool zeroed = launch_fast_score(st, img, score, w, h, n, threshold, cnt, n * nchunks);
-    if (clip_w && n == 1 && (clip_w < w || clip_h < h))
-      GS_LAUNCH(k_fast_clip, grid2d(w, h, 1), dim3(64, 4), 0, st, score, w, h, clip_w, clip_h);
-    if (!zeroed) GS_HIP(hipMemsetAsync(cnt, 0, (size_t)n * nchunks * 4, st));
-    for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
-      const unsigned nn = std::min(kMaxZ, n - f0);
-      const StripCfg c = strip_cfg(w, h - 6, nn);
-      GS_LAUNCH(k_fast_nms16, c.grid, c.block, 0, st, (const uint8_t *)score + fb * f0, w, h, c.T, fb | c.xcd_flag,
-                mask + (size_t)f0 * nchunks * kChunkWords, cnt + (size_t)f0 * nchunks, wpr, nchunks);
-    }
-    /* (Tried and not kept: eight chunks per emit wave -- fewer waves, loads batched -- 19 -> 33 us per 32 x 720p: the pass is
-     * one wave's latency chain, and 14,464 small waves hide it better than 1,808 long ones.  Bands of 16 rows for the NMS
-     * kernel: 23.6 -> 25 us.  profiles/r03m_fast_emit_not_kept.log) */
-    run_compaction(mask, cnt, nchunks, n, nkps, counts,
-                   FastEmitPadded{score, w, wpr * 64u, fb, kps, nkps, ((uintptr_t)kps & 15) == 0}, st, pfx);
-    return;
   }
   launch_fast_score(st, img, score, w, h, n, threshold);
   const unsigned nitems = (w - 6) * (h - 6);
@@ -482,7 +418,9 @@ void launch_lbp_padded(const gsh_cascade *dc, const LbpGeomCache &gc, const unsi
     }
     s0 = s1;
   }
+#ifdef GS_EXPERIMENT
   if (g_tune[16] == 1) return; /* timing aid (scripts/bench_lbp_stages.py): the cascade kernels alone, no rect emission */
+#endif
   run_compaction(mask, cnt, nch, n, max_rects, counts,
                  LbpEmit{gc.d_scales, (unsigned)gc.scales.size(), step, rects, max_rects});
 }
@@ -574,14 +512,16 @@ void orb_extract_libm(OrbJob *J, unsigned nj, unsigned threshold) {
     GS_LAUNCH(k_orient_moments, dim3(q.nkps, q.n), dim3(64), 0, st, q.img, q.w, q.h, (const unsigned *)(sel + koff[j] * 12), 12u, 15u,
               mom + koff[j] * 2, (const unsigned *)(selcnt + foff[j]), fb);
   }
-  std::vector<unsigned> hk(ktot * 12), hn(ftot);
-  std::vector<int> hm(ktot * 2);
-  GS_HIP(hipMemcpyAsync(hn.data(), selcnt, ftot * 4, hipMemcpyDeviceToHost, st));
-  GS_HIP(hipMemcpyAsync(hk.data(), sel, ktot * 48, hipMemcpyDeviceToHost, st));
-  GS_HIP(hipMemcpyAsync(hm.data(), mom, ktot * 8, hipMemcpyDeviceToHost, st));
+  /* pinned staging (Ctx::pinned): the records come back at PCIe rate instead of through the runtime's pageable path */
+  unsigned *hn = (unsigned *)ctx().pinned(Ctx::PIN_A, ftot * 4);
+  unsigned *hk = (unsigned *)ctx().pinned(Ctx::PIN_B, ktot * 48);
+  int *hm = (int *)ctx().pinned(Ctx::PIN_C, ktot * 8);
+  GS_HIP(hipMemcpyAsync(hn, selcnt, ftot * 4, hipMemcpyDeviceToHost, st));
+  GS_HIP(hipMemcpyAsync(hk, sel, ktot * 48, hipMemcpyDeviceToHost, st));
+  GS_HIP(hipMemcpyAsync(hm, mom, ktot * 8, hipMemcpyDeviceToHost, st));
   ctx().sync();
   /* host half of ref :662-665: the angle and the two sines of every kept keypoint, frame by frame */
-  std::vector<KpIn> kin(ktot);
+  KpIn *kin = (KpIn *)ctx().pinned(Ctx::PIN_D, ktot * sizeof(KpIn));
   struct Item { unsigned j, f; };
   std::vector<Item> items;
   size_t kept_total = 0;
@@ -604,7 +544,7 @@ void orb_extract_libm(OrbJob *J, unsigned nj, unsigned threshold) {
   };
   unsigned nthreads = 1;
   if (kept_total >= 4096 && items.size() > 1)
-    nthreads = (unsigned)std::min<size_t>({8, std::max(1u, std::thread::hardware_concurrency()), items.size(), kept_total / 2048});
+    nthreads = (unsigned)std::min<size_t>({12, std::max(1u, std::thread::hardware_concurrency()), items.size(), kept_total / 1024});
   if (nthreads > 1) {
     std::vector<std::thread> th;
     for (unsigned t = 1; t < nthreads; t++) th.emplace_back(do_items, items.size() * t / nthreads, items.size() * (t + 1) / nthreads);
@@ -622,13 +562,13 @@ void orb_extract_libm(OrbJob *J, unsigned nj, unsigned threshold) {
   if (!kept_total) return;
   KpIn *dk = (KpIn *)ctx().scratch(SL_KIN, ktot * sizeof(KpIn));
   uint32_t *dd = (uint32_t *)ctx().scratch(SL_DESC, ktot * 32);
-  GS_HIP(hipMemcpyAsync(dk, kin.data(), ktot * sizeof(KpIn), hipMemcpyHostToDevice, st));
+  GS_HIP(hipMemcpyAsync(dk, kin, ktot * sizeof(KpIn), hipMemcpyHostToDevice, st));
   for (unsigned j = 0; j < nj; j++)
     if (J[j].n)
       GS_LAUNCH(k_brief, dim3(J[j].nkps, J[j].n), dim3(256), 0, st, J[j].img, J[j].w, J[j].h, (const KpIn *)(dk + koff[j]),
                 dd + koff[j] * 8, (const unsigned *)(selcnt + foff[j]), (size_t)J[j].w * J[j].h);
-  std::vector<uint32_t> hd(ktot * 8);
-  GS_HIP(hipMemcpyAsync(hd.data(), dd, ktot * 32, hipMemcpyDeviceToHost, st));
+  uint32_t *hd = (uint32_t *)hk; /* the records are consumed: their staging buffer (48 B per keypoint) takes the 32-byte descriptors */
+  GS_HIP(hipMemcpyAsync(hd, dd, ktot * 32, hipMemcpyDeviceToHost, st));
   ctx().sync();
   for (unsigned j = 0; j < nj; j++)
     for (unsigned f = 0; f < J[j].n; f++) {
@@ -679,7 +619,7 @@ void launch_match(const uint32_t *k1, unsigned n1, const uint32_t *k2, unsigned 
 
 extern "C" {
 
-void gsh_probe_fast_score(uint8_t *score, const uint8_t *img, unsigned w, unsigned h, unsigned n, unsigned threshold) {
+void gsh_fast_score_batch(uint8_t *score, const uint8_t *img, unsigned w, unsigned h, unsigned n, unsigned threshold) {
   GS_ASSERT(score && img && w >= 7 && h >= 7 && n >= 1 && n <= kMaxZ);
   launch_fast_score(ctx().s(), img, score, w, h, n, threshold);
 }

@@ -131,6 +131,24 @@ struct Ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false, user_stream = false, async = false;
   struct Buf { void *p = nullptr; size_t cap = 0; } slot[SL_COUNT];
+  /* grow-only PINNED host staging (hipHostMalloc) for the few paths that bring records back to the host inside a call: a
+   * copy into pageable memory is staged by the runtime at a few GB/s and blocks the stream meanwhile */
+  enum { PIN_A = 0, PIN_B, PIN_C, PIN_D, PIN_COUNT };
+  Buf pin[PIN_COUNT];
+  void *pinned(int i, size_t bytes) {
+    ensure_device();
+    Buf &b = pin[i];
+    if (b.cap < bytes) {
+      if (b.p) {
+        sync();
+        GS_HIP(hipHostFree(b.p));
+      }
+      const size_t cap = bytes + bytes / 4 + 256;
+      GS_HIP(hipHostMalloc(&b.p, cap, 0));
+      b.cap = cap;
+    }
+    return b.p;
+  }
   bool jump_ready = false; /* SL_JUMP holds the xorshift jump table of gsh_synth_batch */
   std::map<unsigned long long, LbpGeomCache> geom_cache; /* keyed by gsh_cascade::id */
   /* flattened copy of the caller's struct gs_lbp_cascade for the drop-in gs_lbp_* calls, keyed by a hash
@@ -229,6 +247,10 @@ struct Ctx {
   void release() {
     for (auto &b : slot) {
       if (b.p) (void)hipFree(b.p);
+      b.p = nullptr, b.cap = 0;
+    }
+    for (auto &b : pin) {
+      if (b.p) (void)hipHostFree(b.p);
       b.p = nullptr, b.cap = 0;
     }
     jump_ready = false;

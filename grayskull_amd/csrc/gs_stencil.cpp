@@ -93,7 +93,9 @@ StripCfg strip_cfg(unsigned w, unsigned rows, unsigned n, unsigned waves_per_sim
  * the frame afterwards), which saves one dword load per row in the two edge lanes. */
 void launch_sobel(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned n, bool keep_cols) {
   if (w < 3 || h < 3 || n == 0) return;
+#ifdef GS_EXPERIMENT
   if (g_tune[22] == 1) keep_cols = false; /* probe: without the dst column reads (columns 0 / w-1 then receive junk) */
+#endif
   hipStream_t st = ctx().s();
   const size_t fb = (size_t)w * h;
   for (unsigned f0 = 0; f0 < n; f0 += kMaxZ) {
@@ -387,6 +389,7 @@ void launch_integral_pad(dim3 grid, hipStream_t st, const unsigned *ii, unsigned
 
 extern "C" {
 
+#ifdef GS_EXPERIMENT
 void gsh_probe_strip_copy(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned n) {
   GS_ASSERT(dst && src && w >= 32);
   const StripCfg c = strip_cfg(w, h, n, 5, 2, g_tune[0] > 0 ? (unsigned)g_tune[0] : 8u, ragged(w) ? 1 : 0);
@@ -394,6 +397,7 @@ void gsh_probe_strip_copy(uint8_t *dst, const uint8_t *src, unsigned w, unsigned
   else if (ragged(w)) GS_LAUNCH(k_strip_copy<1>, c.grid, c.block, 0, ctx().s(), dst, src, w, h, c.T, (size_t)w * h | c.xcd_flag);
   else GS_LAUNCH(k_strip_copy<0>, c.grid, c.block, 0, ctx().s(), dst, src, w, h, c.T, (size_t)w * h | c.xcd_flag);
 }
+#endif
 /* ---------------------------------------------------------------- batch: stencils */
 void gsh_blur_batch(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned n,
                     unsigned radius) {

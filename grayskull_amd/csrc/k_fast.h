@@ -9,10 +9,13 @@
  * UNSIGNED arithmetic (`v > p + t`, else `v < p - t` with unsigned t): when p < t the darker
  * bound wraps and every non-brighter pixel counts as darker (ref :496-498).
  *
- * Algorithmic traffic is 3 B/px (score pass 1 R + 1 W, NMS pass 1 R), but the score pass is
- * VALU-bound (16 ring pixels x two class masks + the minimum |v - p|: ~1.3 VALU wave-instructions per
- * pixel on textured frames); three score kernels: k_fast_score_tile (default: ring bytes from an LDS
- * tile), k_fast_score4 (strip form), k_fast_score_px (one global byte load per ring pixel).
+ * Algorithmic traffic is 3 B/px (score pass 1 R + 1 W, NMS pass 1 R), but the score pass is VALU-bound (0.76 VALU
+ * wave-instructions per pixel on the block-noise frames of configs[3], profiles/fast_valu_pmc.json).  Two score kernels:
+ * k_fast_score_q4 (default: LDS tile, 4 px per thread through the compass filter, candidates queued and scored 64 to a wave)
+ * and k_fast_score_px (one global byte load per ring pixel; any threshold, incl. those where p + t wraps in 32 bits).  The
+ * kernels that lost to them over rounds 2-4 -- the one-pixel-per-lane LDS tile form, its candidate-queue variant, the strip
+ * form with image rows in registers, the strip NMS over every pixel -- were deleted in round 5 (scripts/experiments/not_kept/
+ * keeps what was measured; profiles/r02i_fast_tile.log, r03i_fast_candidate_queue.log, r04z_fast.log).
  */
 #ifndef GS_K_FAST_H
 #define GS_K_FAST_H
@@ -55,20 +58,22 @@ GS_DEV unsigned fast_score_u32(unsigned p, const unsigned (&v)[16], unsigned thr
 
 GS_DEV unsigned fast_score(unsigned p, const unsigned (&v)[16], unsigned threshold) {
   if (threshold > 0xffffff00u) return fast_score_u32(p, v, threshold); /* kernel argument: uniform */
-  /* v, p <= 255; t in [256, 2^32-256] behaves like 256 (never brighter, p - t wraps).  Round 5: the class bits are pushed
-   * into the masks with compare + add-with-carry pairs (push_gt_u32: two full-rate instructions per ring pixel and class;
-   * the sign-bit form before it paid a half-rate v_alignbit_b32 each), in the reference's own UNSIGNED arithmetic:
-   * lo = p - t wraps to a huge value when p < t and every ring pixel then compares below it. */
-  const unsigned t = threshold < 256u ? threshold : 256u, hi = p + t, lo = p - t;
+  /* v, p <= 255; t in [256, 2^32-256] behaves like 256 (never brighter, p - t wraps): clamp so the
+   * signed differences below cannot overflow.  (Round 5 tried compare + add-with-carry pairs -- push_gt_u32, two
+   * full-rate instructions per ring pixel and class instead of a subtraction and a half-rate v_alignbit_b32: the score
+   * pass of 32 x 720p block noise went from 46-47 to 49-51 us, the inline-asm pairs pin VCC and keep the scheduler from
+   * interleaving the 32 chains; profiles/r05e_fast.log.  Not kept.) */
+  const int t = (int)(threshold < 256u ? threshold : 256u), hi = (int)p + t, lo = (int)p - t;
   uint32_t bright = 0, dark = 0;
   unsigned mind = 255;
 #pragma unroll
   for (int j = 0; j < 16; j++) {
-    bright = push_gt_u32(bright, v[j], hi); /* v > p + t */
-    dark = push_gt_u32(dark, lo, v[j]);     /* v < p - t (unsigned) */
+    bright = alignbit(bright, (uint32_t)(hi - (int)v[j]), 31); /* sign set <=> v > p + t */
+    dark = alignbit(dark, (uint32_t)((int)v[j] - lo), 31);     /* sign set <=> v < p - t (no wrap) */
     mind = umin(mind, absdiff_u16(v[j], p));
   }
-  if (p < t) dark = bright ^ 0xffffu; /* the wrap: d = !b && v < huge = !b (ref :496-498) */
+  bright &= 0xffffu, dark &= 0xffffu;
+  if (lo < 0) dark = bright ^ 0xffffu; /* unsigned wrap of p - t in the reference */
   return (ring_has_run9(bright) || ring_has_run9(dark)) ? mind : 0u;
 }
 
@@ -109,144 +114,7 @@ __global__ __launch_bounds__(256) void k_fast_score_px(const uint8_t *img, uint8
   if (in) score[(size_t)blockIdx.z * frame_bytes + (size_t)y * w + x] = (uint8_t)s;
 }
 
-/* pass 1, default: the same per-pixel evaluation, but the 17 bytes of a pixel come from an LDS tile instead of
- * 17 global byte loads.  k_fast_score_px spends its time in the texture addresser: 4.5 M wave-level byte loads per
- * 32 x 720p launch at ~8 cycles each are ~90 % of its 98 us, while its VALU is 54 % busy
- * (profiles/r02i_pmc_features.txt).  Here a block of 256 threads copies the (16 + 6) x (64 + 6) pixel region of
- * its 64 x 16 output tile with ~1.5 (unaligned) dword loads per thread and every ring pixel is a ds_read_u8
- * (consecutive lanes read consecutive bytes: conflict-free).  grid (ceil((w-6)/64), ceil((h-6)/16), n), block (64,4);
- * thread (tx, ty) scores rows ty, ty+4, ty+8, ty+12 of the tile. */
-constexpr unsigned kFastTileRows = 16, kFastTileDw = 18; /* 72 bytes per tile row: 64 + 6, rounded up to dwords */
-__global__ __launch_bounds__(256) void k_fast_score_tile(const uint8_t *img, uint8_t *score, unsigned w, unsigned h,
-                                                         size_t frame_bytes, unsigned threshold) {
-  __shared__ uint32_t tile32[(kFastTileRows + 6) * kFastTileDw];
-  const uint8_t *frame = img + (size_t)blockIdx.z * frame_bytes;
-  const unsigned tid = threadIdx.y * 64u + threadIdx.x;
-  const unsigned x_t = blockIdx.x * 64u, y_t = blockIdx.y * kFastTileRows; /* image position of tile byte (0, 0) */
-  for (unsigned i = tid; i < (kFastTileRows + 6) * kFastTileDw; i += 256u) {
-    const unsigned r = i / kFastTileDw, c = i - r * kFastTileDw;
-    /* rows / columns past the image are only ever ring pixels of positions that are not scored: whatever the
-     * frame holds there will do, but the last bytes of the frame are real ring pixels -- byte by byte */
-    const size_t off = (size_t)(y_t + r) * w + x_t + c * 4u;
-    uint32_t v = 0;
-    if (off + 4 <= frame_bytes) {
-      v = load_u32_unaligned(frame + off);
-    } else {
-      for (unsigned b = 0; b < 4; b++)
-        if (off + b < frame_bytes) v |= (uint32_t)frame[off + b] << (8 * b);
-    }
-    tile32[i] = v;
-  }
-  __syncthreads();
-  const uint8_t *tb = (const uint8_t *)tile32;
-  constexpr int S = (int)kFastTileDw * 4; /* tile row stride in bytes */
-  const unsigned x = 3 + x_t + threadIdx.x;
-#pragma unroll
-  for (unsigned k = 0; k < kFastTileRows / 4; k++) {
-    const unsigned ry = threadIdx.y + 4u * k, y = 3 + y_t + ry;
-    const bool in = x + 3 < w && y + 3 < h;
-    const uint8_t *c = tb + (ry + 3) * S + threadIdx.x + 3;
-    const unsigned p = c[0], v0 = c[-3 * S], v4 = c[3], v8 = c[3 * S], v12 = c[-3];
-    const bool cand = in && fast_compass_candidate(p, v0, v4, v8, v12, threshold);
-    unsigned sc = 0;
-    if (ballot(cand) != 0) { /* wave-uniform */
-      const unsigned v[16] = {v0,  c[-3 * S + 1], c[-2 * S + 2], c[-S + 3],
-                              v4,  c[S + 3],      c[2 * S + 2],  c[3 * S + 1],
-                              v8,  c[3 * S - 1],  c[2 * S - 2],  c[S - 3],
-                              v12, c[-S - 3],     c[-2 * S - 2], c[-3 * S - 1]};
-      sc = fast_score(p, v, threshold);
-    }
-    if (in) score[(size_t)blockIdx.z * frame_bytes + (size_t)y * w + x] = (uint8_t)sc;
-  }
-}
-
-/* pass 1 with block-local candidate compaction.  k_fast_score_tile is VALU-bound (0.70 of the issue rate,
- * profiles/fast_valu_pmc.json) and a wave scores all 64 of its pixels as soon as ONE passes the compass filter;
- * on the block-noise frames of configs[3] nearly every wave holds one, but only a quarter of the pixels do.  Here
- * the 1024 pixels of the tile go through the compass filter first (5 LDS bytes each); those that pass are queued
- * in LDS (one ds_add per wave row, order irrelevant) and the queue is scored 64 candidates to a wave -- every lane
- * of every fast_score is a real candidate; the others' score is 0 and is stored right away.  Tiles in which most
- * pixels pass (regions with p < threshold: the reference's unsigned wrap makes every pixel a candidate) gain
- * nothing and lose the queue round trip, so from half the tile on the rows are scored in place like
- * k_fast_score_tile does.  Same scores, same stores.  grid / block as k_fast_score_tile. */
-__global__ __launch_bounds__(256) void k_fast_score_cq(const uint8_t *img, uint8_t *score, unsigned w, unsigned h,
-                                                       size_t frame_bytes, unsigned threshold) {
-  __shared__ uint32_t tile32[(kFastTileRows + 6) * kFastTileDw];
-  __shared__ uint16_t queue[64 * kFastTileRows];
-  __shared__ unsigned qn;
-  const uint8_t *frame = img + (size_t)blockIdx.z * frame_bytes;
-  uint8_t *out = score + (size_t)blockIdx.z * frame_bytes;
-  const unsigned tid = threadIdx.y * 64u + threadIdx.x;
-  const unsigned x_t = blockIdx.x * 64u, y_t = blockIdx.y * kFastTileRows;
-  if (tid == 0) qn = 0;
-  for (unsigned i = tid; i < (kFastTileRows + 6) * kFastTileDw; i += 256u) {
-    const unsigned r = i / kFastTileDw, c = i - r * kFastTileDw;
-    const size_t off = (size_t)(y_t + r) * w + x_t + c * 4u;
-    uint32_t v = 0;
-    if (off + 4 <= frame_bytes) {
-      v = load_u32_unaligned(frame + off);
-    } else {
-      for (unsigned b = 0; b < 4; b++)
-        if (off + b < frame_bytes) v |= (uint32_t)frame[off + b] << (8 * b);
-    }
-    tile32[i] = v;
-  }
-  __syncthreads();
-  const uint8_t *tb = (const uint8_t *)tile32;
-  constexpr int S = (int)kFastTileDw * 4;
-  auto score_at = [&](const uint8_t *c) {
-    const unsigned v[16] = {c[-3 * S],     c[-3 * S + 1], c[-2 * S + 2], c[-S + 3], c[3],  c[S + 3],  c[2 * S + 2],  c[3 * S + 1],
-                            c[3 * S],      c[3 * S - 1],  c[2 * S - 2],  c[S - 3],  c[-3], c[-S - 3], c[-2 * S - 2], c[-3 * S - 1]};
-    return fast_score(c[0], v, threshold);
-  };
-  const unsigned x = 3 + x_t + threadIdx.x;
-  unsigned mine = 0; /* bit k: this thread's pixel of row ty + 4k passed the compass filter */
-#pragma unroll
-  for (unsigned k = 0; k < kFastTileRows / 4; k++) {
-    const unsigned ry = threadIdx.y + 4u * k, y = 3 + y_t + ry;
-    const bool in = x + 3 < w && y + 3 < h;
-    const uint8_t *c = tb + (ry + 3) * S + threadIdx.x + 3;
-    const bool cand = in && fast_compass_candidate(c[0], c[-3 * S], c[3], c[3 * S], c[-3], threshold);
-    mine |= (cand ? 1u : 0u) << k;
-    if (in && !cand) out[(size_t)y * w + x] = 0;
-  }
-  const unsigned total = wave_sum((unsigned)__popc(mine)); /* this wave's candidates */
-  __shared__ unsigned wtot[4];
-  if ((tid & 63u) == 0) wtot[tid >> 6] = total;
-  __syncthreads();
-  const unsigned ncand = wtot[0] + wtot[1] + wtot[2] + wtot[3]; /* block-uniform */
-  if (ncand == 0) return;
-  if (ncand * 2u >= 64u * kFastTileRows) { /* dense tile: in place, a whole wave row at a time */
-#pragma unroll
-    for (unsigned k = 0; k < kFastTileRows / 4; k++) {
-      const unsigned ry = threadIdx.y + 4u * k, y = 3 + y_t + ry;
-      if (ballot((mine >> k) & 1u) != 0) { /* wave-uniform */
-        const unsigned sc = score_at(tb + (ry + 3) * S + threadIdx.x + 3);
-        if ((mine >> k) & 1u) out[(size_t)y * w + x] = (uint8_t)sc;
-      }
-    }
-    return;
-  }
-#pragma unroll
-  for (unsigned k = 0; k < kFastTileRows / 4; k++) {
-    const bool cand = (mine >> k) & 1u;
-    const uint64_t m = ballot(cand);
-    if (m) {
-      const unsigned lane = lane_id();
-      unsigned base = 0;
-      if (lane == 0) base = atomicAdd(&qn, (unsigned)__popcll(m));
-      base = readlane0(base);
-      if (cand) queue[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)((threadIdx.y + 4u * k) * 64u + threadIdx.x);
-    }
-  }
-  __syncthreads();
-  for (unsigned i0 = 0; i0 < ncand; i0 += 256u) { /* block-uniform trip count */
-    const unsigned i = i0 + tid;
-    const unsigned e = queue[i < ncand ? i : ncand - 1u], ry = e >> 6, tx = e & 63u;
-    const unsigned sc = score_at(tb + (ry + 3) * S + tx + 3);
-    if (i < ncand) out[(size_t)(3 + y_t + ry) * w + 3 + x_t + tx] = (uint8_t)sc;
-  }
-}
+constexpr unsigned kFastTileDw = 18; /* 72 bytes per tile row of k_fast_score_q4: 64 + 6, rounded up to dwords */
 
 /* pass 1, round 3 default (threshold <= 0xffffff00): LDS tile, FOUR pixels per thread for the compass filter, candidates
  * queued and scored 64 to a wave.  Where k_fast_score_tile's time goes on the configs[3] frames (72 us per 32 x 720p):
@@ -271,7 +139,6 @@ template <unsigned ROWS, unsigned NT = 256>
 __global__ __launch_bounds__(NT, (NT == 256 && ROWS <= 48) ? 8 : 1) void k_fast_score_q4(const uint8_t *img, uint8_t *score, unsigned w, unsigned h,
                                                        size_t frame_bytes, unsigned threshold, unsigned tiles_x,
                                                        unsigned tiles_y, unsigned ntiles, unsigned xcd_share,
-                                                       unsigned *zero_words, unsigned zero_n,
                                                        unsigned long long *nz = nullptr, size_t nz_frame_words = 0) {
   static_assert(ROWS % 16 == 0 && ROWS >= 16 && ROWS <= 64 && (NT == 128 || NT == 256), "a thread takes one row of every group of NT / 16; queue entries are 16-bit");
   constexpr unsigned RG = NT / 16; /* tile rows per row group */
@@ -287,8 +154,6 @@ __global__ __launch_bounds__(NT, (NT == 256 && ROWS <= 48) ? 8 : 1) void k_fast_
    * (FETCH_SIZE 4.1 x the frame bytes, WRITE_SIZE 1.46 x from the split lines of the score map).  xcd_share != 0: a 1-D
    * grid of 8 * xcd_share blocks, XCD k walks tiles [k * xcd_share, (k + 1) * xcd_share) in order, so the tiles in flight
    * on one XCD are a few consecutive tile rows of one frame. */
-  /* the chunk counters of pass 2 are zeroed here (zero_n words, spread over the grid) instead of by a 5-us fill launch */
-  for (unsigned i = blockIdx.x * NT + threadIdx.y * 64u + threadIdx.x; i < zero_n; i += gridDim.x * NT) zero_words[i] = 0;
   unsigned tile = blockIdx.x;
   if (xcd_share) {
     tile = (blockIdx.x & 7u) * xcd_share + (blockIdx.x >> 3);
@@ -431,122 +296,6 @@ __global__ __launch_bounds__(NT, (NT == 256 && ROWS <= 48) ? 8 : 1) void k_fast_
     if (tid < ROWS && y_t + tid + 6u < h)
       nz[(size_t)tframe * nz_frame_words + (size_t)(y_t + tid) * tiles_x + tcol] =
           ncand ? (unsigned long long)nzw[2u * tid] | ((unsigned long long)nzw[2u * tid + 1u] << 32) : 0ull;
-  }
-}
-
-/* pass 1, strips (w % 4 == 0, 4-byte aligned frames, threshold <= 0xffffff00): a lane owns 4
- * consecutive pixels (one dword per row), a wave 256 px of a row, and walks DOWN a band of T rows
- * with the 7 image rows y-3..y+3 in registers as 12-byte windows (L, C, R: the neighbour lanes'
- * dwords come by v_mov_b32_dpp, only lanes 0 / 63 fetch a halo dword), so every image byte is
- * loaded once per band and every ring pixel is a static byte of a register.
- *   Per row the wave first runs the compass filter on packed u16 pairs: with S2 / s2 the second
- * largest / second smallest of the four compass pixels (8 packed min/max per pair of pixels),
- * ">= 2 brighter" is S2 > p + t and ">= 2 darker" is s2 < p - t; p < t (the reference's unsigned
- * wrap, ref :496-498) always passes.  Only pixel slots in which some lane of the wave passes are
- * scored with fast_score -- the same function as the per-pixel kernel, so scores are identical.
- * grid (ceil(w/256), ceil(bands/4), n), block (64, 4): the 4 waves of a block are 4 bands. */
-struct FastRow { uint32_t L, C, R; };
-template <int B> GS_DEV unsigned fast_wbyte(const FastRow &r) { /* byte B (0..11) of the window */
-  static_assert(B >= 0 && B < 12, "window byte");
-  const uint32_t d = B < 4 ? r.L : B < 8 ? r.C : r.R;
-  return (d >> (8 * (B & 3))) & 0xffu;
-}
-template <int K> GS_DEV unsigned fast_score_slot(const FastRow (&rw)[7], unsigned threshold) {
-  /* rw[d + 3] = image row y + d; pixel K is window byte 4 + K; ring order of ref :485-486 */
-  const unsigned p = fast_wbyte<4 + K>(rw[3]);
-  const unsigned v[16] = {fast_wbyte<4 + K>(rw[0]),     fast_wbyte<4 + K + 1>(rw[0]), fast_wbyte<4 + K + 2>(rw[1]),
-                          fast_wbyte<4 + K + 3>(rw[2]), fast_wbyte<4 + K + 3>(rw[3]), fast_wbyte<4 + K + 3>(rw[4]),
-                          fast_wbyte<4 + K + 2>(rw[5]), fast_wbyte<4 + K + 1>(rw[6]), fast_wbyte<4 + K>(rw[6]),
-                          fast_wbyte<4 + K - 1>(rw[6]), fast_wbyte<4 + K - 2>(rw[5]), fast_wbyte<4 + K - 3>(rw[4]),
-                          fast_wbyte<4 + K - 3>(rw[3]), fast_wbyte<4 + K - 3>(rw[2]), fast_wbyte<4 + K - 2>(rw[1]),
-                          fast_wbyte<4 + K - 1>(rw[0])};
-  return fast_score(p, v, threshold);
-}
-
-__global__ __launch_bounds__(256) void k_fast_score4(const uint8_t *img, uint8_t *score, unsigned w,
-                                                     unsigned h, unsigned T, size_t frame_bytes,
-                                                     unsigned threshold) {
-  const BufRsrc src = make_buf(img + (size_t)blockIdx.z * frame_bytes, frame_bytes);
-  const unsigned lane = threadIdx.x & 63u, x0 = (blockIdx.x * 64u + threadIdx.x) * 4u;
-  const unsigned band = uniform(blockIdx.y * blockDim.y + threadIdx.y);
-  const int y0 = 3 + (int)(band * T);
-  if (y0 >= (int)h - 3) return; /* whole wave */
-  const int nrows = ((int)h - 3 - y0) < (int)T ? ((int)h - 3 - y0) : (int)T;
-  uint8_t *out = score + (size_t)blockIdx.z * frame_bytes;
-  struct Raw { uint32_t c, hh; };
-  auto load = [&](int y) { /* rows outside the image are never used by an interior pixel */
-    const bool ok = (unsigned)y < h && x0 < w;
-    const uint32_t base = (uint32_t)y * w + x0;
-    uint32_t ho = kOOB;
-    if (lane == 0 && x0 > 0) ho = base - 4;
-    if (lane == 63 && x0 + 4 < w) ho = base + 4;
-    Raw r;
-    r.c = buf_load4(src, ok ? base : kOOB);
-    r.hh = buf_load4(src, ok ? ho : kOOB);
-    return r;
-  };
-  auto widen = [&](const Raw &r) { return FastRow{wave_shr1(r.c, r.hh), r.c, wave_shl1(r.c, r.hh)}; };
-  /* which of this lane's 4 pixels are interior columns (3 <= x < w - 3) */
-  bool col_in[4];
-#pragma unroll
-  for (int k = 0; k < 4; k++) col_in[k] = x0 + k >= 3u && x0 + k + 3u < w;
-  const uint32_t in01 = (col_in[0] ? 0xffffu : 0u) | (col_in[1] ? 0xffff0000u : 0u);
-  const uint32_t in23 = (col_in[2] ? 0xffffu : 0u) | (col_in[3] ? 0xffff0000u : 0u);
-  const bool whole = col_in[0] && col_in[3];
-  const uint32_t t16 = threshold < 256u ? threshold : 256u, tt = t16 | (t16 << 16);
-
-  FastRow ring[7]; /* iteration I (mod 7): image row y + d sits in slot (I + d + 3) % 7 */
-  static_for<6>([&](auto K) { ring[decltype(K)::value] = widen(load(y0 - 3 + decltype(K)::value)); });
-  Raw raw = load(y0 + 3);
-  for (int base = 0; base < nrows; base += 7) {
-    static_for<7>([&](auto I) {
-      constexpr int ii = decltype(I)::value;
-      const int i = base + ii;
-      if (i >= nrows) return; /* wave-uniform */
-      const int y = y0 + i;
-      ring[(ii + 6) % 7] = widen(raw);
-      raw = load(y + 4);
-      const FastRow(&r0)[7] = ring;
-      const FastRow rw[7] = {r0[(ii + 0) % 7], r0[(ii + 1) % 7], r0[(ii + 2) % 7], r0[(ii + 3) % 7],
-                             r0[(ii + 4) % 7], r0[(ii + 5) % 7], r0[(ii + 6) % 7]};
-      /* compass filter, pixels (0,1) and (2,3) as u16 pairs */
-      uint32_t cand[2];
-#pragma unroll
-      for (int hp = 0; hp < 2; hp++) {
-        const uint32_t P = hp ? unpack_hi(rw[3].C) : unpack_lo(rw[3].C);
-        const uint32_t a = hp ? unpack_hi(rw[0].C) : unpack_lo(rw[0].C);  /* ( 0, -3) */
-        const uint32_t c = hp ? unpack_hi(rw[6].C) : unpack_lo(rw[6].C);  /* ( 0, +3) */
-        /* (+3, 0): window bytes 7+k;  (-3, 0): window bytes 1+k */
-        const uint32_t b = hp ? perm_b32(rw[3].R, rw[3].C, 0x0c060c05u) : perm_b32(rw[3].R, rw[3].C, 0x0c040c03u);
-        const uint32_t d = hp ? perm_b32(rw[3].C, rw[3].L, 0x0c040c03u) : perm_b32(rw[3].C, rw[3].L, 0x0c020c01u);
-        const uint32_t x = pk_max_u16(a, b), yv = pk_min_u16(a, b), z = pk_max_u16(c, d), u = pk_min_u16(c, d);
-        const uint32_t mid_hi = pk_min_u16(x, z), mid_lo = pk_max_u16(yv, u);
-        const uint32_t S2 = pk_max_u16(mid_hi, mid_lo); /* second largest  */
-        const uint32_t s2 = pk_min_u16(mid_hi, mid_lo); /* second smallest */
-        const uint32_t bright2 = pk_subsat_u16(S2, pk_add_u16(P, tt));   /* != 0 <=> S2 > p + t */
-        const uint32_t dark2 = pk_subsat_u16(pk_subsat_u16(P, tt), s2);  /* != 0 <=> s2 < p - t (p >= t) */
-        const uint32_t wrap = pk_subsat_u16(tt, P);                      /* != 0 <=> p < t */
-        cand[hp] = bright2 | dark2 | wrap;
-      }
-      cand[0] &= in01, cand[1] &= in23;
-      unsigned s[4] = {0, 0, 0, 0};
-      if (ballot((cand[0] | cand[1]) != 0) != 0) { /* wave-uniform; slot by slot */
-        if (ballot((cand[0] & 0xffffu) != 0) != 0) s[0] = fast_score_slot<0>(rw, threshold);
-        if (ballot((cand[0] >> 16) != 0) != 0) s[1] = fast_score_slot<1>(rw, threshold);
-        if (ballot((cand[1] & 0xffffu) != 0) != 0) s[2] = fast_score_slot<2>(rw, threshold);
-        if (ballot((cand[1] >> 16) != 0) != 0) s[3] = fast_score_slot<3>(rw, threshold);
-      }
-      if (x0 < w) {
-        uint8_t *o = out + (size_t)y * w + x0;
-        if (whole) {
-          *(uint32_t *)o = s[0] | (s[1] << 8) | (s[2] << 16) | (s[3] << 24);
-        } else { /* lanes holding border columns: the 3-px frame of the scoremap is never written (ref :489) */
-#pragma unroll
-          for (int k = 0; k < 4; k++)
-            if (col_in[k]) o[k] = (uint8_t)s[k];
-        }
-      }
-    });
   }
 }
 

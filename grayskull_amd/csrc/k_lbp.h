@@ -64,6 +64,14 @@ struct LbpArgs {
                                     counted here; the buffer keeps its four entries) */
 };
 constexpr unsigned kLbpGroupShift = 5, kLbpSuperShift = 10; /* chunks per group / super-group (log2) */
+/* a detection counter as the L2 holds it (the L1 is per CU and not coherent): a stale value is harmless, it only skips less */
+GS_DEV unsigned lbp_counter_load(const unsigned *p) {
+#ifdef GS_EMU
+  return *p;
+#else
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); /* global_load_dword sc1: device scope, no L1 hit */
+#endif
+}
 
 /* cascade tables of one scale, staged in LDS by the block: every lane of every wave evaluates
  * the same weak classifier of the same scale, so these reads are same-address broadcasts
@@ -310,7 +318,7 @@ __global__ __launch_bounds__(256) void k_lbp_cascade(LbpArgs a, LbpPhases ph) {
    * the FIRST max_rects hits in (scale, y, x) order.  Detections published by chunks that precede
    * this one in that order can only grow, so once they reach the cap no window of this chunk can
    * be among the first max_rects: skip the block (its mask words and counter stay zero).  The
-   * counters are read with returning atomics (served where the adds are performed); a stale or
+   * counters are read at device scope (past the CU's L1, where the adds are performed); a stale or
    * partial sum only skips less, so the result is exact for any dispatch order -- and blocks are
    * dispatched scale by scale (inside a scale: in chunk order, or as eight bands side by side with the
    * XCD-aware mapping), so on frames that reach the cap every later scale is skipped, and most of the
@@ -322,9 +330,14 @@ __global__ __launch_bounds__(256) void k_lbp_cascade(LbpArgs a, LbpPhases ph) {
     unsigned *hs = a.hits_super + (size_t)blockIdx.z * a.nsupers;
     unsigned *hg = a.hits_group + (size_t)blockIdx.z * a.ngroups;
     unsigned before = 0;
-    for (unsigned q = tid; q < g2; q += 64u) before += atomicAdd(&hs[q], 0u);
-    const unsigned gq = (g2 << (kLbpSuperShift - kLbpGroupShift)) + tid; /* the <= 31 earlier groups of the own super-group */
-    if (gq < g1) before += atomicAdd(&hg[gq], 0u);
+    /* round 5: while the frame's total is below the cap nothing can be skipped -- one load instead of ~60-90 counters -- and
+     * the counters are read with plain loads that bypass the L1 (the returning atomics of rounds 2-4 were serialised per
+     * address by the L2; a stale value only skips less) */
+    if (a.cap < a.nwindows_cap && lbp_counter_load(&a.hits_total[blockIdx.z]) >= a.cap) {
+      for (unsigned q = tid; q < g2; q += 64u) before += lbp_counter_load(&hs[q]);
+      const unsigned gq = (g2 << (kLbpSuperShift - kLbpGroupShift)) + tid; /* the <= 31 earlier groups of the own super-group */
+      if (gq < g1) before += lbp_counter_load(&hg[gq]);
+    }
     before = wave_sum(before);
     if (tid == 0) before_s = before;
   }

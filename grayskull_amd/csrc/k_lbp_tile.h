@@ -202,23 +202,26 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 8 : 1) void k_lbp_tile(LbpArgs a, 
     tp.nwy = sc.ny - tp.y0w < TH ? sc.ny - tp.y0w : TH;
   }
   /* max_rects early exit (k_lbp.h): everything that lies wholly before the group of the tile's FIRST window precedes
-   * every window of the tile in the reference's scan order */
+   * every window of the tile in the reference's scan order.  The counters are requested here and summed behind the
+   * staging below, so their round trip to the L2 (returning atomics) hides under the table / tile copies; a skipped block
+   * has staged for nothing, but blocks are only skipped once a frame has reached the cap. */
   __shared__ unsigned before_s;
-  if (a.cap < a.nwindows_cap) {
+  const bool capped = a.cap < a.nwindows_cap;
+  unsigned before_part = 0;
+  if (capped && tid < 64u) {
     const unsigned lin = sc.chunk_base + (tp.y0w * sc.nx + tp.x0w) / kChunkItems;
-    if (tid < 64u) {
-      const unsigned g1 = lin >> kLbpGroupShift, g2 = lin >> kLbpSuperShift;
-      unsigned *hs = a.hits_super + (size_t)blockIdx.z * a.nsupers;
-      unsigned *hg = a.hits_group + (size_t)blockIdx.z * a.ngroups;
-      unsigned before = 0;
-      for (unsigned q = tid; q < g2; q += 64u) before += atomicAdd(&hs[q], 0u);
+    const unsigned g1 = lin >> kLbpGroupShift, g2 = lin >> kLbpSuperShift;
+    unsigned *hs = a.hits_super + (size_t)blockIdx.z * a.nsupers;
+    unsigned *hg = a.hits_group + (size_t)blockIdx.z * a.ngroups;
+    /* everything published so far bounds what lies before this tile: while the frame's total is below the cap nothing can
+     * be skipped and ONE load settles it (round 5: every block used to read ~60-90 counters with returning atomics, which
+     * the L2 serialises per address -- the late scales, whose chunk numbers are large, paid for it).  Plain loads that
+     * bypass the L1 do: a stale value only skips less. */
+    if (lbp_counter_load(&a.hits_total[blockIdx.z]) >= a.cap) {
+      for (unsigned q = tid; q < g2; q += 64u) before_part += lbp_counter_load(&hs[q]);
       const unsigned gq = (g2 << (kLbpSuperShift - kLbpGroupShift)) + tid;
-      if (gq < g1) before += atomicAdd(&hg[gq], 0u);
-      before = wave_sum(before);
-      if (tid == 0) before_s = before;
+      if (gq < g1) before_part += lbp_counter_load(&hg[gq]);
     }
-    __syncthreads();
-    if (before_s >= a.cap) return;
   }
   /* ---- LDS: stages | geometry re-based to the tile's row stride | subsets | truth tables | lane layouts | queues | tile */
   const unsigned step = (unsigned)a.step;
@@ -279,7 +282,12 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 8 : 1) void k_lbp_tile(LbpArgs a, 
       }
     }
   }
+  if (capped && tid < 64u) {
+    const unsigned before = wave_sum(before_part);
+    if (tid == 0) before_s = before;
+  }
   __syncthreads();
+  if (capped && before_s >= a.cap) return; /* whole block */
   /* ---- from here on the waves are on their own */
   const LbpTileTables t{l_stage, l_geom, l_sub, l_truth, l_pst, a.weak};
   uint16_t *queue = queue_all + wave * (R * 64u);

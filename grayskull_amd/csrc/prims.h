@@ -7,6 +7,14 @@
 #ifndef GS_PRIMS_H
 #define GS_PRIMS_H
 
+/* The compile-time experiment hooks (each `#ifndef X / #define X <default>` further down in the sources) may only be set in
+ * builds that say so: a release library cannot be built with one of them flipped by accident. */
+#if !defined(GS_EXPERIMENT) && (defined(GS_FUSED_SPARE) || defined(GS_FUSED_VGPR_ATTR) || defined(GS_EVENT_FLAGS) ||       \
+                                defined(GS_ORDER_EVENT_FLAGS) || defined(GS_LOAD_AUX) || defined(GS_STORE_AUX) ||         \
+                                defined(GS_LBP_PREFETCH) || defined(GS_MAD2_OPAQUE) || defined(GS_LBP_TILE_ODD_STRIDE))
+#error "experiment hook set without -DGS_EXPERIMENT (make variant / make experiment add it)"
+#endif
+
 #ifdef GS_EMU
 #include "hip_emu.h"
 #define GS_DYN_LDS(name) char *name = emu::S().dyn_lds

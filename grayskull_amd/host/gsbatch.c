@@ -478,6 +478,14 @@ static void frame_range(unsigned rank, unsigned world, unsigned total, unsigned 
   *hi = *lo + base + (rank < rem ? 1 : 0);
 }
 
+/* A worker that left early would strand its peers inside the next collective (--gpus N: they would wait in RCCL for ever
+ * and the process would hang in pthread_join instead of failing).  The only early exits were host allocation failures, so
+ * they end the process the way the library ends on its own errors: message + abort(). */
+static void gsb_oom(int line) {
+  fprintf(stderr, "gsbatch: out of host memory (gsbatch.c:%d)\n", line);
+  abort();
+}
+
 static void *worker(void *arg) {
   struct job *jb = (struct job *)arg;
   const struct stage *st = jb->st;
@@ -504,7 +512,7 @@ static void *worker(void *arg) {
     else gsh_memset(blob_dev, 0, (size_t)len);
     gsh_comm_broadcast(jb->comm, blob_dev, (size_t)len, 0);
     blob = (uint8_t *)malloc((size_t)len);
-    if (!blob) return jb->rc = 1, (void *)0;
+    if (!blob) gsb_oom(__LINE__);
     gsh_download(blob, blob_dev, (size_t)len);
     gsh_free(blob_dev), gsh_free(len_dev);
     if (parse_cascade(blob, (size_t)len, &mine) != 0) {
@@ -532,7 +540,7 @@ static void *worker(void *arg) {
     tkps = (struct gs_keypoint *)malloc(5000 * sizeof *tkps); /* nanomagick.c:301 */
     skps = (struct gs_keypoint *)malloc(5000 * sizeof *skps);
     matches = (struct gs_match *)malloc(kOrbMatches * sizeof *matches);
-    if (!tkps || !skps || !matches) return jb->rc = 1, (void *)0;
+    if (!tkps || !skps || !matches) gsb_oom(__LINE__);
   }
 
   for (g = 0; g < jb->ngroups; g++) {
@@ -567,7 +575,7 @@ static void *worker(void *arg) {
       if ((size_t)ow * oh > max_fb) max_fb = (size_t)ow * oh;
     }
     idx = (int *)malloc(ngroup * sizeof *idx);
-    if (!idx) return jb->rc = 1, (void *)0;
+    if (!idx) gsb_oom(__LINE__);
     for (i = 0, f = 0; i < nf; i++)
       if (fr[i].group == g) idx[f++] = i;
     if (bad) { /* nanomagick: the verb prints its message, then "did not produce output image" */
@@ -595,7 +603,7 @@ static void *worker(void *arg) {
     stage = (uint8_t *)gsh_host_alloc(max_fb * cap); /* page-locked: one DMA each way per slice */
     sums_dev = (uint64_t *)gsh_malloc((size_t)cap * 8);
     sums_host = (uint64_t *)malloc((size_t)cap * 8);
-    if (!sums_host) return jb->rc = 1, (void *)0;
+    if (!sums_host) gsb_oom(__LINE__);
     if (term && term->v == V_ORB) {
       /* one scratch buffer for both pyramids, like nanomagick's (there: a static 1 MiB array, which a
        * frame beyond ~700x500 overruns; here: as large as the bigger pyramid needs) */
@@ -615,10 +623,10 @@ static void *worker(void *arg) {
         rects_dev = (struct gs_rect *)gsh_malloc((size_t)cap * kFaceCap * sizeof *rects_dev);
         rects_host = (struct gs_rect *)malloc((size_t)cap * kFaceCap * sizeof *rects_host);
       }
-      if (!cnt_host || (term->v == V_KEYPOINTS ? !kps_host : !rects_host)) return jb->rc = 1, (void *)0;
+      if (!cnt_host || (term->v == V_KEYPOINTS ? !kps_host : !rects_host)) gsb_oom(__LINE__);
     }
     jb->t_alloc += now_ms() - t0;
-    if (!p.thr_host || !failed) return jb->rc = 1, (void *)0;
+    if (!p.thr_host || !failed) gsb_oom(__LINE__);
 
     for (b0 = 0; b0 < n; b0 += cap) {
       const unsigned nb = n - b0 < cap ? n - b0 : cap;
@@ -714,7 +722,7 @@ static void *worker(void *arg) {
           { /* stitched picture: template left, frame right, the 15 best matches as lines (nanomagick.c:321-342) */
             const unsigned sw = tmpl.w + ow, sh = tmpl.h > oh ? tmpl.h : oh;
             out = (uint8_t *)calloc((size_t)sw * sh, 1);
-            if (!out) return jb->rc = 1, (void *)0;
+            if (!out) gsb_oom(__LINE__);
             for (y = 0; y < tmpl.h; y++) memcpy(out + (size_t)y * sw, tmpl_host + (size_t)y * tmpl.w, tmpl.w);
             for (y = 0; y < oh; y++) memcpy(out + (size_t)y * sw + tmpl.w, img + (size_t)y * ow, ow);
             for (k = 0; k < (nm < 15 ? nm : 15); k++) {
@@ -809,7 +817,7 @@ static void *worker(void *arg) {
     uint64_t *send_dev = (uint64_t *)gsh_malloc(per), *recv_dev = (uint64_t *)gsh_malloc(per * (size_t)world);
     double *t_dev = (double *)gsh_malloc(8);
     int r;
-    if (!send_host || !recv_host) return jb->rc = 1, (void *)0;
+    if (!send_host || !recv_host) gsb_oom(__LINE__);
     memcpy(send_host, jb->file_sum, (size_t)nf * 8), memcpy(send_host + nf, jb->file_cnt, (size_t)nf * 8);
     gsh_upload(send_dev, send_host, per);
     gsh_comm_all_gather(jb->comm, send_dev, recv_dev, per);

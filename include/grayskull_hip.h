@@ -33,35 +33,44 @@ void *gsh_get_stream(void);
 void gsh_set_async(int on);               /* drop-in gs_* calls on device pointers skip
                                              the final stream sync when on             */
 void gsh_sync(void);                      /* hipStreamSynchronize(current stream)       */
-/* launch tuning of the strip kernels: key 0 rows per band (0 = auto), 1 block shape
- * (0: 64x4, 1: 256x1, 2: 128x2), 3 set to 1 to disable the fused pipeline kernel, 4 preset of
- * the cascade stages at which gs_lbp_detect re-packs survivors (1: never), 5 frames per chunk of
- * gsh_edge_pipeline_batch's internal overlap (0 = default 32, negative = never split),
- * 6 comparison switches: 1 = generic two-pass gs_integral, 2 = block-per-band gs_integral,
- * 3 = integral-image route for gs_blur(radius > 3) / gs_adaptive_threshold instead of the sliding
- * box kernel, 4 = the any-radius box kernel k_box16 also for radii <= 16 (instead of the register-ring form k_box16r),
- * 7 score kernel of gs_fast: 0 = LDS tile, 4 px per thread through the compass filter, candidates queued (default),
- * 1 = strip kernel (lane = 4 px, image rows in registers), 2 = one global byte load per ring pixel (round 1), 3 = LDS tile, one
- * pixel per lane + candidate queue, 4 = LDS tile, one pixel per lane, whole wave rows scored (round 2),
- * 8 frames per launch (test hook for the batch splitting of every launcher), 9 LBP: stages / survivor
- * share at which a block first re-packs (max stages + 16 * tenths [+ later points]; key 4 >= 1000 = custom fixed split),
- * 10 trips per block gs_histogram aims at, 11 its blocks per frame, 12 bytes per histogram piece (test
- * hook for images above 1 GiB), 13 chunk-to-XCD mapping of the LBP cascade (1 = dispatch order, 2 = XCD-aware always),
- * 14, 15 unused (round 3's optional LBP stage prefilter, removed in round 4), 16 = 1: gs_lbp_detect runs its cascade
- * kernels but emits nothing (timing aid; counts / rects are NOT written), 17 = 1: the cascade evaluates re-packed windows
- * one per lane instead of one per quad of lanes, 18 band-to-XCD mapping of the strip kernels and tile-to-XCD mapping of the gs_fast score pass (1 = dispatch order, 2 = XCD-aware
- * always), 19: pass 2 of gs_fast -- 0 the sparse kernel behind the score kernel's bitmap of scored pixels (round 4), 2 the
- * strip kernel over every pixel (round 3), 1 item by item (round 2).
- * 20 = 1: gs_match_template on the VALU dot-product kernels instead of the matrix cores (2 / 3: the matrix-core kernel with
- * 64 x 128 tiles / with 32 x 64 tiles and the template rows split over four waves, whatever the image size; 4 / 5: its window
- * sums of squares always from the row-prefix + sliding-column passes / always from the integral table of squares -- default: the
- * table from 4 Mpx),
- * 21 = 1: the round-3 rule for the strip kernels (whole 16-px strips at 16-byte aligned addresses only; everything else per
- * pixel), 22 = 1: gs_sobel without the reads that preserve columns 0 / w-1 (probe; those columns receive junk), 23 = 1: the
- * strip-copy probe keeps the stencils' halo load, 24 the realigning strip flavour (1 = never, 2 = always; 0 = by address
- * phase and width, csrc/gs_stencil.cpp strip_mode), 25 = 16 / 32 / 64: tile rows of the gs_fast score kernel (default 48), 26 = 128: its
- * 128-thread variant.  Process-wide, every entry an atomic.
- * Results never change (keys 16 and 22 excepted). */
+/* ---- launch tuning.  gsh_tune(key, value) sets one entry of a PROCESS-WIDE table of launch heuristics (every entry an
+ * atomic; nothing in a product path writes them): measurement scripts and the test-suite use it to force the paths a
+ * heuristic would not take on a given input.  RESULTS NEVER DEPEND ON ANY KEY.  (The two probes that did change results --
+ * the cascade without rect emission, gs_sobel without its column reads -- exist only in builds with -DGS_EXPERIMENT, see
+ * below.)  0 is every key's default. */
+enum gsh_tune_key {
+  GSH_TUNE_STRIP_BAND_ROWS = 0,   /* rows per band of the strip kernels (0 = auto) */
+  GSH_TUNE_STRIP_BLOCK_SHAPE = 1, /* 0: 64x4, 1: 256x1, 2: 128x2, 3: by frame width (default) */
+  GSH_TUNE_2 = 2,                 /* reserved (default 1) */
+  GSH_TUNE_NO_FUSED_PIPELINE = 3, /* 1: gsh_edge_pipeline_batch on the separate per-call kernels */
+  GSH_TUNE_LBP_PHASE_PRESET = 4,  /* k_lbp_cascade: preset of the stages at which a block re-packs survivors (1: never; >= 1000: custom split) */
+  GSH_TUNE_PIPELINE_CHUNK = 5,    /* frames per chunk of gsh_edge_pipeline_batch's internal overlap (0 = 32, negative = never split) */
+  GSH_TUNE_COMPARE = 6,           /* 1 generic two-pass gs_integral, 2 block-per-band gs_integral, 3 integral-image route for gs_blur(r > 3) /
+                                     gs_adaptive_threshold, 4 the any-radius box kernel also for radii <= 16 */
+  GSH_TUNE_FAST_SCORE = 7,        /* 0: k_fast_score_q4 (LDS tile, candidates queued), 2: k_fast_score_px (one global byte load per ring pixel) */
+  GSH_TUNE_FRAMES_PER_LAUNCH = 8, /* test hook for the batch splitting of every launcher */
+  GSH_TUNE_LBP_ADAPTIVE = 9,      /* k_lbp_cascade: max stages + 16 * tenths [+ later points] of the first re-packing point */
+  GSH_TUNE_HIST_TRIPS = 10,       /* trips per block gs_histogram aims at */
+  GSH_TUNE_HIST_BLOCKS = 11,      /* its blocks per frame */
+  GSH_TUNE_HIST_PIECE = 12,       /* bytes per histogram piece (test hook for images above 1 GiB) */
+  GSH_TUNE_LBP_XCD = 13,          /* chunk / tile -> XCD mapping of the LBP kernels: 1 dispatch order, 2 XCD-aware always */
+  GSH_TUNE_LBP_KERNEL = 14,       /* 0: per scale by rule (k_lbp_tile with the tile shape the scale's LDS footprint allows, else
+                                     k_lbp_cascade), 1: k_lbp_cascade for every scale, -1: the rule without its one-block-per-CU
+                                     fallback, 2 + i: tile shape i of k_lbp_tile wherever it fits */
+  GSH_TUNE_LBP_TILE_SWITCH = 15,  /* k_lbp_tile: first + 16 * tenths -- dense stages [0, first), then while more than tenths/10 of a
+                                     wave's windows live, then one lane per (window, classifier) pair */
+  GSH_TUNE_EXPERIMENT_16 = 16,    /* GS_EXPERIMENT builds only: gs_lbp_detect runs its kernels but emits nothing */
+  GSH_TUNE_LBP_ONE_LANE = 17,     /* 1: k_lbp_cascade evaluates re-packed windows one per lane instead of one per quad */
+  GSH_TUNE_STRIP_XCD = 18,        /* band -> XCD mapping of the strip kernels / tile -> XCD mapping of the gs_fast score pass: 1 dispatch
+                                     order, 2 XCD-aware always */
+  GSH_TUNE_FAST_NMS = 19,         /* 0: k_fast_nms_sparse behind the score kernel's bitmap, 1: k_fast_nms item by item */
+  GSH_TUNE_TMATCH = 20,           /* 1: gs_match_template on the VALU dot-product kernels; 2 / 3: matrix-core kernel with 64 x 128 / 32 x 64
+                                     tiles whatever the image size; 4 / 5: window sums of squares always by passes / always from the table */
+  GSH_TUNE_STRIP_ROUND3_RULE = 21,/* 1: strip kernels only for whole 16-px strips at 16-byte aligned addresses */
+  GSH_TUNE_EXPERIMENT_22 = 22,    /* GS_EXPERIMENT builds only: gs_sobel without the reads that preserve columns 0 / w-1 */
+  GSH_TUNE_EXPERIMENT_23 = 23,    /* GS_EXPERIMENT builds only: the strip-copy probe keeps the stencils' halo load */
+  GSH_TUNE_STRIP_REALIGN = 24     /* realigning strip flavour: 1 never, 2 always, 0 by address phase and width */
+};
 void gsh_tune(int key, int value);
 /* measurement aid for bench.py: while on, gsh_edge_pipeline_batch brackets every launch of its
  * fused blur+sobel+histogram kernel with HIP events on the stream it is launched on (up to 4096
@@ -70,10 +79,13 @@ void gsh_tune(int key, int value);
  * the last read and their summed duration in milliseconds. */
 void gsh_profile(int on);
 unsigned gsh_profile_read(double *total_ms);
-/* diagnostic: strip-kernel traffic pattern with no arithmetic (access-pattern ceiling) */
+#ifdef GS_EXPERIMENT
+/* Experiment builds only (make experiment -> build_variants/libgs_experiment.so; the release library does not export it):
+ * strip-kernel traffic pattern with no arithmetic (access-pattern ceiling).  The same builds honour the result-changing
+ * keys 16 / 22 / 23 and the compile-time hooks GS_FUSED_SPARE, GS_FUSED_VGPR_ATTR, GS_EVENT_FLAGS, GS_ORDER_EVENT_FLAGS,
+ * GS_LOAD_AUX, GS_STORE_AUX, GS_LBP_PREFETCH, GS_MAD2_OPAQUE, GS_LBP_TILE_ODD_STRIDE. */
 void gsh_probe_strip_copy(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned n);
-/* diagnostic: pass 1 of gs_fast alone (the score map of n frames; w, h >= 7), for timing / counter runs */
-void gsh_probe_fast_score(uint8_t *score, const uint8_t *img, unsigned w, unsigned h, unsigned n, unsigned threshold);
+#endif
 void gsh_shutdown(void);                  /* free this thread's scratch + stream        */
 
 void *gsh_malloc(size_t bytes);           /* hipMalloc; aborts on failure               */
@@ -142,6 +154,9 @@ uint64_t gsh_lbp_window_count(const struct gs_lbp_cascade *c, unsigned iw, unsig
                               float scale_factor, float min_scale, float max_scale, int step);
 
 /* ---- FAST / ORB / matching (ref :482, :651, :680) -------------------------------- */
+/* pass 1 of gs_fast alone (ref :487-513): the FAST-9 score map of n frames (interior pixels; the 3-px frame is not written,
+ * ref :489); w, h >= 7 */
+void gsh_fast_score_batch(uint8_t *score, const uint8_t *img, unsigned w, unsigned h, unsigned n, unsigned threshold);
 /* kps: n*nkps records (device), counts: n (device).  scoremap: n frames; only the interior is
  * written, the 3-px frame is read by the NMS exactly like the reference does. */
 void gsh_fast_batch(const uint8_t *img, uint8_t *scoremap, unsigned w, unsigned h, unsigned n,

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Where the cascade's time goes: gs_lbp_detect with the frontalface cascade TRUNCATED to its first k stages
-(k = 1 .. 20), prefilter off (key 14 = -1) and on, 8 x 4K block-noise frames and 8 x 4K edge maps.
+(k = 1 .. 20), with the rule's kernels (gsh_tune key 14 = 0: k_lbp_tile where its tile fits) and with k_lbp_cascade for every scale
+(key 14 = 1), 8 x 4K block-noise frames and 8 x 4K edge maps.  Needs the experiment library (UB_LIB=build_variants/libgs_experiment.so:
+key 16 drops the rect emission so that a cap that is never reached needs no rect buffer).
 time(k) - time(k-1) = what stage k-1 costs; `alive` = detections of the truncated cascade / windows."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -21,7 +23,7 @@ def timeit(fn, reps=2):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 ks = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "1,2,3,4,5,6,8,10,14,20").split(",")]
-pres = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "0,2").split(",")]
+pres = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "0,1").split(",")]
 w, h, n = 3840, 2160, 8
 src = torch.empty((n, h, w), dtype=torch.uint8, device="cuda"); g.synth_batch(src, 1000)
 a, b = torch.empty_like(src), torch.zeros_like(src)

@@ -9,7 +9,7 @@ src = torch.empty((F, H, W), dtype=torch.uint8, device="cuda"); g.synth_batch(sr
 dst = torch.zeros_like(src); tmp = torch.zeros_like(src)
 hist = torch.zeros((F, 256), dtype=torch.int32, device="cuda"); thr = torch.zeros(F, dtype=torch.uint8, device="cuda")
 for _ in range(3):
-    g.probe_strip_copy(dst, src); g.blur_batch(tmp, src, 2); g.sobel_batch(dst, tmp); g.erode_batch(dst, src)
+    g.blur_batch(tmp, src, 2); g.sobel_batch(dst, tmp); g.erode_batch(dst, src)
     g.otsu_batch(dst, hist, thr); g.threshold_batch(dst, thr)
     g.edge_pipeline_batch(dst, None, src, 2, hist, thr)
 # the "next" rows with their own kernels + the barrier-free integral

@@ -18,7 +18,7 @@ dc = g.cascade_create(Cascade.from_blob(os.path.join(ROOT, "tests/golden/frontal
 rects = torch.zeros((4, 4096, 4), dtype=torch.int32, device="cuda"); counts = torch.zeros(4, dtype=torch.int32, device="cuda")
 for _ in range(3):
     g.fast_batch(src, sm, kps, cnt, 5000, 20)
-    g.tune(7, 2); g.probe_fast_score(sm, src, 20); g.tune(7, 1); g.probe_fast_score(sm, src, 20); g.tune(7, 4); g.probe_fast_score(sm, src, 20); g.tune(7, 0)
+    g.tune(7, 2); g.fast_score_batch(sm, src, 20); g.tune(7, 0)
     g.histogram_batch(big, hist)
     g.lbp_detect_batch(dc, ii, rects, counts, 4096, 1.1, 1.0, 4.0, 1)
 torch.cuda.synchronize()

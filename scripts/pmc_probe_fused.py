@@ -10,7 +10,7 @@ src = torch.empty((F, H, W), dtype=torch.uint8, device="cuda"); g.synth_batch(sr
 dst = torch.zeros_like(src)
 hist = torch.zeros((F, 256), dtype=torch.int32, device="cuda"); thr = torch.zeros(F, dtype=torch.uint8, device="cuda")
 for _ in range(4):
-    g.probe_strip_copy(dst, src)
+    if g.experiment: g.probe_strip_copy(dst, src)  # experiment builds only
     g.blur_sobel_batch(dst, src, 2)
     g.edge_pipeline_batch(dst, None, src, 2, hist, thr)
 torch.cuda.synchronize()

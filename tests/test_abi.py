@@ -15,6 +15,7 @@ def declared_functions():
     for hdr in ("grayskull.h", "grayskull_hip.h"):
         txt = open(os.path.join(INC, hdr)).read()
         txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        txt = re.sub(r"#ifdef GS_EXPERIMENT.*?#endif", "", txt, flags=re.S)  # not in the release library
         txt = "\n".join(ln for ln in txt.splitlines() if not ln.lstrip().startswith("#define"))
         for m in re.finditer(r"\b(gsh?_[a-z0-9_]+)\s*\(", txt):
             names.add(m.group(1))

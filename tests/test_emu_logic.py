@@ -61,7 +61,7 @@ def test_next_rows(emu, oracle, shape):
                                    (64, 40), (48, 7), (32, 16), (1040, 9), (2064, 8)])
 def test_fast(emu, oracle, shape):
     w, h = shape
-    for strip in ((0, 1, 2, 3, 4) if w % 4 == 0 else (0, 2, 3, 4)):  # gsh_tune key 7: 0 LDS tile, 4 px per thread + candidate queue (default), 1 strip kernel, 2 one global byte load per ring pixel, 3 LDS tile + candidate queue, 4 LDS tile (round 2)
+    for strip in (0, 2):  # gsh_tune key 7: 0 LDS tile, 4 px per thread + candidate queue (default), 2 one global byte load per ring pixel
         emu.tune(7, strip)
         try:
             pc.fast(emu, oracle, Oracle.synth(w, h, 5), MEM)
@@ -75,32 +75,26 @@ def test_fast(emu, oracle, shape):
             emu.tune(7, 0)
 
 
-@pytest.mark.parametrize("rows", [16, 32, 48, 64])
-def test_fast_score_tile_heights(emu, oracle, rows):
-    """k_fast_score_q4<ROWS> (gsh_tune key 25; 48 by default since round 4): a thread filters 4 pixels of ROWS / 16 tile rows,
-    the candidate queue and the in-place path for dense tiles span the taller tile; heights that leave ragged last tiles"""
+def test_fast_score_tiles_that_stick_out_of_the_frame(emu, oracle):
+    """k_fast_score_q4<48>: a thread filters 4 pixels of three tile rows, the candidate queue and the in-place path for dense
+    tiles span the 48-row tile; frame heights that leave ragged last tiles"""
     rs = np.random.RandomState(31)
-    try:
-        emu.tune(25, rows)
-        for (w, h) in ((70, 23), (131, 77), (64, 38), (200, 135)):
-            pc.fast(emu, oracle, Oracle.synth(w, h, 5), MEM)
-            pc.fast(emu, oracle, rs.randint(0, 256, (h, w)).astype(np.uint8), MEM, threshold=5, caps=(5000,))   # dense: scored in place
-            pc.fast(emu, oracle, (rs.randint(0, 256, (h, w)) * (rs.rand(h, w) < 0.2)).astype(np.uint8), MEM, threshold=40)
-    finally:
-        emu.tune(25, 0)
+    for (w, h) in ((70, 23), (131, 77), (64, 38), (200, 135)):
+        pc.fast(emu, oracle, Oracle.synth(w, h, 5), MEM)
+        pc.fast(emu, oracle, rs.randint(0, 256, (h, w)).astype(np.uint8), MEM, threshold=5, caps=(5000,))   # dense: scored in place
+        pc.fast(emu, oracle, (rs.randint(0, 256, (h, w)) * (rs.rand(h, w) < 0.2)).astype(np.uint8), MEM, threshold=40)
 
 
-def test_fast_strip_kernel_equals_per_pixel_kernel(emu, oracle):
-    """k_fast_score4 (w % 4 == 0: lane = 4 px, rows in registers, compass filter) against k_fast_score_tile
-    (the default), k_fast_score_px and the oracle; gsh_tune key 7 = 1 selects the strip kernel, 2 the per-pixel global-load kernel:
-    block corners, noise and a p < t region, two waves wide"""
+def test_fast_tile_kernel_equals_per_pixel_kernel(emu, oracle):
+    """k_fast_score_q4 (the default) against k_fast_score_px (gsh_tune key 7 = 2: one global byte load per ring pixel) and the
+    oracle: block corners, noise and a p < t region, two waves wide"""
     rs = np.random.RandomState(11)
     img = Oracle.synth(264, 40, 9)
     img[8:20, 100:140] = rs.randint(0, 12, (12, 40))       # p < threshold: the unsigned-wrap class
     img[25:33, 250:264] = rs.randint(0, 256, (8, 14))      # texture up to the right border
     for t in (20, 3, 200):
         pc.fast(emu, oracle, img, MEM, threshold=t, caps=(5000,))
-        for mode in (1, 2, 3, 4):
+        for mode in (2,):
             emu.tune(7, mode)
             try:
                 pc.fast(emu, oracle, img, MEM, threshold=t, caps=(5000,))
@@ -114,25 +108,22 @@ def test_fast_strip_kernel_equals_per_pixel_kernel(emu, oracle):
 
 
 @pytest.mark.parametrize("shape", [(96, 80), (64, 40), (1040, 9), (32, 7), (272, 33)])
-def test_fast_nms_strip_kernel_equals_item_kernel(emu, oracle, shape):
-    """pass 2 of gs_fast: k_fast_nms_sparse (default: only the pixels of the score kernel's bitmap), k_fast_nms16 (strip
-    form over every pixel, items over word-padded rows; gsh_tune key 19 = 2) and k_fast_nms (item by item, key 19 = 1)
-    give the oracle's keypoints in the oracle's order -- plateaus
-    (ties survive), peaks next to the never-written 3-px frame of a caller's non-zero score map, caps that cut the
-    list inside a row, every strip band height"""
+def test_fast_sparse_nms_kernel_equals_item_kernel(emu, oracle, shape):
+    """pass 2 of gs_fast: k_fast_nms_sparse (default: only the pixels of the score kernel's bitmap) and k_fast_nms (item by
+    item, gsh_tune key 19 = 1) give the oracle's keypoints in the oracle's order -- plateaus (ties survive), peaks next to the
+    never-written 3-px frame of a caller's non-zero score map, caps that cut the list inside a row"""
     w, h = shape
     rs = np.random.RandomState(w + h)
     flat = np.full((h, w), 100, np.uint8)
     flat[::3, ::3] = 140                      # a lattice of equal corners: plateaus / ties everywhere
     imgs = [Oracle.synth(w, h, 8), rs.randint(0, 256, (h, w)).astype(np.uint8), flat]
-    for key19 in (0, 2, 1):
-        for T in ((0, 1, 3) if key19 == 2 else (0,)):
-            try:
-                emu.tune(19, key19), emu.tune(0, T)
-                for img in imgs:
-                    pc.fast(emu, oracle, img, MEM, threshold=12, caps=(5000, 9, 1))
-            finally:
-                emu.tune(19, 0), emu.tune(0, 0)
+    for key19 in (0, 1):
+        try:
+            emu.tune(19, key19)
+            for img in imgs:
+                pc.fast(emu, oracle, img, MEM, threshold=12, caps=(5000, 9, 1))
+        finally:
+            emu.tune(19, 0)
 
 
 def test_fast_quirk(emu, oracle):

@@ -115,7 +115,7 @@ def test_next_rows(hip, oracle, shape, mem):
 @pytest.mark.parametrize("shape", [(67, 45), (96, 80), (7, 7), (6, 30), (40, 8), (640, 480), (1283, 517), (260, 17), (8, 8), (1284, 100)])
 def test_fast(hip, oracle, shape, mem):
     w, h = shape
-    for strip in ((0, 1, 2) if w % 4 == 0 else (0, 2)):  # gsh_tune key 7: 0 LDS-tile score kernel (default), 1 strip kernel, 2 global byte loads
+    for strip in (0, 2):  # gsh_tune key 7: 0 LDS-tile score kernel (default), 2 global byte loads
         hip.tune(7, strip)
         try:
             pc.fast(hip, oracle, Oracle.synth(w, h, 5), mem)
@@ -126,15 +126,15 @@ def test_fast(hip, oracle, shape, mem):
             hip.tune(7, 0)
 
 
-def test_fast_strip_kernel_equals_per_pixel_kernel(hip, oracle):
-    """k_fast_score4 (gsh_tune key 7 = 1), k_fast_score_px (2) and k_fast_score_tile (default) against the oracle on a 1280x720 frame with a
-    dark (p < t) region and random texture, thresholds incl. one that puts every pixel in the wrap class"""
+def test_fast_tile_kernel_equals_per_pixel_kernel(hip, oracle):
+    """k_fast_score_q4 (default) and k_fast_score_px (gsh_tune key 7 = 2) against the oracle on a 1280x720 frame with a dark
+    (p < t) region and random texture, thresholds incl. one that puts every pixel in the wrap class"""
     rs = np.random.RandomState(11)
     img = Oracle.synth(1280, 720, 9)
     img[80:200, 100:400] = rs.randint(0, 12, (120, 300))
     img[500:620, 1100:1280] = rs.randint(0, 256, (120, 180))
     for t in (20, 3, 200, 300):
-        for force_px in (0, 1, 2):
+        for force_px in (0, 2):
             hip.tune(7, force_px)
             try:
                 pc.fast(hip, oracle, img, DEV, threshold=t, caps=(5000,))
@@ -142,16 +142,16 @@ def test_fast_strip_kernel_equals_per_pixel_kernel(hip, oracle):
                 hip.tune(7, 0)
 
 
-def test_fast_three_nms_kernels(hip, oracle):
-    """pass 2: the sparse kernel behind the score kernel's bitmap (default), the strip kernel over every pixel (key 19 = 2)
-    and the item-by-item kernel (1): the oracle's keypoints in the oracle's order, caps that cut the list, a caller's
-    non-zero score-map frame, widths that are no multiple of 64 / 16"""
+def test_fast_both_nms_kernels(hip, oracle):
+    """pass 2: the sparse kernel behind the score kernel's bitmap (default) and the item-by-item kernel (key 19 = 1): the
+    oracle's keypoints in the oracle's order, caps that cut the list, a caller's non-zero score-map frame, widths that are
+    no multiple of 64 / 16"""
     rs = np.random.RandomState(5)
     for (w, h) in ((1280, 720), (1000, 333), (70, 71), (131, 64)):
         flat = np.full((h, w), 100, np.uint8)
         flat[::3, ::3] = 140
         for img in (Oracle.synth(w, h, 8), rs.randint(0, 256, (h, w)).astype(np.uint8), flat):
-            for key19 in (0, 2, 1):
+            for key19 in (0, 1):
                 hip.tune(19, key19)
                 try:
                     pc.fast(hip, oracle, img, DEV, threshold=12, caps=(30000, 9, 1))

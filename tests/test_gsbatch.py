@@ -526,7 +526,8 @@ def test_gsbatch_collectives_checksum_of_checksums_emulated(tmp_path, gpus):
     m = re.search(rb"collectives: (.*?) \| checksum of checksums ([0-9a-f]{16}) over (\d+) file\(s\), (\d+) result record", r.stderr)
     assert m, r.stderr.decode()[-800:]
     assert int(m.group(3)) == len(files) and int(m.group(2), 16) == _digest_of(sums), (m.group(2), "%016x" % _digest_of(sums))
-    assert (b"emulated rendezvous of %d host threads" % gpus) in m.group(1)
+    # one worker: local copies; several: the host-rendezvous backend (the one real GPUs fall back to without librccl)
+    assert (b"local copies" if gpus == 1 else b"host rendezvous of %d worker threads" % gpus) in m.group(1), m.group(1)
     # faces: the blob reaches every worker through the broadcast; counts come back through the all-gather
     from grayskull_amd.cascade import Cascade
     casc = Cascade.from_blob(CASCADE)
@@ -562,8 +563,9 @@ def test_gsbatch_rccl_world1_on_gpu(tmp_path):
         sums.append(_wsum(o.threshold(e, o.otsu_threshold(e))))
     out = tmp_path / "o1"
     out.mkdir()
+    env = dict(os.environ, GS_COMM_RCCL="1")  # a world of one takes local copies unless asked: here the real library is the point
     r = subprocess.run([exe, "-v", "--gpus", "1", "-o", str(out), "blur", "2", ":", "sobel", ":", "threshold", "otsu", "--", *files],
-                       capture_output=True, timeout=600)
+                       capture_output=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr.decode()[-800:]
     m = re.search(rb"collectives: (.*?) \| checksum of checksums ([0-9a-f]{16}) over (\d+) file", r.stderr)
     assert m, r.stderr.decode()[-800:]
@@ -573,7 +575,7 @@ def test_gsbatch_rccl_world1_on_gpu(tmp_path):
     out2 = tmp_path / "o2"
     out2.mkdir()
     r = subprocess.run([exe, "-v", "--gpus", "1", "--cascade", CASCADE, "-o", str(out2), "faces", "1", "--", *files[:3]],
-                       capture_output=True, timeout=600)
+                       capture_output=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr.decode()[-800:]
     m = re.search(rb"collectives: (rccl .*?) \| .* over (\d+) file\(s\), (\d+) result record", r.stderr)
     want = sum(len(o.lbp_detect(casc, o.integral(read_pgm(f)), 100, 1.2, 1.0, 4.0, 1)) for f in files[:3])

@@ -111,8 +111,9 @@ def _body_fast_orb_match_any_shape(emu, oracle, w, h, seed, kind, threshold, nkp
             assert_same(emu.match_orb(ka, kb, mm, md), oracle.match_orb(kao, kbo, mm, md), "gs_match_orb")
 
 
-def _body_fast_strip_kernel(emu, oracle, w4, h, seed, kind, threshold, dark):
-    """gsh_tune key 7 = 1: k_fast_score4 (w % 4 == 0; widths around one and two 256-px waves)"""
+def _body_fast_px_kernel(emu, oracle, w4, h, seed, kind, threshold, dark):
+    """gsh_tune key 7 = 2: k_fast_score_px + the item-by-item NMS (the generic pair behind huge thresholds); widths around one and
+    two 256-px spans"""
     rs = np.random.RandomState(seed)
     w = 4 * w4
     img = _img(rs, w, h, kind)
@@ -120,19 +121,19 @@ def _body_fast_strip_kernel(emu, oracle, w4, h, seed, kind, threshold, dark):
         img[h // 3: 2 * h // 3, w // 4: w // 2] = rs.randint(0, max(2, min(threshold, 255)), (2 * h // 3 - h // 3, w // 2 - w // 4))
     sm0 = rs.randint(0, 256, (h, w)).astype(np.uint8)
     ko, smo = oracle.fast(img, 5000, threshold, sm0)
-    emu.tune(7, 1)
+    emu.tune(7, 2)
     try:
         sm = sm0.copy()
         k = emu.fast(img.copy(), sm, 5000, threshold)
     finally:
         emu.tune(7, 0)
-    assert_same(k, ko, "gs_fast (strip kernel) %dx%d t=%d" % (w, h, threshold))
-    assert_same(sm, smo, "gs_fast scoremap (strip kernel)")
+    assert_same(k, ko, "gs_fast (per-pixel kernel) %dx%d t=%d" % (w, h, threshold))
+    assert_same(sm, smo, "gs_fast scoremap (per-pixel kernel)")
 
 
 def _body_fast_wide(emu, oracle, w, h, seed, kind, threshold, cap, key19):
     """gs_fast on frames several score tiles wide and tall (64 x 48-px tiles, bitmap words, chunks of 32 words that straddle
-    rows), a caller's non-zero score map, caps that cut the list; key19: 0 sparse NMS, 2 strip NMS, 1 item by item"""
+    rows), a caller's non-zero score map, caps that cut the list; key19: 0 sparse NMS, 1 item by item"""
     rs = np.random.RandomState(seed)
     img = _img(rs, w, h, kind)
     if kind == 1:  # p < threshold regions: every pixel a candidate under the reference's unsigned wrap
@@ -260,21 +261,21 @@ def test_fast_orb_match_any_shape(emu, oracle, w, h, seed, kind, threshold, nkps
 @_cfg(12)
 @given(w4=st.sampled_from([2, 3, 16, 63, 64, 65, 67, 128, 130]), h=st.integers(7, 30), seed=st.integers(0, 2 ** 16),
        kind=st.integers(0, 2), threshold=st.sampled_from([0, 1, 5, 20, 60, 200, 255, 256, 300]), dark=st.booleans())
-def test_fast_strip_kernel(emu, oracle, w4, h, seed, kind, threshold, dark):
-    _body_fast_strip_kernel(emu, oracle, w4=w4, h=h, seed=seed, kind=kind, threshold=threshold, dark=dark)
+def test_fast_px_kernel(emu, oracle, w4, h, seed, kind, threshold, dark):
+    _body_fast_px_kernel(emu, oracle, w4=w4, h=h, seed=seed, kind=kind, threshold=threshold, dark=dark)
 
 
 @pytest.mark.gpu
 @_cfg(20)
 @given(w4=st.sampled_from([2, 3, 16, 63, 64, 65, 67, 128, 130, 320]), h=st.integers(7, 90), seed=st.integers(0, 2 ** 16),
        kind=st.integers(0, 2), threshold=st.sampled_from([0, 1, 5, 20, 60, 200, 255, 256, 300]), dark=st.booleans())
-def test_gpu_fast_strip_kernel(hip, oracle, w4, h, seed, kind, threshold, dark):
-    _body_fast_strip_kernel(hip, oracle, w4=w4, h=h, seed=seed, kind=kind, threshold=threshold, dark=dark)
+def test_gpu_fast_px_kernel(hip, oracle, w4, h, seed, kind, threshold, dark):
+    _body_fast_px_kernel(hip, oracle, w4=w4, h=h, seed=seed, kind=kind, threshold=threshold, dark=dark)
 
 
 @_cfg(10)
 @given(w=st.integers(60, 300), h=st.integers(40, 130), seed=st.integers(0, 2 ** 16), kind=st.integers(0, 2),
-       threshold=st.sampled_from([1, 12, 20, 60, 255]), cap=st.sampled_from([1, 50, 20000]), key19=st.sampled_from([0, 0, 2, 1]))
+       threshold=st.sampled_from([1, 12, 20, 60, 255]), cap=st.sampled_from([1, 50, 20000]), key19=st.sampled_from([0, 0, 1]))
 def test_fast_wide_shapes(emu, oracle, w, h, seed, kind, threshold, cap, key19):
     _body_fast_wide(emu, oracle, w, h, seed, kind, threshold, cap, key19)
 
@@ -282,7 +283,7 @@ def test_fast_wide_shapes(emu, oracle, w, h, seed, kind, threshold, cap, key19):
 @pytest.mark.gpu
 @_cfg(25)
 @given(w=st.integers(60, 700), h=st.integers(40, 300), seed=st.integers(0, 2 ** 16), kind=st.integers(0, 2),
-       threshold=st.sampled_from([1, 12, 20, 60, 255]), cap=st.sampled_from([1, 50, 20000]), key19=st.sampled_from([0, 0, 2, 1]))
+       threshold=st.sampled_from([1, 12, 20, 60, 255]), cap=st.sampled_from([1, 50, 20000]), key19=st.sampled_from([0, 0, 1]))
 def test_gpu_fast_wide_shapes(hip, oracle, w, h, seed, kind, threshold, cap, key19):
     _body_fast_wide(hip, oracle, w, h, seed, kind, threshold, cap, key19)
 
