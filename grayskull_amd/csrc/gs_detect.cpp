@@ -363,9 +363,12 @@ void launch_lbp_padded(const gsh_cascade *dc, const LbpGeomCache &gc, const unsi
     const size_t ts = lbp_tile_stride(c.tw, (unsigned)step, (unsigned)sc.win_w), tr = (size_t)(c.th - 1) * step + sc.win_h + 1;
     return lbp_tile_lds_bytes(dc->nstages, dc->nweaks, dc->nsub, dc->ntruth, c.tw * c.th, ts * tr);
   };
-  auto tile_blocks = [&](const TileCfg &c, const LbpScale &sc) { /* blocks a CU holds: LDS, and 32 waves */
+  /* blocks a CU holds: LDS (a block's dynamic part + the kernel's few static words, in the allocator's 512-byte granules --
+   * counting a whole KB per block put scale 2.36 of a 4K scan at one block per CU when two fit: 0.30 instead of 0.23 ms) and
+   * 32 waves */
+  auto tile_blocks = [&](const TileCfg &c, const LbpScale &sc) {
     const size_t need = tile_lds(c, sc);
-    return need > kLdsDyn ? 0u : (unsigned)std::min<size_t>(kLdsPerCu / (need + 1024), 32u * 64u / c.nt);
+    return need > kLdsDyn ? 0u : (unsigned)std::min<size_t>(kLdsPerCu / ((need + 64 + 511) & ~(size_t)511), 32u * 64u / c.nt);
   };
   struct Choice { int cfg; unsigned blocks; bool operator==(const Choice &o) const { return cfg == o.cfg && blocks == o.blocks; } };
   auto tile_choice = [&](const LbpScale &sc) -> Choice { /* cfg -1: k_lbp_cascade */

@@ -36,6 +36,12 @@
  * LDS tables are kept small (no leaf values: the truth tables replace them) and the code bits are assembled with
  * full-rate compare + add-with-carry pairs (push_ge_u32).
  *
+ * Measured and not kept (profiles/r05g_lbp_tile_runs_of_stages_not_kept.log): passes that evaluate a RUN of stages at once when
+ * a wave has few survivors left (the idle lanes take the following stages' classifiers speculatively, so a lone window
+ * reaches the last stage in 3-4 passes instead of 18) -- 3.570 vs 3.574 ms per 4K edge map on the same box: the tail of
+ * dependent passes is not what a block waits for.  What does matter is blocks per CU: the same shape drops from 0.23 to 0.34
+ * ms per scale where its tile stops fitting twice (scale 2.36 -> 2.59 for 128 x 32 windows).
+ *
  * Not for GUARD geometries (feature rectangles that leave the window: scale < 1) -- those stay with k_lbp_cascade.
  */
 #ifndef GS_K_LBP_TILE_H

@@ -147,7 +147,10 @@ template <bool INVERT = false, int RG = 0> struct Strip {
   }
   GS_DEV bool in_image() const { return col_off != kOOB; }
   GS_DEV uint32_t row_off(int y, bool ok = true) const { /* y, ok wave-uniform */
-    return (ok && (unsigned)y < h) ? (uint32_t)y * w : kRowOOB;
+    /* RG == 2 adds the base's byte phase bp (1..3) to the sum: three less keeps kRowOOB + bp + kOOB from wrapping to 0..2
+     * (the frame's first bytes instead of the zero fill; those lanes' values were always masked, but the invariant above
+     * should hold for every flavour) while row + bp + any valid column still lands beyond a frame of < 0x7fff0000 bytes */
+    return (ok && (unsigned)y < h) ? (uint32_t)y * w : (RG == 2 ? kRowOOB - 3u : kRowOOB);
   }
   /* row y: this lane's 16 B; lane 0 also fetches the 4 B left of the wave's 1 KiB, lane 63 the
    * 4 B right of it (one shared instruction).  Everything outside the image reads 0. */
