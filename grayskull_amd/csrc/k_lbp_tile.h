@@ -162,19 +162,47 @@ GS_DEV bool lbp_tile_window_stages(const LbpTileTables &t, const unsigned *tile,
 
 struct LbpTilePos { unsigned x0w, y0w, nwx, nwy; }; /* the tile's first window (in window indices) and its extent */
 
-/* the window whose top-left corner sits at dword `odw` of the tile passed the last stage (rare: a division is fine) */
-GS_DEV void lbp_tile_publish(const LbpArgs &a, const LbpScale &sc, const LbpTilePos &tp, unsigned odw, unsigned TS) {
-  const unsigned ry = odw / TS, rx = odw - ry * TS, ly = ry / (unsigned)a.step, lx = rx / (unsigned)a.step;
+/* The windows of the lanes with `lead` (top-left corner at dword `odw` of the tile) passed the last stage.  Called by the
+ * whole wave.  Detections are rare with a real cascade, but a permissive one can pass a tenth of all windows, and then one
+ * atomic per detection on its chunk's counter serialises in the L2 (a truncated frontalface cascade: 8.4 instead of 1.9 ms
+ * per 4K edge map, profiles/r05y_lbp_stage_costs.log).  So the wave aggregates: one atomicOr per distinct mask word (the
+ * lanes' bits are distinct, so their OR is their sum) and one add per distinct chunk. */
+GS_DEV void lbp_tile_publish_wave(const LbpArgs &a, const LbpScale &sc, const LbpTilePos &tp, bool lead, unsigned odw, unsigned TS) {
+  uint64_t todo = ballot(lead);
+  if (!todo) return; /* wave-uniform */
+  const unsigned ry = odw / TS, rx = odw - ry * TS, ly = ry / (unsigned)a.step, lx = rx / (unsigned)a.step; /* rare: a division is fine */
   const unsigned idx = (tp.y0w + ly) * sc.nx + tp.x0w + lx; /* raster index inside the scale */
   const unsigned lin = sc.chunk_base + idx / kChunkItems, bit = idx & (kChunkItems - 1u);
-  const size_t chunk = (size_t)blockIdx.z * a.total_chunks + lin;
-  atomicOr(&a.mask[chunk * kChunkWords + (bit >> 6)], 1ull << (bit & 63u));
-  atomicAdd(&a.chunk_count[chunk], 1u);
-  if (a.cap < a.nwindows_cap) {
-    atomicAdd(&a.hits_group[(size_t)blockIdx.z * a.ngroups + (lin >> kLbpGroupShift)], 1u);
-    atomicAdd(&a.hits_super[(size_t)blockIdx.z * a.nsupers + (lin >> kLbpSuperShift)], 1u);
-    atomicAdd(&a.hits_total[blockIdx.z], 1u);
+  const unsigned wid = lin * kChunkWords + (bit >> 6); /* mask word inside the frame's array */
+  const uint32_t blo = (bit & 32u) ? 0u : 1u << (bit & 31u), bhi = (bit & 32u) ? 1u << (bit & 31u) : 0u;
+  const unsigned lane = lane_id();
+  const size_t frame_chunk0 = (size_t)blockIdx.z * a.total_chunks;
+  while (todo) { /* one distinct mask word per trip */
+    const unsigned first = (unsigned)__builtin_ctzll(todo);
+    const unsigned w0 = readlane_at(wid, first);
+    const bool mine = lead && wid == w0;
+    const uint64_t same = ballot(mine);
+    const uint32_t lo = wave_sum(mine ? blo : 0u), hi = wave_sum(mine ? bhi : 0u);
+    if (lane == first) atomicOr(&a.mask[frame_chunk0 * kChunkWords + w0], (unsigned long long)lo | ((unsigned long long)hi << 32));
+    todo &= ~same;
   }
+  todo = ballot(lead);
+  const unsigned total = (unsigned)__popcll(todo);
+  while (todo) { /* one distinct chunk per trip */
+    const unsigned first = (unsigned)__builtin_ctzll(todo);
+    const unsigned l0 = readlane_at(lin, first);
+    const uint64_t same = ballot(lead && lin == l0);
+    if (lane == first) {
+      const unsigned c = (unsigned)__popcll(same);
+      atomicAdd(&a.chunk_count[frame_chunk0 + l0], c);
+      if (a.cap < a.nwindows_cap) {
+        atomicAdd(&a.hits_group[(size_t)blockIdx.z * a.ngroups + (l0 >> kLbpGroupShift)], c);
+        atomicAdd(&a.hits_super[(size_t)blockIdx.z * a.nsupers + (l0 >> kLbpSuperShift)], c);
+      }
+    }
+    todo &= ~same;
+  }
+  if (a.cap < a.nwindows_cap && lane == 0) atomicAdd(&a.hits_total[blockIdx.z], total);
 }
 
 /* grid (max tiles per scale [rounded up to 8 with the XCD mapping], scales of this launch, n frames), block NT;
@@ -334,8 +362,7 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 8 : 1) void k_lbp_tile(LbpArgs a, 
     if (m) {
       if (e >= a.nstages) { /* short cascade: the dense phase was all of it */
 #pragma unroll
-        for (unsigned k = 0; k < R; k++)
-          if ((alive >> k) & 1u) lbp_tile_publish(a, sc, tp, odw_of(k), TS);
+        for (unsigned k = 0; k < R; k++) lbp_tile_publish_wave(a, sc, tp, (alive >> k) & 1u, odw_of(k), TS);
         m = 0;
       } else { /* re-pack the wave's survivors */
         unsigned out = 0;
@@ -390,7 +417,7 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 8 : 1) void k_lbp_tile(LbpArgs a, 
         const uint64_t pm = ballot(lead);
         if (pm) {
           if (lastst) {
-            if (lead) lbp_tile_publish(a, sc, tp, odw, TS);
+            lbp_tile_publish_wave(a, sc, tp, lead, odw, TS);
           } else {
             if (lead) queue[out + mbcnt(pm)] = (uint16_t)odw; /* in place: out <= b, and this trip's reads are done (the ballot) */
             out += (unsigned)__popcll(pm);
@@ -407,7 +434,7 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 8 : 1) void k_lbp_tile(LbpArgs a, 
         const uint64_t pm = ballot(pass);
         if (pm) {
           if (lastst) {
-            if (pass) lbp_tile_publish(a, sc, tp, odw, TS);
+            lbp_tile_publish_wave(a, sc, tp, pass, odw, TS);
           } else {
             if (pass) queue[out + mbcnt(pm)] = (uint16_t)odw;
             out += (unsigned)__popcll(pm);

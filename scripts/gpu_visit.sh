@@ -67,10 +67,12 @@ for sec in "$@"; do
         PMC_SETS="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_WAVES SQ_INSTS_LDS" bash scripts/pmc_fused.sh 2>&1 | grep -v amdgpu.ids | tee ${O}_pmc_features.txt
       python scripts/pmc_fast_json.py > ${O}_pmc_fast_json.log 2>&1; tail -2 ${O}_pmc_fast_json.log | cut -c1-300 ;;
     extras)
+      export UB_LIB=$R/build_variants/libgs_experiment.so  # the strip-copy probe lives in experiment builds only
       RG_CHECK=0 timeout 500 python scripts/ubench_ragged.py 2>&1 | grep -v amdgpu.ids | tee ${O}_ragged.log | tail -40
       timeout 300 python scripts/ubench_box_offsets.py 2>&1 | grep -v amdgpu.ids | tee ${O}_box_offsets.log
       timeout 300 python scripts/ubench_next_rows.py 2>&1 | grep -v amdgpu.ids | tee ${O}_next_rows.log | tail -12
-      timeout 300 python scripts/ubench_tmatch.py 2>&1 | grep -v amdgpu.ids | tee ${O}_tmatch.log | tail -12 ;;
+      timeout 300 python scripts/ubench_tmatch.py 2>&1 | grep -v amdgpu.ids | tee ${O}_tmatch.log | tail -12
+      unset UB_LIB ;;
     *) echo "unknown section $sec" ;;
   esac
 done

@@ -3,7 +3,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, grayskull_amd as gs
-g = gs.lib(); g.use_torch_stream()
+g = gs.Grayskull(os.environ["UB_LIB"]) if os.environ.get("UB_LIB") else gs.lib(); g.use_torch_stream()  # UB_LIB=build_variants/libgs_experiment.so for the strip-copy probe
 F, H, W = 64, 2160, 3840
 src = torch.empty((F, H, W), dtype=torch.uint8, device="cuda"); g.synth_batch(src, 1000)
 dst = torch.zeros_like(src); tmp = torch.zeros_like(src)
