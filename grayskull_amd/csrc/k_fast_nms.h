@@ -7,6 +7,12 @@
  * 3 x 3 maximum over every pixel on the strip machinery instead (23 us); round 4's sparse pass below visits only the 3 %
  * of the pixels that have a score (9.5 us) and the strip form was deleted in round 5.
  *
+ * Round 5 measured the ordered emit INSIDE this kernel (one launch less: a status word per chunk, zeroed by the score
+ * kernel; every wave publishes its count and adds up its predecessors' -- as a decoupled look-back to the nearest published
+ * prefix, then as one scan over all earlier chunks): 84 resp. 79 us per 32 x 720p against 70 with the separate k_emit launch
+ * (flat frames 50 against 39).  Device-scope loads of words other workgroups just wrote cost more than the kernel boundary
+ * they replace; not kept (profiles/r05h_fast_lookback_not_kept.log, r05i_fast_nms_emit_one_launch_not_kept.log).
+ *
  * Items are numbered over the interior padded to whole words: item = (y - 3) * 64 tiles_x + (x - 3), so a 64-px tile row of
  * the score kernel is one mask word.  Raster order of the items is the reference's emit order (ref :518-530);
  * FastEmitPadded maps an item back to (x, y).
