@@ -470,6 +470,76 @@ __global__ void k_lbp_single(LbpArgs a, const LbpGeom *geom, unsigned *out) {
  *   (2) device: BRIEF for every kept keypoint of every job, one launch per job; one copy-back of the descriptors.
  * (Round 4 copied every FAST candidate back -- up to 5000 x 48 B per frame -- and sorted on the host: 153 us per 720p
  * frame, of which ~100 were the copy and the sort.) */
+/* A few parked host threads for the libm half of the ORB batch (creating a thread costs 20-50 us on these boxes, twelve of
+ * them per call were a third of a 32-frame batch's time).  Workers are created on first use and parked on a condition
+ * variable; run(n, fn) executes fn(0 .. n-1), the caller taking index 0; one run at a time (callers of different host
+ * threads queue on the mutex).  The pool is a function-local static: its destructor wakes the workers up and joins them. */
+class HostPool {
+ public:
+  static constexpr unsigned kMax = 11;
+  template <class F> void run(unsigned n, F fn) {
+    if (n <= 1) {
+      fn(0u);
+      return;
+    }
+    std::lock_guard<std::mutex> one_run(run_mutex_);
+    std::function<void(unsigned)> f = fn;
+    {
+      std::unique_lock<std::mutex> lk(m_);
+      while (workers_.size() + 1 < n && workers_.size() < kMax) {
+        const unsigned id = (unsigned)workers_.size() + 1u;
+        workers_.emplace_back([this, id] { loop(id); });
+      }
+      n = std::min<unsigned>(n, (unsigned)workers_.size() + 1u);
+      job_ = &f, njobs_ = n, pending_ = n - 1, gen_++;
+    }
+    cv_.notify_all();
+    f(0u);
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [&] { return pending_ == 0; });
+    job_ = nullptr;
+  }
+  ~HostPool() {
+    {
+      std::unique_lock<std::mutex> lk(m_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto &w : workers_) w.join();
+  }
+
+ private:
+  void loop(unsigned id) {
+    unsigned long long seen = 0;
+    for (;;) {
+      std::function<void(unsigned)> *f = nullptr;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+        if (stop_) return;
+        seen = gen_;
+        if (id < njobs_) f = job_;
+      }
+      if (f) {
+        (*f)(id);
+        std::unique_lock<std::mutex> lk(m_);
+        if (--pending_ == 0) done_.notify_all();
+      }
+    }
+  }
+  std::mutex m_, run_mutex_;
+  std::condition_variable cv_, done_;
+  std::vector<std::thread> workers_;
+  std::function<void(unsigned)> *job_ = nullptr;
+  unsigned njobs_ = 0, pending_ = 0;
+  unsigned long long gen_ = 0;
+  bool stop_ = false;
+};
+HostPool &host_pool() {
+  static HostPool p;
+  return p;
+}
+
 struct OrbJob {
   const uint8_t *img;
   unsigned w, h, n; /* n frames, w * h bytes apart */
@@ -547,15 +617,9 @@ void orb_extract_libm(OrbJob *J, unsigned nj, unsigned threshold) {
   };
   unsigned nthreads = 1;
   if (kept_total >= 4096 && items.size() > 1)
-    nthreads = (unsigned)std::min<size_t>({12, std::max(1u, std::thread::hardware_concurrency()), items.size(), kept_total / 1024});
-  if (nthreads > 1) {
-    std::vector<std::thread> th;
-    for (unsigned t = 1; t < nthreads; t++) th.emplace_back(do_items, items.size() * t / nthreads, items.size() * (t + 1) / nthreads);
-    do_items(0, items.size() / nthreads);
-    for (auto &x : th) x.join();
-  } else {
-    do_items(0, items.size());
-  }
+    nthreads = (unsigned)std::min<size_t>({HostPool::kMax + 1, std::max(1u, std::thread::hardware_concurrency()), items.size(), kept_total / 1024});
+  if (nthreads > 1) host_pool().run(nthreads, [&](unsigned t) { do_items(items.size() * t / nthreads, items.size() * (t + 1) / nthreads); });
+  else do_items(0, items.size());
   for (unsigned j = 0; j < nj; j++)
     for (unsigned f = 0; f < J[j].n; f++) {
       const unsigned m = std::min(hn[foff[j] + f], J[j].nkps);

@@ -31,8 +31,8 @@
  * --gpus N shards the files of every size group over N GPUs (contiguous, balanced blocks of the
  * group's files: the frame_range rule of grayskull_amd/shard.py), one host thread per device
  * (gsh_set_device); frames never leave their GPU.  What crosses GPUs is SURVEY.md 8(e)'s control traffic, over RCCL
- * (gsh_comm_*, one communicator per worker from ncclCommInitAll; librccl is looked up at run time and one GPU works
- * without it): the cascade blob is read by worker 0 and BROADCAST, every worker's per-file counts and output checksums
+ * (gsh_comm_*, one communicator per worker from ncclCommInitAll; librccl is looked up at run time, one GPU takes local
+ * copies and several GPUs without a usable librccl a host-rendezvous backend): the cascade blob is read by worker 0 and BROADCAST, every worker's per-file counts and output checksums
  * are ALL-GATHERED, the job's wall time is the ALL-REDUCE(max) of the workers'.  -v prints the checksum of checksums
  * over the files in command-line order -- for the same frames and chain the digest bench.py reports as
  * output_checksum_of_checksums.
@@ -925,10 +925,10 @@ int main(int argc, char **argv) {
   th = (pthread_t *)calloc((size_t)ngpus, sizeof *th);
   comms = (gsh_comm **)calloc((size_t)ngpus, sizeof *comms);
   if (!jobs || !th || !comms) return 1;
-  /* one RCCL communicator per GPU, created together (ncclCommInitAll); librccl is looked up at run time and a single
-   * GPU works without it */
+  /* one communicator per GPU, created together: RCCL (ncclCommInitAll; librccl is looked up at run time), local copies for
+   * one GPU, a host-rendezvous backend when librccl cannot be used */
   if (gsh_comm_init_all(comms, ngpus, NULL) != 0) {
-    fprintf(stderr, "Error: --gpus %d needs RCCL (librccl.so)\n", ngpus);
+    fprintf(stderr, "Error: no communicator for --gpus %d\n", ngpus);
     return 1;
   }
   t0 = now_ms();

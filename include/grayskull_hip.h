@@ -216,12 +216,14 @@ void gsh_checksum_batch(const uint8_t *img, size_t frame_bytes, unsigned n, uint
  * ncclCommInitAll over the listed devices (devices == NULL: 0 .. ndev-1).  RCCL over xGMI carries control traffic
  * only -- the cascade blob, per-file counts and checksums, the closing max of the elapsed time; frames shard by
  * file / frame and never cross GPUs (the reference has no counterpart: grayskull.h holds no state across images).
- * librccl.so is dlopen()ed by gsh_comm_init_all: ndev == 1 works without it (local copies), ndev > 1 returns -1.
+ * librccl.so is dlopen()ed by gsh_comm_init_all: ndev == 1 takes local copies (GS_COMM_RCCL=1 asks for a one-rank RCCL
+ * communicator), ndev > 1 without a usable librccl (or with GS_COMM_BACKEND=host) a host-rendezvous backend: the KB-scale
+ * payloads bounce through host memory, the worker threads meet at a rendezvous.
  * Every collective takes DEVICE buffers, must be called by the thread that drives that communicator's device and is
  * enqueued on that thread's stream (gsh_sync() before the host reads a result).  Precondition failures and RCCL
  * errors abort like everything else here. */
 typedef struct gsh_comm gsh_comm;
-int gsh_comm_init_all(gsh_comm **comms, int ndev, const int *devices); /* 0, or -1: RCCL unavailable for ndev > 1 */
+int gsh_comm_init_all(gsh_comm **comms, int ndev, const int *devices); /* 0 (a backend is always found) */
 void gsh_comm_destroy_all(gsh_comm **comms, int ndev);
 int gsh_comm_rank(const gsh_comm *c);
 int gsh_comm_world(const gsh_comm *c);

@@ -202,6 +202,17 @@ def test_orb_batch(emu, oracle):
     pc.orb_batch(emu, oracle, np.stack([Oracle.synth(40, 6, 1)]), MEM)  # below FAST's minimum size
 
 
+def test_orb_batch_with_the_host_thread_pool(emu, oracle):
+    """gsh_orb_extract_batch with more than 4096 kept keypoints: the libm half (atan2f / sinf per keypoint) is spread over
+    the library's parked host threads (HostPool); twice, so that the second call runs on workers that already exist"""
+    rs = np.random.RandomState(21)
+    frames = rs.randint(0, 256, (12, 96, 176)).astype(np.uint8)  # noise: hundreds of corners per frame
+    for _ in range(2):
+        pc.orb_batch(emu, oracle, frames, MEM, nkps=400)
+    got = emu.orb_extract_batch_dev(MEM.put(frames), MEM.put(np.zeros_like(frames)), 400, 20)
+    assert sum(len(k) for k in got) >= 4096, "the case must reach the pool's threshold"
+
+
 def test_lbp(emu, oracle, cascade):
     img = Oracle.synth(96, 80, 7)
     pc.lbp(emu, oracle, img, MEM, cascade, params=((4096, 1.1, 1.0, 4.0, 1), (10, 1.3, 1.0, 2.0, 3)),

@@ -499,11 +499,11 @@ def _wsum(a):
     return int(np.sum(np.arange(1, b.size + 1, dtype=np.uint64) * (b + np.uint64(1)), dtype=np.uint64))
 
 
-@pytest.mark.parametrize("gpus", [1, 2, 3])
+@pytest.mark.parametrize("gpus", [1, 2, 3, 8])  # 8: the world size north_star is quoted on; three workers own no file
 def test_gsbatch_collectives_checksum_of_checksums_emulated(tmp_path, gpus):
     """SURVEY 8(e) in the C driver: the cascade blob is broadcast, every worker's per-file counts and output checksums
     are all-gathered, the wall time all-reduced (gsh_comm_*: RCCL on GPUs, a rendezvous of the emulated devices' threads
-    here).  `-v` prints the checksum of checksums over the files in command-line order: the same for 1, 2 and 3
+    here).  `-v` prints the checksum of checksums over the files in command-line order: the same for 1, 2, 3 and 8
     workers, and equal to the digest bench.py computes (FNV-style fold of the per-frame wsum of the oracle's outputs)"""
     import re
     from oracle.pyoracle import Oracle
