@@ -274,7 +274,14 @@ void launch_lbp_padded(const gsh_cascade *dc, const LbpGeomCache &gc, const unsi
   /* XCD-aware chunk mapping (k_lbp.h) once the integral image no longer fits one XCD's 4 MB L2: 1080p -3 %, 4K block
    * noise -4 %, 4K edge maps -12 % (5.76 -> 5.08 ms per frame); 720p (3.7 MB) is 1-4 % better off in dispatch order
    * (profiles/r02l_lbp_xcd.log).  Key 13: 1 = never, 2 = always. */
-  a.xcd_swizzle = g_tune[13] == 1 ? 0u : g_tune[13] == 2 ? 1u : ((a.frame_stride * 4 >= (size_t)6 << 20 && topo().eight_xcds()) ? 1u : 0u);
+  a.xcd_swizzle = g_tune[13] == 1 ? 0u : g_tune[13] >= 2 ? 1u : ((a.frame_stride * 4 >= (size_t)6 << 20 && topo().eight_xcds()) ? 1u : 0u);
+  /* k_lbp_tile's tiles go out in dispatch order = the reference's scan order within a scale, whatever the table's size: a
+   * tile is read once into the LDS, so the L2 mapping is worth 1 % (eighths: 1080p block noise 0.621 vs 0.628 ms), while a
+   * frame that reaches max_rects stops evaluating sooner when the tiles before the cap run first -- configs[4]'s 4K edge maps
+   * (4096 rectangles reached in the last scale) 3.41 -> 3.19 ms per frame; per scale, uncapped, the two mappings are equal
+   * (profiles/r05j_lbp_xcd*.log).  Key 13 = 2: eighths for the tiles too; 16 + G: runs of G tiles dealt round the XCDs
+   * (not kept: 2 and 4 equal dispatch order, 8 and 16 are 1-10 % slower). */
+  const unsigned tile_map = g_tune[13] >= 17 ? (unsigned)g_tune[13] : g_tune[13] == 2 ? 1u : 0u;
   const size_t lds = (size_t)dc->nstages * sizeof(LbpStage) +
                      (size_t)dc->nweaks * (sizeof(LbpWeak) + sizeof(LbpGeom)) + (size_t)dc->nsub * 4;
   GS_ASSERT(lds <= 60 * 1024 && "cascade tables must fit the block's LDS");
@@ -410,14 +417,18 @@ void launch_lbp_padded(const gsh_cascade *dc, const LbpGeomCache &gc, const unsi
       const TileCfg &c = cfgs[choice.cfg];
       unsigned mt = 0;
       size_t need = 0;
+      LbpArgs at = a;
+      at.xcd_swizzle = tile_map;
       for (unsigned s = s0; s < s1; s++) {
         const LbpScale &sc = gc.scales[s];
-        mt = std::max(mt, ((sc.nx + c.tw - 1) / c.tw) * ((sc.ny + c.th - 1) / c.th));
+        const unsigned tx = (sc.nx + c.tw - 1) / c.tw, ty = (sc.ny + c.th - 1) / c.th;
+        const unsigned per = tile_map >= 16u ? 8u * (tile_map - 16u) : tile_map == 1u ? 8u : 1u;
+        mt = std::max(mt, (tx * ty + per - 1u) / per * per);
         need = std::max(need, tile_lds(c, sc));
       }
-      const dim3 g(a.xcd_swizzle ? (mt + 7u) & ~7u : mt, s1 - s0, n);
-      if (a.evaluated) GS_LAUNCH(c.fn_count, g, dim3(c.nt), need, st, a, ph);
-      else GS_LAUNCH(c.fn, g, dim3(c.nt), need, st, a, ph);
+      const dim3 g(mt, s1 - s0, n);
+      if (a.evaluated) GS_LAUNCH(c.fn_count, g, dim3(c.nt), need, st, at, ph);
+      else GS_LAUNCH(c.fn, g, dim3(c.nt), need, st, at, ph);
     }
     s0 = s1;
   }

@@ -221,10 +221,13 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 8 : 1) void k_lbp_tile(LbpArgs a, 
   const LbpScale sc = a.scales[si];
   const unsigned tiles_x = (sc.nx + TW - 1u) / TW, tiles_y = (sc.ny + TH - 1u) / TH, ntiles = tiles_x * tiles_y;
   unsigned tix = blockIdx.x;
-  if (a.xcd_swizzle) { /* XCD k takes the k-th eighth of the scale's tiles: a band of tile rows that stays in its L2 (k_lbp.h) */
+  if (a.xcd_swizzle == 1u) { /* XCD k takes the k-th eighth of the scale's tiles: a band of tile rows that stays in its L2 (k_lbp.h) */
     const unsigned per = (ntiles + 7u) >> 3, j = blockIdx.x >> 3;
     if (j >= per) return;
     tix = (blockIdx.x & 7u) * per + j;
+  } else if (a.xcd_swizzle >= 16u) { /* experiments: runs of G = xcd_swizzle - 16 tiles dealt round the XCDs */
+    const unsigned G = a.xcd_swizzle - 16u, j = blockIdx.x >> 3;
+    tix = ((j / G) * 8u + (blockIdx.x & 7u)) * G + j % G;
   }
   if (tix >= ntiles) return; /* whole block */
   const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;

@@ -53,7 +53,7 @@ enum gsh_tune_key {
   GSH_TUNE_HIST_TRIPS = 10,       /* trips per block gs_histogram aims at */
   GSH_TUNE_HIST_BLOCKS = 11,      /* its blocks per frame */
   GSH_TUNE_HIST_PIECE = 12,       /* bytes per histogram piece (test hook for images above 1 GiB) */
-  GSH_TUNE_LBP_XCD = 13,          /* chunk / tile -> XCD mapping of the LBP kernels: 1 dispatch order, 2 XCD-aware always */
+  GSH_TUNE_LBP_XCD = 13,          /* chunk / tile -> XCD mapping of the LBP kernels: 1 dispatch order, 2 XCD-aware always (0: k_lbp_cascade by table size, k_lbp_tile in dispatch order) */
   GSH_TUNE_LBP_KERNEL = 14,       /* 0: per scale by rule (k_lbp_tile with the tile shape the scale's LDS footprint allows, else
                                      k_lbp_cascade), 1: k_lbp_cascade for every scale, -1: the rule without its one-block-per-CU
                                      fallback, 2 + i: tile shape i of k_lbp_tile wherever it fits */

@@ -626,7 +626,7 @@ def test_histogram_of_an_image_larger_than_one_launch_frame(emu, oracle):
         emu.tune(12, 0)
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 19])
 def test_lbp_chunk_to_xcd_mapping_never_changes_results(emu, oracle, cascade, mode):
     """gsh_tune key 13: 1 = chunks in dispatch order, 2 = XCD-aware mapping (chunk = (block % 8) * ceil(nchunks / 8) + block / 8,
     grid padded to a multiple of 8) -- forced on small images: scales with 1, 7, 9 and a few dozen chunks, caps reached early"""

@@ -891,7 +891,7 @@ def test_histogram_of_a_1_2_gigabyte_image(hip):
     assert int(hist.sum()) == w * h
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 19])
 def test_lbp_chunk_to_xcd_mapping(hip, oracle, cascade, mode):
     """the cascade with chunks in dispatch order (key 13 = 1) and with the XCD-aware mapping forced (2): same rectangles as the
     oracle on a 720p edge map (default: dispatch order at this size) and a 1080p noise frame (default: XCD-aware), caps incl. 5"""
