@@ -35,6 +35,13 @@ void launch_box(int mode, unsigned ring_radius, dim3 grid, unsigned threads, hip
   }
 }
 
+/* ragged rows under a ring kernel: columns (w & ~15) - 16 .. w - 1 (k_box_edge), one wave per band of T rows */
+void launch_box_edge(int mode, dim3 grid, hipStream_t st, uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned T,
+                     size_t frame_bytes, unsigned r, int c) {
+  if (mode == 0) GS_LAUNCH(k_box_edge<0>, grid, dim3(64), 0, st, dst, src, w, h, T, frame_bytes, r, c);
+  else GS_LAUNCH(k_box_edge<1>, grid, dim3(64), 0, st, dst, src, w, h, T, frame_bytes, r, c);
+}
+
 /* blocks of `threads` threads of that kernel a CU holds at once (256 threads: register-limited, 4 up to r = 9 / 7, then
  * 3, then 2; narrower blocks: also the 8 x 19.7 KB of LDS): the launcher sizes its bands for whole rounds of 256 x
  * this many blocks */

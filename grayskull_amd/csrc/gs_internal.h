@@ -68,6 +68,8 @@ void launch_blur_sobel(unsigned radius, dim3 grid, dim3 block, hipStream_t st, u
 /* gs_box.cpp */
 void launch_box(int mode, unsigned ring_radius, dim3 grid, unsigned threads, hipStream_t st, uint8_t *dst, const uint8_t *src, unsigned w,
                 unsigned h, unsigned T, size_t frame_bytes, unsigned r, int c);
+void launch_box_edge(int mode, dim3 grid, hipStream_t st, uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned T,
+                     size_t frame_bytes, unsigned r, int c);
 unsigned box_blocks_per_cu(int mode, unsigned ring_radius, unsigned threads);
 unsigned box_ring_max();
 }

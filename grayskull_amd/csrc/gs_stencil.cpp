@@ -205,10 +205,14 @@ void launch_box_generic(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h
       const unsigned nn = std::min(kMaxZ, n - f0);
       /* r <= 16: the window's raw rows stay in registers (k_box16r: 2 B/px instead of 3-4; 64 x 4K: 0.22 ms for r <= 9,
        * 0.28 up to 16, against 0.31-0.42 -- profiles/r03r_box_ring.log).  Key 6 = 4: k_box16 always. */
-      /* ragged rows take the any-radius kernel: a RAGGED form of the ring kernels (per-pixel choice between two edge
-       * divisors, shifted tail loads) was built in round 4 and was no faster -- 116-152 registers at r = 4..5 instead of 84-92,
-       * one wave per SIMD from r = 12 (profiles/r04k_box_ring_ragged_not_kept.log: 3838 x 2160 r = 5 0.446 vs 0.434 ms, r = 16 0.73 vs 0.53) */
-      const bool ring = g_tune[6] != 4 && !ragged(w) && r <= box_ring_max() && w >= 32 && h >= 2 * r + 1 && (MODE == 0 || (c > -(1 << 30) && c < (1 << 30)));
+      /* ragged rows: the ring kernel over the whole strips (the last one only feeds its neighbour) + k_box_edge for the
+       * last 16 + w % 16 columns in a launch of its own (round 5).  Round 4's RAGGED form of the ring kernels (per-pixel
+       * choice between two edge divisors, shifted tail loads inside the block) was no faster than the any-radius kernel --
+       * 116-152 registers at r = 4..5 instead of 84-92, one wave per SIMD from r = 12
+       * (profiles/r04k_box_ring_ragged_not_kept.log: 3838 x 2160 r = 5 0.446 vs 0.434 ms, r = 16 0.73 vs 0.53).
+       * Key 6 = 5: ragged rows on the any-radius kernel (rounds 2-4). */
+      const bool ring = g_tune[6] != 4 && !(g_tune[6] == 5 && ragged(w)) && r <= box_ring_max() && w >= 32 && h >= 2 * r + 1 &&
+                        (MODE == 0 || (c > -(1 << 30) && c < (1 << 30)));
       /* band height: the launch should be whole rounds of the blocks the chip holds (256 CUs x 4 of them, fewer for the
        * register-heavy ring kernels of r >= 8 / 10), and a band first loads 2r+1 rows it does not output -- loads and
        * adds only since the vertical-first form, ~0.3 of an output row each.  Pick the band count with the smallest
@@ -241,6 +245,12 @@ void launch_box_generic(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h
       }
       const unsigned nb = (h + T - 1) / T;
       launch_box(MODE, ring ? r : 0u, dim3(1, nb, nn), threads, st, dst + fp * f0, src + fp * f0, w, h, T, fp, r, c);
+      if (ring && ragged(w)) {
+        /* about four waves per SIMD, and bands at least two windows tall (a band starts with 2 r + 1 rows of loads) */
+        const unsigned want = std::max(1u, 4u * 4u * topo().cus / nn);
+        const unsigned Te = g_tune[0] > 0 ? (unsigned)g_tune[0] : std::max((h + want - 1) / want, std::min(h, 2u * (2u * r + 1u)));
+        launch_box_edge(MODE, dim3(1, (h + Te - 1) / Te, nn), st, dst + fp * f0, src + fp * f0, w, h, Te, fp, r, c);
+      }
     }
     return;
   }

@@ -221,7 +221,13 @@ __global__ __launch_bounds__(256) GS_BOXR_ATTR void k_box16r(uint8_t *dst, const
   static constexpr BoxMagic<RR> kMagic{};
   __shared__ __attribute__((aligned(16))) uint8_t rows[2][kBoxRowBytes];
   const unsigned tid = threadIdx.x, x0 = tid * 16u;
-  const bool act = x0 < w, first = x0 == 0, last = x0 + 16u == w;
+  /* Ragged rows (w % 16 != 0, round 5): this kernel is the BODY -- the whole strips only, and the last of them is a feeder:
+   * its column sums enter the LDS row for its left neighbour's windows, its results (clipped at the wrong column) are
+   * dropped.  No pixel left of it is within RR <= 16 columns of the row's end, so nothing here depends on w % 16;
+   * k_box_edge writes columns (w & ~15) - 16 .. w - 1 in a launch of its own. */
+  const unsigned wb = w & ~15u;
+  const bool feeder = wb != w && x0 + 16u == wb;
+  const bool act = x0 < wb, first = x0 == 0, last = x0 + 16u == w, keep = act && !feeder;
   const BufRsrc S = make_buf(src + (size_t)blockIdx.z * frame_bytes, frame_bytes);
   const BufRsrc D = make_buf(dst + (size_t)blockIdx.z * frame_bytes, frame_bytes);
   const int y0 = (int)(blockIdx.y * T);
@@ -316,8 +322,62 @@ __global__ __launch_bounds__(256) GS_BOXR_ATTR void k_box16r(uint8_t *dst, const
         }
         od[j >> 2] |= o << (8 * (j & 3));
       }
-      buf_store16(D, act ? (uint32_t)y * w + x0 : kOOB, U4{od[0], od[1], od[2], od[3]});
+      buf_store16(D, keep ? (uint32_t)y * w + x0 : kOOB, U4{od[0], od[1], od[2], od[3]});
     });
+  }
+}
+
+/* ------------------------------------------------------------------ the ragged edge of k_box16r's frames */
+/* Columns (w & ~15) - 16 .. w - 1 of a frame whose rows are no multiple of 16 long (the last whole strip, which the body
+ * launch only feeds on, and the m = w % 16 columns behind it): one WAVE per band of rows, lane l <-> column
+ * (w & ~15) - 16 - r + l, so the 16 + m output columns and the r columns either side of them are all in the wave
+ * (16 + m + 2 r <= 63 for r <= 16).  Vertical first like the body: a lane slides the sum of its column over rows
+ * y - r .. y + r (two byte loads per row, one step ahead); the window sums are then two reads of the wave's inclusive scan.
+ * 0.8 % of a 4K frame's pixels, in a launch of its own so that no block of the body waits at its per-row barrier for a
+ * tail strip's shifts and partial stores (rounds 3-4: k_box16's ragged rows, 1.3 x the aligned time; a ragged form of
+ * the ring kernel, no faster than that).  Divisions as in k_box16. */
+template <int MODE>
+__global__ __launch_bounds__(64) void k_box_edge(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h, unsigned T,
+                                                 size_t frame_bytes, unsigned r, int c) {
+  const unsigned lane = threadIdx.x;
+  const int xo0 = (int)(w & ~15u) - 16, x = xo0 - (int)r + (int)lane;
+  const bool col = x >= 0 && x < (int)w, outl = x >= xo0 && x < (int)w;
+  const uint8_t *S = src + (size_t)blockIdx.z * frame_bytes;
+  uint8_t *D = dst + (size_t)blockIdx.z * frame_bytes;
+  const int y0 = (int)(blockIdx.y * T);
+  if (y0 >= (int)h) return; /* whole wave */
+  const int nrows = ((int)h - y0) < (int)T ? ((int)h - y0) : (int)T;
+  auto ld = [&](int yy) -> unsigned { return (col && yy >= 0 && yy < (int)h) ? (unsigned)S[(size_t)yy * w + (unsigned)x] : 0u; };
+  unsigned Vc = 0;
+  for (int yy = y0 - (int)r; yy <= y0 + (int)r; yy++) Vc += ld(yy); /* wave-uniform trip count */
+  const int xa = x - (int)r < 0 ? 0 : x - (int)r, xb = x + (int)r > (int)w - 1 ? (int)w - 1 : x + (int)r;
+  const unsigned cx = outl ? (unsigned)(xb - xa + 1) : 1u;
+  const float rcx = 1.0f / (float)cx;
+  const unsigned l_hi = lane + r < 63u ? lane + r : 63u, l_lo = lane > r ? lane - r - 1u : 0u;
+  unsigned nin = ld(y0 + (int)r + 1), nout = ld(y0 - (int)r), ncen = MODE ? ld(y0) : 0u;
+  const bool by_product = MODE == 1 && c > -(1 << 30) && c < (1 << 30);
+  for (int i = 0; i < nrows; i++) { /* wave-uniform */
+    const int y = y0 + i;
+    const unsigned in = nin, out = nout, cen = ncen;
+    nin = ld(y + (int)r + 2), nout = ld(y - (int)r + 1);
+    if (MODE) ncen = ld(y + 1);
+    const unsigned P = wave_incl_scan(Vc);
+    const unsigned p_hi = shfl(P, (int)l_hi), p_lo = shfl(P, (int)l_lo);
+    const unsigned H = p_hi - (lane > r ? p_lo : 0u);
+    Vc += in - out;
+    const int ya = y - (int)r < 0 ? 0 : y - (int)r, yb = y + (int)r > (int)h - 1 ? (int)h - 1 : y + (int)r;
+    const unsigned cy = (unsigned)(yb - ya + 1);
+    unsigned o;
+    if (MODE == 1 && by_product) { /* see k_box16 */
+      const int k = (int)cen + c;
+      const unsigned kc = (unsigned)(k < 0 ? 0 : k > 256 ? 256 : k);
+      o = kc * (cx * cy) > H ? 255u : 0u;
+    } else {
+      const unsigned q = box_div(H, cx, cy, rcx, 1.0f / (float)cy);
+      if (MODE == 0) o = q & 0xffu;
+      else o = (int)cen > (int)(q - (unsigned)c) ? 255u : 0u;
+    }
+    if (outl) D[(size_t)y * w + (unsigned)x] = (uint8_t)o;
   }
 }
 

@@ -36,10 +36,13 @@ if os.environ.get("RG_CHECK", "1") == "1":
             for r in (1, 2, 3): exp["blur%d" % r] = np.stack([o.blur(img[i], r) for i in range(n)])
             exp["erode"] = np.stack([o.erode(img[i]) for i in range(n)]); exp["dilate"] = np.stack([o.dilate(img[i]) for i in range(n)])
             exp["filter"] = np.stack([o.filter(img[i], k3, 8) for i in range(n)])
+            for r in (5, 11): exp["blur%d" % r] = np.stack([o.blur(img[i], r) for i in range(n)])  # ring kernel + k_box_edge on ragged rows
+            exp["adaptive7"] = np.stack([o.adaptive_threshold(img[i], 7, 5) for i in range(n)])
             for name in exp:
                 db, d = guarded(n, h, w, off, d0)
                 if name == "sobel": g.sobel_batch(d, s)
-                elif name.startswith("blur"): g.blur_batch(d, s, int(name[4]))
+                elif name.startswith("blur"): g.blur_batch(d, s, int(name[4:]))
+                elif name == "adaptive7": g.adaptive_threshold_batch(d, s, 7, 5)
                 elif name == "erode": g.erode_batch(d, s)
                 elif name == "dilate": g.dilate_batch(d, s)
                 else: g.filter_batch(d, s, k3, 8)

@@ -657,12 +657,14 @@ def test_box_radii_around_the_quotient_switch_and_up_to_127(emu, oracle):
             assert_same(d, oracle.adaptive_threshold(img, r, -3), "gs_adaptive_threshold r=%d %dx%d" % (r, w, h))
 
 
-@pytest.mark.parametrize("shape", [(32, 17), (48, 40), (272, 33), (96, 17), (1040, 19), (64, 70)])
+@pytest.mark.parametrize("shape", [(32, 17), (48, 40), (272, 33), (96, 17), (1040, 19), (64, 70),
+                                   (33, 17), (47, 40), (270, 33), (63, 35), (1038, 19), (65, 70), (81, 33)])
 def test_box_register_ring_kernel_every_radius(emu, oracle, shape):
     """k_box16r<MODE, r> for r = 1 .. 16 (the window's raw rows in a register ring, constant tap counts, multiply-high
     quotient from a table for clipped rows too) against the oracle and against k_box16 (gsh_tune key 6 = 4): widths of 2
     threads up to 65, heights down to 2 r + 1, bright images (largest sums), bands of 1 .. h rows, and compare constants
-    on both sides of every clamp of the product form"""
+    on both sides of every clamp of the product form.  Ragged widths (w % 16 = 1, 15, 14, ...; round 5): the ring kernel
+    over the whole strips with the last one a feeder + k_box_edge (one wave per band) for the last 16 + w % 16 columns."""
     w, h = shape
     rng = np.random.RandomState(w + h)
     imgs = [rng.randint(0, 256, (h, w)).astype(np.uint8), np.full((h, w), 255, np.uint8), Oracle.synth(w, h, 7)]
