@@ -244,12 +244,36 @@ void launch_box_generic(uint8_t *dst, const uint8_t *src, unsigned w, unsigned h
         }
       }
       const unsigned nb = (h + T - 1) / T;
-      launch_box(MODE, ring ? r : 0u, dim3(1, nb, nn), threads, st, dst + fp * f0, src + fp * f0, w, h, T, fp, r, c);
       if (ring && ragged(w)) {
         /* about four waves per SIMD, and bands at least two windows tall (a band starts with 2 r + 1 rows of loads) */
         const unsigned want = std::max(1u, 4u * 4u * topo().cus / nn);
         const unsigned Te = g_tune[0] > 0 ? (unsigned)g_tune[0] : std::max((h + want - 1) / want, std::min(h, 2u * (2u * r + 1u)));
-        launch_box_edge(MODE, dim3(1, (h + Te - 1) / Te, nn), st, dst + fp * f0, src + fp * f0, w, h, Te, fp, r, c);
+        const dim3 ge(1, (h + Te - 1) / Te, nn);
+        /* The edge launch is a chain of memory latencies (15-30 us however little it computes, growing with the 2 r + 1
+         * start-up rows) and touches other columns of dst than the body.  For r >= 12 on large batches it goes to the side
+         * stream, ordered behind everything the caller's stream holds so far, and the caller's stream waits for it after the
+         * body: it hides under the body launch instead of following it (64 x 3838x2160: r = 16 0.307 -> 0.296 ms, adaptive
+         * r = 15 0.308 -> 0.292; r = 5 and 9 are 2 % better off in sequence -- profiles/r05l_box_ragged_buffer_ops.log).
+         * Key 6 = 6: always on the caller's stream, 7: always on the side stream. */
+        bool side = false;
+#ifndef GS_EMU
+        side = g_tune[6] == 7 || (g_tune[6] != 6 && r >= 12u && (size_t)nn * fp >= ((size_t)16 << 20));
+        if (side) {
+          Ctx &cx = ctx();
+          cx.ensure_side();
+          GS_HIP(hipEventRecord(cx.ev_chunk[0], st));
+          GS_HIP(hipStreamWaitEvent(cx.side, cx.ev_chunk[0], 0));
+          launch_box_edge(MODE, ge, cx.side, dst + fp * f0, src + fp * f0, w, h, Te, fp, r, c);
+          GS_HIP(hipEventRecord(cx.ev_join, cx.side));
+        }
+#endif
+        launch_box(MODE, r, dim3(1, nb, nn), threads, st, dst + fp * f0, src + fp * f0, w, h, T, fp, r, c);
+#ifndef GS_EMU
+        if (side) GS_HIP(hipStreamWaitEvent(st, ctx().ev_join, 0));
+#endif
+        if (!side) launch_box_edge(MODE, ge, st, dst + fp * f0, src + fp * f0, w, h, Te, fp, r, c);
+      } else {
+        launch_box(MODE, ring ? r : 0u, dim3(1, nb, nn), threads, st, dst + fp * f0, src + fp * f0, w, h, T, fp, r, c);
       }
     }
     return;

@@ -342,42 +342,77 @@ __global__ __launch_bounds__(64) void k_box_edge(uint8_t *dst, const uint8_t *sr
   const unsigned lane = threadIdx.x;
   const int xo0 = (int)(w & ~15u) - 16, x = xo0 - (int)r + (int)lane;
   const bool col = x >= 0 && x < (int)w, outl = x >= xo0 && x < (int)w;
-  const uint8_t *S = src + (size_t)blockIdx.z * frame_bytes;
-  uint8_t *D = dst + (size_t)blockIdx.z * frame_bytes;
+  const BufRsrc S = make_buf(src + (size_t)blockIdx.z * frame_bytes, frame_bytes);
+  const BufRsrc D = make_buf(dst + (size_t)blockIdx.z * frame_bytes, frame_bytes);
   const int y0 = (int)(blockIdx.y * T);
   if (y0 >= (int)h) return; /* whole wave */
   const int nrows = ((int)h - y0) < (int)T ? ((int)h - y0) : (int)T;
-  auto ld = [&](int yy) -> unsigned { return (col && yy >= 0 && yy < (int)h) ? (unsigned)S[(size_t)yy * w + (unsigned)x] : 0u; };
+  /* every load and store is issued unconditionally (rows / columns outside the image: the buffer's out-of-range offset,
+   * which reads 0 and drops writes), so hipcc can count them: with loads inside branches it waited for ALL outstanding
+   * memory operations -- the previous rows' stores included -- at the top of every trip */
+  auto ld = [&](int yy) -> unsigned { return buf_load1(S, (col && yy >= 0 && yy < (int)h) ? (uint32_t)yy * w + (uint32_t)x : kOOB); };
   unsigned Vc = 0;
-  for (int yy = y0 - (int)r; yy <= y0 + (int)r; yy++) Vc += ld(yy); /* wave-uniform trip count */
+  for (int yy = y0 - (int)r; yy <= y0 + (int)r; yy += 8) { /* wave-uniform trip count; eight loads in flight (one at a time:
+                                                            * 2 r + 1 memory latencies in a row before the first result) */
+    unsigned t[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) t[j] = ld(yy + j <= y0 + (int)r ? yy + j : -1);
+#pragma unroll
+    for (int j = 0; j < 8; j++) Vc += t[j];
+  }
   const int xa = x - (int)r < 0 ? 0 : x - (int)r, xb = x + (int)r > (int)w - 1 ? (int)w - 1 : x + (int)r;
   const unsigned cx = outl ? (unsigned)(xb - xa + 1) : 1u;
   const float rcx = 1.0f / (float)cx;
+  const unsigned full = 2u * r + 1u, cnt_full = cx * full, Mi = 0xffffffffu / cnt_full + 1u;
   const unsigned l_hi = lane + r < 63u ? lane + r : 63u, l_lo = lane > r ? lane - r - 1u : 0u;
-  unsigned nin = ld(y0 + (int)r + 1), nout = ld(y0 - (int)r), ncen = MODE ? ld(y0) : 0u;
+  /* A wave's rows are 0.5-1 us of memory latency apart (every row of the strip is a line of its own) and depend on each
+   * other through Vc: the loads run U rows ahead (first form, one row ahead and the start-up loads one at a time: 41 / 61 us
+   * per 64 x 3838x2160 for blur / adaptive -- a fifth of the body launch's time for 0.8 % of its pixels;
+   * profiles/r05l_box_edge_one_row_ahead.log). */
+  constexpr int U = 8;
+  unsigned nin[U], nout[U], ncen[U];
+#pragma unroll
+  for (int j = 0; j < U; j++) nin[j] = ld(y0 + (int)r + 1 + j), nout[j] = ld(y0 - (int)r + j), ncen[j] = MODE ? ld(y0 + j) : 0u;
   const bool by_product = MODE == 1 && c > -(1 << 30) && c < (1 << 30);
-  for (int i = 0; i < nrows; i++) { /* wave-uniform */
-    const int y = y0 + i;
-    const unsigned in = nin, out = nout, cen = ncen;
-    nin = ld(y + (int)r + 2), nout = ld(y - (int)r + 1);
-    if (MODE) ncen = ld(y + 1);
-    const unsigned P = wave_incl_scan(Vc);
-    const unsigned p_hi = shfl(P, (int)l_hi), p_lo = shfl(P, (int)l_lo);
-    const unsigned H = p_hi - (lane > r ? p_lo : 0u);
-    Vc += in - out;
-    const int ya = y - (int)r < 0 ? 0 : y - (int)r, yb = y + (int)r > (int)h - 1 ? (int)h - 1 : y + (int)r;
-    const unsigned cy = (unsigned)(yb - ya + 1);
-    unsigned o;
-    if (MODE == 1 && by_product) { /* see k_box16 */
-      const int k = (int)cen + c;
-      const unsigned kc = (unsigned)(k < 0 ? 0 : k > 256 ? 256 : k);
-      o = kc * (cx * cy) > H ? 255u : 0u;
-    } else {
-      const unsigned q = box_div(H, cx, cy, rcx, 1.0f / (float)cy);
-      if (MODE == 0) o = q & 0xffu;
-      else o = (int)cen > (int)(q - (unsigned)c) ? 255u : 0u;
+  for (int i0 = 0; i0 < nrows; i0 += U) { /* wave-uniform */
+    unsigned in[U], out[U], cen[U];
+#pragma unroll
+    for (int j = 0; j < U; j++) in[j] = nin[j], out[j] = nout[j], cen[j] = ncen[j];
+#pragma unroll
+    for (int j = 0; j < U; j++) { /* the next trip's rows (past the band's end: loaded for nothing, at most once per band) */
+      const int yn = y0 + i0 + U + j;
+      nin[j] = ld(yn + (int)r + 1), nout[j] = ld(yn - (int)r);
+      if (MODE) ncen[j] = ld(yn);
     }
-    if (outl) D[(size_t)y * w + (unsigned)x] = (uint8_t)o;
+#pragma unroll
+    for (int j = 0; j < U; j++) {
+      const int y = y0 + i0 + j;
+      const unsigned P = wave_incl_scan(Vc);
+      const unsigned p_hi = shfl(P, (int)l_hi), p_lo = shfl(P, (int)l_lo);
+      const unsigned H = p_hi - (lane > r ? p_lo : 0u);
+      Vc += in[j] - out[j];
+      const int ya = y - (int)r < 0 ? 0 : y - (int)r, yb = y + (int)r > (int)h - 1 ? (int)h - 1 : y + (int)r;
+      const unsigned cy = yb >= ya ? (unsigned)(yb - ya + 1) : 1u; /* rows past the image's end (never stored): any divisor */
+      unsigned o;
+      if (cy == full && (MODE == 0 || by_product)) { /* wave-uniform: the rows whose window is not clipped vertically */
+        if (MODE == 0) {
+          o = __umulhi(H, Mi) & 0xffu; /* exact for cnt <= 4103 (k_box16); here cnt <= 33 * 33 */
+        } else {
+          const int k = (int)cen[j] + c;
+          const unsigned kc = (unsigned)(k < 0 ? 0 : k > 256 ? 256 : k);
+          o = __umul24(kc, cnt_full) > H ? 255u : 0u; /* both factors below 2^24 */
+        }
+      } else if (MODE == 1 && by_product) { /* see k_box16 */
+        const int k = (int)cen[j] + c;
+        const unsigned kc = (unsigned)(k < 0 ? 0 : k > 256 ? 256 : k);
+        o = kc * (cx * cy) > H ? 255u : 0u;
+      } else {
+        const unsigned q = box_div(H, cx, cy, rcx, 1.0f / (float)cy);
+        if (MODE == 0) o = q & 0xffu;
+        else o = (int)cen[j] > (int)(q - (unsigned)c) ? 255u : 0u;
+      }
+      buf_store1(D, (outl && i0 + j < nrows) ? (uint32_t)y * w + (uint32_t)x : kOOB, o);
+    }
   }
 }
 

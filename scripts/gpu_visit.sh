@@ -18,6 +18,7 @@
 #   fast         scripts/ubench_fast.py (flat / block noise / lena / random)
 #   fastpmc      SQ_INSTS_VALU of the gs_fast passes -> profiles/fast_valu_pmc.json workflow
 #   extras       ragged shapes, box offsets, next rows, template matching micro-benchmarks
+#   boxragged    scripts/ubench_box_ragged.py (sliding box on ragged / aligned batches, k_box_edge on the side / the caller's stream) + its kernels under rocprofv3
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R; mkdir -p gpurun_out; export TMPDIR=/tmp
 TAG=${1:?usage: gpu_visit.sh TAG section...}; shift
@@ -73,6 +74,11 @@ for sec in "$@"; do
       timeout 300 python scripts/ubench_next_rows.py 2>&1 | grep -v amdgpu.ids | tee ${O}_next_rows.log | tail -12
       timeout 300 python scripts/ubench_tmatch.py 2>&1 | grep -v amdgpu.ids | tee ${O}_tmatch.log | tail -12
       unset UB_LIB ;;
+    boxragged)
+      timeout 600 python scripts/ubench_box_ragged.py 2>&1 | grep -v amdgpu.ids | tee ${O}_box_ragged.log
+      rm -rf gpurun_out/prof_box
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_box -o box -- python $R/scripts/prof_box_ragged.py > /dev/null 2>&1)
+      f=$(find gpurun_out/prof_box -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" ${O}_box_ragged_kernel_stats.csv && head -12 "$f" | cut -c1-160 ;;
     *) echo "unknown section $sec" ;;
   esac
 done

@@ -142,6 +142,7 @@ inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __ffs(int v) { return __builtin_ffs(v); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((uint64_t)a * b) >> 32); }
+inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 
 /* ---- tiny HIP runtime shim: "device" memory is host memory ---- */
 #define hipMemcpyHostToDevice 1

@@ -180,8 +180,8 @@ def test_emu_box_integral_downsample_any_width(emu, request):
 
 def check_ring_box(g, o, bufs, shapes, radii, rs, n=2):
     """gs_blur / gs_adaptive_threshold with 4 <= r <= 16 on ragged rows tall enough for a whole window (the radii the
-    register-ring kernels take on whole-strip rows; ragged rows go to the any-radius kernel): a bright right edge, where a
-    wrong edge divisor would show, positive and negative c"""
+    register-ring kernels take: on ragged rows the whole strips with the last one a feeder + k_box_edge for the last
+    16 + w % 16 columns): a bright right edge, where a wrong edge divisor would show, positive and negative c"""
     sync = bufs.torch.cuda.synchronize if bufs.kind == "gpu" else (lambda: None)
     for (w, h, off) in shapes:
         img = rs.randint(0, 256, (n, h, w)).astype(np.uint8)
@@ -260,6 +260,13 @@ def test_gpu_ring_box_on_ragged_rows(hip, request):
     o, bufs, rs = _oracle(request), Bufs("gpu"), np.random.RandomState(27)
     check_ring_box(hip, o, bufs, ((33, 40, 0), (47, 35, 1), (100, 33, 3), (612, 120, 5), (1039, 64, 0), (1366, 70, 15), (3838, 40, 2)),
                    (4, 9, 16), rs)
+    try:  # k_box_edge on the side stream whatever the batch size and radius (the rule: r >= 12 on batches of 16 Mpx and more)
+        hip.tune(6, 7)
+        check_ring_box(hip, o, bufs, ((47, 35, 1), (612, 120, 5), (1366, 70, 15), (3838, 70, 2)), (5, 16), rs)
+    finally:
+        hip.tune(6, 0)
+    # the rule's own choice on a batch large enough for the side stream: 9 x 1918 x 1080 = 18.6 Mpx
+    check_ring_box(hip, o, bufs, ((1918, 1080, 0),), (13,), rs, n=9)
 
 
 @pytest.mark.gpu
