@@ -305,6 +305,11 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 8 : 1) void k_lbp_tile(LbpArgs a, 
     const unsigned *Pg = a.padded + (size_t)blockIdx.z * a.frame_stride;
     const unsigned rows = (unsigned)(a.frame_stride / a.S);
     const unsigned gx0 = tp.x0w * step, gy0 = tp.y0w * step;
+    /* (Round 5, measured and not kept: four trips at a time with sixteen unconditional buffer loads in flight -- hipcc puts each
+     * trip's four bounds-tested loads behind branches and waits for them before the next trip's are issued, up to eight memory
+     * latencies in a row per block.  1-3 % SLOWER at every size: 8 x 4K edge maps 3.23 vs 3.19 ms, 1080p block noise 0.64 vs
+     * 0.62, per scale +0.5-1 %; profiles/r05m_lbp_staging_16_loads_not_kept.log.  The other blocks of the CU cover the
+     * staging as it is.) */
     for (unsigned r0 = wave * 4u; r0 < TR; r0 += NW * 4u) { /* four table rows per wave and trip: loads first, stores after */
       for (unsigned c = lane; c < TS; c += 64u) {
         unsigned v[4];

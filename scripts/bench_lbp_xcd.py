@@ -26,7 +26,7 @@ for (kind, w, h, n) in (("edges", 3840, 2160, 8), ("noise", 3840, 2160, 8), ("ed
     rects = torch.zeros((n, 4096, 4), dtype=torch.int32, device="cuda"); counts = torch.zeros(n, dtype=torch.int32, device="cuda")
     for rnd in range(2):
         for k14 in (0,):
-            for k13 in (2, 4):
+            for k13 in (0, 2):
                 g.tune(14, k14); g.tune(13, k13)
                 ms = timeit(lambda: g.lbp_detect_batch(dc, ii, rects, counts, 4096, 1.1, 1.0, 4.0, 1))
                 print("%s %dx%d %-14s key 13 = %d: %.3f ms/frame" % (kind, w, h, "rule" if k14 == 0 else "k_lbp_cascade", k13, ms / n), flush=True)
