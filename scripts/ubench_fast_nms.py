@@ -26,5 +26,5 @@ for (W, H, F, cap) in ((1280, 720, 32, 2000), (1280, 720, 32, 5000), (3840, 2160
                 crc = zlib.crc32(kps.cpu().numpy().tobytes()) ^ zlib.crc32(cnt.cpu().numpy().tobytes())
                 ref = ref or crc
                 print("%dx%d x%d cap %d %-6s NMS %-14s %.4f ms per frame (%.1f us per batch)  n0=%d same=%s"
-                      % (W, H, F, cap, name, "item kernel" if k19 else "strip (default)", ms / F, ms * 1e3, int(cnt[0]), crc == ref), flush=True)
+                      % (W, H, F, cap, name, "item kernel" if k19 else "sparse (default)", ms / F, ms * 1e3, int(cnt[0]), crc == ref), flush=True)
         g.tune(19, 0)
