@@ -15,6 +15,7 @@
  */
 #ifndef GS_K_ORB_H
 #define GS_K_ORB_H
+#include <type_traits>
 #include "k_compact.h"
 
 namespace gs {
@@ -30,6 +31,27 @@ GS_CONST_TABLE int8_t k_brief_pattern[1024] = {
 
 struct KpIn { unsigned x, y; float sin_a, cos_a; }; /* host -> device per keypoint */
 
+/* gs_get (ref :23-26): the pixel, 0 outside the image.  Frames below 2 GiB go through an unconditional buffer load (outside:
+ * the out-of-range offset), so that a thread's pixels are requested together -- hipcc turns `in ? img[..] : 0` into a branch
+ * around the load and waits for each one before the next is issued; larger frames keep that form. */
+struct PxReader {
+  const uint8_t *img;
+  BufRsrc B;
+  unsigned w, h;
+  bool small;
+  GS_DEV PxReader(const uint8_t *p, unsigned w_, unsigned h_) : img(p), B(make_buf(p, (size_t)w_ * h_)), w(w_), h(h_), small((size_t)w_ * h_ < 0x7fffffffull) {}
+  template <bool SMALL> GS_DEV unsigned get(unsigned sx, unsigned sy, bool also = true) const {
+    const bool in = also && sx < w && sy < h;
+    if constexpr (SMALL) return buf_load1(B, in ? sy * w + sx : kOOB);
+    else return in ? img[(size_t)sy * w + sx] : 0u;
+  }
+  /* f(std::true_type / false_type): the caller's whole group of reads in one of the two forms (block-uniform choice) */
+  template <class F> GS_DEV void with(F &&f) const {
+    if (small) f(std::true_type{});
+    else f(std::false_type{});
+  }
+};
+
 /* grid nkp (or an upper bound, with the true count in *count_dev), block 64.
  * pts: (x,y) pairs; out: (m01, m10) int pairs */
 /* blockIdx.y = frame of a batch (frames frame_bytes apart; pts / out / count_dev hold gridDim.x
@@ -44,15 +66,25 @@ __global__ __launch_bounds__(64) void k_orient_moments(const uint8_t *img, unsig
   out += (size_t)blockIdx.y * gridDim.x * 2;
   const unsigned x = pts[(size_t)blockIdx.x * pt_stride], y = pts[(size_t)blockIdx.x * pt_stride + 1];
   const int side = 2 * (int)r + 1, total = side * side, rr = (int)(r * r);
+  /* The patch is read eight pixels per lane at a time with unconditional buffer loads (a pixel outside the disc or the
+   * image: the out-of-range offset, which reads 0 = gs_get's value there).  With the load inside the tests every one of a
+   * lane's 16 pixels (r = 15) was a memory latency of its own: 20.7 us per 32 x 500 keypoints (profiles/r05n_orb_kernels.log). */
+  const PxReader px(img, w, h);
   int m01 = 0, m10 = 0;
-  for (int t = (int)threadIdx.x; t < total; t += 64) {
-    const int dy = t / side - (int)r, dx = t % side - (int)r;
-    if (dx * dx + dy * dy <= rr) {
-      const unsigned sx = x + (unsigned)dx, sy = y + (unsigned)dy; /* gs_get: wrap => 0 */
-      const int I = (sx < w && sy < h) ? img[(size_t)sy * w + sx] : 0;
-      m01 += dy * I, m10 += dx * I;
+  px.with([&](auto SM) {
+    for (int t0 = (int)threadIdx.x; t0 < total; t0 += 64 * 8) { /* wave-uniform trip count */
+      int I[8], dyv[8], dxv[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int t = t0 + 64 * u;
+        dyv[u] = t / side - (int)r, dxv[u] = t % side - (int)r;
+        const unsigned sx = x + (unsigned)dxv[u], sy = y + (unsigned)dyv[u]; /* gs_get: wrap => 0 */
+        I[u] = (int)px.template get<decltype(SM)::value>(sx, sy, t < total && dxv[u] * dxv[u] + dyv[u] * dyv[u] <= rr);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) m01 += dyv[u] * I[u], m10 += dxv[u] * I[u];
     }
-  }
+  });
   m01 = wave_sum_i(m01), m10 = wave_sum_i(m10);
   if (threadIdx.x == 0) out[2 * blockIdx.x] = m01, out[2 * blockIdx.x + 1] = m10;
 }
@@ -104,8 +136,9 @@ __global__ __launch_bounds__(256) void k_brief(const uint8_t *img, unsigned w, u
   const float dx1 = m00 - m01, dy1 = m10 + m11, dx2 = n00 - n01, dy2 = n10 + n11;
   const unsigned x1 = (unsigned)((int)kp.x + (int)dx1), y1 = (unsigned)((int)kp.y + (int)dy1);
   const unsigned x2 = (unsigned)((int)kp.x + (int)dx2), y2 = (unsigned)((int)kp.y + (int)dy2);
-  const unsigned I1 = (x1 < w && y1 < h) ? img[(size_t)y1 * w + x1] : 0u;
-  const unsigned I2 = (x2 < w && y2 < h) ? img[(size_t)y2 * w + x2] : 0u;
+  const PxReader px(img, w, h); /* both pixels requested before either is used */
+  unsigned I1 = 0, I2 = 0;
+  px.with([&](auto SM) { I1 = px.template get<decltype(SM)::value>(x1, y1), I2 = px.template get<decltype(SM)::value>(x2, y2); });
   const uint64_t m = ballot(I1 > I2);
   if (lane_id() == 0) {
     const unsigned wv = i >> 6;
@@ -150,7 +183,7 @@ GS_HD float gs_sin_poly(float x) { /* ref :80-88 */
  * a scoremap byte, so: count the in-border candidates per response (256 LDS counters), rank of a
  * candidate = (in-border candidates with a larger response) + (earlier in-border candidates with the
  * same response), keep rank < nkps.  The "earlier, same response" part is resolved 64 candidates at a
- * time: the wave peels off one distinct response per iteration (readfirstlane + ballot).
+ * time: a lane finds the lanes that share its response with one ballot per response bit.
  * grid n frames, block 64.  cand: n x cap records (12 u32), out: n x nkps records. */
 __global__ __launch_bounds__(64) void k_orb_select(const unsigned *cand, const unsigned *cand_count, unsigned cap,
                                                   unsigned w, unsigned h, unsigned nkps, unsigned *out,
@@ -162,9 +195,19 @@ __global__ __launch_bounds__(64) void k_orb_select(const unsigned *cand, const u
   unsigned *o = out + (size_t)f * nkps * 12u;
   for (unsigned i = lane; i < 256u; i += 64u) cnt[i] = 0;
   __syncthreads();
-  for (unsigned i = lane; i < n; i += 64u) {
-    const unsigned x = c[(size_t)i * 12u], y = c[(size_t)i * 12u + 1], resp = c[(size_t)i * 12u + 2] & 255u;
-    if (x >= r && y >= r && x < w - r && y < h - r) atomicAdd(&cnt[resp], 1u);
+  /* candidate records are read eight trips of 64 at a time, from clamped indices (no load inside a bounds test: a trip is one
+   * memory latency, and hipcc does not overlap the trips of a loop whose loads sit in branches) */
+  constexpr unsigned U = 8;
+  for (unsigned i0 = 0; i0 < n; i0 += 64u * U) { /* wave-uniform */
+    unsigned x[U], y[U], resp[U];
+#pragma unroll
+    for (unsigned u = 0; u < U; u++) {
+      const unsigned i = i0 + 64u * u + lane, ic = i < n ? i : n - 1u;
+      x[u] = c[(size_t)ic * 12u], y[u] = c[(size_t)ic * 12u + 1], resp[u] = c[(size_t)ic * 12u + 2] & 255u;
+    }
+#pragma unroll
+    for (unsigned u = 0; u < U; u++)
+      if (i0 + 64u * u + lane < n && x[u] >= r && y[u] >= r && x[u] < w - r && y[u] < h - r) atomicAdd(&cnt[resp[u]], 1u);
   }
   __syncthreads();
   /* base[v] = in-border candidates with a response > v: suffix sums, 4 bins per lane (lane 0 = bins 252..255) */
@@ -179,32 +222,40 @@ __global__ __launch_bounds__(64) void k_orb_select(const unsigned *cand, const u
     if (lane == 0) out_count[f] = total < nkps ? total : nkps;
   }
   __syncthreads();
-  for (unsigned i0 = 0; i0 < n; i0 += 64u) { /* wave-uniform trip count */
-    const unsigned i = i0 + lane;
-    unsigned x = 0, y = 0, resp = 0;
-    bool ok = false;
-    if (i < n) {
-      x = c[(size_t)i * 12u], y = c[(size_t)i * 12u + 1], resp = c[(size_t)i * 12u + 2];
-      ok = x >= r && y >= r && x < w - r && y < h - r;
-    }
-    uint64_t todo = ballot(ok);
-    unsigned rank = 0xffffffffu;
-    while (todo) { /* one distinct response per iteration */
-      const unsigned first = (unsigned)__builtin_ctzll(todo);
-      const unsigned v = readlane_at(resp, first) & 255u;
-      const uint64_t same = ballot(ok && (resp & 255u) == v) & todo;
-      const unsigned start = base[v];
-      if ((same >> lane) & 1ull) rank = start + (unsigned)__popcll(same & ((1ull << lane) - 1ull));
-      __syncthreads(); /* every lane has read base[v] */
-      if (lane == first) base[v] = start + (unsigned)__popcll(same);
-      __syncthreads();
-      todo &= ~same;
-    }
-    if (ok && rank < nkps) {
-      unsigned *q = o + (size_t)rank * 12u;
-      q[0] = x, q[1] = y, q[2] = resp;
+  for (unsigned j0 = 0; j0 < n; j0 += 64u * U) { /* wave-uniform */
+    unsigned xs[U], ys[U], rs[U];
 #pragma unroll
-      for (int k = 3; k < 12; k++) q[k] = 0;
+    for (unsigned u = 0; u < U; u++) {
+      const unsigned i = j0 + 64u * u + lane, ic = i < n ? i : n - 1u;
+      xs[u] = c[(size_t)ic * 12u], ys[u] = c[(size_t)ic * 12u + 1], rs[u] = c[(size_t)ic * 12u + 2];
+    }
+#pragma unroll
+    for (unsigned u = 0; u < U; u++) { /* the trips in scan order */
+      if (j0 + 64u * u >= n) break; /* wave-uniform */
+      const unsigned x = xs[u], y = ys[u], resp = rs[u];
+      const bool ok = j0 + 64u * u + lane < n && x >= r && y >= r && x < w - r && y < h - r;
+      /* the in-border lanes with this lane's response: eight ballots, one per bit of the response (rounds 2-4 peeled off one
+       * distinct response per iteration with two barriers each -- ~1000 iterations per 2000 candidates) */
+      const unsigned rv = resp & 255u;
+      uint64_t same = ballot(ok);
+#pragma unroll
+      for (unsigned b = 0; b < 8u; b++) {
+        const bool bit = ((rv >> b) & 1u) != 0u;
+        const uint64_t m = ballot(ok && bit);
+        same &= bit ? m : ~m;
+      }
+      const unsigned start = base[ok ? rv : 0u];
+      const unsigned before = (unsigned)__popcll(same & ((1ull << lane) - 1ull));
+      const unsigned rank = ok ? start + before : 0xffffffffu;
+      __syncthreads(); /* every lane has read base[] */
+      if (ok && before == 0u) base[rv] = start + (unsigned)__popcll(same); /* the first lane of each response's group */
+      __syncthreads();
+      if (ok && rank < nkps) {
+        unsigned *q = o + (size_t)rank * 12u;
+        q[0] = x, q[1] = y, q[2] = resp;
+#pragma unroll
+        for (int k = 3; k < 12; k++) q[k] = 0;
+      }
     }
   }
 }
@@ -226,15 +277,20 @@ __global__ __launch_bounds__(256) void k_orb_describe(const uint8_t *img, unsign
   unsigned *kp = kps + ((size_t)f * nkps + k) * 12u;
   const unsigned x = kp[0], y = kp[1];
   const int r = 15, side = 2 * r + 1, total = side * side;
+  const PxReader px(img, w, h);
   int m01 = 0, m10 = 0;
-  for (int t = (int)i; t < total; t += 256) {
-    const int dy = t / side - r, dx = t % side - r;
-    if (dx * dx + dy * dy <= r * r) {
-      const unsigned sx = x + (unsigned)dx, sy = y + (unsigned)dy;
-      const int I = (sx < w && sy < h) ? img[(size_t)sy * w + sx] : 0;
-      m01 += dy * I, m10 += dx * I;
+  px.with([&](auto SM) { /* a thread's four pixels of the 31 x 31 patch, requested together (see k_orient_moments) */
+    int I[4], dyv[4], dxv[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int t = (int)i + 256 * u;
+      dyv[u] = t / side - r, dxv[u] = t % side - r;
+      const unsigned sx = x + (unsigned)dxv[u], sy = y + (unsigned)dyv[u];
+      I[u] = (int)px.template get<decltype(SM)::value>(sx, sy, t < total && dxv[u] * dxv[u] + dyv[u] * dyv[u] <= r * r);
     }
-  }
+#pragma unroll
+    for (int u = 0; u < 4; u++) m01 += dyv[u] * I[u], m10 += dxv[u] * I[u];
+  });
   m01 = wave_sum_i(m01), m10 = wave_sum_i(m10);
   if ((i & 63u) == 0) part[0][i >> 6] = m01, part[1][i >> 6] = m10;
   __syncthreads();
@@ -255,8 +311,8 @@ __global__ __launch_bounds__(256) void k_orb_describe(const uint8_t *img, unsign
   const float dx1 = m00 - m01f, dy1 = m10f + m11, dx2 = n00 - n01, dy2 = n10 + n11;
   const unsigned x1 = (unsigned)((int)x + (int)dx1), y1 = (unsigned)((int)y + (int)dy1);
   const unsigned x2 = (unsigned)((int)x + (int)dx2), y2 = (unsigned)((int)y + (int)dy2);
-  const unsigned I1 = (x1 < w && y1 < h) ? img[(size_t)y1 * w + x1] : 0u;
-  const unsigned I2 = (x2 < w && y2 < h) ? img[(size_t)y2 * w + x2] : 0u;
+  unsigned I1 = 0, I2 = 0;
+  px.with([&](auto SM) { I1 = px.template get<decltype(SM)::value>(x1, y1), I2 = px.template get<decltype(SM)::value>(x2, y2); });
   const uint64_t m = ballot(I1 > I2);
   if (lane_id() == 0) {
     const unsigned wv = i >> 6;
