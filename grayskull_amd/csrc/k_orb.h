@@ -340,14 +340,29 @@ __global__ __launch_bounds__(256) void k_match(const uint32_t *k1, unsigned n1, 
   for (int q = 0; q < 8; q++) d1[q] = k1[(size_t)i * 12u + 4 + q];
   float best = max_distance + 1, second = max_distance + 1;
   unsigned arg = 0;
-  for (unsigned j = lane; j < n2; j += 64u) {
-    const uint32_t *d2 = k2 + (size_t)j * 12u + 4;
-    unsigned bits = 0;
+  /* four train descriptors per lane and trip, all thirty-two dwords requested before the first is used (index clamped, the
+   * surplus ones ignored): a trip is one memory latency, and 2500 train descriptors were 40 of them in a row (round 5:
+   * 2500 x 2500 62 -> 45 us, 500 x 500 27 -> 25; eight per trip: no further gain, profiles/r05n_match_*.log) */
+  for (unsigned j0 = lane; j0 < n2; j0 += 256u) { /* a lane's indices in ascending order: the first minimum wins (ref :690) */
+    uint32_t d2[4][8];
 #pragma unroll
-    for (int q = 0; q < 8; q++) bits += (unsigned)__popc(d1[q] ^ d2[q]);
-    const float d = (float)bits;
-    if (d < best) second = best, best = d, arg = j;
-    else if (d < second) second = d;
+    for (unsigned u = 0; u < 4u; u++) {
+      const unsigned j = j0 + 64u * u, jc = j < n2 ? j : n2 - 1u;
+#pragma unroll
+      for (int q = 0; q < 8; q++) d2[u][q] = k2[(size_t)jc * 12u + 4 + q];
+    }
+#pragma unroll
+    for (unsigned u = 0; u < 4u; u++) {
+      const unsigned j = j0 + 64u * u;
+      unsigned bits = 0;
+#pragma unroll
+      for (int q = 0; q < 8; q++) bits += (unsigned)__popc(d1[q] ^ d2[u][q]);
+      const float d = (float)bits;
+      if (j < n2) {
+        if (d < best) second = best, best = d, arg = j;
+        else if (d < second) second = d;
+      }
+    }
   }
 #pragma unroll
   for (int sft = 32; sft >= 1; sft >>= 1) { /* butterfly merge of the 64 lane states */
