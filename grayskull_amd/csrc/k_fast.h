@@ -170,15 +170,26 @@ __global__ __launch_bounds__(NT, (NT == 256 && ROWS <= 48) ? 8 : 1) void k_fast_
    * the copy is a plain loop: (row, column) advance by NT = 14 x 18 + 4 dwords without a division, no bounds test per load */
   const bool tile_inside = ((size_t)(y_t + ROWS + 5u) * w + x_t + kFastTileDw * 4u <= frame_bytes) && frame_bytes < 0x7fffffffull;
   if (tile_inside) {
-    constexpr unsigned dr = NT / kFastTileDw, dc = NT - dr * kFastTileDw;
+    /* Round 5: the thread's (up to) four dwords are requested TOGETHER, as unconditional buffer loads (past the tile's last
+     * dword: the out-of-range offset), and stored to the LDS afterwards.  With `if (i < ...) tile32[i] = load(...)` hipcc put
+     * every load behind a branch and waited for it before issuing the next: four memory latencies in a row at the top of
+     * every block.  Worth ~1 us of 70 (profiles/r05o_fast_tile_loads_together.log: flat 27.6 -> 25.9-27.8, block noise 48.4-50.8
+     * -> 47.6-49.0 for the score pass): eight blocks per CU already covered the waits -- flat frames are VALU time too,
+     * ~25 lane-operations per pixel for the tile copy, the compass filter and the zero stores. */
+    constexpr unsigned dr = NT / kFastTileDw, dc = NT - dr * kFastTileDw, LIM = (ROWS + 6) * kFastTileDw, NIT = (LIM + NT - 1) / NT;
+    const BufRsrc FB = make_buf(frame, frame_bytes); /* frame_bytes < 2 GiB on this path */
     unsigned r = tid / kFastTileDw, c = tid - r * kFastTileDw;
-    const uint8_t *p0 = frame + (size_t)y_t * w + x_t;
+    const unsigned base = y_t * w + x_t;
+    uint32_t v[NIT];
 #pragma unroll
-    for (unsigned i = tid, it = 0; it < ((ROWS + 6) * kFastTileDw + NT - 1) / NT; it++, i += NT) {
-      if (i < (ROWS + 6) * kFastTileDw) tile32[i] = load_u32_unaligned(p0 + r * w + c * 4u);
+    for (unsigned it = 0; it < NIT; it++) {
+      v[it] = buf_load4(FB, tid + it * NT < LIM ? base + r * w + c * 4u : kOOB);
       r += dr, c += dc;
       if (c >= kFastTileDw) c -= kFastTileDw, r++;
     }
+#pragma unroll
+    for (unsigned it = 0; it < NIT; it++)
+      if (tid + it * NT < LIM) tile32[tid + it * NT] = v[it];
   } else {
     for (unsigned i = tid; i < (ROWS + 6) * kFastTileDw; i += NT) {
       const unsigned r = i / kFastTileDw, c = i - r * kFastTileDw;
