@@ -11,7 +11,8 @@
  * builds that say so: a release library cannot be built with one of them flipped by accident. */
 #if !defined(GS_EXPERIMENT) && (defined(GS_FUSED_SPARE) || defined(GS_FUSED_VGPR_ATTR) || defined(GS_EVENT_FLAGS) ||       \
                                 defined(GS_ORDER_EVENT_FLAGS) || defined(GS_LOAD_AUX) || defined(GS_STORE_AUX) ||         \
-                                defined(GS_LBP_PREFETCH) || defined(GS_MAD2_OPAQUE) || defined(GS_LBP_TILE_ODD_STRIDE))
+                                defined(GS_LBP_PREFETCH) || defined(GS_MAD2_OPAQUE) || defined(GS_LBP_TILE_ODD_STRIDE) ||   \
+                                defined(GS_LBP_SENS))
 #error "experiment hook set without -DGS_EXPERIMENT (make variant / make experiment add it)"
 #endif
 

@@ -42,16 +42,6 @@
  * dependent passes is not what a block waits for.  What does matter is blocks per CU: the same shape drops from 0.23 to 0.34
  * ms per scale where its tile stops fitting twice (scale 2.36 -> 2.59 for 128 x 32 windows).
  *
- * Stage 0 by chains (round 5, measured and not kept; scripts/experiments/not_kept/k_lbp_tile_stage0_chains.h): windows one cell
- * height apart share three of the four rows of a classifier's corner grid, so a wave that walks down such a chain reads 4
- * corners per window instead of 16 -- and 12 corner reads MORE per dense evaluation cost 7-9 % of a scan (the GS_LBP_SENS hook
- * below, profiles/r05p_lbp_dense_sensitivity.log).  The cell height differs per classifier, so stage 0 had to leave the waves'
- * own phases: (classifier, column segment, window row) units listed in chain order, an equal run per wave, the 64 lookup bits
- * of a unit left as a word in the LDS, two more barriers, truth table per window afterwards.  Same rectangles, 7-10 % SLOWER
- * at every size (8 x 4K edge maps 3.66 vs 3.42 ms, 1080p block noise 0.69 vs 0.62; profiles/r05q_lbp_stage0_chains_not_kept.log):
- * a chain is a dependent sequence (shift the grid, read a row, evaluate) where the window-per-lane form requests the next
- * classifier's sixteen corners before it evaluates the current one, and the waves wait for each other twice.
- *
  * Not for GUARD geometries (feature rectangles that leave the window: scale < 1) -- those stay with k_lbp_cascade.
  */
 #ifndef GS_K_LBP_TILE_H
@@ -330,6 +320,30 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 8 : 1) void k_lbp_tile(LbpArgs a, 
       l_geom[i] = r;
     }
   }
+  /* ---- stage 0 by chains (round 5).  Windows one cell height apart share three of the four rows of a classifier's 4 x 4
+   * corner grid, so a wave that walks down such a chain reads 4 corners per window instead of 16 (k_lbp_tile's LDS pipe is
+   * 75 % busy, and 12 corner reads more per dense evaluation cost 7-9 % of a scan: profiles/r05p_lbp_dense_sensitivity.log).
+   * The cell height differs per classifier, so stage 0 is taken out of the waves' own phases: the n0 * SEG * TH (classifier,
+   * column segment, window row) units are listed classifier by classifier, segment by segment, rows in CHAIN order
+   * (row r, r + fh, r + 2 fh, ...: perm), every wave takes an equal run of the list and leaves each unit's 64 lookup bits
+   * as one word in the LDS (hits, in the not yet used queue area); behind a barrier every wave picks up the n0 words of
+   * its own wave-rows and reads the stage's truth table.  Only for step 1 (chains of whole window rows), stages with a
+   * truth table, and shapes whose list divides evenly among the waves. */
+  const unsigned n0 = uniform(a.stage[0].count), first0 = uniform(a.stage[0].first);
+  constexpr unsigned kChainMaxCls = 8;
+  const bool chains = ph.tile_chains && step == 1u && uniform(a.stage[0].truth) != 0u && n0 >= 1u && n0 <= kChainMaxCls && a.nstages > 1u &&
+                      ph.tile_first == 1u && (n0 * SEG * TH) % NW == 0u && TH <= 64u &&
+                      (size_t)n0 * TH * SEG * 8u + (size_t)n0 * (TH + 1u) <= (size_t)TW * TH * 2u; /* block-uniform */
+  unsigned long long *hits = (unsigned long long *)queue_all;        /* [n0][TH][SEG] */
+  uint8_t *perm = (uint8_t *)queue_all + (size_t)n0 * TH * SEG * 8u; /* [n0][TH] window rows in chain order, then [n0] cell heights */
+  if (chains && tid < n0) {
+    const unsigned fh = (unsigned)a.geom[(size_t)si * a.nweaks + first0 + tid].pad; /* the classifier's cell height in table rows */
+    uint8_t *pm = perm + tid * TH;
+    unsigned k = 0;
+    for (unsigned rho = 0; rho < fh && rho < TH; rho++)
+      for (unsigned ly = rho; ly < TH; ly += fh) pm[k++] = (uint8_t)ly;
+    perm[n0 * TH + tid] = (uint8_t)(fh < 255u ? fh : 255u);
+  }
   {
     const unsigned *Pg = a.padded + (size_t)blockIdx.z * a.frame_stride;
     const unsigned rows = (unsigned)(a.frame_stride / a.S);
@@ -376,17 +390,66 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 8 : 1) void k_lbp_tile(LbpArgs a, 
     alive |= ((lx < tp.nwx && ly < tp.nwy) ? 1u : 0u) << k;
   }
   const unsigned nvalid = wave_sum((unsigned)__popc(alive));
+  if (chains) { /* block-uniform */
+    const unsigned E = n0 * SEG * TH / NW; /* units per wave */
+    unsigned G[4][4];
+    unsigned pc = ~0u, pseg = ~0u, prow = ~0u; /* the unit before this one (wave-uniform) */
+#pragma clang loop unroll(disable)
+    for (unsigned u = wave * E; u < (wave + 1u) * E; u++) { /* wave-uniform */
+      const unsigned c = u / (SEG * TH), rem = u - c * (SEG * TH), seg = rem / TH, idx = rem - seg * TH;
+      const unsigned ly = uniform((unsigned)perm[c * TH + idx]), fh = uniform((unsigned)perm[n0 * TH + c]);
+      if (ly >= tp.nwy) { /* below the scale's last window row: nobody reads this unit */
+        pc = ~0u; /* and the grid registers are not its chain's any more */
+        continue;
+      }
+      const LbpTileGeom g = l_geom[first0 + c];
+      const unsigned lx = seg * 64u + lane;
+      const unsigned base = (ly * TS + lx) * 4u + uniform(g.off0), fw = uniform(g.fw), fhs = uniform(g.fh_stride);
+      if (c == pc && seg == pseg && ly == prow + fh) { /* one cell further down the chain: rows 1..3 become rows 0..2 */
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+          for (int i = 0; i < 4; i++) G[j][i] = G[j + 1][i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) G[3][i] = *(const unsigned *)((const char *)tile + (base + 3u * fhs + (unsigned)i * fw));
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+          for (int i = 0; i < 4; i++) G[j][i] = *(const unsigned *)((const char *)tile + (base + (unsigned)j * fhs + (unsigned)i * fw));
+      }
+      pc = c, pseg = seg, prow = ly;
+      const unsigned bit = lbp_subset_bit(l_sub, uniform(g.sub), lbp_code_of(G));
+      const uint64_t hm = ballot(bit != 0u && lx < tp.nwx);
+      if (lane == 0) hits[(c * TH + ly) * SEG + seg] = hm;
+    }
+    __syncthreads(); /* every unit's word is in place */
+    const unsigned tt0 = uniform(l_stage[0].truth);
+#pragma unroll
+    for (unsigned k = 0; k < R; k++) {
+      const unsigned q = wave + NW * k, ly = q / SEG, seg = q - ly * SEG;
+      if ((alive >> k) & 1u) { /* lanes of valid windows (their row is below nwy, so its words were written) */
+        unsigned pat = 0;
+        for (unsigned c = 0; c < n0; c++) pat |= (unsigned)((hits[(c * TH + ly) * SEG + seg] >> lane) & 1ull) << c;
+        if (!((l_truth[tt0 - 1u + (pat >> 5)] >> (pat & 31u)) & 1u)) alive &= ~(1u << k);
+        if constexpr (COUNT) evals += n0;
+      }
+    }
+    __syncthreads(); /* the hit words live where the waves' queues begin */
+  }
   unsigned m = 0; /* survivors in the wave's queue */
   unsigned e = 0;
   if (nvalid) {
     const unsigned emax = ph.adaptive_max ? ph.adaptive_max : ph.end[0];
-    unsigned s_prev = 0;
+    unsigned s_prev = chains ? 1u : 0u; /* chains: stage 0 is done */
     e = ph.tile_first < a.nstages ? ph.tile_first : a.nstages;
     for (;;) { /* wave-uniform */
+      if (e > s_prev) {
 #pragma clang loop unroll(disable) /* one copy of the stage loop, not R: registers (64 for the 1024-thread shapes) and code size */
-      for (unsigned k = 0; k < R; k++) {
-        if ((alive >> k) & 1u) {
-          if (!lbp_tile_window_stages<COUNT>(t, tile, odw_of(k) * 4u, s_prev, e, &evals)) alive &= ~(1u << k);
+        for (unsigned k = 0; k < R; k++) {
+          if ((alive >> k) & 1u) {
+            if (!lbp_tile_window_stages<COUNT>(t, tile, odw_of(k) * 4u, s_prev, e, &evals)) alive &= ~(1u << k);
+          }
         }
       }
       const unsigned c = wave_sum((unsigned)__popc(alive));
