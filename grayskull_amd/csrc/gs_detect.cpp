@@ -57,7 +57,9 @@ bool launch_fast_score(hipStream_t on, const uint8_t *img, uint8_t *score, unsig
   GS_ASSERT(nt < (1ull << 24)); /* the kernel's 32-bit strides (tile index) stay clear of 2^32: 2^24 tiles = 2^34 pixels per call */
   const unsigned share = (g_tune[18] == 1 || !topo().eight_xcds()) ? 0u : (unsigned)((nt + 7) / 8); /* key 18 = 1: tiles in launch order */
   const dim3 grid(share ? share * 8u : (unsigned)nt), block(64, 4);
-  GS_LAUNCH(k_fast_score_q4<rows>, grid, block, 0, on, img, score, w, h, fb, threshold, tx, ty, (unsigned)nt, share, nz, nz_frame_words);
+  const auto magic = [](unsigned d) { return d <= 1u ? 0xffffffffu : (unsigned)((1ull << 32) / d); }; /* floor(2^32 / d) */
+  GS_LAUNCH(k_fast_score_q4<rows>, grid, block, 0, on, img, score, w, h, fb, threshold, tx, ty, (unsigned)nt, share, nz, nz_frame_words,
+            magic(tx), magic(tx * ty));
   return true;
 }
 

@@ -114,6 +114,14 @@ __global__ __launch_bounds__(256) void k_fast_score_px(const uint8_t *img, uint8
   if (in) score[(size_t)blockIdx.z * frame_bytes + (size_t)y * w + x] = (uint8_t)s;
 }
 
+/* idx / d for any idx with M = floor(2^32 / d) (0xffffffff for d = 1): the estimate is at most 2 short */
+GS_DEV unsigned udiv_by_magic(unsigned idx, unsigned d, unsigned M) {
+  unsigned q = __umulhi(idx, M), r = idx - q * d;
+  if (r >= d) q++, r -= d;
+  if (r >= d) q++;
+  return q;
+}
+
 constexpr unsigned kFastTileDw = 18; /* 72 bytes per tile row of k_fast_score_q4: 64 + 6, rounded up to dwords */
 
 /* pass 1, round 3 default (threshold <= 0xffffff00): LDS tile, FOUR pixels per thread for the compass filter, candidates
@@ -139,7 +147,8 @@ template <unsigned ROWS, unsigned NT = 256>
 __global__ __launch_bounds__(NT, (NT == 256 && ROWS <= 48) ? 8 : 1) void k_fast_score_q4(const uint8_t *img, uint8_t *score, unsigned w, unsigned h,
                                                        size_t frame_bytes, unsigned threshold, unsigned tiles_x,
                                                        unsigned tiles_y, unsigned ntiles, unsigned xcd_share,
-                                                       unsigned long long *nz = nullptr, size_t nz_frame_words = 0) {
+                                                       unsigned long long *nz, size_t nz_frame_words,
+                                                       unsigned magic_x, unsigned magic_xy) { /* floor(2^32 / tiles_x), floor(2^32 / (tiles_x tiles_y)) */
   static_assert(ROWS % 16 == 0 && ROWS >= 16 && ROWS <= 64 && (NT == 128 || NT == 256), "a thread takes one row of every group of NT / 16; queue entries are 16-bit");
   constexpr unsigned RG = NT / 16; /* tile rows per row group */
   __shared__ uint32_t tile32[(ROWS + 6) * kFastTileDw + 2]; /* + 2: the last thread's third centre dword */
@@ -159,7 +168,11 @@ __global__ __launch_bounds__(NT, (NT == 256 && ROWS <= 48) ? 8 : 1) void k_fast_
     tile = (blockIdx.x & 7u) * xcd_share + (blockIdx.x >> 3);
     if (tile >= ntiles) return;
   }
-  const unsigned tcol = tile % tiles_x, trow = (tile / tiles_x) % tiles_y, tframe = tile / (tiles_x * tiles_y);
+  /* tile -> (frame, tile row, tile column): wave-uniform, but the scalar unit has no division and hipcc emitted three float
+   * reciprocal sequences on the VALU (~70 of the ~440 VALU instructions a wave executes on a flat tile); with the host's
+   * floor(2^32 / d) they are scalar multiply-highs with a fix-up (round 5). */
+  const unsigned txy = tiles_x * tiles_y, tframe = udiv_by_magic(tile, txy, magic_xy), trem = tile - tframe * txy;
+  const unsigned trow = udiv_by_magic(trem, tiles_x, magic_x), tcol = trem - trow * tiles_x;
   const uint8_t *frame = img + (size_t)tframe * frame_bytes;
   uint8_t *out = score + (size_t)tframe * frame_bytes;
   const unsigned tid = threadIdx.y * 64u + threadIdx.x;
