@@ -27,6 +27,10 @@ import socket
 import sys
 import time
 
+# the host driver only supports dmabuf IPC: without this RCCL fails with `hipIpcGetMemHandle: invalid argument` (exported on the
+# GPU boxes already; set here too so that every way of launching the ranks has it before torch / HIP start)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
