@@ -268,3 +268,26 @@ def orb_nostdlib(g, o_nostdlib, frames, nkps=60, threshold=20):
 
 def _is_gpu(g):
     return "emulator" not in g.version()
+
+
+def match_random(g, o, n1, n2):
+    """gs_match_orb on random descriptors: partners at distance 0 / 3 / 40, some of them twice in the train set (ties: the first
+    index of the minimum wins, ref :690; equal best and second fail the 0.8 ratio test), three (max_matches, max_distance)"""
+    from grayskull_amd import KEYPOINT_DTYPE
+    rng = np.random.RandomState(1000 * n1 + n2)
+    k1, k2 = np.zeros(n1, KEYPOINT_DTYPE), np.zeros(n2, KEYPOINT_DTYPE)
+    raw1, raw2 = k1.view(np.uint32).reshape(n1, 12), k2.view(np.uint32).reshape(n2, 12)
+    raw1[:, 4:] = rng.randint(0, 2 ** 32, (n1, 8), dtype=np.uint64).astype(np.uint32)
+    raw2[:, 4:] = rng.randint(0, 2 ** 32, (n2, 8), dtype=np.uint64).astype(np.uint32)
+    for i in range(n1):
+        j = int(rng.randint(0, n2))
+        raw2[j, 4:] = raw1[i, 4:]
+        if i % 3 == 1:
+            raw2[j, 4] ^= 0x7
+        if i % 3 == 2:
+            raw2[j, 5] ^= 0xFFFFF00F
+            raw2[j, 6] ^= 0xFFFF
+        if i % 2 and n2 > 2:
+            raw2[(j + n2 // 2) % n2, 4:] = raw2[j, 4:]
+    for mm, md in ((n1 + 3, 60.0), (max(1, n1 // 2), 256.0), (n1, 2.0)):
+        assert_same(g.match_orb(k1, k2, mm, md), o.match_orb(k1, k2, mm, md), "gs_match_orb %d x %d max=%d dist=%g" % (n1, n2, mm, md))

@@ -136,6 +136,14 @@ def test_orb_and_match(emu, oracle, shape):
     pc.orb(emu, oracle, Oracle.synth(w, h, 7), MEM)
 
 
+@pytest.mark.parametrize("n1,n2", [(1, 1), (5, 63), (7, 64), (3, 65), (9, 255), (4, 257), (6, 300), (70, 513), (2, 1030)])
+def test_match_orb_on_random_descriptors_around_the_trip_sizes(emu, oracle, n1, n2):
+    """k_match reads four train descriptors per lane and trip (64 lanes x 4 = 256 per trip, index clamped past the end): train
+    sets of 1, 63 .. 65, 255 .. 257, 300, 513, 1030 descriptors, with duplicated train descriptors (the FIRST index of the
+    minimum wins, ref :690), exact partners, near partners and the 0.8 ratio test on both sides"""
+    pc.match_random(emu, oracle, n1, n2)
+
+
 @pytest.mark.parametrize("shape,levels,nkps", [((130, 70), 4, 50), ((96, 80), 3, 31), ((64, 64), 3, 10)])
 def test_orb_pyramid(emu, oracle, shape, levels, nkps):
     w, h = shape

@@ -906,3 +906,10 @@ def test_lbp_chunk_to_xcd_mapping(hip, oracle, cascade, mode):
                             "mode %d cap %d" % (mode, cap))
     finally:
         hip.tune(13, 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n1,n2", [(1, 1), (5, 63), (3, 65), (9, 255), (4, 257), (70, 513), (300, 1030), (2500, 2500)])
+def test_match_orb_on_random_descriptors(hip, oracle, n1, n2):
+    """k_match reads four train descriptors per lane and trip (round 5): train sets around the trip sizes, ties, near partners"""
+    pc.match_random(hip, oracle, n1, n2)
