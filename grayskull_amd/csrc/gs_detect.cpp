@@ -5,6 +5,7 @@
  * progression of gs_lbp_detect (ref :819-821, :799-804) and the stable sort of <= 5000 candidates (ref :639).
  */
 #include "gs_internal.h"
+#include <pthread.h>
 
 #include "k_fast.h"
 #include "k_fast_nms.h"
@@ -323,7 +324,11 @@ void launch_lbp_padded(const gsh_cascade *dc, const LbpGeomCache &gc, const unsi
      * block noise (8 x 1080p 0.76 vs 0.80 ms for +1 +3 +6, 4K 3.15 vs 3.17) and within 0.5 % of the best on edge maps */
     ph.adaptive_next[0] = 1u, ph.adaptive_next[1] = 2u, ph.adaptive_next[2] = 4u;
     ph.tile_first = 1u, ph.tile_tenths = 7u;
-    if (g_tune[15] > 0) ph.tile_first = (unsigned)g_tune[15] & 15u, ph.tile_tenths = ((unsigned)g_tune[15] >> 4) & 15u; /* experiments: first + 16 * tenths */
+    if (g_tune[15] > 0) { /* experiments: first + 16 * tenths.  first = 0 (e.g. key 15 = 112) means "no dense stage": the dense loop still
+                           * has to run stage 0 for a wave to have survivors at all, so it is taken as 1 (results never depend on a key) */
+      ph.tile_first = std::max(1u, (unsigned)g_tune[15] & 15u), ph.tile_tenths = ((unsigned)g_tune[15] >> 4) & 15u;
+    }
+    GS_ASSERT(ph.tile_first >= 1u && ph.tile_first <= 15u && ph.tile_tenths <= 15u);
     if (ph.adaptive_max && g_tune[9] > 0) { /* experiments: key 9 = max + 16 * tenths (+ 256 d1 + 4096 d2 + 65536 d3: later points) */
       const unsigned v = (unsigned)g_tune[9];
       ph.adaptive_max = v & 15u, ph.adaptive_tenths = (v >> 4) & 15u;
@@ -356,16 +361,12 @@ void launch_lbp_padded(const gsh_cascade *dc, const LbpGeomCache &gc, const unsi
   constexpr int kNumCfgs = (int)(sizeof(cfgs) / sizeof(cfgs[0]));
   constexpr size_t kLdsPerCu = 160 * 1024, kLdsDyn = kLdsPerCu - 1024; /* the kernels' static __shared__ words count against the CU's LDS */
 #ifndef GS_EMU
-  {
-    static std::atomic<unsigned long long> lds_raised{0};
-    const unsigned long long dev_bit = 1ull << ((unsigned)ctx().device & 63u);
-    if (ctx().device >= 64 || !(lds_raised.load(std::memory_order_acquire) & dev_bit)) {
-      for (const TileCfg &c : cfgs) {
-        GS_HIP(hipFuncSetAttribute((const void *)c.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsDyn));
-        GS_HIP(hipFuncSetAttribute((const void *)c.fn_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsDyn));
-      }
-      lds_raised.fetch_or(dev_bit, std::memory_order_release);
+  if (!ctx().lbp_lds_raised) { /* per thread + device, cleared by Ctx::release(): a re-initialised runtime gets its attributes again */
+    for (const TileCfg &c : cfgs) {
+      GS_HIP(hipFuncSetAttribute((const void *)c.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsDyn));
+      GS_HIP(hipFuncSetAttribute((const void *)c.fn_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsDyn));
     }
+    ctx().lbp_lds_raised = true;
   }
 #endif
   auto tile_lds = [&](const TileCfg &c, const LbpScale &sc) {
@@ -486,7 +487,7 @@ __global__ void k_lbp_single(LbpArgs a, const LbpGeom *geom, unsigned *out) {
 /* A few parked host threads for the libm half of the ORB batch (creating a thread costs 20-50 us on these boxes, twelve of
  * them per call were a third of a 32-frame batch's time).  Workers are created on first use and parked on a condition
  * variable; run(n, fn) executes fn(0 .. n-1), the caller taking index 0; one run at a time (callers of different host
- * threads queue on the mutex).  The pool is a function-local static: its destructor wakes the workers up and joins them. */
+ * threads queue on the mutex).  One pool per process (host_pool() below); its destructor wakes the workers up and joins them. */
 class HostPool {
  public:
   static constexpr unsigned kMax = 11;
@@ -548,9 +549,33 @@ class HostPool {
   unsigned long long gen_ = 0;
   bool stop_ = false;
 };
+/* One pool per PROCESS.  A fork()ed child (Python multiprocessing) inherits the object but none of its threads -- run() would
+ * wait on `done_` forever and the destructor would join threads that do not exist -- and possibly mutexes some parent thread
+ * held at that moment.  So the pool lives on the heap behind a pointer that the child's atfork handler drops (the parent's
+ * object is abandoned there, not destroyed); the child builds its own on first use.  The janitor joins the workers of the
+ * pool this process owns at exit / dlclose, like the function-local static did. */
+static std::atomic<HostPool *> g_host_pool{nullptr};
+static std::mutex *g_host_pool_make = new std::mutex; /* never destroyed: usable from any static destructor */
+static void host_pool_atfork_child() {
+  g_host_pool.store(nullptr, std::memory_order_relaxed); /* single-threaded here */
+  g_host_pool_make = new std::mutex;
+}
+static struct HostPoolJanitor {
+  ~HostPoolJanitor() { delete g_host_pool.exchange(nullptr); }
+} g_host_pool_janitor;
 HostPool &host_pool() {
-  static HostPool p;
-  return p;
+  HostPool *p = g_host_pool.load(std::memory_order_acquire);
+  if (!p) {
+    std::lock_guard<std::mutex> lk(*g_host_pool_make);
+    p = g_host_pool.load(std::memory_order_acquire);
+    if (!p) {
+      static const int registered = pthread_atfork(nullptr, nullptr, host_pool_atfork_child);
+      (void)registered;
+      p = new HostPool;
+      g_host_pool.store(p, std::memory_order_release);
+    }
+  }
+  return *p;
 }
 
 struct OrbJob {
@@ -1093,7 +1118,13 @@ float gs_compute_orientation(struct gs_image img, unsigned x, unsigned y, unsign
  * binds gs_compute_orientation / gs_brief_descriptor / gs_orb_extract to these three symbols under the same macro, so a
  * caller built that way keeps bit-for-bit parity with ITS reference build.  No precondition aborts, like ref :69. */
 float gs_compute_orientation_nostdlib(struct gs_image img, unsigned x, unsigned y, unsigned r) {
-  if (!(GS_VALID(img) && x >= r && y >= r && x < img.w - r && y < img.h - r)) return 0.0f; /* the reference reads out of bounds as 0 here; no abort */
+  /* no precondition on x, y, r: the reference built this way has no gs_assert (ref :69) and still forms the moments, its
+   * gs_get reading 0 outside the image (ref :41-43; x + dx wraps as unsigned and fails the range test) -- stage_patch
+   * zero-fills the same pixels.  Only an invalid image (nothing to read at all) returns early. */
+  if (!GS_VALID(img)) return 0.0f;
+  /* x, y act as signed there (x + dx wraps): a centre further than r outside the image sees no pixel at all */
+  const long long xs = (int)x, ys = (int)y, rr = r;
+  if (xs + rr < 0 || ys + rr < 0 || xs - rr >= (long long)img.w || ys - rr >= (long long)img.h) return gs_atan2_poly(0.0f, 0.0f);
   float m01, m10;
   orientation_moments(img, x, y, r, m01, m10);
   return gs_atan2_poly(m01, m10);

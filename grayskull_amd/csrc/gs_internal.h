@@ -155,6 +155,7 @@ struct Ctx {
     return b.p;
   }
   bool jump_ready = false; /* SL_JUMP holds the xorshift jump table of gsh_synth_batch */
+  bool lbp_lds_raised = false; /* k_lbp_tile's hipFuncAttributeMaxDynamicSharedMemorySize set on this device (gs_detect.cpp) */
   std::map<unsigned long long, LbpGeomCache> geom_cache; /* keyed by gsh_cascade::id */
   /* flattened copy of the caller's struct gs_lbp_cascade for the drop-in gs_lbp_* calls, keyed by a hash
    * of the table contents (cached_cascade); owned here so that it goes away with the context, in order */
@@ -259,6 +260,7 @@ struct Ctx {
       b.p = nullptr, b.cap = 0;
     }
     jump_ready = false;
+    lbp_lds_raised = false;
     drop_geom();
     if (dropin_cascade) gsh_cascade_tables_deleter()(dropin_cascade);
     dropin_cascade = nullptr;

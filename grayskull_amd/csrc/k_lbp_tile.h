@@ -130,6 +130,7 @@ GS_DEV bool lbp_pair_hit(const LbpTileTables &t, const unsigned *tile, unsigned 
 template <bool COUNT>
 GS_DEV bool lbp_tile_window_stages(const LbpTileTables &t, const unsigned *tile, unsigned origin, unsigned s0, unsigned s1,
                                    unsigned *evals) {
+  if (s1 <= s0) return true; /* wave-uniform; an empty run of stages rejects nothing (and stage[s1 - 1] would be stage[-1]) */
   const unsigned wend = uniform(t.stage[s1 - 1].first) + uniform(t.stage[s1 - 1].count);
   unsigned wi = uniform(t.stage[s0].first);
 #ifdef GS_LBP_SENS

@@ -7,7 +7,10 @@
  *   test_nostdlib in.bin out.bin     in.bin: u32 w, h, nkps, threshold, then w*h bytes
  *                                    out.bin: u32 n, n keypoints (48 B), then for the first min(n, 8) keypoints the
  *                                    angle of a separate gs_compute_orientation call (f32) and the descriptor of a
- *                                    separate gs_brief_descriptor call (8 x u32)
+ *                                    separate gs_brief_descriptor call (8 x u32); then the angles (f32) of four
+ *                                    gs_compute_orientation calls closer than r to the border: (2, 3), (w - 1, h - 1),
+ *                                    (0, 0), (w - 5, 7) -- the reference built this way has no assert (ref :69) and
+ *                                    reads the pixels outside the image as 0 (gs_get, ref :41-43)
  * GS_NO_STDLIB drops the header's own <stdio.h>/<stdlib.h> (ref :68); this test harness includes them itself.
  */
 #ifndef GS_NO_STDLIB
@@ -47,6 +50,13 @@ int main(int argc, char **argv) {
     gs_brief_descriptor(img, &k);                              /* -> gs_brief_descriptor_nostdlib */
     fwrite(&a, 4, 1, f);
     fwrite(k.descriptor, 4, 8, f);
+  }
+  {
+    const unsigned bx[4] = {2, img.w - 1, 0, img.w - 5}, by[4] = {3, img.h - 1, 0, 7};
+    for (i = 0; i < 4; i++) {
+      float a = gs_compute_orientation(img, bx[i], by[i], 15);
+      fwrite(&a, 4, 1, f);
+    }
   }
   fclose(f);
   printf("n=%u\n", n);

@@ -9,12 +9,12 @@ configs[1], all frames f = 0..4095:  img = synth(3840, 2160, 1000 + f);  e = gs_
 into a zeroed dst;  t = gs_otsu_threshold(e);  gs_threshold(e, t).  Stored: t and
 wsum(e) = sum_i (i + 1) * (byte_i + 1) mod 2^64 (what gsh_checksum_batch computes on the device).
 
-configs[4], a sample of frames (the first and last frame of every rank's shard at N = 1, 2, 4, 8 with 512
-frames per GPU, frames 1..3, and 72 frames drawn over the whole batch with a fixed seed):  e as above before thresholding;  ii = gs_integral(e);
+configs[4], frames 0..511 (one GPU's whole share) and a sample of the rest (the first and last frame of every rank's shard
+at N = 1, 2, 4, 8 with 512 frames per GPU and 72 frames drawn over the whole batch with a fixed seed):  e as above before thresholding;  ii = gs_integral(e);
 gs_lbp_detect(frontalface, ii, 4096 rects, 1.1, 1.0, 4.0, step 1).  Stored: the count and wsum over the
 count * 16 bytes of gs_rect records.
 
-    python tests/golden/make_batch_golden.py --write [--jobs 8]     # ~5 min on 8 cores
+    python tests/golden/make_batch_golden.py --write [--jobs 8]     # ~35 min on 8 cores (24 s per configs[4] frame and core)
     python tests/golden/make_batch_golden.py [--sample 64]          # verify a random sample (exit 1 on a difference)
 
 Needs /root/reference (build container); the committed JSON is what travels to the GPU box."""
@@ -35,7 +35,10 @@ LBP = {"max_rects": 4096, "scale_factor": 1.1, "min_scale": 1.0, "max_scale": 4.
 CFG4_BOUNDARY = sorted({0, 1, 2, 3} | {k * 512 for k in range(8)} | {k * 512 + 511 for k in range(8)})
 # round 4: + 72 frames drawn once over the whole batch (fixed seed), so that every rank's shard at any N has frames to check
 CFG4_RANDOM = sorted(int(x) for x in np.random.RandomState(4096).choice(4096, 72, replace=False))
-CFG4_FRAMES = sorted(set(CFG4_BOUNDARY) | set(CFG4_RANDOM))
+# round 6: + every frame of the first 512 (the whole share of one GPU at N = 1 and of rank 0 at N = 8), so that the default
+# bench run checks ALL of its configs[4] rect lists, not a sample
+CFG4_FIRST_SHARE = list(range(512))
+CFG4_FRAMES = sorted(set(CFG4_BOUNDARY) | set(CFG4_RANDOM) | set(CFG4_FIRST_SHARE))
 OUT = os.path.join(HERE, "batch_checksums.json")
 
 

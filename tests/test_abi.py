@@ -101,13 +101,14 @@ def run_nostdlib_program(tmp_path, libdir, libname, frame, nkps, threshold):
     raw = open(fout, "rb").read()
     n = int(np.frombuffer(raw[:4], np.uint32)[0])
     kps = np.frombuffer(raw[4:4 + 48 * n], KEYPOINT_DTYPE).copy()
-    rest = np.frombuffer(raw[4 + 48 * n:], np.uint32).reshape(-1, 9)
-    return kps, [(int(r[0]), r[1:].copy()) for r in rest]
+    tail = np.frombuffer(raw[4 + 48 * n:], np.uint32)
+    rest, border = tail[:-4].reshape(-1, 9), [int(b) for b in tail[-4:]]
+    return kps, [(int(r[0]), r[1:].copy()) for r in rest], border
 
 
 def check_nostdlib_program(tmp_path, libdir, libname, ref_ns, frame, nkps, threshold=20):
     import numpy as np
-    kps, singles = run_nostdlib_program(tmp_path, libdir, libname, frame, nkps, threshold)
+    kps, singles, border = run_nostdlib_program(tmp_path, libdir, libname, frame, nkps, threshold)
     ko = ref_ns.orb_extract(frame, nkps, threshold)
     assert len(kps) == len(ko), "%d vs %d keypoints" % (len(kps), len(ko))
     assert kps.tobytes() == ko.tobytes(), "gs_orb_extract under -DGS_NO_STDLIB differs from the reference built the same way"
@@ -117,6 +118,10 @@ def check_nostdlib_program(tmp_path, libdir, libname, ref_ns, frame, nkps, thres
         assert abits == int(np.float32(k["angle"]).view(np.uint32))
         assert np.array_equal(desc, ref_ns.brief(frame, int(k["x"]), int(k["y"]), float(k["angle"])))
         assert np.array_equal(desc, k["desc"])
+    # keypoints closer than r to the border: no assert under GS_NO_STDLIB (ref :69), out-of-image pixels read 0 (ref :41-43)
+    h, w = frame.shape
+    for abits, (x, y) in zip(border, [(2, 3), (w - 1, h - 1), (0, 0), (w - 5, 7)]):
+        assert abits == int(np.float32(ref_ns.orientation(frame, x, y, 15)).view(np.uint32)), (x, y)
 
 
 def test_c99_nostdlib_caller_gets_the_polynomial_flavour(tmp_path, emu):

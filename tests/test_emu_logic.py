@@ -3,6 +3,7 @@ compiled for the host-fiber SIMT emulator (tests/emu) and compared with the orac
 inputs.  This is a development/CI aid for a container without a GPU -- the real parity tests are
 the `-m gpu` ones in test_gpu_parity.py, which run the HIP build on the MI355X."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -221,6 +222,30 @@ def test_orb_batch_with_the_host_thread_pool(emu, oracle):
     assert sum(len(k) for k in got) >= 4096, "the case must reach the pool's threshold"
 
 
+def test_orb_batch_host_pool_survives_fork(emu, oracle):
+    """a fork()ed child (Python multiprocessing's default start method) inherits the pool object but none of its parked
+    threads: it must build its own workers instead of waiting for the parent's (which hung gsh_orb_extract_batch), and its
+    exit must not join threads that do not exist.  Emulator only: a forked HIP runtime is not supported by ROCm itself."""
+    import signal
+    rs = np.random.RandomState(22)
+    frames = rs.randint(0, 256, (12, 96, 176)).astype(np.uint8)
+    want = emu.orb_extract_batch_dev(MEM.put(frames), MEM.put(np.zeros_like(frames)), 400, 20)  # parent: workers exist now
+    assert sum(len(k) for k in want) >= 4096
+    pid = os.fork()
+    if pid == 0:
+        code = 3
+        try:
+            signal.alarm(60)  # a hang ends the child, not the test session
+            got = emu.orb_extract_batch_dev(MEM.put(frames), MEM.put(np.zeros_like(frames)), 400, 20)
+            code = 0 if all(a.tobytes() == b.tobytes() for a, b in zip(got, want)) and len(got) == len(want) else 4
+        finally:
+            os._exit(code)
+    _, status = os.waitpid(pid, 0)
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0, "child: status %#x" % status
+    again = emu.orb_extract_batch_dev(MEM.put(frames), MEM.put(np.zeros_like(frames)), 400, 20)  # the parent's pool is intact
+    assert all(a.tobytes() == b.tobytes() for a, b in zip(again, want))
+
+
 def test_lbp(emu, oracle, cascade):
     img = Oracle.synth(96, 80, 7)
     pc.lbp(emu, oracle, img, MEM, cascade, params=((4096, 1.1, 1.0, 4.0, 1), (10, 1.3, 1.0, 2.0, 3)),
@@ -418,10 +443,11 @@ def test_lbp_tile_shapes_never_change_results(emu, oracle, cascade, mode):
         emu.tune(14, 0)
 
 
-@pytest.mark.parametrize("knob", [1 + 16 * 2, 2 + 16 * 8, 3 + 16 * 0, 1 + 16 * 10])
+@pytest.mark.parametrize("knob", [1 + 16 * 2, 2 + 16 * 8, 3 + 16 * 0, 1 + 16 * 10, 0 + 16 * 7])
 def test_lbp_tile_dense_to_pair_switch_never_changes_results(emu, oracle, cascade, knob):
     """key 15 = first + 16 * tenths: how long a wave of k_lbp_tile stays dense (stages [0, first), then while more than
-    tenths/10 of its windows live) before it goes to one lane per (window, classifier) pair -- early, late, never-early"""
+    tenths/10 of its windows live) before it goes to one lane per (window, classifier) pair -- early, late, never-early;
+    first = 0 (key 112) is taken as 1 (it used to read stage[-1])"""
     edges = oracle.sobel(oracle.blur(Oracle.synth(200, 150, 1000), 2))
     try:
         emu.tune(15, knob)
