@@ -63,7 +63,10 @@ class Sharder:
 
     def barrier(self):
         if self.dist:
-            self.dist.barrier()
+            if self.backend == "nccl":  # name the rank's GPU: without it RCCL guesses the device from the current one
+                self.dist.barrier(device_ids=[self.local_rank])
+            else:
+                self.dist.barrier()
 
     def max_over_ranks(self, value):
         if not self.dist:
