@@ -155,7 +155,15 @@ bool launch_integral(const uint8_t *src, unsigned w, unsigned h, unsigned n, uns
     const unsigned nn = std::min(kMaxZ, n - f0);
     if (banded) {
       const bool wide = w > 4096;
-      unsigned nb = std::max(1u, 8u * topo().cus / nn);      /* ~8 blocks per CU in flight */
+      /* bands per frame: ~8 blocks per CU in flight, and for narrow frames no band taller than 32 rows (48 up to 2048 px).
+       * A wave of k_integral_wave owns one band and walks it row by row; a 4K row is 16 tiles of arithmetic and 8 waves per
+       * CU keep HBM busy, a 612-px row is three, and a large batch of such frames -- 8 bands of 102 rows each -- ran at
+       * 2.5 TB/s (256 x 612x816 0.255 ms; with bands of 26 rows and 4-tile waves 0.21; profiles/r06h_integral_ab_tiles_and_band_height.log).
+       * Every band costs 12 B per column (its sums: written, scanned, read), which is why wide frames keep tall bands:
+       * 64 x 1080p with 64 bands instead of 32 measured 9 % slower. */
+      unsigned nb = std::max(1u, 8u * topo().cus / nn);
+      if (w <= 1024) nb = std::max(nb, (h + 31u) / 32u);
+      else if (w <= 2048) nb = std::max(nb, (h + 47u) / 48u);
       nb = std::min(nb, std::max(1u, h / 8));
       if (wide) nb = std::max(nb, (h + kIntegralWideRows - 1) / kIntegralWideRows); /* a row's carry waits in LDS */
       const unsigned BH = (h + nb - 1) / nb;
@@ -177,6 +185,11 @@ bool launch_integral(const uint8_t *src, unsigned w, unsigned h, unsigned n, uns
         GS_LAUNCH(k_integral_band, dim3(1, nb, nn), dim3(256), 0, st, s, w, h, BH, nb, (const unsigned *)cs, o);
       else if (wide && rg) GS_LAUNCH((k_integral_wave<16, true, true>), gw, dim3(256), 0, st, s, w, h, BH, nb, (const unsigned *)cs, o);
       else if (wide) GS_LAUNCH((k_integral_wave<16, false, true>), gw, dim3(256), 0, st, s, w, h, BH, nb, (const unsigned *)cs, o);
+      /* tiles of 256 px per row: the smallest of 2 / 4 / 8 / 16 that spans it (a tile past the row's end still costs its wave scan) */
+      else if (w <= 512 && rg) GS_LAUNCH((k_integral_wave<2, true>), gw, dim3(256), 0, st, s, w, h, BH, nb, (const unsigned *)cs, o);
+      else if (w <= 512) GS_LAUNCH(k_integral_wave<2>, gw, dim3(256), 0, st, s, w, h, BH, nb, (const unsigned *)cs, o);
+      else if (w <= 1024 && rg) GS_LAUNCH((k_integral_wave<4, true>), gw, dim3(256), 0, st, s, w, h, BH, nb, (const unsigned *)cs, o);
+      else if (w <= 1024) GS_LAUNCH(k_integral_wave<4>, gw, dim3(256), 0, st, s, w, h, BH, nb, (const unsigned *)cs, o);
       else if (w <= 2048 && rg) GS_LAUNCH((k_integral_wave<8, true>), gw, dim3(256), 0, st, s, w, h, BH, nb, (const unsigned *)cs, o);
       else if (w <= 2048) GS_LAUNCH(k_integral_wave<8>, gw, dim3(256), 0, st, s, w, h, BH, nb, (const unsigned *)cs, o);
       else if (rg) GS_LAUNCH((k_integral_wave<16, true>), gw, dim3(256), 0, st, s, w, h, BH, nb, (const unsigned *)cs, o);
