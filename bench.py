@@ -266,6 +266,19 @@ def load_golden_batch(w, h, r):
     return gold if (gold["w"], gold["h"], gold["radius"]) == (w, h, r) else None
 
 
+def frame_ranges(frames):
+    """[0, 1, 2, 3, 7, 9, 10] -> '0-3, 7, 9-10' (the golden-checked frames of a share can be all 512 of them)"""
+    out, fs = [], sorted(frames)
+    i = 0
+    while i < len(fs):
+        j = i
+        while j + 1 < len(fs) and fs[j + 1] == fs[j] + 1:
+            j += 1
+        out.append("%d" % fs[i] if i == j else "%d-%d" % (fs[i], fs[j]))
+        i = j + 1
+    return ", ".join(out)
+
+
 def wsum_bytes(np, a):
     """sum (i+1)*(byte+1) mod 2^64 over raw bytes: the host twin of gsh_checksum_batch, for KB-sized result lists"""
     b = np.ascontiguousarray(a).view(np.uint8).reshape(-1).astype(np.uint64)
@@ -380,8 +393,8 @@ def run_cfg4(args, sh, g, torch, np, w, h, F, r, lo, total):
                 bad.append("live:0")
         if sh.rank == 0:
             parity = ("MISMATCH at frames %s" % bad if bad else
-                      "rect lists of frames %s (of %d, all ranks) == reference golden (count + checksum)%s"
-                      % (checked, total, "; frame 0 bit-exact vs %s oracle live" % o.kind if live else ""))
+                      "rect lists of %d of the %d frames (all ranks; frames %s) == reference golden (count + checksum)%s"
+                      % (len(checked), total, frame_ranges(checked), "; frame 0 bit-exact vs %s oracle live" % o.kind if live else ""))
     ranks_seen = sh.ranks_seen()  # a collective: every rank takes part (it used to sit inside rank 0's print -- found by the 8-rank rehearsal)
     if sh.rank == 0:
         print(json.dumps({
@@ -923,7 +936,8 @@ def extras(g, torch, np, src, tmp, dst, w, h, reps, lo=0, args=None):
         "Gwindows/s_evaluated": round(nev5 / ms5_lbp_plain / 1e6, 2), "lbp_ms_per_frame": round(ms5_lbp_plain / n1, 3), "detections": cn5.cpu().tolist()[:4],
         "lbp_roofline": lbp_gather_block(nweak5, nload5, ms5_lbp_plain),
         "parity": ("MISMATCH at global frames %s" % bad5 if bad5 else
-                   "rect lists of global frames %s == reference golden (count + checksum)" % checked5) if checked5 else "no golden frame in this share",
+                   "rect lists of %d of this share's %d frames (global frames %s) == reference golden (count + checksum)"
+                   % (len(checked5), F5, frame_ranges(checked5))) if checked5 else "no golden frame in this share",
         "note": "one timed pass over all %d frames of this GPU in groups of %d; frames shard across GPUs with no exchange: 4096 frames on "
                 "8 GPUs = 512 per GPU; the cascade dominates (120 M windows per frame; chunks behind the 4096th detection are skipped "
                 "like the reference stops there)" % (F5, G5)}

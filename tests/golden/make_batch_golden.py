@@ -94,6 +94,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--write", action="store_true")
     ap.add_argument("--add-cfg4", action="store_true", help="generate the configs[4] frames of CFG4_FRAMES the file lacks and merge them in")
+    ap.add_argument("--all-cfg4", action="store_true", help="with --add-cfg4: every frame of the batch, not only CFG4_FRAMES (~7 h on 4 cores)")
     ap.add_argument("--jobs", type=int, default=os.cpu_count() or 1)
     ap.add_argument("--sample", type=int, default=32, help="verify mode: configs[1] frames to re-derive (0 = all)")
     ap.add_argument("--sample4", type=int, default=1, help="verify mode: configs[4] frames to re-derive")
@@ -113,19 +114,30 @@ def main():
         return 0
     gold = json.load(open(OUT))
     if args.add_cfg4:
-        missing = [f for f in CFG4_FRAMES if str(f) not in gold["cfg4"]["frames"]]
-        _, r4 = generate(args.jobs, [], missing)
-        for f, n, s in r4:
-            gold["cfg4"]["frames"][str(f)] = {"n": n, "wsum": "%016x" % s}
-        gold["cfg4"]["frames"] = {k: gold["cfg4"]["frames"][k] for k in sorted(gold["cfg4"]["frames"], key=int)}
-        with open(OUT, "w") as fh:
-            json.dump(gold, fh, separators=(",", ":"))
-            fh.write("\n")
-        print("added %d configs[4] frames: %s" % (len(r4), [f for f, _, _ in r4]))
+        want = list(range(FRAMES)) if args.all_cfg4 else CFG4_FRAMES
+        missing = [f for f in want if str(f) not in gold["cfg4"]["frames"]]
+
+        def save():
+            gold["cfg4"]["frames"] = {k: gold["cfg4"]["frames"][k] for k in sorted(gold["cfg4"]["frames"], key=int)}
+            with open(OUT + ".tmp", "w") as fh:
+                json.dump(gold, fh, separators=(",", ":"))
+                fh.write("\n")
+            os.replace(OUT + ".tmp", OUT)
+
+        done = 0
+        with mp.get_context("spawn").Pool(args.jobs) as pool:  # 24 s per frame and core: the file is rewritten every 32 frames
+            for f, n, s in pool.imap_unordered(cfg4_frame, missing, chunksize=1):
+                gold["cfg4"]["frames"][str(f)] = {"n": n, "wsum": "%016x" % s}
+                done += 1
+                if done % 32 == 0:
+                    save()
+                    print("%d / %d" % (done, len(missing)), flush=True)
+        save()
+        print("added %d configs[4] frames" % done)
         return 0
     rng = np.random.default_rng(int.from_bytes(os.urandom(4), "little"))
     f1 = list(range(FRAMES)) if args.sample == 0 else sorted(int(x) for x in rng.choice(FRAMES, args.sample, replace=False))
-    have4 = [f for f in CFG4_FRAMES if str(f) in gold["cfg4"]["frames"]]
+    have4 = [int(f) for f in gold["cfg4"]["frames"]]
     f4 = [int(x) for x in rng.choice(have4, min(args.sample4, len(have4)), replace=False)]
     r1, r4 = generate(args.jobs, f1, f4)
     bad = [f for f, t, s in r1 if gold["cfg1"]["otsu"][f] != t or gold["cfg1"]["wsum"][f] != "%016x" % s]
