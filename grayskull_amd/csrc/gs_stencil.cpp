@@ -171,7 +171,14 @@ bool launch_integral(const uint8_t *src, unsigned w, unsigned h, unsigned n, uns
       unsigned *cs = (unsigned *)ctx().scratch(SL_HISTP, (size_t)nn * nb * w * 4);
       const uint8_t *s = src + fp * f0;
       unsigned *o = ii + fp * f0;
+      /* source planes the Infinity Cache (256 MB, shared with the table being written) cannot keep between the first pass and
+       * the third: both read them with streaming loads (k_integral.h).  Same-box A/B of that policy for every batch: 16 x 4096^2
+       * (256 MiB) -7 %, 64 x 4K -4 ... -12 %, 64 x 1080p (133 MB) +-0, 8 x 1080p +22 %, 32 x 720p +23 %
+       * (profiles/r06i_integral_nt_loads.log, r06j_integral_ab.log).  The plain table of frames wider than 2048 px only --
+       * the 16-tile waves -- to keep the instantiations few. */
+      const bool nt = !sq && w > 2048 && (size_t)nn * fp >= ((size_t)192 << 20) && g_tune[6] != 8; /* key 6 = 8: default policy for every batch (A/B) */
       if (sq) GS_LAUNCH(k_integral_colsum<true>, dim3((w + 4095) / 4096, nb, nn), dim3(256), 0, st, s, w, h, BH, nb, cs);
+      else if (nt) GS_LAUNCH((k_integral_colsum<false, true>), dim3((w + 4095) / 4096, nb, nn), dim3(256), 0, st, s, w, h, BH, nb, cs);
       else GS_LAUNCH(k_integral_colsum<false>, dim3((w + 4095) / 4096, nb, nn), dim3(256), 0, st, s, w, h, BH, nb, cs);
       GS_LAUNCH(k_integral_colbase, dim3((w + 63) / 64, nn), dim3(64, 16), 0, st, cs, w, nb);
       const dim3 gw(1, (nb + 3) / 4, nn);
@@ -183,6 +190,10 @@ bool launch_integral(const uint8_t *src, unsigned w, unsigned h, unsigned n, uns
         else GS_LAUNCH((k_integral_wave<16, false, false, true>), gw, dim3(256), 0, st, s, w, h, BH, nb, (const unsigned *)cs, o);
       } else if (g_tune[6] == 2 && !rg && !wide && w % 16 == 0) /* the block-per-band form (one barrier per row), kept for comparison */
         GS_LAUNCH(k_integral_band, dim3(1, nb, nn), dim3(256), 0, st, s, w, h, BH, nb, (const unsigned *)cs, o);
+      else if (nt && wide && rg) GS_LAUNCH((k_integral_wave<16, true, true, false, true>), gw, dim3(256), 0, st, s, w, h, BH, nb, (const unsigned *)cs, o);
+      else if (nt && wide) GS_LAUNCH((k_integral_wave<16, false, true, false, true>), gw, dim3(256), 0, st, s, w, h, BH, nb, (const unsigned *)cs, o);
+      else if (nt && rg) GS_LAUNCH((k_integral_wave<16, true, false, false, true>), gw, dim3(256), 0, st, s, w, h, BH, nb, (const unsigned *)cs, o);
+      else if (nt) GS_LAUNCH((k_integral_wave<16, false, false, false, true>), gw, dim3(256), 0, st, s, w, h, BH, nb, (const unsigned *)cs, o);
       else if (wide && rg) GS_LAUNCH((k_integral_wave<16, true, true>), gw, dim3(256), 0, st, s, w, h, BH, nb, (const unsigned *)cs, o);
       else if (wide) GS_LAUNCH((k_integral_wave<16, false, true>), gw, dim3(256), 0, st, s, w, h, BH, nb, (const unsigned *)cs, o);
       /* tiles of 256 px per row: the smallest of 2 / 4 / 8 / 16 that spans it (a tile past the row's end still costs its wave scan) */

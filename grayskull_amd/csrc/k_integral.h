@@ -104,7 +104,10 @@ GS_DEV unsigned integral_term(unsigned b, bool sq) {
   const int v = (int)b - 128;
   return sq ? (unsigned)(v * v) : b;
 }
-template <bool SQ = false>
+/* NT: the batch's source planes are more than the Infinity Cache keeps -- nothing of this pass's reads will be found there by
+ * the third pass, so they stream (64 x 4K -4 ... -12 %, 16 x 4096^2 -7 %; on batches that fit, the same policy costs 20-36 %:
+ * profiles/r06i_integral_nt_loads.log; the launcher decides) */
+template <bool SQ = false, bool NT = false>
 __global__ __launch_bounds__(256) void k_integral_colsum(const uint8_t *src, unsigned w, unsigned h,
                                                          unsigned BH, unsigned nbands,
                                                          unsigned *colsum) {
@@ -117,10 +120,10 @@ __global__ __launch_bounds__(256) void k_integral_colsum(const uint8_t *src, uns
   unsigned V[16];
 #pragma unroll
   for (int k = 0; k < 16; k++) V[k] = 0;
-  U4 nxt = buf_load16(S, act ? y0 * w + x0 : kOOB);
+  U4 nxt = buf_load16_pol<NT>(S, act ? y0 * w + x0 : kOOB);
   for (unsigned y = y0; y < y1; y++) {
     const U4 cur = nxt;
-    nxt = buf_load16(S, (act && y + 1 < y1) ? (y + 1) * w + x0 : kOOB);
+    nxt = buf_load16_pol<NT>(S, (act && y + 1 < y1) ? (y + 1) * w + x0 : kOOB);
     const uint32_t d[4] = {cur.x, cur.y, cur.z, cur.w};
 #pragma unroll
     for (int k = 0; k < 16; k++) V[k] += integral_term((d[k >> 2] >> (8 * (k & 3))) & 0xffu, SQ);
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(256) void k_integral_band(const uint8_t *src, unsig
  * bottom inside each; what a row hands from chunk to chunk -- its prefix at the chunk's left edge -- waits in a
  * register of lane (row - y0): v_readlane / one masked move per row, no LDS (BH <= kIntegralWideRows = 64). */
 constexpr unsigned kIntegralWideRows = 64;
-template <int TILES, bool RAGGED = false, bool WIDE = false, bool SQ = false>
+template <int TILES, bool RAGGED = false, bool WIDE = false, bool SQ = false, bool NT = false>
 __global__ __launch_bounds__(256) void k_integral_wave(const uint8_t *src, unsigned w, unsigned h,
                                                        unsigned BH, unsigned nbands,
                                                        const unsigned *colbase, unsigned *ii) {
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(256) void k_integral_wave(const uint8_t *src, unsig
       xo[t] = in ? x : kOOB;
       const U4 b = buf_load16(C, in ? x * 4u : kOOB); /* zero beyond w */
       V[t][0] = b.x, V[t][1] = b.y, V[t][2] = b.z, V[t][3] = b.w;
-      nxt[t] = buf_load4(S, in ? y0 * w + x : kOOB);
+      nxt[t] = buf_load4_pol<NT>(S, in ? y0 * w + x : kOOB);
     }
     for (unsigned y = y0; y < y1; y++) { /* wave-uniform trip count */
       uint32_t cur[TILES];
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(256) void k_integral_wave(const uint8_t *src, unsig
 #pragma unroll
       for (int t = 0; t < TILES; t++) {
         cur[t] = nxt[t];
-        nxt[t] = buf_load4(S, (more && xo[t] != kOOB) ? (y + 1) * w + xo[t] : kOOB);
+        nxt[t] = buf_load4_pol<NT>(S, (more && xo[t] != kOOB) ? (y + 1) * w + xo[t] : kOOB);
       }
       unsigned carry = 0; /* sum of the tiles to the left, wave-uniform */
       if constexpr (WIDE) {

@@ -128,6 +128,8 @@ GS_DEV uint32_t buf_load4(const BufRsrc &b, uint32_t off) {
   if (off < b.n) memcpy(&v, b.base + off, 4);
   return v;
 }
+template <bool NT> GS_DEV U4 buf_load16_pol(const BufRsrc &b, uint32_t off) { return buf_load16(b, off); }
+template <bool NT> GS_DEV uint32_t buf_load4_pol(const BufRsrc &b, uint32_t off) { return buf_load4(b, off); }
 GS_DEV void store_u32x4(void *p, const U4 &v) { memcpy(p, &v, 16); }
 GS_DEV void store_u32x4_any(void *p, const U4 &v) { memcpy(p, &v, 16); }
 GS_DEV U4 load_u32x4_any(const void *p) { U4 v; memcpy(&v, p, 16); return v; }
@@ -272,6 +274,14 @@ GS_DEV U4 buf_load16(const BufRsrc &b, uint32_t off) { /* buffer_load_dwordx4 of
 }
 GS_DEV uint32_t buf_load4(const BufRsrc &b, uint32_t off) { /* buffer_load_dword offen */
   return __builtin_amdgcn_raw_buffer_load_b32(b.r, (int)off, 0, GS_LOAD_AUX);
+}
+/* NT = true: streaming (nt) policy for data that is read once and is too large to be found in the Infinity Cache again */
+template <bool NT> GS_DEV U4 buf_load16_pol(const BufRsrc &b, uint32_t off) {
+  const gs_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(b.r, (int)off, 0, NT ? 2 : GS_LOAD_AUX);
+  return U4{v.x, v.y, v.z, v.w};
+}
+template <bool NT> GS_DEV uint32_t buf_load4_pol(const BufRsrc &b, uint32_t off) {
+  return __builtin_amdgcn_raw_buffer_load_b32(b.r, (int)off, 0, NT ? 2 : GS_LOAD_AUX);
 }
 struct U2 { uint32_t x, y; };
 GS_DEV U2 buf_load8(const BufRsrc &b, uint32_t off) { /* buffer_load_dwordx2 offen */

@@ -46,7 +46,8 @@ enum gsh_tune_key {
   GSH_TUNE_LBP_PHASE_PRESET = 4,  /* k_lbp_cascade: preset of the stages at which a block re-packs survivors (1: never; >= 1000: custom split) */
   GSH_TUNE_PIPELINE_CHUNK = 5,    /* frames per chunk of gsh_edge_pipeline_batch's internal overlap (0 = 32, negative = never split) */
   GSH_TUNE_COMPARE = 6,           /* 1 generic two-pass gs_integral, 2 block-per-band gs_integral, 3 integral-image route for gs_blur(r > 3) /
-                                     gs_adaptive_threshold, 4 the any-radius box kernel also for radii <= 16, 5 ... for ragged rows only, 6 / 7 k_box_edge always on the caller's / on the side stream */
+                                     gs_adaptive_threshold, 4 the any-radius box kernel also for radii <= 16, 5 ... for ragged rows only, 6 / 7 k_box_edge always on the caller's / on the side stream,
+                                     8 gs_integral without the streaming loads of batches beyond the Infinity Cache */
   GSH_TUNE_FAST_SCORE = 7,        /* 0: k_fast_score_q4 (LDS tile, candidates queued), 2: k_fast_score_px (one global byte load per ring pixel) */
   GSH_TUNE_FRAMES_PER_LAUNCH = 8, /* test hook for the batch splitting of every launcher */
   GSH_TUNE_LBP_ADAPTIVE = 9,      /* k_lbp_cascade: max stages + 16 * tenths [+ later points] of the first re-packing point */

@@ -669,6 +669,31 @@ def test_integral_wraps_mod_2_32_like_the_reference(hip, oracle):
     assert int(exp[-1, -1]) == (255 * 4200 * 4200) % 2 ** 32
 
 
+@pytest.mark.parametrize("shape", [(3840, 2160, 33), (3838, 1080, 67), (4100, 600, 110)])
+def test_integral_batches_beyond_the_infinity_cache(hip, oracle, shape):
+    """source planes of more than 256 MB at more than 2048 px per row: gs_integral's two passes read them with streaming
+    loads (k_integral_colsum<.., NT> / k_integral_wave<16, .., NT>: whole strips, ragged rows, column chunks beyond 4096 px);
+    tune key 6 = 8 takes the default policy -- the tables must be the same either way"""
+    import torch
+    w, h, n = shape
+    assert w * h * n > 256 << 20
+    src = torch.empty((n, h, w), dtype=torch.uint8, device="cuda")
+    hip.synth_batch(src, 300)
+    ii = torch.zeros((n, h, w), dtype=torch.int32, device="cuda")
+    hip.integral_batch(src, ii)
+    hip.sync()
+    for f in (0, n // 2, n - 1):
+        assert_same(ii[f].cpu().numpy().view(np.uint32), oracle.integral(src[f].cpu().numpy()), "integral frame %d of %s" % (f, shape))
+    ii2 = torch.zeros_like(ii)
+    try:
+        hip.tune(6, 8)
+        hip.integral_batch(src, ii2)
+        hip.sync()
+    finally:
+        hip.tune(6, 0)
+    assert torch.equal(ii, ii2)
+
+
 def test_more_frames_than_grid_z(hip, oracle):
     """40000 tiny frames in one batch call: launches are split at the grid.z limit"""
     import torch
