@@ -364,10 +364,14 @@ unsigned hist_bpf(size_t frame_bytes, unsigned n) {
   return (unsigned)std::max<size_t>(1, std::min<size_t>(std::max(by_size, by_fill), 2048));
 }
 void launch_hist_partial(dim3 grid, hipStream_t st, const uint8_t *img, size_t frame_bytes, unsigned *partial) {
+  /* more bytes than the Infinity Cache keeps (192 MiB and up): streaming loads (k_pointwise.h); key 10 = -1: never */
+  const bool nt = (size_t)grid.y * grid.z * frame_bytes >= ((size_t)192 << 20) && g_tune[10] != -1;
   switch (hist_threads()) {
     case 512: GS_LAUNCH(k_hist_partial<512>, grid, dim3(512), 0, st, img, frame_bytes, partial); break;
     case 1024: GS_LAUNCH(k_hist_partial<1024>, grid, dim3(1024), 0, st, img, frame_bytes, partial); break;
-    default: GS_LAUNCH(k_hist_partial<256>, grid, dim3(256), 0, st, img, frame_bytes, partial);
+    default:
+      if (nt) GS_LAUNCH((k_hist_partial<256, true>), grid, dim3(256), 0, st, img, frame_bytes, partial);
+      else GS_LAUNCH(k_hist_partial<256>, grid, dim3(256), 0, st, img, frame_bytes, partial);
   }
 }
 void launch_histogram(const uint8_t *img, size_t frame_bytes, unsigned n, unsigned *hist) {

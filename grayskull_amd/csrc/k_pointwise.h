@@ -85,6 +85,11 @@ __global__ __launch_bounds__(256) void k_threshold(uint8_t *img, size_t frame_by
 #define GS_HIST_DEPTH 3
 #endif
 constexpr unsigned kHistDepth = GS_HIST_DEPTH;
+/* NT: every byte is read once, and when the launch covers more than the Infinity Cache keeps, its loads stream (round 6,
+ * same-box A/B of the load policy: 512 x 4K 0.67 -> 0.70 of 8 TB/s, 64 x 4096^2 0.685 -> 0.77; a handful of frames that
+ * the benchmark loop finds in that cache again: 8 x 1080p 14.2 -> 15.8 us -- the launcher decides;
+ * profiles/r06l_hist_nt_ab.log.  The strip kernels, which find their halo rows in the caches, lose 15-25 % to the same
+ * policy: profiles/r06k_bench_nt_loads_ab.log.) */
 constexpr size_t kHistMaxFrame = (size_t)1 << 30; /* bytes per k_hist_partial frame (32-bit buffer offsets) */
 GS_DEV void hist_count16(unsigned *lh, unsigned copy, const U4 &v, unsigned inc) {
   const uint32_t d[4] = {v.x, v.y, v.z, v.w};
@@ -92,7 +97,7 @@ GS_DEV void hist_count16(unsigned *lh, unsigned copy, const U4 &v, unsigned inc)
   for (int k = 0; k < 16; k++) atomicAdd(&lh[((d[k >> 2] >> (8 * (k & 3))) & 0xffu) * 32u + copy], inc);
 }
 /* BT threads share the block's 32 KB of counters: more waves per CU next to the same LDS footprint */
-template <unsigned BT>
+template <unsigned BT, bool NT = false>
 __global__ __launch_bounds__(BT) void k_hist_partial(const uint8_t *img, size_t frame_bytes,
                                                      unsigned *partial) {
   __shared__ unsigned lh[256 * 32];
@@ -119,7 +124,7 @@ __global__ __launch_bounds__(BT) void k_hist_partial(const uint8_t *img, size_t 
     U4 q[kHistDepth];
 #pragma unroll
     for (unsigned k = 0; k < kHistDepth; k++) {
-      q[k] = buf_load16(src, mine + k * step);
+      q[k] = buf_load16_pol<NT>(src, mine + k * step);
       sched_fence(); /* issue order = consumption order, or the first trip (hence every trip) waits for all of them */
     }
     uint32_t off = mine;
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(BT) void k_hist_partial(const uint8_t *img, size_t 
 #pragma unroll
       for (unsigned k = 0; k < kHistDepth; k++) { /* static register names: the queue is a rotation of q[] */
         hist_count16(lh, copy, q[k], off < end ? 1u : 0u);
-        q[k] = buf_load16(src, off + kHistDepth * step); /* straight into the slot just consumed: no copies to wait for */
+        q[k] = buf_load16_pol<NT>(src, off + kHistDepth * step); /* straight into the slot just consumed: no copies to wait for */
         off += step;
         sched_fence(); /* keep the steps apart: the scheduler would otherwise hoist all 48 address computations above
                           one wait for every load */

@@ -51,7 +51,7 @@ enum gsh_tune_key {
   GSH_TUNE_FAST_SCORE = 7,        /* 0: k_fast_score_q4 (LDS tile, candidates queued), 2: k_fast_score_px (one global byte load per ring pixel) */
   GSH_TUNE_FRAMES_PER_LAUNCH = 8, /* test hook for the batch splitting of every launcher */
   GSH_TUNE_LBP_ADAPTIVE = 9,      /* k_lbp_cascade: max stages + 16 * tenths [+ later points] of the first re-packing point */
-  GSH_TUNE_HIST_TRIPS = 10,       /* trips per block gs_histogram aims at */
+  GSH_TUNE_HIST_TRIPS = 10,       /* trips per block gs_histogram aims at; -1: default-policy loads also for batches beyond the Infinity Cache (A/B) */
   GSH_TUNE_HIST_BLOCKS = 11,      /* its blocks per frame */
   GSH_TUNE_HIST_PIECE = 12,       /* bytes per histogram piece (test hook for images above 1 GiB) */
   GSH_TUNE_LBP_XCD = 13,          /* chunk / tile -> XCD mapping of the LBP kernels: 1 dispatch order, 2 XCD-aware always (0: k_lbp_cascade by table size, k_lbp_tile in dispatch order) */
