@@ -46,7 +46,7 @@ def test_bench_cfg1_under_rccl_world1_checks_every_frame():
 def test_bench_cfg4_under_rccl_world1_broadcast_and_rect_gather():
     d = _torchrun_bench("--workload", "cfg4", "--frames", "3", "--steps", "1", "--warmup", "0")
     assert d["backend"] == "nccl" and d["rccl_ranks_seen"] == 1
-    assert "MISMATCH" not in d["parity"] and "[0, 1, 2]" in d["parity"], d["parity"]
+    assert "MISMATCH" not in d["parity"] and "3 of the 3 frames" in d["parity"] and "frames 0-2" in d["parity"], d["parity"]
     assert d["detections_total"] > 0 and len(d["detections_first_frames"]) == 3
 
 
