@@ -353,6 +353,31 @@ def test_fused_edge_pipeline_equals_separate_calls(emu, oracle, radius, shape):
     emu.tune(0, 0)
 
 
+@pytest.mark.parametrize("chunk,n", [(3, 7), (2, 6), (4, 5), (1, 3), (8, 5)])
+def test_fused_edge_pipeline_in_chunks(emu, oracle, chunk, n):
+    """gsh_edge_pipeline_batch cut into chunks (key 5 = frames per chunk): whole chunks, a shorter last chunk, one frame per
+    chunk, one chunk; two band heights.  (On the GPU every chunk's Otsu + threshold pass runs on a side stream under the next
+    chunk's kernel; the emulator runs the launches in order.)"""
+    w, h = 80, 37
+    src = np.stack([Oracle.synth(w, h, 900 + i) for i in range(n)])
+    try:
+        emu.tune(5, chunk)
+        for T in (0, 5):
+            emu.tune(0, T)
+            out = np.full_like(src, 9)
+            hist = np.zeros((n, 256), np.uint32)
+            thr = np.zeros(n, np.uint8)
+            emu.edge_pipeline_batch(out, None, src, 2, hist, thr)
+            for i in range(n):
+                s = oracle.sobel(oracle.blur(src[i], 2))
+                t = oracle.otsu_threshold(s)
+                assert np.array_equal(hist[i], oracle.histogram(s)), "histogram of frame %d" % i
+                assert thr[i] == t, "threshold of frame %d" % i
+                assert np.array_equal(out[i], oracle.threshold(s, t)), "frame %d" % i
+    finally:
+        emu.tune(5, 0), emu.tune(0, 0)
+
+
 @pytest.mark.parametrize("preset", [0, 1, 2, 3])
 def test_lbp_survivor_repacking_never_changes_results(emu, oracle, cascade, preset):
     """gsh_tune 4: dense single phase vs block-local survivor re-packing at various stage splits"""
