@@ -9,8 +9,9 @@ configs[1], all frames f = 0..4095:  img = synth(3840, 2160, 1000 + f);  e = gs_
 into a zeroed dst;  t = gs_otsu_threshold(e);  gs_threshold(e, t).  Stored: t and
 wsum(e) = sum_i (i + 1) * (byte_i + 1) mod 2^64 (what gsh_checksum_batch computes on the device).
 
-configs[4], frames 0..511 (one GPU's whole share) and a sample of the rest (the first and last frame of every rank's shard
-at N = 1, 2, 4, 8 with 512 frames per GPU and 72 frames drawn over the whole batch with a fixed seed):  e as above before thresholding;  ii = gs_integral(e);
+configs[4], since round 6 every frame of the batch (`--add-cfg4 --all-cfg4`: 24 s of one host core per frame, the file is
+rewritten every 32 frames; CFG4_FRAMES below is the subset a plain `--write` regenerates: one GPU's whole share plus a sample
+of the rest):  e as above before thresholding;  ii = gs_integral(e);
 gs_lbp_detect(frontalface, ii, 4096 rects, 1.1, 1.0, 4.0, step 1).  Stored: the count and wsum over the
 count * 16 bytes of gs_rect records.
 
