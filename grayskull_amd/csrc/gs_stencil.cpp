@@ -177,8 +177,11 @@ bool launch_integral(const uint8_t *src, unsigned w, unsigned h, unsigned n, uns
        * (profiles/r06i_integral_nt_loads.log, r06j_integral_ab.log).  The plain table of frames wider than 2048 px only --
        * the 16-tile waves -- to keep the instantiations few. */
       const bool nt = !sq && w > 2048 && (size_t)nn * fp >= ((size_t)192 << 20) && g_tune[6] != 8; /* key 6 = 8: default policy for every batch (A/B) */
+      /* the first pass streams at that size whatever the width (256 x 720p -4 %); from 48 MiB it cost 64 - 75 MiB batches 7-12 %:
+       * the third pass then misses the cache for its source (profiles/r06aa_integral_first_pass_nt.log) */
+      const bool nt_first = !sq && (size_t)nn * fp >= ((size_t)192 << 20) && g_tune[6] != 8;
       if (sq) GS_LAUNCH(k_integral_colsum<true>, dim3((w + 4095) / 4096, nb, nn), dim3(256), 0, st, s, w, h, BH, nb, cs);
-      else if (nt) GS_LAUNCH((k_integral_colsum<false, true>), dim3((w + 4095) / 4096, nb, nn), dim3(256), 0, st, s, w, h, BH, nb, cs);
+      else if (nt || nt_first) GS_LAUNCH((k_integral_colsum<false, true>), dim3((w + 4095) / 4096, nb, nn), dim3(256), 0, st, s, w, h, BH, nb, cs);
       else GS_LAUNCH(k_integral_colsum<false>, dim3((w + 4095) / 4096, nb, nn), dim3(256), 0, st, s, w, h, BH, nb, cs);
       GS_LAUNCH(k_integral_colbase, dim3((w + 63) / 64, nn), dim3(64, 16), 0, st, cs, w, nb);
       const dim3 gw(1, (nb + 3) / 4, nn);
