@@ -669,11 +669,11 @@ def test_integral_wraps_mod_2_32_like_the_reference(hip, oracle):
     assert int(exp[-1, -1]) == (255 * 4200 * 4200) % 2 ** 32
 
 
-@pytest.mark.parametrize("shape", [(3840, 2160, 33), (3838, 1080, 67), (4100, 600, 110)])
+@pytest.mark.parametrize("shape", [(3840, 2160, 33), (3838, 1080, 67), (4100, 600, 110), (1282, 720, 300)])
 def test_integral_batches_beyond_the_infinity_cache(hip, oracle, shape):
-    """source planes of more than 256 MB at more than 2048 px per row: gs_integral's two passes read them with streaming
-    loads (k_integral_colsum<.., NT> / k_integral_wave<16, .., NT>: whole strips, ragged rows, column chunks beyond 4096 px);
-    tune key 6 = 8 takes the default policy -- the tables must be the same either way"""
+    """source planes of more than 256 MB: gs_integral's first pass reads them with streaming loads (k_integral_colsum<.., NT>),
+    and so does the third for rows of more than 2048 px (k_integral_wave<16, .., NT>: whole strips, ragged rows, column chunks
+    beyond 4096 px); tune key 6 = 8 takes the default policy -- the tables must be the same either way"""
     import torch
     w, h, n = shape
     assert w * h * n > 256 << 20
